@@ -1,0 +1,589 @@
+"""Host-side mirror of the reference's CommonSolve surface for the low-rank GDRE path.
+
+Same names, argument meaning and error behaviour as mpimd-csc/DifferentialRiccatiEquations.jl v0.5.5
+(`GDREProblem`, `GALEProblem`, `Ros1`, `Ros2`, `ADI`, `Shifts.{Cyclic,Projection,Heuristic,Wrapped}`, `lowrank`,
+`concatenate_`, `compress_`, `residual`, `solve`, `Callbacks`), written in Python because the reference's own
+host language (Julia) is not installed in this image; the Julia shim with identical structure is
+`julia/DREHip.jl`.  Every arithmetic operation is executed by libdre_hip on the GPU through the C ABI —
+this module holds no numerical fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import warnings
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import device as dev
+from ._lib import DREError
+
+EPS = np.finfo(np.float64).eps
+
+
+# ------------------------------------------------------------------------------------------------
+# LDLᵀ                                                          /root/reference/src/LDLt.jl
+# ------------------------------------------------------------------------------------------------
+class LDLt:
+    """Lazy `sum_i alpha_i L_i D_i L_i'` (LDLt.jl:29-33).  Factors live on the host as NumPy arrays or,
+    for results produced by the engine, on the device until first touched."""
+
+    def __init__(self, alphas, Ls, Ds, _handle: dev.DeviceLDLt | None = None):
+        self._alphas, self._Ls, self._Ds = list(alphas), list(Ls), list(Ds)
+        self._handle = _handle
+
+    # lazy materialisation of device results
+    def _host(self):
+        if self._handle is not None and not self._Ls:
+            a, L, D = self._handle.destructure()
+            self._alphas, self._Ls, self._Ds = [a], [L], [D]
+        return self
+
+    @property
+    def alphas(self):
+        return self._host()._alphas
+
+    @property
+    def Ls(self):
+        return self._host()._Ls
+
+    @property
+    def Ds(self):
+        return self._host()._Ds
+
+    @property
+    def n(self):
+        if self._handle is not None and not self._Ls:
+            return self._handle.info()[0]
+        return self._Ls[0].shape[0]
+
+    def size(self):
+        return (self.n, self.n)
+
+    def rank(self):                      # LDLt.jl:112
+        if self._handle is not None and not self._Ls:
+            return self._handle.info()[1]
+        return sum(L.shape[1] for L in self._Ls)
+
+    def iszero(self):                    # LDLt.jl:114
+        return self.rank() == 0 or all(a == 0 for a in self.alphas)
+
+    def zero(self):                      # LDLt.jl:116-121
+        return lowrank(np.zeros((self.n, 0)), np.zeros((0, 0)))
+
+    def dense(self):                     # Matrix(X), LDLt.jl:41-51 (testing only)
+        M = np.zeros((self.n, self.n))
+        for a, L, D in zip(self.alphas, self.Ls, self.Ds):
+            M += L @ (a * D) @ L.T
+        return M
+
+    def __add__(self, other):            # LDLt.jl:131-148
+        if self.n != other.n:
+            raise ValueError(f"outer dimensions must match, got {self.n} and {other.n} instead")
+        if self.iszero():
+            return other
+        if other.iszero():
+            return self
+        return LDLt(self.alphas + other.alphas, self.Ls + other.Ls, self.Ds + other.Ds)
+
+    def __neg__(self):                   # LDLt.jl:150-153
+        return LDLt([-a for a in self.alphas], self.Ls, self.Ds)
+
+    def __sub__(self, other):
+        return self + (-other)
+
+    def __rmul__(self, alpha):           # LDLt.jl:156-159: factors are shared, only alphas change
+        out = LDLt([alpha * a for a in self.alphas], [], [])
+        out._Ls, out._Ds = self.Ls, self.Ds
+        return out
+
+    def __truediv__(self, alpha):
+        return (1.0 / alpha) * self
+
+    def __eq__(self, other):             # LDLt.jl:35
+        return (self.alphas == other.alphas and len(self.Ls) == len(other.Ls)
+                and all(np.array_equal(a, b) for a, b in zip(self.Ls, other.Ls))
+                and all(np.array_equal(a, b) for a, b in zip(self.Ds, other.Ds)))
+
+    def __iter__(self):                  # alpha, L, D = X  (LDLt.jl:54-60)
+        if len(self.Ls) > 1:
+            compress_(self)
+        return iter((self.alphas[0], self.Ls[0], self.Ds[0]))
+
+    # upload as a device object (one device block per host block)
+    def _to_device(self, ctx, pencil) -> dev.DeviceLDLt:
+        if self._handle is not None and self._handle.pencil is pencil and not self._dirty_host():
+            return self._handle
+        if self.rank() == 0:
+            return dev.DeviceLDLt.zero(ctx, pencil, self.n)
+        h = None
+        for a, L, D in zip(self.alphas, self.Ls, self.Ds):
+            D = np.eye(L.shape[1]) if D is None else np.asarray(D, dtype=float)
+            b = dev.DeviceLDLt.create(ctx, pencil, L, D, a)
+            h = b if h is None else h.add(b)
+        return h
+
+    def _dirty_host(self):
+        return False
+
+    def _adopt(self, handle: dev.DeviceLDLt):
+        a, L, D = handle.destructure()
+        self._alphas[:] = [a]
+        self._Ls[:] = [L]
+        self._Ds[:] = [D]
+
+
+def lowrank(L, D=None) -> LDLt:
+    """lowrank(L, D=I)  (LDLt.jl:24-27)"""
+    L = np.asfortranarray(np.asarray(L, dtype=float))
+    D = np.eye(L.shape[1]) if D is None else np.asarray(D, dtype=float)
+    return LDLt([1.0], [L], [D])
+
+
+def _on_device(X: LDLt, ctx=None):
+    ctx = ctx or dev.default_context()
+    return X._to_device(ctx, None)
+
+
+def concatenate_(X: LDLt) -> LDLt:
+    """concatenate!(X)  (LDLt.jl:174-191)"""
+    if len(X.alphas) == 1:
+        return X
+    h = _on_device(X)
+    h.concatenate()
+    X._adopt(h)
+    return X
+
+
+def compress_(X: LDLt) -> LDLt:
+    """compress!(X)  (LDLt.jl:204-225) — QR + early-terminating symmetric eigensolver on the GPU."""
+    if X.rank() == 0:
+        return X
+    h = _on_device(X)
+    h.compress()
+    X._adopt(h)
+    return X
+
+
+def norm(X: LDLt) -> float:
+    """norm(X::LDLᵀ)  (LDLt.jl:77-89)"""
+    if X.rank() == 0:
+        return 0.0
+    return _on_device(X).norm()
+
+
+def orthf(L):
+    """orthf(L) -> Q, R  (LDLt.jl:237-245)"""
+    ctx = dev.default_context()
+    Ld = ctx.upload(L)
+    q, r = C.c_void_p(), C.c_void_p()
+    ctx.chk(ctx.lib.dre_orthf(ctx.ptr, Ld.ptr, C.byref(q), C.byref(r)))
+    return dev.DenseMatrix(ctx, q).numpy(), dev.DenseMatrix(ctx, r).numpy()
+
+
+def delta(a, b):
+    """Stuff.delta (src/Stuff.jl:21)"""
+    return np.linalg.norm(a - b) / max(np.linalg.norm(a), np.linalg.norm(b))
+
+
+# ------------------------------------------------------------------------------------------------
+# LowRankUpdate                                              /root/reference/src/LowRankUpdate.jl
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class LowRankUpdate:
+    """Lazy `A + inv(alpha)*U*V` with sparse `A` (LowRankUpdate.jl:18-26)."""
+    A: Any
+    alpha: float
+    U: np.ndarray
+    V: np.ndarray
+
+    @property
+    def shape(self):
+        return self.A.shape
+
+
+def lr_update(A, alpha, U, V):
+    """lr_update (LowRankUpdate.jl:38-39): dense -> Matrix, sparse -> lazy."""
+    if sp.issparse(A):
+        return LowRankUpdate(A, alpha, np.asarray(U, float), np.asarray(V, float))
+    return np.asarray(A) + (1.0 / alpha) * (np.asarray(U) @ np.asarray(V))
+
+
+# ------------------------------------------------------------------------------------------------
+# Shifts                                                      /root/reference/src/Shifts.jl, src/shifts/*
+# ------------------------------------------------------------------------------------------------
+class Shifts:
+    class Strategy:
+        pass
+
+    class Cyclic(Strategy):
+        """Cyclic(values) or Cyclic(strategy)  (shifts/helpers.jl:19-21,91-93)"""
+
+        def __init__(self, inner):
+            self.inner = inner
+
+    class Wrapped(Strategy):
+        """Wrapped(func, strategy)  (shifts/helpers.jl:48-51)"""
+
+        def __init__(self, func, inner):
+            self.func, self.inner = func, inner
+
+    class Projection(Strategy):
+        """Projection(u)  (shifts/projection.jl:25-33)"""
+
+        def __init__(self, u: int):
+            if u % 2 == 1:
+                raise ValueError(f"History must be even; got {u}")
+            self.n_history = u
+
+    class Heuristic(Strategy):
+        """Heuristic(nshifts, k₊, k₋)  (shifts/heuristic.jl:22-31)"""
+
+        def __init__(self, nshifts, k_plus, k_minus):
+            self.nshifts, self.k_plus, self.k_minus = nshifts, k_plus, k_minus
+
+    # helpers (shifts/helpers.jl:122-140)
+    @staticmethod
+    def isstable(v):
+        return np.real(v) < 0
+
+    @staticmethod
+    def flip(x):
+        if isinstance(x, complex):
+            return complex(-x.real, x.imag)
+        return -x
+
+    @staticmethod
+    def stabilize_ritz_values(lam, desc):
+        assert len(lam) > 0
+        nun = sum(1 for v in lam if not Shifts.isstable(v))
+        if 0 < nun < len(lam):
+            warnings.warn(f"Discarding unstable Ritz values of {desc}")
+            return [v for v in lam if Shifts.isstable(v)]
+        if nun == len(lam):
+            warnings.warn(f"All Ritz values of {desc} are unstable; flipping along imaginary axis")
+            return [Shifts.flip(v) for v in lam]
+        return list(lam)
+
+    @staticmethod
+    def safe_sort(shifts):
+        return sorted(shifts, key=lambda v: (np.real(v), abs(np.imag(v))))
+
+    @staticmethod
+    def heuristic(R, nshifts=None):
+        """Penzl's greedy selection (shifts/heuristic.jl:82-101)."""
+        R = [complex(v) for v in R]
+        nshifts = len(R) if nshifts is None else nshifts
+
+        def s(t, P):
+            out = 1.0
+            for p in P:
+                out *= abs(t - p) / abs(t + p)
+            return out
+
+        p = min(R, key=lambda p: max(s(t, (p,)) for t in R))
+        P = [p] if p.imag == 0 else [p, p.conjugate()]
+        while len(P) < nshifts:
+            p = max(R, key=lambda t: s(t, P))
+            P += [p] if p.imag == 0 else [p, p.conjugate()]
+        return P
+
+
+def _arnoldi_ritz(op, b0, k, desc):
+    """compute_ritz_values (shifts/heuristic.jl:103-130); `op` runs on the device."""
+    n = b0.shape[0]
+    H = np.zeros((k + 1, k))
+    V = np.zeros((n, k + 1))
+    V[:, 0] = b0 / np.linalg.norm(b0)
+    for j in range(k):
+        w = np.array(op(V[:, j]), dtype=float).reshape(-1)
+        for _ in range(2):
+            for i in range(j + 1):
+                g = V[:, i] @ w
+                H[i, j] += g
+                w -= V[:, i] * g
+        beta = np.linalg.norm(w)
+        H[j + 1, j] = beta
+        V[:, j + 1] = w / beta
+    return Shifts.stabilize_ritz_values(list(np.linalg.eigvals(H[:k, :k])), desc)
+
+
+def heuristic_shifts(strategy: "Shifts.Heuristic", pencil: dev.Pencil):
+    """Shifts.init(::Heuristic, prob) (shifts/heuristic.jl:39-66).  The device holds E' and A', so the Arnoldi
+    processes run with E'^-1 A' and A'^-1 E', which have the same spectra as E^-1 A and A^-1 E."""
+    n = pencil.n
+    b0 = np.ones(n)
+    fE = pencil.factor(0.0, 1.0)
+    Rp = _arnoldi_ritz(lambda x: fE.solve(pencil.spmm(1, x.reshape(-1, 1)).numpy()), b0, strategy.k_plus, "E⁻¹A")
+    fA = pencil.factor(1.0, 0.0)
+    Rm = _arnoldi_ritz(lambda x: fA.solve(pencil.spmm(0, x.reshape(-1, 1)).numpy()), b0, strategy.k_minus, "A⁻¹E")
+    return Shifts.heuristic(list(Rp) + [1.0 / v for v in Rm], strategy.nshifts)
+
+
+def _resolve_shifts(strategy, pencil):
+    """Map a strategy object to (shift_kind, n_history, values) of the C ABI."""
+    S = Shifts
+    if isinstance(strategy, S.Projection):
+        return 1, strategy.n_history, None
+    if isinstance(strategy, S.Cyclic):
+        inner = strategy.inner
+        if isinstance(inner, S.Heuristic):
+            vals = heuristic_shifts(inner, pencil)
+        elif isinstance(inner, S.Wrapped):
+            if not isinstance(inner.inner, S.Heuristic):
+                raise NotImplementedError("Cyclic(Wrapped(f, s)) is supported for s = Heuristic only")
+            vals = list(inner.func(heuristic_shifts(inner.inner, pencil)))
+        elif isinstance(inner, S.Strategy):
+            raise NotImplementedError(f"Cyclic({type(inner).__name__}) is not supported")
+        else:
+            vals = list(inner)
+        if len(vals) == 0:
+            raise ValueError("Cyclic: empty shift list")
+        return 0, 2, vals
+    if isinstance(strategy, S.Heuristic):
+        raise NotImplementedError("use Cyclic(Heuristic(...)) — a bare Heuristic list would be exhausted")
+    raise TypeError(f"unknown shift strategy {strategy!r}")
+
+
+# ------------------------------------------------------------------------------------------------
+# Problems, algorithms                    src/lyapunov/types.jl, src/riccati/types.jl, DifferentialRiccatiEquations.jl:55-60
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class GALEProblem:
+    """A'XE + E'XA = -C with low-rank C (lyapunov/types.jl:10-16)."""
+    E: Any
+    A: Any
+    C: LDLt
+
+
+@dataclass
+class ADI:
+    """ADI options (lyapunov/types.jl:20-30)."""
+    maxiters: int = 100
+    reltol: Optional[float] = None
+    abstol: Optional[float] = None
+    shifts: Any = field(default_factory=lambda: Shifts.Projection(2))
+    ignore_initial_guess: bool = False
+    compression_interval: int = 10
+    compression: bool = True
+    warn_convergence: bool = True
+
+
+@dataclass
+class GDREProblem:
+    """E'ẊE = C'C + A'XE + E'XA − E'XBB'XE, X(t0) = X0 (riccati/types.jl:11-20)."""
+    E: Any
+    A: Any
+    B: np.ndarray
+    C: np.ndarray
+    X0: Any
+    tspan: tuple
+
+
+@dataclass
+class DRESolution:
+    """riccati/types.jl:35-39"""
+    X: list
+    K: list
+    t: np.ndarray
+
+
+@dataclass
+class Ros1:
+    inner_alg: Optional[ADI] = None
+
+
+@dataclass
+class Ros2:
+    inner_alg: Optional[ADI] = None
+
+
+class Callbacks:
+    """Observer hooks (src/Callbacks.jl:97-187).  The loop is device resident, so the per-iteration hooks are
+    replayed in order after each Lyapunov solve with the recorded norms / shifts; `X` and `residual` are None
+    for intermediate iterations."""
+    NAMES = ("observe_gale_start", "observe_gale_step", "observe_gale_done", "observe_gale_failed",
+             "observe_gale_metadata", "observe_gdre_start", "observe_gdre_step", "observe_gdre_done")
+
+
+def _call(obs, name, *args):
+    if obs is not None and hasattr(obs, name):
+        getattr(obs, name)(*args)
+
+
+_pencil_cache: dict = {}
+
+
+def _pencil_for(E, A, ctx):
+    key = (id(E), id(A), id(ctx))
+    hit = _pencil_cache.get(key)
+    if hit is not None and hit[0] is E and hit[1] is A:
+        return hit[2]
+    P = dev.Pencil(E, A, ctx)
+    if len(_pencil_cache) > 8:
+        _pencil_cache.clear()
+    _pencil_cache[key] = (E, A, P)
+    return P
+
+
+def _split_operator(E, A):
+    """GALE coefficient -> (sparse part, cA, cE, low-rank triple) with F = cA*A0 + cE*E + inv(alpha) U V."""
+    if isinstance(A, LowRankUpdate):
+        return A.A, (A.alpha, A.U, A.V)
+    return A, None
+
+
+def _adi_options(alg: ADI, pencil):
+    kind, nh, vals = _resolve_shifts(alg.shifts, pencil)
+    return dev.make_adi_options(alg.maxiters, alg.reltol, alg.abstol, alg.ignore_initial_guess, alg.compression_interval,
+                                alg.compression, kind, nh, vals)
+
+
+def _replay_gale(observer, prob, alg, info):
+    _call(observer, "observe_gale_start", prob, alg)
+    shifts = info["shifts"]
+    pos = 0
+    for it, nrm in zip(info["norm_iters"], info["norms"]):
+        while pos < it:
+            _call(observer, "observe_gale_metadata", "ADI shifts", shifts[pos])
+            pos += 1
+        _call(observer, "observe_gale_step", int(it), None, None, float(nrm))
+    if not info["converged"]:
+        _call(observer, "observe_gale_failed")
+
+
+def _adi_result_info(ctx, rptr):
+    lib = ctx.lib
+    ii = (C.c_int64 * 5)()
+    dd = (C.c_double * 3)()
+    lib.dre_adi_result_info(rptr, ii, dd)
+    nn, iters = ii[3], ii[0]
+    norms = np.zeros(nn)
+    nit = np.zeros(nn, dtype=np.int32)
+    sre, sim = np.zeros(max(iters, 1)), np.zeros(max(iters, 1))
+    lib.dre_adi_result_history(rptr, norms.ctypes.data_as(C.POINTER(C.c_double)), nit.ctypes.data_as(C.POINTER(C.c_int32)),
+                               sre.ctypes.data_as(C.POINTER(C.c_double)), sim.ctypes.data_as(C.POINTER(C.c_double)))
+    return dict(iters=iters, converged=bool(ii[1]), warnings=ii[2], rhs_cols=ii[4], res_norm=dd[0], abstol=dd[1],
+                initial_norm=dd[2], norms=norms, norm_iters=nit, shifts=(sre + 1j * sim)[:iters])
+
+
+def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, observer=None, ctx=None, return_info=False):
+    """solve(::GALEProblem{<:LDLᵀ}, ::ADI; initial_guess, observer)  (adi.jl:29-89)"""
+    ctx = ctx or dev.default_context()
+    A0, lr = _split_operator(prob.E, prob.A)
+    pencil = _pencil_for(prob.E, A0, ctx)
+    opt, keep = _adi_options(alg, pencil)
+    Cd = prob.C._to_device(ctx, pencil)
+    X0d = initial_guess._to_device(ctx, pencil) if initial_guess is not None else None
+    U = Vt = None
+    alpha = 1.0
+    if lr is not None:
+        alpha, Uh, Vh = lr
+        U, Vt = ctx.upload(Uh), ctx.upload(np.asarray(Vh).T)
+    r = C.c_void_p()
+    ctx.chk(ctx.lib.dre_gale_solve(ctx.ptr, pencil.ptr, 1.0, 0.0, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
+                                   Cd.ptr, X0d.ptr if X0d else None, C.byref(opt), C.byref(r)))
+    try:
+        info = _adi_result_info(ctx, r)
+        xp = C.c_void_p()
+        ctx.lib.dre_adi_result_take_x(r, C.byref(xp))
+        X = LDLt([], [], [], _handle=dev.DeviceLDLt(ctx, xp, pencil))
+    finally:
+        ctx.lib.dre_adi_result_free(r)
+    _replay_gale(observer, prob, alg, info)
+    _call(observer, "observe_gale_done", info["iters"], X, None, info["res_norm"])
+    if not info["converged"] and alg.warn_convergence:
+        warnings.warn(f"ADI did not converge: residual={info['res_norm']} abstol={info['abstol']} maxiters={alg.maxiters}")
+    return (X, info) if return_info else X
+
+
+def residual(prob: GALEProblem, X: LDLt, ctx=None) -> LDLt:
+    """residual(::GALEProblem{<:LDLᵀ}, ::LDLᵀ)  (lyapunov/residual.jl:3-31)"""
+    ctx = ctx or dev.default_context()
+    A0, lr = _split_operator(prob.E, prob.A)
+    pencil = _pencil_for(prob.E, A0, ctx)
+    Cd = prob.C._to_device(ctx, pencil)
+    Xd = X._to_device(ctx, pencil)
+    U = Vt = None
+    alpha = 1.0
+    if lr is not None:
+        alpha, Uh, Vh = lr
+        U, Vt = ctx.upload(Uh), ctx.upload(np.asarray(Vh).T)
+    out = C.c_void_p()
+    ctx.chk(ctx.lib.dre_gale_residual(ctx.ptr, pencil.ptr, 1.0, 0.0, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
+                                      Cd.ptr, Xd.ptr, C.byref(out)))
+    return LDLt([], [], [], _handle=dev.DeviceLDLt(ctx, out, pencil))
+
+
+def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=None, return_stats=False):
+    """solve(::GDREProblem{<:LDLᵀ}, ::Ros1/Ros2; dt, save_state, observer)
+    (DifferentialRiccatiEquations.jl:78-94, riccati/lowrank_ros1.jl, lowrank_ros2.jl)"""
+    if not isinstance(prob.X0, LDLt):
+        raise TypeError("this engine implements the low-rank path only: X0 must be an LDLᵀ object (lowrank(L, D)); "
+                        "the dense Rosenbrock methods of the reference are outside the accelerated path")
+    order = 1 if isinstance(alg, Ros1) else 2 if isinstance(alg, Ros2) else None
+    if order is None:
+        raise TypeError("only Ros1 and Ros2 have a low-rank formulation")
+    ctx = ctx or dev.default_context()
+    inner = alg.inner_alg if alg.inner_alg is not None else ADI()
+    _call(observer, "observe_gdre_start", prob, alg)
+    pencil = _pencil_for(prob.E, prob.A, ctx)
+    opt, keep = _adi_options(inner, pencil)
+    X0d = prob.X0._to_device(ctx, pencil)
+    Bd, Cd = ctx.upload(prob.B), ctx.upload(prob.C)
+    r = C.c_void_p()
+    ctx.chk(ctx.lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0d.ptr, float(prob.tspan[0]), float(prob.tspan[1]),
+                                   float(dt), order, int(bool(save_state)), C.byref(opt), C.byref(r)))
+    lib = ctx.lib
+    try:
+        ii = (C.c_int64 * 7)()
+        lib.dre_gdre_result_info(r, ii)
+        nt, nx, iters, nfac, ngale, m, n = list(ii)
+        t = np.zeros(nt)
+        lib.dre_gdre_result_times(r, t.ctypes.data_as(C.POINTER(C.c_double)))
+        Ks = []
+        for i in range(nt):
+            K = np.zeros((m, n), order="F")
+            ctx.chk(lib.dre_gdre_result_K(ctx.ptr, r, i, K.ctypes.data_as(C.POINTER(C.c_double)), m))
+            Ks.append(K)
+        Xs = [prob.X0]                    # first(sol.X) === prob.X0  (test/rail.jl:40)
+        for i in range(1, nx):
+            xp = C.c_void_p()
+            lib.dre_gdre_result_X(r, i, C.byref(xp))
+            Xs.append(LDLt([], [], [], _handle=dev.DeviceLDLt(ctx, xp, pencil)))
+        gales = []
+        for j in range(ngale):
+            gi = (C.c_int64 * 4)()
+            gd = (C.c_double * 2)()
+            lib.dre_gdre_result_gale(r, j, gi, gd)
+            gales.append(dict(iters=gi[0], converged=bool(gi[1]), warnings=gi[2], rhs_cols=gi[3], res_norm=gd[0], abstol=gd[1]))
+    finally:
+        lib.dre_gdre_result_free(r)
+    per_step = ngale // max(nt - 1, 1) if nt > 1 else 0
+    _call(observer, "observe_gdre_step", t[0], Xs[0], Ks[0])
+    for i in range(1, nt):
+        for g in gales[(i - 1) * per_step:i * per_step]:
+            _call(observer, "observe_gale_done", g["iters"], None, None, g["res_norm"])
+            if not g["converged"]:
+                _call(observer, "observe_gale_failed")
+                if inner.warn_convergence:
+                    warnings.warn(f"ADI did not converge: residual={g['res_norm']} abstol={g['abstol']} maxiters={inner.maxiters}")
+        Xi = Xs[i] if save_state else (Xs[-1] if i == nt - 1 else None)
+        _call(observer, "observe_gdre_step", t[i], Xi, Ks[i])
+    _call(observer, "observe_gdre_done")
+    sol = DRESolution(Xs, Ks, t)
+    if return_stats:
+        return sol, dict(adi_iters=iters, factorizations=nfac, gales=gales)
+    return sol
+
+
+def solve(prob, alg, **kw):
+    """CommonSolve.solve for the problems of this path."""
+    if isinstance(prob, GDREProblem):
+        return solve_gdre(prob, alg, **kw)
+    if isinstance(prob, GALEProblem):
+        return solve_gale(prob, alg, **kw)
+    raise TypeError(f"unsupported problem type {type(prob).__name__}")

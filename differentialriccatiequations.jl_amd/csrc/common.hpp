@@ -1,0 +1,160 @@
+// Common infrastructure of libdre_hip: context, error handling, stream-ordered device pool,
+// dense device matrix views.  gfx950 (MI355X) only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace dre {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// status codes of the C ABI (include/dre_hip.h)
+enum : int {
+    ERR_OK = 0,
+    ERR_INVALID = -1,
+    ERR_HIP = -2,
+    ERR_ALLOC = -3,
+    ERR_SINGULAR = -4,
+    ERR_INTERNAL = -5,
+    ERR_NODEVICE = -6,
+};
+
+#define DRE_HIP(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            throw ::dre::Error(::dre::ERR_HIP, std::string(#expr) + ": " +              \
+                                                       hipGetErrorString(e__));             \
+    } while (0)
+
+#define DRE_REQUIRE(cond, msg)                                                              \
+    do {                                                                                    \
+        if (!(cond)) throw ::dre::Error(::dre::ERR_INVALID, std::string(msg));          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Stream-ordered caching device allocator.  Everything the library launches goes to ONE private
+// stream per context, so a block released by the host may be handed out again immediately: the
+// next kernel that touches it is ordered after the last kernel that used it.
+// ---------------------------------------------------------------------------------------------
+class DevicePool {
+  public:
+    ~DevicePool() { trim(); }
+    void* alloc(size_t bytes) {
+        size_t sz = round_up(bytes);
+        auto it = free_.lower_bound(sz);
+        if (it != free_.end() && it->first <= sz * 2) {
+            void* p = it->second;
+            live_[p] = it->first;
+            free_.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, sz);
+        if (e != hipSuccess) {
+            trim();
+            e = hipMalloc(&p, sz);
+            if (e != hipSuccess) throw Error(ERR_ALLOC, "hipMalloc failed for " + std::to_string(sz) + " bytes");
+        }
+        live_[p] = sz;
+        total_ += sz;
+        return p;
+    }
+    void release(void* p) {
+        if (!p) return;
+        auto it = live_.find(p);
+        if (it == live_.end()) return;
+        free_.emplace(it->second, p);
+        live_.erase(it);
+    }
+    void trim() {
+        for (auto& kv : free_) { (void)hipFree(kv.second); total_ -= kv.first; }
+        free_.clear();
+    }
+    size_t total_bytes() const { return total_; }
+
+  private:
+    static size_t round_up(size_t b) {
+        if (b < 256) b = 256;
+        size_t g = b < (1u << 20) ? 4096 : (1u << 20);
+        return (b + g - 1) / g * g;
+    }
+    std::multimap<size_t, void*> free_;
+    std::unordered_map<void*, size_t> live_;
+    size_t total_ = 0;
+};
+
+struct KernelTimer;  // profiling.hpp
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevicePool pool;
+    std::string last_error;
+    int num_cus = 256;
+    // optional per-kernel-class timing with HIP events (bench.py's roofline leg)
+    std::unique_ptr<KernelTimer> timer;
+    // pinned scratch for small device->host reads
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
+};
+
+struct Buf {
+    Ctx* ctx;
+    void* p;
+    size_t bytes;
+    Buf(Ctx* c, size_t b) : ctx(c), p(c->pool.alloc(b ? b : 8)), bytes(b) {}
+    ~Buf() { ctx->pool.release(p); }
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+};
+using BufP = std::shared_ptr<Buf>;
+
+template <typename T>
+struct DevArr {  // typed owning device array
+    BufP buf;
+    T* p = nullptr;
+    size_t n = 0;
+    DevArr() = default;
+    DevArr(Ctx* c, size_t n_) : buf(std::make_shared<Buf>(c, n_ * sizeof(T))), p((T*)buf->p), n(n_) {}
+    void upload(Ctx* c, const T* h, size_t cnt) {
+        DRE_HIP(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, c->stream));
+        DRE_HIP(hipStreamSynchronize(c->stream));
+    }
+    void upload(Ctx* c, const std::vector<T>& h) { if (!h.empty()) upload(c, h.data(), h.size()); }
+};
+
+// Column-major dense f64 matrix view on the device (Julia `Matrix{Float64}` layout).
+struct Mat {
+    BufP buf;
+    double* p = nullptr;
+    int rows = 0, cols = 0, ld = 0;
+    Mat() = default;
+    Mat(Ctx* c, int r, int cc) : buf(std::make_shared<Buf>(c, (size_t)(r > 0 ? r : 1) * (cc > 0 ? cc : 1) * sizeof(double))),
+                                  p((double*)buf->p), rows(r), cols(cc), ld(r > 0 ? r : 1) {}
+    Mat view(int r0, int c0, int r, int c) const {
+        Mat m;
+        m.buf = buf; m.p = p + (size_t)r0 + (size_t)c0 * ld; m.rows = r; m.cols = c; m.ld = ld;
+        return m;
+    }
+    Mat colsview(int c0, int c) const { return view(0, c0, rows, c); }
+    bool empty() const { return rows == 0 || cols == 0; }
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace dre

@@ -1,0 +1,716 @@
+// Dense f64 kernels for gfx950: MFMA GEMM, Householder QR, symmetric eigensolver, small helpers.
+#include "dense.hpp"
+#include "profiling.hpp"
+
+namespace dre {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// =============================================================================================
+// GEMM: 64x64 block tile, 4 waves (2x2), each wave 2x2 tiles of v_mfma_f64_16x16x4_f64, BK = 16.
+// MFMA operand map (cdna_hip_programming.md §3): A: lane l holds A[l&15][l>>4]; B: B[l>>4][l&15];
+// C/D (f64 form): col = lane&15, row = (lane>>4) + 4*reg.
+// LDS rows are padded to 81 doubles so that both the k-fastest (transposed) and the m-fastest
+// staging writes and the fragment reads stay (nearly) bank-conflict free.
+// =============================================================================================
+#define GB_M 64
+#define GB_N 64
+#define GB_K 16
+#define GB_LD 81
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
+                                              int lda, const double* __restrict__ B, int ldb, double beta,
+                                              double* __restrict__ C, int ldc, int kchunk,
+                                              double* __restrict__ partial, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double As[GB_K][GB_LD];
+    __shared__ double Bs[GB_K][GB_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = min(K, kbeg + kchunk);
+    v4d acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    const int lr = lane & 15, lk = lane >> 4;
+
+    for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
+        if (!TA) {
+            const int m = tid & 63, kq = tid >> 6, gm = m0 + m;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = kq + 4 * p, gk = k0 + k;
+                As[k][m] = (gm < M && gk < kend) ? A[gm + (size_t)gk * lda] : 0.0;
+            }
+        } else {
+            const int k = tid & 15, mq = tid >> 4, gk = k0 + k;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int m = mq + 16 * p, gm = m0 + m;
+                As[k][m] = (gm < M && gk < kend) ? A[gk + (size_t)gm * lda] : 0.0;
+            }
+        }
+        if (!TB) {
+            const int k = tid & 15, nq = tid >> 4, gk = k0 + k;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int n = nq + 16 * p, gn = n0 + n;
+                Bs[k][n] = (gn < N && gk < kend) ? B[gk + (size_t)gn * ldb] : 0.0;
+            }
+        } else {
+            const int n = tid & 63, kq = tid >> 6, gn = n0 + n;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int k = kq + 4 * p, gk = k0 + k;
+                Bs[k][n] = (gn < N && gk < kend) ? B[gn + (size_t)gk * ldb] : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int k = kk * 4 + lk;
+            const double a0 = As[k][wm + lr], a1 = As[k][wm + 16 + lr];
+            const double b0 = Bs[k][wn + lr], b1 = Bs[k][wn + 16 + lr];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + (lane >> 4) + 4 * r;
+                const int col = n0 + wn + j * 16 + (lane & 15);
+                if (row < M && col < N) {
+                    if (partial) {
+                        partial[(size_t)blockIdx.z * M * N + row + (size_t)col * M] = acc[i][j][r];
+                    } else {
+                        double* c = C + row + (size_t)col * ldc;
+                        *c = (beta == 0.0) ? alpha * acc[i][j][r] : alpha * acc[i][j][r] + beta * (*c);
+                    }
+                }
+            }
+}
+
+__global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const double* __restrict__ partial,
+                              double beta, double* __restrict__ C, int ldc, const AdiState* st) {
+    if (st && st->done) return;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * M * N + idx];   // fixed order: deterministic
+    int row = idx % M, col = idx / M;
+    double* c = C + row + (size_t)col * ldc;
+    *c = (beta == 0.0) ? alpha * s : alpha * s + beta * (*c);
+}
+
+void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+          int ldb, double beta, double* C, int ldc, const AdiState* st, const char* tag) {
+    if (M <= 0 || N <= 0) return;
+    TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
+    const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
+    int splits = 1;
+    if (K >= 512) {
+        int want = ceil_div(2 * ctx->num_cus, tm * tn);
+        splits = std::max(1, std::min(want, K / 256));
+    }
+    int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_K) * GB_K : GB_K;
+    splits = K > 0 ? ceil_div(K, kchunk) : 1;
+    dim3 grid(tm, tn, splits), block(256);
+    BufP pb;
+    double* partial = nullptr;
+    if (splits > 1) {
+        pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
+        partial = (double*)pb->p;
+    }
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
+    if (splits > 1) {
+        size_t tot = (size_t)M * N;
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, M, N, splits, alpha, partial, beta, C, ldc, st);
+    }
+    DRE_HIP(hipGetLastError());
+}
+
+// =============================================================================================
+// small helpers
+// =============================================================================================
+__global__ void k_copy(int rows, int cols, const double* __restrict__ src, int lds, double* __restrict__ dst, int ldd,
+                       double scale, const AdiState* st) {
+    if (st && st->done) return;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r = idx % rows, c = idx / rows;
+    dst[r + (size_t)c * ldd] = scale * src[r + (size_t)c * lds];
+}
+void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale, const AdiState* st) {
+    DRE_REQUIRE(src.rows == dst.rows && src.cols == dst.cols, "copy_mat: shape mismatch");
+    size_t tot = (size_t)src.rows * src.cols;
+    if (!tot) return;
+    TimedScope ts(ctx, "copy", 16.0 * tot, 0);
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src.rows, src.cols, src.p, src.ld, dst.p, dst.ld, scale, st);
+}
+__global__ void k_fill(int rows, int cols, double* __restrict__ dst, int ldd, double v, double dv) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r = idx % rows, c = idx / rows;
+    dst[r + (size_t)c * ldd] = (r == c) ? dv : v;
+}
+void fill_mat(Ctx* ctx, Mat& dst, double v) {
+    size_t tot = (size_t)dst.rows * dst.cols;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dst.rows, dst.cols, dst.p, dst.ld, v, v);
+}
+void set_identity(Ctx* ctx, Mat& dst, double v) {
+    size_t tot = (size_t)dst.rows * dst.cols;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, dst.rows, dst.cols, dst.p, dst.ld, 0.0, v);
+}
+__global__ void k_transpose(int rows, int cols, const double* __restrict__ src, int lds, double* __restrict__ dst, int ldd) {
+    __shared__ double tile[32][33];
+    int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in 0..7
+    for (int j = ty; j < 32; j += 8) {
+        int r = bx + tx, c = by + j;
+        tile[j][tx] = (r < rows && c < cols) ? src[r + (size_t)c * lds] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        int r = by + tx, c = bx + j;   // dst is cols x rows
+        if (r < cols && c < rows) dst[r + (size_t)c * ldd] = tile[tx][j];
+    }
+}
+void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst) {
+    DRE_REQUIRE(src.rows == dst.cols && src.cols == dst.rows, "transpose: shape mismatch");
+    if (src.empty()) return;
+    hipLaunchKernelGGL(k_transpose, dim3(ceil_div(src.rows, 32), ceil_div(src.cols, 32)), dim3(256), 0, ctx->stream, src.rows, src.cols, src.p, src.ld, dst.p, dst.ld);
+}
+__global__ void k_add_diag(int n, double* __restrict__ dst, int ld, const double* __restrict__ v, double scale) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i + (size_t)i * ld] += scale * (v ? v[i] : 1.0);
+}
+void add_diag(Ctx* ctx, Mat& dst, const double* v, double scale) {
+    int n = std::min(dst.rows, dst.cols);
+    if (!n) return;
+    hipLaunchKernelGGL(k_add_diag, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, n, dst.p, dst.ld, v, scale);
+}
+__global__ void k_symmetrize(int n, double* __restrict__ S, int ld) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    int r = idx % n, c = idx / n;
+    if (r > c) {
+        double a = S[r + (size_t)c * ld], b = S[c + (size_t)r * ld];
+        double m = 0.5 * (a + b);
+        S[r + (size_t)c * ld] = m;
+        S[c + (size_t)r * ld] = m;
+    }
+}
+void symmetrize(Ctx* ctx, Mat& S) {
+    DRE_REQUIRE(S.rows == S.cols, "symmetrize: square matrix expected");
+    size_t tot = (size_t)S.rows * S.rows;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, S.rows, S.p, S.ld);
+}
+__global__ void k_scale_cols(int rows, int cols, const double* __restrict__ L, int ldl, const double* __restrict__ D, int ldd,
+                             double* __restrict__ out, int ldo, double alpha) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r = idx % rows, c = idx / rows;
+    out[r + (size_t)c * ldo] = alpha * D[c + (size_t)c * ldd] * L[r + (size_t)c * ldl];
+}
+void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double alpha) {
+    size_t tot = (size_t)L.rows * L.cols;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, L.rows, L.cols, L.p, L.ld, D.p, D.ld, out.p, out.ld, alpha);
+}
+
+// block-wide sum, result valid in every thread; blockDim.x multiple of 64, <= 1024
+__device__ inline double block_sum(double v, double* red /* >= 17 doubles */) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[w];
+        red[16] = s;
+    }
+    __syncthreads();
+    return red[16];
+}
+__device__ inline double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_frob2(int rows, int cols, const double* __restrict__ A, int ld, double* out) {
+    __shared__ double red[17];
+    double s = 0.0;
+    size_t tot = (size_t)rows * cols;
+    for (size_t idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+        double v = A[idx % rows + (idx / rows) * (size_t)ld];
+        s += v * v;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+static double read_scalar(Ctx* ctx, const double* dev) {
+    double h;
+    DRE_HIP(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    return h;
+}
+double frob_norm_host(Ctx* ctx, const Mat& A) {
+    if (A.empty()) return 0.0;
+    DevArr<double> out(ctx, 1);
+    hipLaunchKernelGGL(k_frob2, dim3(1), dim3(1024), 0, ctx->stream, A.rows, A.cols, A.p, A.ld, out.p);
+    return std::sqrt(read_scalar(ctx, out.p));
+}
+__global__ __launch_bounds__(256) void k_offdiag_max(int n, const double* __restrict__ D, int ld, double* out) {
+    __shared__ double red[17];
+    double s = 0.0;
+    for (size_t idx = threadIdx.x; idx < (size_t)n * n; idx += blockDim.x) {
+        int r = idx % n, c = idx / n;
+        if (r != c) s += fabs(D[r + (size_t)c * ld]);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+bool is_diagonal_host(Ctx* ctx, const Mat& D) {
+    if (D.empty()) return true;
+    DevArr<double> out(ctx, 1);
+    hipLaunchKernelGGL(k_offdiag_max, dim3(1), dim3(256), 0, ctx->stream, D.rows, D.p, D.ld, out.p);
+    return read_scalar(ctx, out.p) == 0.0;
+}
+
+// nrm^2 = sum_ij (T G)_ij (T G)_ji ; single block, k <= a few hundred
+__global__ __launch_bounds__(1024) void k_ldlt_norm(int k, const double* __restrict__ G, int ldg, const double* __restrict__ T, int ldt,
+                                                    int tdiag, double alpha, AdiState* st, int iters_after, double* out) {
+    __shared__ double red[17];
+    if (st && st->done) return;
+    double s = 0.0;
+    if (tdiag) {
+        for (size_t idx = threadIdx.x; idx < (size_t)k * k; idx += blockDim.x) {
+            int i = idx % k, j = idx / k;
+            double g = G[i + (size_t)j * ldg];
+            s += T[i + (size_t)i * ldt] * T[j + (size_t)j * ldt] * g * g;
+        }
+    } else {
+        // (TG)_ij = sum_l T_il G_lj ; (TG)_ji = sum_l T_jl G_li
+        for (size_t idx = threadIdx.x; idx < (size_t)k * k; idx += blockDim.x) {
+            int i = idx % k, j = idx / k;
+            double a = 0.0, b = 0.0;
+            for (int l = 0; l < k; ++l) {
+                a += T[i + (size_t)l * ldt] * G[l + (size_t)j * ldg];
+                b += T[j + (size_t)l * ldt] * G[l + (size_t)i * ldg];
+            }
+            s += a * b;
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        if (out) out[0] = nrm;
+        if (st) {
+            st->res_norm = nrm;
+            st->iters = iters_after;
+            if (iters_after < 512) st->norms[iters_after] = nrm;
+            if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+        }
+    }
+}
+void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
+    TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
+    hipLaunchKernelGGL(k_ldlt_norm, dim3(1), dim3(1024), 0, ctx->stream, G.rows, G.p, G.ld, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after, (double*)nullptr);
+}
+double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
+    if (L.cols == 0) return 0.0;
+    Mat G(ctx, L.cols, L.cols);
+    gemm(ctx, true, false, 1.0, L, L, 0.0, G, nullptr, "gemm_gram");
+    DevArr<double> out(ctx, 1);
+    hipLaunchKernelGGL(k_ldlt_norm, dim3(1), dim3(1024), 0, ctx->stream, G.rows, G.p, G.ld, D.p, D.ld, 0, alpha, (AdiState*)nullptr, 0, out.p);
+    return read_scalar(ctx, out.p);
+}
+
+// =============================================================================================
+// Blocked Householder QR (compact WY), panel width 16.
+// =============================================================================================
+#define QR_NB 16
+
+// One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed) and T are written too.
+__global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
+                                                   double* __restrict__ V, int ldv, double* __restrict__ T, int ldt) {
+    __shared__ double red[17];
+    __shared__ double Tsh[QR_NB][QR_NB + 1];
+    __shared__ double z[QR_NB];
+    __shared__ double sc[4];  // tau, beta, scale
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) (&Tsh[0][0])[i] = 0.0;
+    __syncthreads();
+    for (int jj = 0; jj < jb; ++jj) {
+        const int c = j0 + jj;
+        double* col = A + (size_t)c * lda;
+        // 1. norm of the sub-column
+        double s = 0.0;
+        for (int i = c + 1 + tid; i < m; i += blockDim.x) s += col[i] * col[i];
+        s = block_sum(s, red);
+        if (tid == 0) {
+            double alpha = col[c], tau = 0.0, beta = alpha, scale = 0.0;
+            if (s > 0.0) {
+                double nrm = sqrt(alpha * alpha + s);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            sc[0] = tau; sc[1] = beta; sc[2] = scale;
+        }
+        __syncthreads();
+        const double tau = sc[0], beta = sc[1], scale = sc[2];
+        // 2. scale v, write explicit V column
+        for (int i = c + 1 + tid; i < m; i += blockDim.x) {
+            double v = col[i] * scale;
+            col[i] = v;
+            V[i + (size_t)c * ldv] = v;
+        }
+        if (tid == 0) { V[c + (size_t)c * ldv] = 1.0; col[c] = beta; }
+        __syncthreads();
+        // 3. apply H to the remaining panel columns (one wave per column)
+        for (int j = c + 1 + wave; j < j0 + jb; j += nw) {
+            double* cj = A + (size_t)j * lda;
+            double w = 0.0;
+            for (int i = c + 1 + lane; i < m; i += 64) w += col[i] * cj[i];
+            w = wave_sum(w) + cj[c];
+            const double tw = tau * w;
+            for (int i = c + 1 + lane; i < m; i += 64) cj[i] -= tw * col[i];
+            if (lane == 0) cj[c] -= tw;
+        }
+        // 4. z_i = V(:, j0+i)' v  for i < jj (one wave per i)
+        for (int i = wave; i < jj; i += nw) {
+            const double* vi = A + (size_t)(j0 + i) * lda;   // reflector i stored below its diagonal
+            double w = 0.0;
+            for (int r = c + 1 + lane; r < m; r += 64) w += vi[r] * col[r];
+            w = wave_sum(w);
+            if (lane == 0) z[i] = w + vi[c];   // vi[c] * v[c], v[c] = 1 (c > j0+i so vi[c] is a stored entry)
+        }
+        __syncthreads();
+        if (tid < jj) {
+            double t = 0.0;
+            for (int l = tid; l < jj; ++l) t += Tsh[tid][l] * z[l];
+            Tsh[tid][jj] = -tau * t;
+        }
+        if (tid == 0) Tsh[jj][jj] = tau;
+        __syncthreads();
+    }
+    for (int i = tid; i < QR_NB * jb; i += blockDim.x) {
+        int r = i % QR_NB, cc = i / QR_NB;
+        T[r + (size_t)(j0 + cc) * ldt] = Tsh[r][cc];
+    }
+}
+
+__global__ void k_extract_upper(int kq, int n, const double* __restrict__ A, int lda, double* __restrict__ R, int ldr) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)kq * n) return;
+    int r = idx % kq, c = idx / kq;
+    R[r + (size_t)c * ldr] = (r <= c) ? A[r + (size_t)c * lda] : 0.0;
+}
+
+QRFact qr_factor(Ctx* ctx, Mat& A) {
+    QRFact f;
+    f.m = A.rows; f.n = A.cols; f.kq = std::min(A.rows, A.cols); f.nb = QR_NB;
+    f.V = Mat(ctx, f.m, f.kq);
+    f.T = Mat(ctx, QR_NB, std::max(f.kq, 1));
+    f.R = Mat(ctx, f.kq, f.n);
+    fill_mat(ctx, f.V, 0.0);
+    for (int j0 = 0; j0 < f.kq; j0 += QR_NB) {
+        const int jb = std::min(QR_NB, f.kq - j0);
+        {
+            TimedScope ts(ctx, "qr_panel", 8.0 * (f.m - j0) * jb * (jb + 2), 2.0 * (f.m - j0) * jb * jb);
+            hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(1024), 0, ctx->stream, A.p, A.ld, f.m, j0, jb, f.V.p, f.V.ld, f.T.p, f.T.ld);
+        }
+        const int n2 = f.n - j0 - jb;
+        if (n2 > 0) {
+            Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
+            Mat A2 = A.view(j0, j0 + jb, f.m - j0, n2);
+            Mat Tp = f.T.view(0, j0, jb, jb);
+            Mat W(ctx, jb, n2), W2(ctx, jb, n2);
+            gemm(ctx, true, false, 1.0, Vp, A2, 0.0, W, nullptr, "gemm_qr");
+            gemm(ctx, true, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_qr");   // T' W   (Q' = I - V T' V')
+            gemm(ctx, false, false, -1.0, Vp, W2, 1.0, A2, nullptr, "gemm_qr");
+        }
+    }
+    size_t tot = (size_t)f.kq * f.n;
+    if (tot) hipLaunchKernelGGL(k_extract_upper, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, f.kq, f.n, A.p, A.ld, f.R.p, f.R.ld);
+    DRE_HIP(hipGetLastError());
+    return f;
+}
+
+void qr_apply_q(Ctx* ctx, const QRFact& f, Mat& B, bool transpose) {
+    DRE_REQUIRE(B.rows == f.m, "qr_apply_q: row mismatch");
+    if (B.cols == 0 || f.kq == 0) return;
+    const int np = ceil_div(f.kq, QR_NB);
+    for (int pp = 0; pp < np; ++pp) {
+        const int p = transpose ? pp : np - 1 - pp;
+        const int j0 = p * QR_NB, jb = std::min(QR_NB, f.kq - j0);
+        Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
+        Mat B2 = B.view(j0, 0, f.m - j0, B.cols);
+        Mat Tp = f.T.view(0, j0, jb, jb);
+        Mat W(ctx, jb, B.cols), W2(ctx, jb, B.cols);
+        gemm(ctx, true, false, 1.0, Vp, B2, 0.0, W, nullptr, "gemm_qr");
+        gemm(ctx, transpose, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_qr");
+        gemm(ctx, false, false, -1.0, Vp, W2, 1.0, B2, nullptr, "gemm_qr");
+    }
+}
+
+// =============================================================================================
+// Symmetric eigensolver: early-terminating Householder tridiagonalisation + implicit QL.
+// =============================================================================================
+struct TridiagInfo { int jdim; int nref; double snorm; };
+
+// Single workgroup.  S: q x q full symmetric (both triangles kept up to date).
+// V(:, j) receives reflector j (v[j+1] = 1, zeros above; V pre-zeroed), d/e the tridiagonal.
+__global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S, int lds_, double* __restrict__ V, int ldv,
+                                                  double* __restrict__ tau_out, double* __restrict__ d, double* __restrict__ e,
+                                                  double tolfac, TridiagInfo* info) {
+    extern __shared__ double sm[];
+    double* v = sm;          // q
+    double* w = sm + q;      // q
+    __shared__ double red[17];
+    __shared__ double sc[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    // ||S||_F^2
+    double s = 0.0;
+    for (size_t idx = tid; idx < (size_t)q * q; idx += blockDim.x) {
+        double x = S[idx % q + (idx / q) * (size_t)lds_];
+        s += x * x;
+    }
+    double rem2 = block_sum(s, red);          // ||S[j:, j:]||_F^2 for j = 0
+    const double snorm = sqrt(rem2);
+    const double tol = tolfac * 2.220446049250313e-16 * snorm;
+    const double tol2 = tol * tol;
+    int jdim = q, nref = 0;
+    double eprev = 0.0;
+    for (int j = 0; j < q; ++j) {
+        if (rem2 + 2.0 * eprev * eprev <= tol2) { jdim = j; break; }   // nothing left worth reducing
+        if (j == q - 1) { if (tid == 0) d[j] = S[j + (size_t)j * lds_]; break; }
+        const int nr = q - j - 1;                         // order of the trailing block
+        double* colj = S + (size_t)j * lds_;
+        // Householder vector from S[j+1:, j]
+        double xs = 0.0;
+        for (int r = j + 2 + tid; r < q; r += blockDim.x) xs += colj[r] * colj[r];
+        xs = block_sum(xs, red);
+        if (tid == 0) {
+            double alpha = colj[j + 1], tau = 0.0, beta = alpha, scale = 0.0;
+            if (xs > 0.0) {
+                double nrm = sqrt(alpha * alpha + xs);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+            sc[0] = tau; sc[1] = beta; sc[2] = scale;
+            d[j] = colj[j];
+            e[j] = beta;
+            tau_out[j] = tau;
+        }
+        __syncthreads();
+        const double tau = sc[0], beta = sc[1], scale = sc[2];
+        for (int r = tid; r < nr; r += blockDim.x) {      // v indexed from row j+1
+            double x = (r == 0) ? 1.0 : colj[j + 1 + r] * scale;
+            v[r] = x;
+            V[(j + 1 + r) + (size_t)j * ldv] = x;
+        }
+        __syncthreads();
+        nref = j + 1;
+        eprev = beta;
+        if (tau != 0.0) {
+            // p = tau * S22 * v   (column r of the symmetric block dotted with v; one wave per column)
+            for (int r = wave; r < nr; r += nw) {
+                const double* cr = S + (size_t)(j + 1 + r) * lds_ + (j + 1);
+                double acc = 0.0;
+                for (int c = lane; c < nr; c += 64) acc += cr[c] * v[c];
+                acc = wave_sum(acc);
+                if (lane == 0) w[r] = tau * acc;
+            }
+            __syncthreads();
+            double pv = 0.0;
+            for (int r = tid; r < nr; r += blockDim.x) pv += w[r] * v[r];
+            pv = block_sum(pv, red);
+            const double K = -0.5 * tau * pv;
+            for (int r = tid; r < nr; r += blockDim.x) w[r] += K * v[r];
+            __syncthreads();
+        }
+        // S22 -= v w' + w v'  and  ||S22||_F^2 for the next termination test
+        double acc2 = 0.0;
+        for (size_t idx = tid; idx < (size_t)nr * nr; idx += blockDim.x) {
+            const int r = idx % nr, c = idx / nr;
+            double* p = S + (size_t)(j + 1 + c) * lds_ + (j + 1 + r);
+            double x = *p;
+            if (tau != 0.0) { x -= v[r] * w[c] + w[r] * v[c]; *p = x; }
+            acc2 += x * x;
+        }
+        rem2 = block_sum(acc2, red);
+    }
+    if (tid == 0) { info->jdim = jdim; info->nref = nref; info->snorm = snorm; }
+}
+
+// Implicit QL with Wilkinson shift on (d, e) of order n; Z (n x n, identity on entry) accumulates the
+// rotations.  Thread 0 generates each sweep's rotation chain, all threads apply it to their rows of Z.
+__global__ __launch_bounds__(256) void k_tql(int n, double* __restrict__ dg, double* __restrict__ eg, double* __restrict__ Z, int ldz,
+                                             double anorm, int* fail) {
+    extern __shared__ double sm[];
+    double* d = sm;            // n
+    double* e = sm + n;        // n
+    double* cs = sm + 2 * n;   // n
+    double* sn = sm + 3 * n;   // n
+    __shared__ int ctl[3];     // m, ilo, stop
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += blockDim.x) { d[i] = dg[i]; e[i] = (i < n - 1) ? eg[i] : 0.0; }
+    __syncthreads();
+    const double eps = 2.220446049250313e-16;
+    const double abstiny = 1e-3 * eps * anorm;
+    for (int l = 0; l < n; ++l) {
+        int iter = 0;
+        while (true) {
+            if (tid == 0) {
+                int m = l;
+                for (; m < n - 1; ++m) {
+                    double dd = fabs(d[m]) + fabs(d[m + 1]);
+                    if (fabs(e[m]) <= eps * dd || fabs(e[m]) <= abstiny) break;
+                }
+                int ilo = l;
+                if (m != l) {
+                    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                    double r = sqrt(g * g + 1.0);
+                    g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                    double s = 1.0, c = 1.0, p = 0.0;
+                    int i;
+                    bool broke = false;
+                    for (i = m - 1; i >= l; --i) {
+                        double f = s * e[i], b = c * e[i];
+                        r = sqrt(f * f + g * g);
+                        e[i + 1] = r;
+                        if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; broke = true; break; }
+                        s = f / r; c = g / r;
+                        g = d[i + 1] - p;
+                        r = (d[i] - g) * s + 2.0 * c * b;
+                        p = s * r;
+                        d[i + 1] = g + p;
+                        g = c * r - b;
+                        cs[i] = c; sn[i] = s;
+                    }
+                    if (broke) ilo = i + 1;
+                    else { d[l] -= p; e[l] = g; e[m] = 0.0; }
+                }
+                ctl[0] = m; ctl[1] = ilo; ctl[2] = (m != l && iter >= 80) ? 1 : 0;
+            }
+            __syncthreads();
+            const int m = ctl[0], ilo = ctl[1];
+            if (ctl[2]) { if (tid == 0) *fail = 1; break; }
+            if (m == l) break;
+            for (int k = tid; k < n; k += blockDim.x) {
+                double zi1 = Z[k + (size_t)m * ldz];
+                for (int i = m - 1; i >= ilo; --i) {
+                    const double zi = Z[k + (size_t)i * ldz];
+                    const double c = cs[i], s = sn[i];
+                    Z[k + (size_t)(i + 1) * ldz] = s * zi + c * zi1;
+                    zi1 = c * zi - s * zi1;
+                }
+                Z[k + (size_t)ilo * ldz] = zi1;
+            }
+            ++iter;
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += blockDim.x) dg[i] = d[i];
+}
+
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac) {
+    DRE_REQUIRE(S.rows == S.cols, "sym_eig: square matrix expected");
+    SymEig out;
+    const int q = S.rows;
+    out.q = q;
+    if (q == 0) return out;
+    DRE_REQUIRE(q <= 8192, "sym_eig: order above 8192 not supported by the single-workgroup reduction");
+    out.V = Mat(ctx, q, q);
+    fill_mat(ctx, out.V, 0.0);
+    out.tau = DevArr<double>(ctx, q);
+    DevArr<double> d(ctx, q), e(ctx, q);
+    DevArr<TridiagInfo> info(ctx, 1);
+    DRE_HIP(hipMemsetAsync(out.tau.p, 0, q * sizeof(double), ctx->stream));
+    {
+        TimedScope ts(ctx, "sym_tridiag", 0, 0);
+        size_t shm = 2 * (size_t)q * sizeof(double);
+        hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, info.p);
+    }
+    TridiagInfo hi;
+    DRE_HIP(hipMemcpyAsync(&hi, info.p, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    out.j = hi.jdim;
+    if (out.j == 0) return out;
+    const int j = out.j;
+    out.Z = Mat(ctx, j, j);
+    set_identity(ctx, out.Z, 1.0);
+    DevArr<int> fail(ctx, 1);
+    DRE_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), ctx->stream));
+    {
+        TimedScope ts(ctx, "sym_tql", 0, 0);
+        size_t shm = 4 * (size_t)j * sizeof(double);
+        hipLaunchKernelGGL(k_tql, dim3(1), dim3(256), shm, ctx->stream, j, d.p, e.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
+    }
+    out.w.resize(j);
+    int hfail = 0;
+    DRE_HIP(hipMemcpyAsync(out.w.data(), d.p, j * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipMemcpyAsync(&hfail, fail.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    if (hfail) throw Error(ERR_INTERNAL, "sym_eig: QL iteration did not converge");
+    out.nref = hi.nref;   // only the first nref columns of V hold reflectors
+    return out;
+}
+
+// One wave per output column: B(:,c) = H_0 H_1 ... H_{nref-1} [Z(:, ids[c]); 0]
+__global__ __launch_bounds__(256) void k_backtransform(int q, int j, int nref, const double* __restrict__ V, int ldv,
+                                                       const double* __restrict__ tau, const double* __restrict__ Z, int ldz,
+                                                       const int* __restrict__ ids, int ncols, double* __restrict__ B, int ldb) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= ncols) return;
+    double* b = B + (size_t)c * ldb;
+    const double* z = Z + (size_t)ids[c] * ldz;
+    for (int r = lane; r < q; r += 64) b[r] = (r < j) ? z[r] : 0.0;
+    for (int i = nref - 1; i >= 0; --i) {
+        const double t = tau[i];
+        if (t == 0.0) continue;
+        const double* v = V + (size_t)i * ldv;
+        double w = 0.0;
+        for (int r = i + 1 + lane; r < q; r += 64) w += v[r] * b[r];
+        w = wave_sum(w) * t;
+        for (int r = i + 1 + lane; r < q; r += 64) b[r] -= w * v[r];
+    }
+}
+
+Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids) {
+    const int r = (int)ids.size();
+    Mat B(ctx, e.q, r);
+    if (r == 0 || e.q == 0) return B;
+    DevArr<int> dids(ctx, r);
+    dids.upload(ctx, ids);
+    TimedScope ts(ctx, "sym_backtransform", 0, 0);
+    hipLaunchKernelGGL(k_backtransform, dim3(ceil_div(r, 4)), dim3(256), 0, ctx->stream, e.q, e.j, e.nref, e.V.p, e.V.ld,
+                       e.tau.p, e.Z.p, e.Z.ld, dids.p, r, B.p, B.ld);
+    DRE_HIP(hipGetLastError());
+    return B;
+}
+
+}  // namespace dre

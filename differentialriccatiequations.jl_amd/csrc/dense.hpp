@@ -1,0 +1,78 @@
+// Dense f64 building blocks (column-major): MFMA GEMM, copies, Gram/trace norms,
+// blocked Householder QR, symmetric eigensolver with early-terminating tridiagonalisation.
+#pragma once
+#include "common.hpp"
+
+namespace dre {
+
+// Device-resident control block of one ADI solve.  Every kernel of an ADI iteration takes a
+// pointer to it and returns immediately once `done` is set, so the host can enqueue iterations
+// speculatively and synchronise only once per compression interval.
+struct AdiState {
+    int done;            // 1 = converged / collapsed / maxiters reached
+    int iters;           // shifts consumed so far (a complex pair counts 2)
+    int maxiters;
+    int zero_increment;  // /root/reference/src/lyapunov/adi.jl:161-165,200-204
+    double abstol;
+    double res_norm;
+    double norms[512];   // residual norm after iteration i (index = shifts consumed)
+};
+
+// C = alpha*op(A)*op(B) + beta*C   (M x N, inner K).  `st` may be null.
+void gemm(Ctx* ctx, bool transA, bool transB, int M, int N, int K, double alpha, const double* A, int lda,
+          const double* B, int ldb, double beta, double* C, int ldc, const AdiState* st = nullptr,
+          const char* tag = "gemm_f64_mfma");
+inline void gemm(Ctx* ctx, bool tA, bool tB, double alpha, const Mat& A, const Mat& B, double beta, Mat& C,
+                 const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma") {
+    int M = tA ? A.cols : A.rows, K = tA ? A.rows : A.cols, N = tB ? B.rows : B.cols;
+    int K2 = tB ? B.cols : B.rows;
+    DRE_REQUIRE(K == K2 && C.rows == M && C.cols == N, "gemm: shape mismatch");
+    gemm(ctx, tA, tB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, st, tag);
+}
+
+void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src
+void fill_mat(Ctx* ctx, Mat& dst, double v);
+void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
+void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst);      // dst = src'
+void add_diag(Ctx* ctx, Mat& dst, const double* diag_dev, double scale);  // dst += scale*diag(v)
+void symmetrize(Ctx* ctx, Mat& S);                           // S = (S+S')/2
+void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double alpha);  // out = alpha * L * diag(D_ii)
+double frob_norm_host(Ctx* ctx, const Mat& A);               // synchronising
+bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (small)
+
+// nrm = |alpha| * sqrt(trace((T*G)^2)) = |alpha| * ||R T R'||_F with G = R'R
+// (/root/reference/src/LDLt.jl:77-89, evaluated through the Gram matrix instead of a pivoted QR).
+// Writes st->res_norm, st->norms[st->iters], and sets st->done on convergence / maxiters.
+void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
+double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
+
+// --- blocked Householder QR (compact WY) ----------------------------------------------------
+struct QRFact {
+    int m = 0, n = 0, kq = 0, nb = 16;
+    Mat V;   // m x kq, explicit unit-lower-trapezoidal reflectors (zeros above the diagonal)
+    Mat T;   // nb x kq, upper-triangular block-reflector factors per panel
+    Mat R;   // kq x n upper trapezoid
+};
+// A (m x n) is destroyed.  (/root/reference/src/LDLt.jl:237-245 `orthf`: any orthogonal-triangular
+// factorisation gives the same X up to roundoff; no pivoting is needed because rank decisions are
+// taken by the eigenvalue threshold afterwards.)
+QRFact qr_factor(Ctx* ctx, Mat& A);
+void qr_apply_q(Ctx* ctx, const QRFact& qr, Mat& B, bool transpose);  // B <- Q*B or Q'*B, B is m x r
+
+// --- symmetric eigensolver --------------------------------------------------------------------
+struct SymEig {
+    int q = 0;       // order of S
+    int j = 0;       // order of the reduced tridiagonal problem (early termination), j <= q
+    int nref = 0;    // Householder reflectors generated
+    std::vector<double> w;  // j eigenvalues (host), UNSORTED (column i of Z belongs to w[i])
+    Mat Z;           // j x j eigenvectors of the tridiagonal matrix (device)
+    Mat V;           // q x q Householder vectors of the reduction (device, column i = reflector i)
+    DevArr<double> tau;
+};
+// Householder tridiagonalisation of S (q x q, full symmetric storage, destroyed) that stops as soon as
+// the not-yet-reduced trailing block is below tolfac*eps*||S||_F, then implicit QL on the tridiagonal.
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0);
+// B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host)
+Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids);
+
+}  // namespace dre

@@ -1,0 +1,824 @@
+// Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
+#include "engine.hpp"
+
+#include <algorithm>
+#include <numeric>
+
+#include "hostla.hpp"
+#include "profiling.hpp"
+
+namespace dre {
+
+static const double EPS = 2.220446049250313e-16;
+
+// =============================================================================================
+// LDL' objects
+// =============================================================================================
+LDLtP ldlt_make(Ctx*, int n, const Mat& L, const Mat& D, double alpha, bool diag) {
+    auto X = std::make_shared<LDLt>();
+    X->n = n;
+    X->blocks.push_back({L, D, alpha, diag});
+    return X;
+}
+LDLtP ldlt_zero(int n) {
+    auto X = std::make_shared<LDLt>();
+    X->n = n;
+    return X;
+}
+LDLtP ldlt_add(const LDLtP& a, const LDLtP& b) {
+    DRE_REQUIRE(a->n == b->n, "outer dimensions must match");
+    if (a->iszero()) return b;
+    if (b->iszero()) return a;
+    auto X = std::make_shared<LDLt>();
+    X->n = a->n;
+    X->blocks = a->blocks;
+    X->blocks.insert(X->blocks.end(), b->blocks.begin(), b->blocks.end());
+    return X;
+}
+LDLtP ldlt_scale(const LDLtP& a, double alpha) {
+    auto X = std::make_shared<LDLt>();
+    X->n = a->n;
+    X->blocks = a->blocks;
+    for (auto& b : X->blocks) b.alpha *= alpha;
+    return X;
+}
+LDLtP ldlt_deepcopy(Ctx* ctx, const LDLtP& a) {
+    auto X = std::make_shared<LDLt>();
+    X->n = a->n;
+    for (auto& b : a->blocks) {
+        LBlock nb;
+        nb.L = Mat(ctx, b.L.rows, b.L.cols);
+        nb.D = Mat(ctx, b.D.rows, b.D.cols);
+        copy_mat(ctx, b.L, nb.L);
+        copy_mat(ctx, b.D, nb.D);
+        nb.alpha = b.alpha; nb.diag = b.diag;
+        X->blocks.push_back(nb);
+    }
+    return X;
+}
+
+static Mat hcat_blocks(Ctx* ctx, const LDLt& X) {
+    const int c = X.rank();
+    Mat L(ctx, X.n, c);
+    int off = 0;
+    for (auto& b : X.blocks) {
+        if (b.L.cols == 0) continue;
+        Mat dst = L.colsview(off, b.L.cols);
+        copy_mat(ctx, b.L, dst);
+        off += b.L.cols;
+    }
+    return L;
+}
+
+void ldlt_concatenate(Ctx* ctx, LDLt& X) {
+    if (X.blocks.size() <= 1) return;
+    const int c = X.rank();
+    Mat L = hcat_blocks(ctx, X);
+    Mat D(ctx, c, c);
+    fill_mat(ctx, D, 0.0);
+    int off = 0;
+    bool diag = true;
+    for (auto& b : X.blocks) {
+        const int k = b.L.cols;
+        if (k == 0) continue;
+        Mat dst = D.view(off, off, k, k);
+        copy_mat(ctx, b.D, dst, b.alpha);
+        diag = diag && b.diag;
+        off += k;
+    }
+    X.blocks.clear();
+    X.blocks.push_back({L, D, 1.0, diag});
+}
+
+// out(:, blk) = alpha_blk * M(:, blk) * D_blk  for every block of X (M has X.rank() columns)
+static void mul_blockdiag(Ctx* ctx, const Mat& M, const LDLt& X, Mat& out) {
+    int off = 0;
+    for (auto& b : X.blocks) {
+        const int k = b.L.cols;
+        if (k == 0) continue;
+        Mat src = M.colsview(off, k), dst = out.colsview(off, k);
+        if (b.diag) scale_cols_by_diag(ctx, src, b.D, dst, b.alpha);
+        else gemm(ctx, false, false, b.alpha, src, b.D, 0.0, dst, nullptr, "gemm_compress");
+        off += k;
+    }
+}
+
+static CompressStats g_cstats;
+CompressStats& compress_stats() { return g_cstats; }
+
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac) {
+    const int n = X.n, c = X.rank();
+    auto set_empty = [&]() {
+        X.blocks.clear();
+        X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true});
+    };
+    if (c == 0) { set_empty(); return; }
+    Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    Mat S;
+    QRFact qr;
+    const bool wide = c >= n;
+    if (wide) {
+        // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
+        Mat LD(ctx, n, c);
+        mul_blockdiag(ctx, Lcat, X, LD);
+        S = Mat(ctx, n, n);
+        gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
+    } else {
+        Mat A(ctx, n, c);
+        copy_mat(ctx, Lcat, A);
+        qr = qr_factor(ctx, A);
+        Mat RD(ctx, c, c);
+        mul_blockdiag(ctx, qr.R, X, RD);
+        S = Mat(ctx, c, c);
+        gemm(ctx, false, true, 1.0, RD, qr.R, 0.0, S, nullptr, "gemm_compress");
+    }
+    symmetrize(ctx, S);
+    SymEig e = sym_eig(ctx, S, tolfac);
+    g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
+    if (e.j == 0) { set_empty(); return; }
+    double wmax = 0.0;
+    for (double w : e.w) wmax = std::max(wmax, std::fabs(w));
+    const double thr = 100.0 * wmax * EPS;
+    std::vector<int> ids;
+    for (int i = 0; i < e.j; ++i)
+        if (std::fabs(e.w[i]) >= thr && wmax > 0.0) ids.push_back(i);
+    std::sort(ids.begin(), ids.end(), [&](int a, int b) { return e.w[a] < e.w[b]; });
+    const int r = (int)ids.size();
+    g_cstats.rank_out += r;
+    if (r == 0) { set_empty(); return; }
+    Mat B = sym_eig_backtransform(ctx, e, ids);
+    Mat Lnew;
+    if (wide) {
+        Lnew = B;
+    } else {
+        Lnew = Mat(ctx, n, r);
+        fill_mat(ctx, Lnew, 0.0);
+        Mat top = Lnew.view(0, 0, c, r);
+        copy_mat(ctx, B, top);
+        qr_apply_q(ctx, qr, Lnew, false);
+    }
+    std::vector<double> hd((size_t)r * r, 0.0);
+    for (int i = 0; i < r; ++i) hd[i + (size_t)i * r] = e.w[ids[i]];
+    Mat Dnew(ctx, r, r);
+    DRE_HIP(hipMemcpyAsync(Dnew.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    X.blocks.clear();
+    X.blocks.push_back({Lnew, Dnew, 1.0, true});
+}
+
+void ldlt_destructure(Ctx* ctx, LDLt& X) {
+    if (X.blocks.size() > 1) ldlt_compress(ctx, X);
+    if (X.blocks.empty()) X.blocks.push_back({Mat(ctx, X.n, 0), Mat(ctx, 0, 0), 1.0, true});
+}
+
+double ldlt_norm(Ctx* ctx, LDLt& X) {
+    if (X.rank() == 0) return 0.0;
+    ldlt_concatenate(ctx, X);
+    auto& b = X.blocks[0];
+    return ldlt_norm_host(ctx, b.L, b.D, b.alpha);
+}
+
+// =============================================================================================
+// Sherman-Morrison-Woodbury pieces (/root/reference/src/blocklinear/sherman-morrison-woodbury.jl:10-45)
+// with  F' + mu E' = M + inv(alpha) Vt U'  :  W = M^-1 [R, Vt];  S = alpha I + U' W_U;  X = W_R - W_U S^-1 (U' W_R)
+// =============================================================================================
+template <typename T> __device__ inline T wave_sum_t(T v);
+template <> __device__ inline double wave_sum_t<double>(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <> __device__ inline cplx wave_sum_t<cplx>(cplx v) {
+    for (int o = 32; o > 0; o >>= 1) { v.re += __shfl_xor(v.re, o, 64); v.im += __shfl_xor(v.im, o, 64); }
+    return v;
+}
+
+// small(0:m, c) = U' * W(:, c); one workgroup per column c
+template <typename T>
+__global__ __launch_bounds__(256) void k_smw_small(int n, int m, const double* __restrict__ U, int ldu, const T* __restrict__ W,
+                                                   int ldw, T* __restrict__ small, int lds_, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double redbuf[4 * 2 * 8];
+    T* red = reinterpret_cast<T*>(redbuf);
+    const int c = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const T* w = W + (size_t)c * ldw;
+    for (int j0 = 0; j0 < m; j0 += 8) {
+        T acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = make_scalar<T>(0.0, 0.0);
+        for (int i = tid; i < n; i += 256) {
+            const T wi = w[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < m) acc[j] += wi * U[i + (size_t)(j0 + j) * ldu];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T s = wave_sum_t<T>(acc[j]);
+            if (lane == 0) red[wave * 8 + j] = s;
+        }
+        __syncthreads();
+        if (tid < 8 && j0 + tid < m) small[(j0 + tid) + (size_t)c * lds_] = red[tid] + red[8 + tid] + red[16 + tid] + red[24 + tid];
+    }
+}
+
+// Sinv = inv(alpha I + Smat) by Gauss-Jordan with partial pivoting; one workgroup, m <= 32
+template <typename T>
+__global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv,
+                                             const AdiState* st, int* err) {
+    if (st && st->done) return;
+    __shared__ double abuf[32 * 64 * 2];
+    __shared__ int piv;
+    __shared__ double colkbuf[32 * 2];
+    T* colk = reinterpret_cast<T*>(colkbuf);
+    T* A = reinterpret_cast<T*>(abuf);   // m x 2m, column-major, ld = 32
+    const int tid = threadIdx.x;
+    for (int id = tid; id < m * 2 * m; id += 64) {
+        const int i = id % m, j = id / m;
+        T v = make_scalar<T>(0.0, 0.0);
+        if (j < m) { v = Smat[i + (size_t)j * lds_]; if (i == j) v = v + make_scalar<T>(alpha, 0.0); }
+        else if (j - m == i) v = make_scalar<T>(1.0, 0.0);
+        A[i + j * 32] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        if (tid == 0) {
+            int p = k; double best = abs1(A[k + k * 32]);
+            for (int i = k + 1; i < m; ++i) { double a = abs1(A[i + k * 32]); if (a > best) { best = a; p = i; } }
+            piv = p;
+            if (best == 0.0) *err = 1;
+        }
+        __syncthreads();
+        const int p = piv;
+        if (tid < 2 * m && p != k) { T t = A[k + tid * 32]; A[k + tid * 32] = A[p + tid * 32]; A[p + tid * 32] = t; }
+        __syncthreads();
+        const T rp = recip(A[k + k * 32]);
+        __syncthreads();
+        if (tid < 2 * m) A[k + tid * 32] *= rp;
+        if (tid < m) colk[tid] = A[tid + k * 32];   // multipliers, read before column k is touched
+        __syncthreads();
+        if (tid < 2 * m) {
+            const T akj = A[k + tid * 32];
+            for (int i = 0; i < m; ++i)
+                if (i != k) A[i + tid * 32] -= colk[i] * akj;
+        }
+        __syncthreads();
+    }
+    for (int id = tid; id < m * m; id += 64) {
+        const int i = id % m, j = id / m;
+        Sinv[i + (size_t)j * m] = A[i + (m + j) * 32];
+    }
+}
+
+#define SMW_CB 8
+// real:    V  = W_R - W_U * (Sinv * small_R)
+// complex: V1 = sqrt2 (Re V + delta Im V),  V2 = sqrt(2 delta^2 + 2) Im V   (/root/reference/src/lyapunov/adi.jl:205-211)
+template <typename T, bool HAS_LR>
+__global__ __launch_bounds__(256) void k_smw_apply(int n, int m, int k, const T* __restrict__ W, int ldw, const T* __restrict__ WU,
+                                                   int ldwu, const T* __restrict__ Sinv, const T* __restrict__ small, int lds_,
+                                                   double* __restrict__ V1, int ldv1, double* __restrict__ V2, int ldv2,
+                                                   double delta, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double ybuf[SMW_CB * 32 * 2];
+    T* y = reinterpret_cast<T*>(ybuf);
+    const int c0 = blockIdx.y * SMW_CB, kc = min(SMW_CB, k - c0);
+    const int tid = threadIdx.x;
+    if (HAS_LR) {
+        for (int id = tid; id < kc * m; id += 256) {
+            const int j = id % m, c = id / m;
+            T acc = make_scalar<T>(0.0, 0.0);
+            for (int l = 0; l < m; ++l) acc += Sinv[j + (size_t)l * m] * small[l + (size_t)(c0 + c) * lds_];
+            y[j + c * 32] = acc;
+        }
+        __syncthreads();
+    }
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    for (int c = 0; c < kc; ++c) {
+        T v = W[i + (size_t)(c0 + c) * ldw];
+        if (HAS_LR)
+            for (int j = 0; j < m; ++j) v -= WU[i + (size_t)j * ldwu] * y[j + c * 32];
+        if constexpr (sizeof(T) == 8) {
+            V1[i + (size_t)(c0 + c) * ldv1] = *reinterpret_cast<double*>(&v);
+        } else {
+            const cplx z = *reinterpret_cast<cplx*>(&v);
+            V1[i + (size_t)(c0 + c) * ldv1] = 1.4142135623730951 * z.re + (1.4142135623730951 * delta) * z.im;
+            V2[i + (size_t)(c0 + c) * ldv2] = sqrt(2.0 * delta * delta + 2.0) * z.im;
+        }
+    }
+}
+
+__global__ void k_real_to_cplx(int rows, int cols, const double* __restrict__ src, int lds_, cplx* __restrict__ dst, int ldd,
+                               const AdiState* st) {
+    if (st && st->done) return;
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)rows * cols) return;
+    int r = id % rows, c = id / rows;
+    dst[r + (size_t)c * ldd] = {src[r + (size_t)c * lds_], 0.0};
+}
+
+// =============================================================================================
+// Shift oracles
+// =============================================================================================
+struct ShiftOracle {
+    virtual ~ShiftOracle() {}
+    virtual std::complex<double> take(int* warn) = 0;
+    virtual void update(const Mat& R, const std::vector<Mat>& Vs) {}
+};
+struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
+    std::vector<std::complex<double>> v;
+    size_t i = 0;
+    std::complex<double> take(int*) override { auto x = v[i % v.size()]; ++i; return x; }
+};
+
+static void apply_Ft(Ctx* ctx, const GaleOperator& op, const Mat& L, Mat& out) {
+    // out = F' L = Fs' L + inv(alpha) Vt (U' L)      (LowRankUpdate.jl:51-54,82-85)
+    const Pencil& P = *op.P;
+    spmm(ctx, P.n, P.ptr.p, P.idx.p, op.valFt.p, L, out, 1.0, 0.0);
+    if (op.has_lr && L.cols > 0) {
+        Mat tmp(ctx, op.U.cols, L.cols);
+        gemm(ctx, true, false, 1.0, op.U, L, 0.0, tmp);
+        gemm(ctx, false, false, 1.0 / op.alpha, op.Vt, tmp, 1.0, out);
+    }
+}
+
+struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
+    Ctx* ctx; const GaleOperator* op; int n_history;
+    const AdiState* st_dev = nullptr;   // speculative enqueueing: never compute Ritz values from skipped steps
+    std::vector<Mat> Vs;   // handles, NOT snapshots
+    std::vector<std::complex<double>> buffer;
+    size_t pos = 0;
+    void update(const Mat& R, const std::vector<Mat>& newVs) override {
+        if (newVs.empty()) Vs.push_back(R);
+        for (auto& v : newVs) Vs.push_back(v);
+        const int lst = (int)Vs.size();
+        const int fst = std::max(0, lst - n_history);
+        Vs.erase(Vs.begin(), Vs.begin() + fst);
+    }
+    void take_many(int* warn) {
+        const Pencil& P = *op->P;
+        if (st_dev) {
+            int done = 0;
+            DRE_HIP(hipMemcpyAsync(&done, &st_dev->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            if (done) { buffer.assign(1, std::complex<double>(-1.0, 0.0)); pos = 0; return; }
+        }
+        int w = 0;
+        for (auto& v : Vs) w += v.cols;
+        DRE_REQUIRE(w > 0, "Projection shifts: empty history");
+        Mat N(ctx, P.n, w);
+        int off = 0;
+        for (auto& v : Vs) { Mat d = N.colsview(off, v.cols); copy_mat(ctx, v, d); off += v.cols; }
+        // orth(N): SVD with absolute cut n*eps (Stuff.jl:13-19) realised as QR + SVD of the small R
+        QRFact qr = qr_factor(ctx, N);
+        const int kq = qr.kq;
+        std::vector<double> hR((size_t)kq * w);
+        DRE_HIP(hipMemcpy2DAsync(hR.data(), kq * sizeof(double), qr.R.p, qr.R.ld * sizeof(double), kq * sizeof(double), w, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<double> Us, sv;
+        host_svd_left(kq, w, hR, Us, sv);      // R = Us diag(sv) W'
+        std::vector<int> keep;
+        for (int i = 0; i < (int)sv.size(); ++i) if (std::fabs(sv[i]) > P.n * EPS) keep.push_back(i);
+        const int r = (int)keep.size();
+        DRE_REQUIRE(r > 0, "Projection shifts: residual factor is numerically zero");
+        std::vector<double> hB((size_t)P.n * r, 0.0);
+        for (int c = 0; c < r; ++c) for (int i = 0; i < kq; ++i) hB[i + (size_t)c * P.n] = Us[i + (size_t)keep[c] * kq];
+        Mat Q(ctx, P.n, r);
+        DRE_HIP(hipMemcpyAsync(Q.p, hB.data(), hB.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        qr_apply_q(ctx, qr, Q, false);
+        // restrictions: Q'EQ = (Q'E'Q)',  Q'FQ = (Q'F'Q)'
+        Mat EQ(ctx, P.n, r), FQ(ctx, P.n, r), Et(ctx, r, r), Ft(ctx, r, r);
+        spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, Q, EQ, 1.0, 0.0);
+        apply_Ft(ctx, *op, Q, FQ);
+        gemm(ctx, true, false, 1.0, Q, EQ, 0.0, Et);
+        gemm(ctx, true, false, 1.0, Q, FQ, 0.0, Ft);
+        std::vector<double> hE((size_t)r * r), hF((size_t)r * r), hEt((size_t)r * r), hFt((size_t)r * r);
+        DRE_HIP(hipMemcpyAsync(hEt.data(), Et.p, hEt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipMemcpyAsync(hFt.data(), Ft.p, hFt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) { hE[i + (size_t)j * r] = hEt[j + (size_t)i * r]; hF[i + (size_t)j * r] = hFt[j + (size_t)i * r]; }
+        std::vector<std::complex<double>> lam = host_gen_eigvals(r, hF, hE);
+        // stabilize_ritz_values! + safe_sort!  (helpers.jl:122-140)
+        int nun = 0;
+        for (auto& l : lam) if (!(l.real() < 0)) ++nun;
+        if (nun > 0 && nun < (int)lam.size()) {
+            if (warn) *warn |= 4;
+            std::vector<std::complex<double>> f;
+            for (auto& l : lam) if (l.real() < 0) f.push_back(l);
+            lam.swap(f);
+        } else if (nun == (int)lam.size()) {
+            if (warn) *warn |= 8;
+            for (auto& l : lam) l = std::complex<double>(-l.real(), l.imag());
+        }
+        std::stable_sort(lam.begin(), lam.end(), [](const std::complex<double>& a, const std::complex<double>& b) {
+            if (a.real() != b.real()) return a.real() < b.real();
+            return std::fabs(a.imag()) < std::fabs(b.imag());
+        });
+        buffer = lam; pos = 0;
+    }
+    std::complex<double> take(int* warn) override {
+        if (pos >= buffer.size()) take_many(warn);
+        return buffer[pos++];
+    }
+};
+
+// =============================================================================================
+// GALE residual (/root/reference/src/lyapunov/residual.jl:3-31)
+// =============================================================================================
+LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X) {
+    auto Cp = std::make_shared<LDLt>(C);
+    if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
+    const Pencil& P = *op.P;
+    ldlt_destructure(ctx, C);
+    ldlt_destructure(ctx, *X);
+    const LBlock& cb = C.blocks[0];
+    const LBlock& xb = X->blocks[0];
+    const int nG = cb.L.cols, n0 = xb.L.cols, dim = nG + 2 * n0;
+    Mat R(ctx, P.n, dim);
+    { Mat d = R.colsview(0, nG); copy_mat(ctx, cb.L, d); }
+    { Mat d = R.colsview(nG, n0); spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, xb.L, d, 1.0, 0.0); }
+    { Mat d = R.colsview(nG + n0, n0); apply_Ft(ctx, op, xb.L, d); }
+    Mat T(ctx, dim, dim);
+    fill_mat(ctx, T, 0.0);
+    { Mat d = T.view(0, 0, nG, nG); copy_mat(ctx, cb.D, d, cb.alpha); }
+    { Mat d = T.view(nG, nG + n0, n0, n0); copy_mat(ctx, xb.D, d, xb.alpha); }
+    { Mat d = T.view(nG + n0, nG, n0, n0); copy_mat(ctx, xb.D, d, xb.alpha); }
+    LDLtP res = ldlt_make(ctx, P.n, R, T, 1.0, false);
+    ldlt_compress(ctx, *res);
+    return res;
+}
+
+// =============================================================================================
+// ADI (/root/reference/src/lyapunov/adi.jl:29-225)
+// =============================================================================================
+template <typename T>
+static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
+                                                  std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
+                                                  std::complex<double> mu) {
+    auto key = std::make_tuple(op.tag, mu.real(), mu.imag());
+    if (cache->enabled) {
+        auto it = store.find(key);
+        if (it != store.end()) return it->second;
+    }
+    auto fe = std::make_shared<FactorEntry<T>>();
+    mf_factor<T>(ctx, *op.P, op.valFt.p, op.P->valEt.p, make_scalar<T>(1.0, 0.0), make_scalar<T>(mu.real(), mu.imag()), fe->f);
+    cache->nfactor++;
+    if (cache->enabled) store[key] = fe;
+    return fe;
+}
+
+struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; };
+
+AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
+                    FactorCache* cache) {
+    const Pencil& P = *op.P;
+    const int n = P.n;
+    FactorCache local;
+    if (!cache) cache = &local;
+    AdiResult res;
+    ldlt_destructure(ctx, C);
+    const double normC = ldlt_norm(ctx, C);
+    const double reltol = opt.reltol >= 0 ? opt.reltol : n * EPS;
+    const double abstol = opt.abstol >= 0 ? opt.abstol : reltol * normC;
+    LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
+    LDLtP resid = gale_residual(ctx, op, C, X);
+    ldlt_destructure(ctx, *resid);
+    LBlock rb = resid->blocks[0];
+    Mat R = rb.L, Tm = rb.D;
+    const double alpha_res = rb.alpha;
+    const int k = R.cols;
+    const bool tdiag = rb.diag || is_diagonal_host(ctx, Tm);
+    const double norm0 = ldlt_norm_host(ctx, R, Tm, alpha_res);
+    res.abstol = abstol; res.initial_norm = norm0; res.rhs_cols = k;
+    res.norms.push_back(norm0); res.norm_iters.push_back(0);
+    res.residual = resid;
+    res.X = X;
+    res.res_norm = norm0;
+    DRE_REQUIRE(opt.maxiters < 500, "ADI: maxiters must be below 500");
+    if (norm0 <= abstol || k == 0) { res.converged = true; return res; }
+
+    std::unique_ptr<ShiftOracle> oracle;
+    if (opt.shifts.kind == ShiftSpec::CYCLIC) {
+        DRE_REQUIRE(!opt.shifts.values.empty(), "Cyclic shifts: empty list");
+        auto o = std::make_unique<CyclicOracle>();
+        o->v = opt.shifts.values;
+        oracle = std::move(o);
+    } else {
+        auto o = std::make_unique<ProjectionOracle>();
+        o->ctx = ctx; o->op = &op; o->n_history = opt.shifts.n_history;
+        oracle = std::move(o);
+    }
+    oracle->update(R, {});
+
+    // device-resident control block
+    DevArr<AdiState> st(ctx, 1);
+    if (auto* po = dynamic_cast<ProjectionOracle*>(oracle.get())) po->st_dev = st.p;
+    {
+        AdiState h;
+        std::memset(&h, 0, sizeof(h));
+        h.maxiters = opt.maxiters; h.abstol = abstol; h.res_norm = norm0; h.norms[0] = norm0;
+        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const int m = op.has_lr ? op.U.cols : 0;
+    DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
+    std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
+    DevArr<int> serr(ctx, 1);
+    DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
+
+    // the iterate: never mutate the caller's initial guess (adi.jl:174 `cache.X += increment` builds a new list)
+    auto Xw = std::make_shared<LDLt>(*X);
+    struct StepRec { int iters_after; size_t nblocks; int nshifts; };
+    int iters_host = 0, last_compression = 0;
+    std::vector<std::complex<double>> all_shifts;
+    bool finished = false;
+    std::vector<std::shared_ptr<FactorEntry<double>>> used_real;
+    std::vector<std::shared_ptr<FactorEntry<cplx>>> used_cplx;
+
+    while (!finished) {
+        std::vector<StepRec> recs;
+        const size_t blocks_before = Xw->blocks.size();
+        const int lc_before = last_compression;
+        int since_sync = 0;
+        while (iters_host < opt.maxiters) {
+            std::complex<double> mu = oracle->take(&res.warnings);
+            all_shifts.push_back(mu);
+            const bool is_real = (mu.imag() == 0.0);
+            const AdiState* dst = st.p;
+            Mat V1, V2;
+            if (is_real) {
+                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu);
+                used_real.push_back(fe);
+                auto key = std::make_pair(mu.real(), 0.0);
+                auto sc = smw_cache.find(key);
+                const bool have = op.has_lr && sc != smw_cache.end();
+                const int ncols = k + ((op.has_lr && !have) ? m : 0);
+                Mat W(ctx, n, ncols);
+                { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
+                if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
+                mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
+                if (op.has_lr) {
+                    V1 = Mat(ctx, n, k);
+                    Mat small(ctx, m, ncols);
+                    { TimedScope ts(ctx, "smw_small");
+                      hipLaunchKernelGGL((k_smw_small<double>), dim3(ncols), dim3(256), 0, ctx->stream, n, m, op.U.p, op.U.ld, W.p, W.ld, small.p, small.ld, dst); }
+                    if (!have) {
+                        SmwCacheEntry en;
+                        en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
+                        en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
+                        sc = smw_cache.emplace(key, en).first;
+                    }
+                    TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
+                    hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
+                                       n, m, k, W.p, W.ld, (const double*)sc->second.WU, sc->second.ldwu, (const double*)sc->second.sinv->p,
+                                       small.p, small.ld, V1.p, V1.ld, (double*)nullptr, 0, 0.0, dst);
+                } else {
+                    V1 = W;
+                }
+                // R <- R - 2 mu E' V   (adi.jl:171)
+                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);
+                Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
+                iters_host += 1; last_compression += 1;
+                oracle->update(R, {V1});
+            } else {
+                std::complex<double> mu2 = oracle->take(&res.warnings);
+                all_shifts.push_back(mu2);
+                DRE_REQUIRE(std::abs(mu2 - std::conj(mu)) <= 1e-8 * std::abs(mu), "complex shifts must come in conjugate pairs (adi.jl:190)");
+                V1 = Mat(ctx, n, k);
+                V2 = Mat(ctx, n, k);
+                auto fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu);
+                used_cplx.push_back(fe);
+                auto key = std::make_pair(mu.real(), mu.imag());
+                auto sc = smw_cache.find(key);
+                const bool have = op.has_lr && sc != smw_cache.end();
+                const int ncols = k + ((op.has_lr && !have) ? m : 0);
+                auto Wb = std::make_shared<Buf>(ctx, (size_t)n * ncols * sizeof(cplx));
+                cplx* W = (cplx*)Wb->p;
+                {
+                    size_t tot = (size_t)n * k;
+                    hipLaunchKernelGGL(k_real_to_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, R.p, R.ld, W, n, dst);
+                    if (op.has_lr && !have) {
+                        tot = (size_t)n * m;
+                        hipLaunchKernelGGL(k_real_to_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, m, op.Vt.p, op.Vt.ld, W + (size_t)k * n, n, dst);
+                    }
+                }
+                mf_solve<cplx>(ctx, P, fe->f, W, n, ncols, dst);
+                const double delta = mu.real() / mu.imag();
+                if (op.has_lr) {
+                    auto sb = std::make_shared<Buf>(ctx, (size_t)m * ncols * sizeof(cplx));
+                    cplx* small = (cplx*)sb->p;
+                    hipLaunchKernelGGL((k_smw_small<cplx>), dim3(ncols), dim3(256), 0, ctx->stream, n, m, op.U.p, op.U.ld, W, n, small, m, dst);
+                    if (!have) {
+                        SmwCacheEntry en;
+                        en.keep = Wb; en.WU = W + (size_t)k * n; en.ldwu = n;
+                        en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(cplx));
+                        hipLaunchKernelGGL((k_sinv<cplx>), dim3(1), dim3(64), 0, ctx->stream, m, small + (size_t)k * m, m, op.alpha, (cplx*)en.sinv->p, dst, serr.p);
+                        sc = smw_cache.emplace(key, en).first;
+                    }
+                    hipLaunchKernelGGL((k_smw_apply<cplx, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
+                                       n, m, k, W, n, (const cplx*)sc->second.WU, sc->second.ldwu, (const cplx*)sc->second.sinv->p,
+                                       small, m, V1.p, V1.ld, V2.p, V2.ld, delta, dst);
+                } else {
+                    hipLaunchKernelGGL((k_smw_apply<cplx, false>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
+                                       n, 0, k, W, n, (const cplx*)nullptr, 0, (const cplx*)nullptr, (const cplx*)nullptr, 0,
+                                       V1.p, V1.ld, V2.p, V2.ld, delta, dst);
+                }
+                // R <- R - 2 sqrt2 Re(mu) E' V1   (adi.jl:217)
+                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * 1.4142135623730951 * mu.real(), 1.0, dst);
+                Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
+                Xw->blocks.push_back({V2, Tm, -2.0 * mu.real() * alpha_res, tdiag});
+                iters_host += 2; last_compression += 2;
+                oracle->update(R, {V1, V2});
+            }
+            // residual norm through the Gram matrix, convergence decision on the device
+            Mat G(ctx, k, k);
+            gemm(ctx, true, false, 1.0, R, R, 0.0, G, dst, "gemm_gram");
+            ldlt_norm_update_state(ctx, G, Tm, tdiag, alpha_res, st.p, iters_host);
+            recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
+            ++since_sync;
+            if (opt.compression && last_compression >= opt.compression_interval) break;
+            if (!opt.compression && since_sync >= 10) break;
+        }
+        // synchronise once per chunk and find out how far the device really got
+        AdiState h;
+        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        size_t nblocks = blocks_before;
+        int lc = lc_before;
+        for (auto& r : recs) {
+            if (r.iters_after <= h.iters) {
+                nblocks = r.nblocks; lc += r.nshifts;
+                res.norms.push_back(h.norms[r.iters_after]);
+                res.norm_iters.push_back(r.iters_after);
+            }
+        }
+        Xw->blocks.resize(nblocks);
+        last_compression = lc;
+        res.iters = h.iters;
+        res.res_norm = h.res_norm;
+        if (h.done || recs.empty()) {
+            finished = true;
+        } else if (opt.compression && last_compression >= opt.compression_interval) {
+            ldlt_compress(ctx, *Xw, opt.compress_tolfac);
+            last_compression = 0;
+        }
+    }
+    {
+        int herr = 0;
+        DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+        for (auto& f : used_real) mf_check(ctx, f->f);
+        for (auto& f : used_cplx) mf_check(ctx, f->f);
+    }
+    if (opt.compression && last_compression > 0) ldlt_compress(ctx, *Xw, opt.compress_tolfac);   // adi.jl:78-80
+    all_shifts.resize(res.iters);
+    res.shifts = all_shifts;
+    res.X = Xw;
+    res.converged = res.res_norm <= abstol;
+    if (!res.converged) res.warnings |= 1;
+    return res;
+}
+
+// =============================================================================================
+// Rosenbrock drivers
+// =============================================================================================
+struct Feedback { Mat L, D, BtLD, EtL, Kt; double alpha; bool diag; };
+
+static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X) {
+    // alpha, L, D = X;  BtLD = (B'L) D [*alpha];  K = BtLD (L'E)     (lowrank_ros1.jl:25-28,53-56)
+    const Pencil& P = *prob.P;
+    ldlt_destructure(ctx, X);
+    const LBlock& b = X.blocks[0];
+    Feedback f;
+    f.L = b.L; f.D = b.D; f.alpha = b.alpha; f.diag = b.diag;
+    const int r = b.L.cols, m = prob.B.cols;
+    Mat BtL(ctx, m, r);
+    gemm(ctx, true, false, 1.0, prob.B, b.L, 0.0, BtL);
+    f.BtLD = Mat(ctx, m, r);
+    gemm(ctx, false, false, b.alpha, BtL, b.D, 0.0, f.BtLD);
+    f.EtL = Mat(ctx, P.n, r);
+    spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, b.L, f.EtL, 1.0, 0.0);
+    f.Kt = Mat(ctx, P.n, m);
+    if (r > 0) gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
+    else fill_mat(ctx, f.Kt, 0.0);
+    return f;
+}
+
+static uint64_t tag_of(int order, double tau) {
+    uint64_t bits;
+    std::memcpy(&bits, &tau, sizeof(bits));
+    return bits * 1315423911ull + (uint64_t)order * 0x9E3779B97F4A7C15ull + 1;
+}
+
+GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {
+    DRE_REQUIRE(order == 1 || order == 2, "only Ros1 and Ros2 have a low-rank formulation");
+    DRE_REQUIRE(dt != 0.0, "dt must be nonzero");
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    GdreResult out;
+    const int nsteps = (int)std::floor((prob.tf - prob.t0) / dt + 1e-9);
+    DRE_REQUIRE(nsteps >= 0, "tspan and dt point in opposite directions");
+    for (int i = 0; i <= nsteps; ++i) out.t.push_back(prob.t0 + i * dt);
+    LDLtP X = prob.X0;
+    out.X.push_back(X);
+    Feedback fb = feedback(ctx, prob, *X);
+    out.Kt.push_back(fb.Kt);
+    FactorCache cache;
+    std::map<uint64_t, DevArr<double>> valF_by_tau;
+    const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
+
+    for (int i = 1; i <= nsteps; ++i) {
+        const double tau = out.t[i - 1] - out.t[i];
+        GaleOperator op;
+        op.P = &P;
+        op.tag = tag_of(order, tau);
+        auto it = valF_by_tau.find(op.tag);
+        if (it == valF_by_tau.end()) {
+            DevArr<double> v(ctx, P.nnz);
+            if (order == 1) vals_axpby(ctx, P.nnz, 1.0, P.valAt.p, -1.0 / (2.0 * tau), P.valEt.p, v.p);      // A - E/(2 tau)
+            else vals_axpby(ctx, P.nnz, gamma * tau, P.valAt.p, -0.5, P.valEt.p, v.p);                         // gamma tau A - E/2
+            it = valF_by_tau.emplace(op.tag, v).first;
+        }
+        op.valFt = it->second;
+        op.has_lr = true;
+        op.U = prob.B;
+        op.Vt = fb.Kt;
+        op.alpha = order == 1 ? -1.0 : 1.0 / (-gamma * tau);
+        const int r = fb.L.cols;
+        if (order == 1) {
+            // G = [C', E'L];  S = blkdiag(I_q, BtLD' BtLD + D/tau);  R = compress!(lowrank(G, S))   (lowrank_ros1.jl:42-44)
+            Mat G(ctx, n, q + r);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            { Mat d = G.colsview(q, r); copy_mat(ctx, fb.EtL, d); }
+            Mat S(ctx, q + r, q + r);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d = S.view(q, q, r, r);
+                copy_mat(ctx, fb.D, d, 1.0 / tau);
+                gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
+            }
+            LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
+            ldlt_compress(ctx, *rhs, adi.compress_tolfac);
+            AdiResult ar = adi_solve(ctx, op, *rhs, X, adi, &cache);
+            X = ar.X;
+            out.adi_iters += ar.iters;
+            ar.X.reset(); ar.residual.reset();
+            out.gale.push_back(std::move(ar));
+        } else {
+            // stage 1: G = [C', A'L, E'L], S = [I 0 0; 0 0 D; 0 D -(BtLD)'BtLD]      (lowrank_ros2.jl:44-58)
+            const int nG = q + 2 * r;
+            Mat G(ctx, n, nG);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            if (r > 0) {
+                Mat d = G.colsview(q, r); spmm(ctx, n, P.ptr.p, P.idx.p, P.valAt.p, fb.L, d, 1.0, 0.0);
+                Mat d2 = G.colsview(q + r, r); copy_mat(ctx, fb.EtL, d2);
+            }
+            Mat S(ctx, nG, nG);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d23 = S.view(q, q + r, r, r); copy_mat(ctx, fb.D, d23);
+                Mat d32 = S.view(q + r, q, r, r); copy_mat(ctx, fb.D, d32);
+                Mat d33 = S.view(q + r, q + r, r, r); gemm(ctx, true, false, -1.0, fb.BtLD, fb.BtLD, 0.0, d33);
+            }
+            LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);
+            ldlt_compress(ctx, *R1, adi.compress_tolfac);
+            AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
+            LDLtP K1 = a1.X;
+            // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)
+            ldlt_destructure(ctx, *K1);
+            const LBlock kb = K1->blocks[0];
+            const int r1 = kb.L.cols;
+            Mat BtT1(ctx, m, r1), BtT1D1(ctx, m, r1);
+            gemm(ctx, true, false, 1.0, prob.B, kb.L, 0.0, BtT1);
+            gemm(ctx, false, false, kb.alpha, BtT1, kb.D, 0.0, BtT1D1);
+            Mat G2(ctx, n, r1);
+            spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, kb.L, G2, 1.0, 0.0);
+            Mat S2(ctx, r1, r1);
+            copy_mat(ctx, kb.D, S2, 2.0 - 1.0 / gamma);
+            if (r1 > 0) gemm(ctx, true, false, tau * tau, BtT1D1, BtT1D1, 1.0, S2);
+            LDLtP R2 = ldlt_make(ctx, n, G2, S2, 1.0, false);
+            AdiResult a2 = adi_solve(ctx, op, *R2, nullptr, adi, &cache);
+            LDLtP K2 = a2.X;
+            // X = X + ((2 - 1/(2 gamma)) tau) K1 + (-tau/2) K2     (lowrank_ros2.jl:72)
+            X = ldlt_add(ldlt_add(X, ldlt_scale(K1, (2.0 - 1.0 / (2.0 * gamma)) * tau)), ldlt_scale(K2, -tau / 2.0));
+            if (X.get() == prob.X0.get()) X = std::make_shared<LDLt>(*X);   // never compress the caller's X0 in place
+            out.adi_iters += a1.iters + a2.iters;
+            a1.X.reset(); a1.residual.reset(); a2.X.reset(); a2.residual.reset();
+            out.gale.push_back(std::move(a1));
+            out.gale.push_back(std::move(a2));
+        }
+        if (save_state) out.X.push_back(X);
+        fb = feedback(ctx, prob, *X);
+        out.Kt.push_back(fb.Kt);
+    }
+    if (!save_state) out.X.push_back(X);
+    out.nfactor = cache.nfactor;
+    return out;
+}
+
+}  // namespace dre

@@ -1,0 +1,118 @@
+// Device-resident low-rank engine: LDL' objects, GALE operators, ADI, shift strategies, Rosenbrock drivers.
+// Mirrors (not translates) the reference's hot path; each routine cites the file:line it replaces.
+#pragma once
+#include <complex>
+#include <functional>
+#include <map>
+
+#include "common.hpp"
+#include "dense.hpp"
+#include "sparse.hpp"
+
+namespace dre {
+
+// ---- LDL' low-rank object (/root/reference/src/LDLt.jl:29-33): lazy sum_i alpha_i L_i D_i L_i' -----------
+struct LBlock {
+    Mat L;          // n x k
+    Mat D;          // k x k (dense storage)
+    double alpha = 1.0;
+    bool diag = false;   // D known to be diagonal
+};
+struct LDLt {
+    int n = 0;
+    std::vector<LBlock> blocks;
+    int rank() const { int r = 0; for (auto& b : blocks) r += b.L.cols; return r; }
+    bool iszero() const {
+        if (rank() == 0) return true;
+        for (auto& b : blocks) if (b.alpha != 0.0) return false;
+        return true;
+    }
+};
+using LDLtP = std::shared_ptr<LDLt>;
+
+LDLtP ldlt_make(Ctx* ctx, int n, const Mat& L, const Mat& D, double alpha = 1.0, bool diag = false);
+LDLtP ldlt_zero(int n);
+LDLtP ldlt_add(const LDLtP& a, const LDLtP& b);                 // LDLt.jl:131-148 (list append, factors shared)
+LDLtP ldlt_scale(const LDLtP& a, double alpha);                  // LDLt.jl:156-159
+LDLtP ldlt_deepcopy(Ctx* ctx, const LDLtP& a);
+void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-191
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0);      // LDLt.jl:204-225
+double ldlt_norm(Ctx* ctx, LDLt& X);                             // LDLt.jl:77-89 (concatenates, synchronises)
+void ldlt_destructure(Ctx* ctx, LDLt& X);                        // LDLt.jl:54-60: compress iff more than one block
+
+struct CompressStats { long calls = 0; long cols_in = 0; long order = 0; long tri_steps = 0; long rank_out = 0; };
+CompressStats& compress_stats();
+
+// ---- GALE operator  F = Fs + inv(alpha) U V  with sparse Fs on the pencil's pattern ----------------------
+// (/root/reference/src/LowRankUpdate.jl:18-26, src/lyapunov/types.jl:10-16)
+template <typename T> struct FactorEntry { Factor<T> f; };
+struct FactorCache {
+    std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<double>>> real;
+    std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
+    long nfactor = 0;
+    bool enabled = true;
+    void clear() { real.clear(); cplx_.clear(); }
+};
+struct GaleOperator {
+    const Pencil* P = nullptr;
+    DevArr<double> valFt;      // values of the sparse part of F' on the pencil's pattern
+    uint64_t tag = 0;          // identity of valFt for the factor cache
+    bool has_lr = false;
+    double alpha = 1.0;        // F = Fs + inv(alpha) * U * V
+    Mat U;                     // n x m
+    Mat Vt;                    // n x m  (V')
+};
+
+// ---- shift strategies (/root/reference/src/Shifts.jl:79-116, src/shifts/*.jl) -----------------------------
+struct ShiftSpec {
+    enum Kind { CYCLIC = 0, PROJECTION = 1 } kind = PROJECTION;
+    std::vector<std::complex<double>> values;   // CYCLIC
+    int n_history = 2;                          // PROJECTION
+};
+
+struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
+    int maxiters = 100;
+    double reltol = -1.0;   // < 0: "nothing" -> n*eps
+    double abstol = -1.0;   // < 0: "nothing" -> reltol*norm(C)
+    bool ignore_initial_guess = false;
+    int compression_interval = 10;
+    bool compression = true;
+    ShiftSpec shifts;
+    double compress_tolfac = 4.0;
+};
+struct AdiResult {
+    LDLtP X;
+    LDLtP residual;
+    int iters = 0;
+    double res_norm = 0.0, abstol = 0.0, initial_norm = 0.0;
+    bool converged = false;
+    int warnings = 0;       // bit 0: not converged (adi.jl:126); 4/8: Ritz values discarded/flipped (helpers.jl:133,136)
+    std::vector<double> norms;                    // residual norm after each observed step (index 0 = initial)
+    std::vector<int> norm_iters;                  // iteration number of each entry of `norms`
+    std::vector<std::complex<double>> shifts;     // shifts consumed
+    int rhs_cols = 0;
+};
+AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
+                    FactorCache* cache);
+// residual of A'XE + E'XA + C for an LDL' iterate (/root/reference/src/lyapunov/residual.jl:3-31)
+LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X);
+
+// ---- Rosenbrock drivers (/root/reference/src/riccati/lowrank_ros1.jl, lowrank_ros2.jl) -------------------
+struct GdreProblem {
+    const Pencil* P = nullptr;
+    Mat B;    // n x m  (solver ordering)
+    Mat Ct;   // n x q  (C')
+    LDLtP X0;
+    double t0 = 0, tf = 0;
+};
+struct GdreResult {
+    std::vector<double> t;
+    std::vector<Mat> Kt;              // K(t_i)' stored as n x m (solver ordering)
+    std::vector<LDLtP> X;             // first/last or all (save_state)
+    std::vector<AdiResult> gale;      // one per Lyapunov solve (Ros2: two per step), X/residual handles dropped
+    long adi_iters = 0;
+    long nfactor = 0;
+};
+GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi);
+
+}  // namespace dre

@@ -1,0 +1,65 @@
+// Per-kernel-class timing with HIP events on the library's own stream.
+// Used by bench.py's roofline leg (torch.cuda.Event only sees torch's stream).
+#pragma once
+#include "common.hpp"
+
+namespace dre {
+
+struct KernelStat {
+    double ms = 0.0;
+    long launches = 0;
+    double bytes = 0.0;   // algorithmic bytes attributed by the launcher
+    double flops = 0.0;
+};
+
+struct KernelTimer {
+    struct Pending { std::string name; hipEvent_t a, b; double bytes, flops; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    std::map<std::string, KernelStat> stats;
+    bool enabled = false;
+
+    hipEvent_t get_event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e; DRE_HIP(hipEventCreate(&e)); return e;
+    }
+    void collect(Ctx* ctx) {
+        if (pending.empty()) return;
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        for (auto& p : pending) {
+            float ms = 0.f;
+            DRE_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+            auto& s = stats[p.name];
+            s.ms += ms; s.launches += 1; s.bytes += p.bytes; s.flops += p.flops;
+            free_events.push_back(p.a); free_events.push_back(p.b);
+        }
+        pending.clear();
+    }
+    ~KernelTimer() {
+        for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+        for (auto e : free_events) (void)hipEventDestroy(e);
+    }
+};
+
+// RAII scope: records an event pair around whatever is launched inside when timing is enabled.
+struct TimedScope {
+    Ctx* ctx; bool on; hipEvent_t a{}, b{}; const char* name; double bytes, flops;
+    TimedScope(Ctx* c, const char* nm, double by = 0, double fl = 0)
+        : ctx(c), on(c->timer && c->timer->enabled), name(nm), bytes(by), flops(fl) {
+        if (on) {
+            a = ctx->timer->get_event(); b = ctx->timer->get_event();
+            (void)hipEventRecord(a, ctx->stream);
+        }
+    }
+    ~TimedScope() {
+        if (on) {
+            (void)hipEventRecord(b, ctx->stream);
+            ctx->timer->pending.push_back({name, a, b, bytes, flops});
+            if (ctx->timer->pending.size() > 4096) {
+                try { ctx->timer->collect(ctx); } catch (...) {}
+            }
+        }
+    }
+};
+
+}  // namespace dre

@@ -1,0 +1,368 @@
+// Sparse kernels for gfx950: CSR SpMM, multifrontal LU (assembly, extend-add, dense partial LU with
+// inverted diagonal blocks) and level-scheduled multi-RHS triangular solves, real and complex.
+#include "sparse.hpp"
+#include "profiling.hpp"
+
+#include <algorithm>
+
+namespace dre {
+
+// =============================================================================================
+// Pencil construction (host)
+// =============================================================================================
+std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const int64_t* Ei, const double* Ev,
+                                      const int64_t* Ap, const int64_t* Ai, const double* Av, int base, int leaf_size,
+                                      bool upload, std::vector<double>* hostE, std::vector<double>* hostA) {
+    DRE_REQUIRE(n > 0, "pencil_create: n must be positive");
+    DRE_REQUIRE(base == 0 || base == 1, "pencil_create: index base must be 0 or 1");
+    auto P = std::make_unique<Pencil>();
+    P->n = n;
+    // The CSC arrays of a matrix are the CSR arrays of its transpose: "row" c below is column c of E / A.
+    std::vector<int> uptr(n + 1, 0), uidx;
+    {
+        std::vector<int> tmp;
+        for (int c = 0; c < n; ++c) {
+            tmp.clear();
+            for (int64_t p = Ep[c] - base; p < Ep[c + 1] - base; ++p) tmp.push_back((int)(Ei[p] - base));
+            for (int64_t p = Ap[c] - base; p < Ap[c + 1] - base; ++p) tmp.push_back((int)(Ai[p] - base));
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            for (int r : tmp) DRE_REQUIRE(r >= 0 && r < n, "pencil_create: row index out of range");
+            uidx.insert(uidx.end(), tmp.begin(), tmp.end());
+            uptr[c + 1] = (int)uidx.size();
+        }
+    }
+    int leaf = leaf_size > 0 ? leaf_size : (n <= 2000 ? 24 : 32);
+    P->sym = symbolic_analyze(n, uptr, uidx, leaf);
+    const Symbolic& S = P->sym;
+    P->nnz = (int)S.idx.size();
+    // scatter values into the permuted pattern
+    std::vector<double> vE(P->nnz, 0.0), vA(P->nnz, 0.0);
+    auto scatter = [&](const int64_t* Cp, const int64_t* Ci, const double* Cv, std::vector<double>& out) {
+        for (int c = 0; c < n; ++c) {
+            const int pr = S.iperm[c];   // row of the transposed, permuted matrix
+            const int* rb = S.idx.data() + S.ptr[pr];
+            const int* re = S.idx.data() + S.ptr[pr + 1];
+            for (int64_t p = Cp[c] - base; p < Cp[c + 1] - base; ++p) {
+                const int pc = S.iperm[(int)(Ci[p] - base)];
+                const int* it = std::lower_bound(rb, re, pc);
+                if (it == re || *it != pc) throw Error(ERR_INTERNAL, "pencil_create: entry missing from union pattern");
+                out[S.ptr[pr] + (it - rb)] += Cv[p];
+            }
+        }
+    };
+    scatter(Ep, Ei, Ev, vE);
+    scatter(Ap, Ai, Av, vA);
+    if (hostE) *hostE = vE;
+    if (hostA) *hostA = vA;
+    P->lvl_maxfront.assign(S.nlevels, 0);
+    for (int t = 0; t < S.nnodes; ++t) P->lvl_maxfront[S.level[t]] = std::max(P->lvl_maxfront[S.level[t]], S.fsize(t));
+    if (!upload) return P;
+
+    auto up_i = [&](DevArr<int>& d, const std::vector<int>& h) { d = DevArr<int>(ctx, std::max<size_t>(h.size(), 1)); d.upload(ctx, h); };
+    auto up_l = [&](DevArr<int64_t>& d, const std::vector<int64_t>& h) { d = DevArr<int64_t>(ctx, std::max<size_t>(h.size(), 1)); d.upload(ctx, h); };
+    up_i(P->ptr, S.ptr); up_i(P->idx, S.idx);
+    P->valEt = DevArr<double>(ctx, P->nnz); P->valEt.upload(ctx, vE);
+    P->valAt = DevArr<double>(ctx, P->nnz); P->valAt.upload(ctx, vA);
+    up_i(P->perm, S.perm); up_i(P->iperm, S.iperm);
+    up_i(P->dev.first, S.first); up_i(P->dev.size, S.size); up_i(P->dev.bptr, S.bptr); up_i(P->dev.bidx, S.bidx);
+    up_i(P->dev.cmap_ptr, S.cmap_ptr); up_i(P->dev.cmap, S.cmap); up_i(P->dev.child_ptr, S.child_ptr);
+    up_i(P->dev.child_idx, S.child_idx); up_i(P->dev.lvl_nodes, S.lvl_nodes);
+    up_l(P->dev.front_off, S.front_off); up_l(P->dev.inv_off, S.inv_off); up_l(P->dev.upd_off, S.upd_off);
+    up_l(P->dev.asm_dest, S.asm_dest);
+    P->has_device = true;
+    return P;
+}
+
+// =============================================================================================
+// SpMM: one thread per row, 8 columns per workgroup column-slice.  Rows of a 7-point FEM operator
+// are short (<= 7 nnz), so a row-per-thread mapping keeps loads of Y/X coalesced along the rows
+// (column-major panels) and the gathered X rows hit L2.
+// =============================================================================================
+#define SPMM_CB 8
+__global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                              const double* __restrict__ val, const double* __restrict__ X, int ldx,
+                                              double* __restrict__ Y, int ldy, int ncols, double alpha, double beta,
+                                              const AdiState* st) {
+    if (st && st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c0 = blockIdx.y * SPMM_CB;
+    const int c1 = min(ncols, c0 + SPMM_CB);
+    const int pb = ptr[i], pe = ptr[i + 1];
+    double acc[SPMM_CB];
+#pragma unroll
+    for (int c = 0; c < SPMM_CB; ++c) acc[c] = 0.0;
+    for (int p = pb; p < pe; ++p) {
+        const double v = val[p];
+        const double* x = X + idx[p] + (size_t)c0 * ldx;
+#pragma unroll
+        for (int c = 0; c < SPMM_CB; ++c)
+            if (c0 + c < c1) acc[c] += v * x[(size_t)c * ldx];
+    }
+#pragma unroll
+    for (int c = 0; c < SPMM_CB; ++c)
+        if (c0 + c < c1) {
+            double* y = Y + i + (size_t)(c0 + c) * ldy;
+            *y = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
+        }
+}
+void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
+          double beta, const AdiState* st) {
+    DRE_REQUIRE(X.rows == n && Y.rows == n && X.cols == Y.cols, "spmm: shape mismatch");
+    if (X.cols == 0) return;
+    // algorithmic bytes: CSR (12 B/nnz + 4 B/row) + X read + Y read/write
+    TimedScope ts(ctx, "spmm_csr", 12.0 * 7.0 * n + 4.0 * n + 8.0 * n * X.cols * (beta == 0.0 ? 2.0 : 3.0), 2.0 * 7.0 * n * X.cols);
+    hipLaunchKernelGGL(k_spmm, dim3(ceil_div(n, 256), ceil_div(X.cols, SPMM_CB)), dim3(256), 0, ctx->stream, n, ptr, idx, val,
+                       X.p, X.ld, Y.p, Y.ld, X.cols, alpha, beta, st);
+    DRE_HIP(hipGetLastError());
+}
+__global__ void k_axpby(int n, double a, const double* __restrict__ x, double b, const double* __restrict__ y, double* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + b * y[i];
+}
+void vals_axpby(Ctx* ctx, int nnz, double a, const double* x, double b, const double* y, double* out) {
+    hipLaunchKernelGGL(k_axpby, dim3(ceil_div(nnz, 256)), dim3(256), 0, ctx->stream, nnz, a, x, b, y, out);
+}
+__global__ void k_permute_rows(int rows, int cols, const double* __restrict__ src, int lds, const int* __restrict__ map,
+                               double* __restrict__ dst, int ldd) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)rows * cols) return;
+    int r = id % rows, c = id / rows;
+    dst[r + (size_t)c * ldd] = src[map[r] + (size_t)c * lds];
+}
+void permute_rows(Ctx* ctx, const Mat& src, const int* map, Mat& dst) {
+    DRE_REQUIRE(src.rows == dst.rows && src.cols == dst.cols, "permute_rows: shape mismatch");
+    size_t tot = (size_t)src.rows * src.cols;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_permute_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src.rows, src.cols, src.p, src.ld, map, dst.p, dst.ld);
+}
+
+// =============================================================================================
+// Multifrontal numeric factorisation
+// =============================================================================================
+template <typename T>
+__global__ void k_assemble(int nnz, const int64_t* __restrict__ dest, const double* __restrict__ vF,
+                           const double* __restrict__ vE, T cF, T cE, T* __restrict__ fronts) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nnz) fronts[dest[p]] = cF * vF[p] + cE * vE[p];
+}
+
+struct MfArgs {
+    const int *first, *size, *bptr, *bidx, *cmap_ptr, *cmap, *child_ptr, *child_idx, *lvl_nodes;
+    const int64_t *front_off, *inv_off, *upd_off;
+};
+
+// One workgroup per front of the level: extend-add the children's Schur complements, eliminate the
+// s pivot columns (right-looking, no pivoting), then invert the two triangular diagonal blocks.
+template <typename T>
+__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err) {
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    T* F = fronts + a.front_off[t];
+    for (int ci = a.child_ptr[t]; ci < a.child_ptr[t + 1]; ++ci) {
+        const int c = a.child_idx[ci];
+        const int sc = a.size[c], bc = a.bptr[c + 1] - a.bptr[c], fc = sc + bc;
+        const T* Fc = fronts + a.front_off[c];
+        const int* map = a.cmap + a.cmap_ptr[c];
+        for (int id = tid; id < bc * bc; id += nt) {
+            const int i = id % bc, j = id / bc;
+            F[map[i] + (size_t)map[j] * f] += Fc[(sc + i) + (size_t)(sc + j) * fc];
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < s; ++k) {
+        __syncthreads();
+        const T piv = F[k + (size_t)k * f];
+        if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) { if (tid == 0) *err = 1; return; }
+        const T rp = recip(piv);
+        for (int i = k + 1 + tid; i < f; i += nt) F[i + (size_t)k * f] *= rp;
+        __syncthreads();
+        const int nr = f - k - 1;
+        for (int id = tid; id < nr * nr; id += nt) {
+            const int i = k + 1 + id % nr, j = k + 1 + id / nr;
+            F[i + (size_t)j * f] -= F[i + (size_t)k * f] * F[k + (size_t)j * f];
+        }
+    }
+    __syncthreads();
+    T* Ti = inv + a.inv_off[t];
+    for (int j = tid; j < s; j += nt) {
+        // column j of inv(L11) (unit lower), stored strictly below the diagonal
+        for (int i = j + 1; i < s; ++i) {
+            T acc = F[i + (size_t)j * f];
+            for (int k = j + 1; k < i; ++k) acc += F[i + (size_t)k * f] * Ti[k + (size_t)j * s];
+            Ti[i + (size_t)j * s] = -acc;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < s; j += nt) {
+        // column j of inv(U11), stored on and above the diagonal
+        T dj = recip(F[j + (size_t)j * f]);
+        Ti[j + (size_t)j * s] = dj;
+        for (int i = j - 1; i >= 0; --i) {
+            T acc = make_scalar<T>(0.0, 0.0);
+            for (int k = i + 1; k <= j; ++k) acc += F[i + (size_t)k * f] * Ti[k + (size_t)j * s];
+            Ti[i + (size_t)j * s] = -(acc * recip(F[i + (size_t)i * f]));
+        }
+    }
+}
+
+static MfArgs mf_args(const Pencil& P) {
+    MfArgs a;
+    a.first = P.dev.first.p; a.size = P.dev.size.p; a.bptr = P.dev.bptr.p; a.bidx = P.dev.bidx.p;
+    a.cmap_ptr = P.dev.cmap_ptr.p; a.cmap = P.dev.cmap.p; a.child_ptr = P.dev.child_ptr.p; a.child_idx = P.dev.child_idx.p;
+    a.lvl_nodes = P.dev.lvl_nodes.p; a.front_off = P.dev.front_off.p; a.inv_off = P.dev.inv_off.p; a.upd_off = P.dev.upd_off.p;
+    return a;
+}
+
+template <typename T>
+void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out) {
+    DRE_REQUIRE(P.has_device, "mf_factor: pencil has no device data");
+    const Symbolic& S = P.sym;
+    if (!out.fronts.p) out.fronts = DevArr<T>(ctx, (size_t)std::max<int64_t>(S.fronts_size, 1));
+    if (!out.inv.p) out.inv = DevArr<T>(ctx, (size_t)std::max<int64_t>(S.inv_size, 1));
+    TimedScope ts(ctx, sizeof(T) == 8 ? "mf_factor_real" : "mf_factor_complex", (double)sizeof(T) * 2.0 * S.fronts_size, 0);
+    DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(T), ctx->stream));
+    if (!out.err.p) out.err = DevArr<int>(ctx, 1);
+    DevArr<int>& err = out.err;
+    DRE_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p);
+    MfArgs a = mf_args(P);
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+        const int nt = P.lvl_maxfront[l] > 96 ? 1024 : 256;
+        hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p);
+    }
+    DRE_HIP(hipGetLastError());
+}
+template <typename T>
+void mf_check(Ctx* ctx, const Factor<T>& F) {
+    if (!F.err.p) return;
+    int herr = 0;
+    DRE_HIP(hipMemcpyAsync(&herr, F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    if (herr) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
+}
+template void mf_check<double>(Ctx*, const Factor<double>&);
+template void mf_check<cplx>(Ctx*, const Factor<cplx>&);
+template void mf_factor<double>(Ctx*, const Pencil&, const double*, const double*, double, double, Factor<double>&);
+template void mf_factor<cplx>(Ctx*, const Pencil&, const double*, const double*, cplx, cplx, Factor<cplx>&);
+
+// =============================================================================================
+// Multi-RHS triangular solves, one launch per tree level; a workgroup owns (front, slice of KC columns).
+// =============================================================================================
+#define MF_KC 8
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mf_forward(MfArgs a, int lvl_begin, const T* __restrict__ fronts,
+                                                    const T* __restrict__ inv, T* __restrict__ W, int ldw, int nrhs,
+                                                    T* __restrict__ upd, int64_t ldu, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double smraw[];
+    T* sm = reinterpret_cast<T*>(smraw);
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
+    const int c0 = blockIdx.y * MF_KC, kc = min(MF_KC, nrhs - c0);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    T* w = sm;               // f x kc
+    T* y = sm + (size_t)f * MF_KC;   // s x kc
+    const T* F = fronts + a.front_off[t];
+    const T* Ti = inv + a.inv_off[t];
+    for (int id = tid; id < f * kc; id += nt) {
+        const int i = id % f, c = id / f;
+        w[i + c * f] = (i < s) ? W[(first + i) + (size_t)(c0 + c) * ldw] : make_scalar<T>(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int ci = a.child_ptr[t]; ci < a.child_ptr[t + 1]; ++ci) {
+        const int ch = a.child_idx[ci];
+        const int bc = a.bptr[ch + 1] - a.bptr[ch];
+        const int* map = a.cmap + a.cmap_ptr[ch];
+        const T* uc = upd + a.upd_off[ch];
+        for (int id = tid; id < bc * kc; id += nt) {
+            const int i = id % bc, c = id / bc;
+            w[map[i] + c * f] += uc[i + (size_t)(c0 + c) * ldu];
+        }
+        __syncthreads();
+    }
+    for (int id = tid; id < s * kc; id += nt) {
+        const int i = id % s, c = id / s;
+        T acc = w[i + c * f];
+        for (int k = 0; k < i; ++k) acc += Ti[i + (size_t)k * s] * w[k + c * f];
+        y[i + c * s] = acc;
+        W[(first + i) + (size_t)(c0 + c) * ldw] = acc;
+    }
+    __syncthreads();
+    T* ut = upd + a.upd_off[t];
+    for (int id = tid; id < b * kc; id += nt) {
+        const int i = id % b, c = id / b;
+        T acc = w[s + i + c * f];
+        for (int k = 0; k < s; ++k) acc -= F[(s + i) + (size_t)k * f] * y[k + c * s];
+        ut[i + (size_t)(c0 + c) * ldu] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mf_backward(MfArgs a, int lvl_begin, const T* __restrict__ fronts,
+                                                     const T* __restrict__ inv, T* __restrict__ W, int ldw, int nrhs,
+                                                     const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double smraw[];
+    T* sm = reinterpret_cast<T*>(smraw);
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
+    const int c0 = blockIdx.y * MF_KC, kc = min(MF_KC, nrhs - c0);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    T* xb = sm;                       // b x kc
+    T* z = sm + (size_t)b * MF_KC;    // s x kc
+    const T* F = fronts + a.front_off[t];
+    const T* Ti = inv + a.inv_off[t];
+    const int* B = a.bidx + a.bptr[t];
+    for (int id = tid; id < b * kc; id += nt) {
+        const int i = id % b, c = id / b;
+        xb[i + c * b] = W[B[i] + (size_t)(c0 + c) * ldw];
+    }
+    __syncthreads();
+    for (int id = tid; id < s * kc; id += nt) {
+        const int i = id % s, c = id / s;
+        T acc = W[(first + i) + (size_t)(c0 + c) * ldw];
+        for (int k = 0; k < b; ++k) acc -= F[i + (size_t)(s + k) * f] * xb[k + c * b];
+        z[i + c * s] = acc;
+    }
+    __syncthreads();
+    for (int id = tid; id < s * kc; id += nt) {
+        const int i = id % s, c = id / s;
+        T acc = make_scalar<T>(0.0, 0.0);
+        for (int k = i; k < s; ++k) acc += Ti[i + (size_t)k * s] * z[k + c * s];
+        W[(first + i) + (size_t)(c0 + c) * ldw] = acc;
+    }
+}
+
+template <typename T>
+void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st) {
+    if (nrhs <= 0) return;
+    const Symbolic& S = P.sym;
+    MfArgs a = mf_args(P);
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    DevArr<T> upd(ctx, (size_t)ldu * nrhs);
+    const int ncb = ceil_div(nrhs, MF_KC);
+    // algorithmic bytes: factor entries once per sweep + panel read/write per sweep
+    const double bytes = 2.0 * sizeof(T) * (double)S.factor_nnz + 4.0 * sizeof(T) * (double)P.n * nrhs;
+    const double flops = (sizeof(T) == 8 ? 2.0 : 8.0) * 2.0 * (double)S.factor_nnz * nrhs;
+    TimedScope ts(ctx, sizeof(T) == 8 ? "mf_solve_real" : "mf_solve_complex", bytes, flops);
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+        const size_t shm = (size_t)(P.lvl_maxfront[l] * 2) * MF_KC * sizeof(T);
+        hipLaunchKernelGGL((k_mf_forward<T>), dim3(nb, ncb), dim3(256), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd.p, ldu, st);
+    }
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+        const size_t shm = (size_t)(P.lvl_maxfront[l]) * MF_KC * sizeof(T);
+        hipLaunchKernelGGL((k_mf_backward<T>), dim3(nb, ncb), dim3(256), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+    }
+    DRE_HIP(hipGetLastError());
+}
+template void mf_solve<double>(Ctx*, const Pencil&, const Factor<double>&, double*, int, int, const AdiState*);
+template void mf_solve<cplx>(Ctx*, const Pencil&, const Factor<cplx>&, cplx*, int, int, const AdiState*);
+
+}  // namespace dre

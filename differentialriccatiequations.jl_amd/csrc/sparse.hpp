@@ -1,0 +1,88 @@
+// Sparse side of the engine: the pencil (E', A' on one union pattern in nested-dissection order),
+// CSR SpMM, and the multifrontal LU of the shifted operator with multi-RHS solves.
+#pragma once
+#include "common.hpp"
+#include "dense.hpp"
+#include "symbolic.hpp"
+
+namespace dre {
+
+struct cplx {
+    double re, im;
+};
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return {a.re - b.re, a.im - b.im}; }
+__host__ __device__ inline cplx operator-(cplx a) { return {-a.re, -a.im}; }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__host__ __device__ inline cplx operator*(cplx a, double b) { return {a.re * b, a.im * b}; }
+__host__ __device__ inline cplx operator*(double b, cplx a) { return {a.re * b, a.im * b}; }
+__host__ __device__ inline cplx& operator+=(cplx& a, cplx b) { a.re += b.re; a.im += b.im; return a; }
+__host__ __device__ inline cplx& operator-=(cplx& a, cplx b) { a.re -= b.re; a.im -= b.im; return a; }
+__host__ __device__ inline cplx& operator*=(cplx& a, cplx b) { a = a * b; return a; }
+__host__ __device__ inline cplx recip(cplx a) {
+    // Smith's algorithm
+    if (fabs(a.re) >= fabs(a.im)) {
+        double r = a.im / a.re, d = a.re + a.im * r;
+        return {1.0 / d, -r / d};
+    }
+    double r = a.re / a.im, d = a.re * r + a.im;
+    return {r / d, -1.0 / d};
+}
+__host__ __device__ inline double recip(double a) { return 1.0 / a; }
+__host__ __device__ inline double abs1(double a) { return fabs(a); }
+__host__ __device__ inline double abs1(cplx a) { return fabs(a.re) + fabs(a.im); }
+template <typename T> __host__ __device__ inline T make_scalar(double re, double im);
+template <> __host__ __device__ inline double make_scalar<double>(double re, double) { return re; }
+template <> __host__ __device__ inline cplx make_scalar<cplx>(double re, double im) { return {re, im}; }
+
+// Device copies of the symbolic structure
+struct SymbolicDev {
+    DevArr<int> first, size, bptr, bidx, cmap_ptr, cmap, child_ptr, child_idx, lvl_nodes;
+    DevArr<int64_t> front_off, inv_off, upd_off, asm_dest;
+};
+
+// E' and A' (CSR == the caller's CSC of E and A) on one union pattern, permuted to the solver ordering.
+struct Pencil {
+    int n = 0, nnz = 0;
+    Symbolic sym;
+    SymbolicDev dev;
+    DevArr<int> ptr, idx;           // permuted union pattern, CSR, 0-based
+    DevArr<double> valEt, valAt;    // values of E' and A' on that pattern
+    DevArr<int> perm, iperm;        // device copies (perm[new] = old)
+    std::vector<int> lvl_maxfront;  // per level: largest front
+    bool has_device = false;
+};
+
+// Build from CSC arrays (1-based or 0-based) of E and A as Julia's SparseMatrixCSC stores them.
+// upload = false builds the host part only (no GPU needed; used by CPU tests of the symbolic phase).
+std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const int64_t* Ei, const double* Ev,
+                                      const int64_t* Ap, const int64_t* Ai, const double* Av, int index_base,
+                                      int leaf_size, bool upload, std::vector<double>* hostE = nullptr,
+                                      std::vector<double>* hostA = nullptr);
+
+// Y = alpha * M * X + beta * Y with M given by CSR (ptr, idx, val) of order n; X, Y are n x ncols.
+void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
+          double beta, const AdiState* st = nullptr);
+// out = a*x + b*y on value arrays of the shared pattern (shifted-operator assembly K4, values only)
+void vals_axpby(Ctx* ctx, int nnz, double a, const double* x, double b, const double* y, double* out);
+// row permutation helpers: dst(i,:) = src(map[i],:)
+void permute_rows(Ctx* ctx, const Mat& src, const int* map_dev, Mat& dst);
+
+template <typename T>
+struct Factor {
+    DevArr<T> fronts;   // all frontal matrices (L\U of the eliminated block, L21, U12, Schur complement)
+    DevArr<T> inv;      // inverted diagonal blocks: strict lower = inv(L11), upper = inv(U11)
+    DevArr<int> err;    // device flag: zero / NaN pivot met (checked lazily by mf_check)
+};
+
+// Numeric multifrontal LU (no pivoting) of  M = cF * F' + cE * E'  where valF/valE live on the pencil's pattern.
+template <typename T>
+void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out);
+// Synchronises and throws ERR_SINGULAR if the factorisation met a zero pivot.
+template <typename T>
+void mf_check(Ctx* ctx, const Factor<T>& F);
+// In-place solve  M * X = W  for the n x nrhs panel W (column-major, leading dimension ldw), solver ordering.
+template <typename T>
+void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& F, T* W, int ldw, int nrhs, const AdiState* st = nullptr);
+
+}  // namespace dre

@@ -1,0 +1,277 @@
+"""Thin object layer over the C ABI: contexts, device matrices, pencils, factors, device LDLᵀ handles."""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _lib
+from ._lib import AdiOptionsC, DREError, check
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i64ptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class Context:
+    """One context per GPU / host thread (dre_ctx_create)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        rc = self.lib.dre_ctx_create(int(device), C.byref(p))
+        if rc != 0:
+            raise DREError(rc, (self.lib.dre_last_error(None) or b"").decode())
+        self.ptr = p
+        self.device = device
+        self._fin = weakref.finalize(self, self.lib.dre_ctx_destroy, p)
+
+    def chk(self, rc):
+        return check(self.ptr, rc)
+
+    def sync(self):
+        self.chk(self.lib.dre_ctx_sync(self.ptr))
+
+    def info(self):
+        a = (C.c_int64 * 2)()
+        self.lib.dre_ctx_info(self.ptr, a)
+        return {"cus": a[0], "pool_bytes": a[1]}
+
+    # --- profiling -------------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self.chk(self.lib.dre_prof_enable(self.ptr, 1 if on else 0))
+
+    def prof_reset(self):
+        self.chk(self.lib.dre_prof_reset(self.ptr))
+
+    def prof_stats(self):
+        n = C.c_int()
+        self.chk(self.lib.dre_prof_count(self.ptr, C.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            ms, by, fl = C.c_double(), C.c_double(), C.c_double()
+            cnt = C.c_int64()
+            self.chk(self.lib.dre_prof_get(self.ptr, i, name, 128, C.byref(ms), C.byref(cnt), C.byref(by), C.byref(fl)))
+            out[name.value.decode()] = dict(ms=ms.value, launches=cnt.value, bytes=by.value, flops=fl.value)
+        return out
+
+    # --- dense -----------------------------------------------------------------------------
+    def upload(self, a) -> "DenseMatrix":
+        a = np.asfortranarray(np.atleast_2d(np.asarray(a, dtype=np.float64)))
+        p = C.c_void_p()
+        self.chk(self.lib.dre_dense_upload(self.ptr, a.shape[0], a.shape[1], _dptr(a), max(a.shape[0], 1), C.byref(p)))
+        return DenseMatrix(self, p)
+
+    def zeros(self, rows, cols) -> "DenseMatrix":
+        p = C.c_void_p()
+        self.chk(self.lib.dre_dense_create(self.ptr, rows, cols, C.byref(p)))
+        return DenseMatrix(self, p)
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def set_default_context(ctx):
+    global _default_ctx
+    _default_ctx = ctx
+
+
+class DenseMatrix:
+    def __init__(self, ctx: Context, ptr):
+        self.ctx, self.ptr = ctx, ptr
+        self._fin = weakref.finalize(self, ctx.lib.dre_dense_free, ctx.ptr, ptr)
+
+    @property
+    def shape(self):
+        r, c = C.c_int(), C.c_int()
+        self.ctx.lib.dre_dense_shape(self.ptr, C.byref(r), C.byref(c))
+        return (r.value, c.value)
+
+    def numpy(self):
+        r, c = self.shape
+        out = np.zeros((r, c), order="F")
+        self.ctx.chk(self.ctx.lib.dre_dense_download(self.ctx.ptr, self.ptr, _dptr(out), max(r, 1)))
+        return out
+
+
+def _csc_arrays(M):
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    return (np.ascontiguousarray(M.indptr, dtype=np.int64), np.ascontiguousarray(M.indices, dtype=np.int64),
+            np.ascontiguousarray(M.data, dtype=np.float64))
+
+
+class Pencil:
+    """(E, A) on one union pattern, nested-dissection ordered, symbolically analysed once (dre_pencil_create)."""
+
+    def __init__(self, E, A, ctx: Context | None = None, leaf_size: int = 0, host_only: bool = False):
+        self.lib = _lib.load()
+        n = E.shape[0]
+        assert E.shape == (n, n) and A.shape == (n, n)
+        Ep, Ei, Ev = _csc_arrays(E)
+        Ap, Ai, Av = _csc_arrays(A)
+        p = C.c_void_p()
+        self.ctx = None if host_only else (ctx or default_context())
+        if host_only:
+            rc = self.lib.dre_pencil_create_host(n, _i64ptr(Ep), _i64ptr(Ei), _dptr(Ev), _i64ptr(Ap), _i64ptr(Ai), _dptr(Av), 0, leaf_size, C.byref(p))
+            if rc != 0:
+                raise DREError(rc, (self.lib.dre_last_error(None) or b"").decode())
+        else:
+            self.ctx.chk(self.lib.dre_pencil_create(self.ctx.ptr, n, _i64ptr(Ep), _i64ptr(Ei), _dptr(Ev), _i64ptr(Ap), _i64ptr(Ai), _dptr(Av), 0, leaf_size, C.byref(p)))
+        self.ptr = p
+        self.n = n
+        self._fin = weakref.finalize(self, self.lib.dre_pencil_free, p)
+
+    def info(self):
+        a = (C.c_int64 * 8)()
+        self.lib.dre_pencil_info(self.ptr, a)
+        keys = ["n", "nnz", "nodes", "levels", "max_front", "max_sep", "factor_nnz", "fronts_size"]
+        return dict(zip(keys, list(a)))
+
+    def array(self, name: str) -> np.ndarray:
+        ln = C.c_int64()
+        rc = self.lib.dre_pencil_get_array(self.ptr, name.encode(), None, 0, C.byref(ln))
+        if rc != 0:
+            raise KeyError(name)
+        out = np.zeros(ln.value, dtype=np.int64)
+        self.lib.dre_pencil_get_array(self.ptr, name.encode(), _i64ptr(out), ln.value, C.byref(ln))
+        return out
+
+    def values(self, which: int) -> np.ndarray:
+        nnz = self.info()["nnz"]
+        out = np.zeros(nnz)
+        rc = self.lib.dre_pencil_get_values(self.ptr, which, _dptr(out), nnz)
+        assert rc == 0
+        return out
+
+    # --- kernels ---------------------------------------------------------------------------
+    def spmm(self, which, X, alpha=1.0, beta=0.0, Y=None):
+        """Y = alpha * M' X + beta * Y with M = E (which=0) or A (which=1)."""
+        ctx = self.ctx
+        Xd = X if isinstance(X, DenseMatrix) else ctx.upload(X)
+        if Y is None:
+            Yd = ctx.zeros(*Xd.shape)
+        else:
+            Yd = Y if isinstance(Y, DenseMatrix) else ctx.upload(Y)
+        ctx.chk(self.lib.dre_spmm(ctx.ptr, self.ptr, which, alpha, Xd.ptr, beta, Yd.ptr))
+        return Yd
+
+    def factor(self, cA: float, cE: complex) -> "Factor":
+        cE = complex(cE)
+        p = C.c_void_p()
+        self.ctx.chk(self.lib.dre_shift_factor(self.ctx.ptr, self.ptr, float(cA), cE.real, cE.imag, C.byref(p)))
+        return Factor(self, p, cE.imag != 0.0)
+
+
+class Factor:
+    """factorize(cA*A' + cE*E') — multifrontal LU on the device."""
+
+    def __init__(self, pencil: Pencil, ptr, is_complex):
+        self.pencil, self.ptr, self.is_complex = pencil, ptr, is_complex
+        self._fin = weakref.finalize(self, pencil.lib.dre_factor_free, pencil.ctx.ptr, ptr)
+
+    def solve(self, B):
+        ctx = self.pencil.ctx
+        Bd = B if isinstance(B, DenseMatrix) else ctx.upload(B)
+        xr, xi = C.c_void_p(), C.c_void_p()
+        ctx.chk(ctx.lib.dre_shift_solve(ctx.ptr, self.ptr, Bd.ptr, C.byref(xr), C.byref(xi)))
+        Xr = DenseMatrix(ctx, xr).numpy()
+        if self.is_complex:
+            return Xr + 1j * DenseMatrix(ctx, xi).numpy()
+        return Xr
+
+
+class DeviceLDLt:
+    """Handle of an LDLᵀ object living on the device (dre_ldlt_*)."""
+
+    def __init__(self, ctx: Context, ptr, pencil: Pencil | None):
+        self.ctx, self.ptr, self.pencil = ctx, ptr, pencil
+        self._fin = weakref.finalize(self, ctx.lib.dre_ldlt_free, ctx.ptr, ptr)
+
+    @classmethod
+    def create(cls, ctx, pencil, L, D, alpha=1.0):
+        Ld, Dd = ctx.upload(L), ctx.upload(D)
+        p = C.c_void_p()
+        ctx.chk(ctx.lib.dre_ldlt_create(ctx.ptr, pencil.ptr if pencil else None, Ld.ptr, Dd.ptr, float(alpha), C.byref(p)))
+        return cls(ctx, p, pencil)
+
+    @classmethod
+    def zero(cls, ctx, pencil, n):
+        p = C.c_void_p()
+        ctx.chk(ctx.lib.dre_ldlt_zero(ctx.ptr, pencil.ptr if pencil else None, n, C.byref(p)))
+        return cls(ctx, p, pencil)
+
+    def info(self):
+        n, r, b = C.c_int(), C.c_int(), C.c_int()
+        self.ctx.lib.dre_ldlt_info(self.ptr, C.byref(n), C.byref(r), C.byref(b))
+        return n.value, r.value, b.value
+
+    def add(self, other):
+        p = C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_ldlt_add(self.ctx.ptr, self.ptr, other.ptr, C.byref(p)))
+        return DeviceLDLt(self.ctx, p, self.pencil)
+
+    def scale(self, alpha):
+        p = C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_ldlt_scale(self.ctx.ptr, self.ptr, float(alpha), C.byref(p)))
+        return DeviceLDLt(self.ctx, p, self.pencil)
+
+    def concatenate(self):
+        self.ctx.chk(self.ctx.lib.dre_ldlt_concatenate(self.ctx.ptr, self.ptr))
+
+    def compress(self):
+        self.ctx.chk(self.ctx.lib.dre_ldlt_compress(self.ctx.ptr, self.ptr))
+
+    def norm(self):
+        out = C.c_double()
+        self.ctx.chk(self.ctx.lib.dre_ldlt_norm(self.ctx.ptr, self.ptr, C.byref(out)))
+        return out.value
+
+    def destructure(self):
+        """alpha, L, D (compresses if more than one component, like iterating the reference's LDLᵀ)."""
+        alpha = C.c_double()
+        self.ctx.chk(self.ctx.lib.dre_ldlt_destructure(self.ctx.ptr, self.ptr, C.byref(alpha), None, 1, None, 1))
+        n, r, _ = self.info()
+        L = np.zeros((n, r), order="F")
+        D = np.zeros((r, r), order="F")
+        self.ctx.chk(self.ctx.lib.dre_ldlt_destructure(self.ctx.ptr, self.ptr, C.byref(alpha), _dptr(L), max(n, 1), _dptr(D), max(r, 1)))
+        return alpha.value, L, D
+
+
+def make_adi_options(maxiters=100, reltol=None, abstol=None, ignore_initial_guess=False, compression_interval=10,
+                     compression=True, shift_kind=1, n_history=2, shifts=None, compress_tolfac=4.0):
+    o = AdiOptionsC()
+    _lib.load().dre_adi_default_options(C.byref(o))
+    o.maxiters = int(maxiters)
+    o.reltol = -1.0 if reltol is None else float(reltol)
+    o.abstol = -1.0 if abstol is None else float(abstol)
+    o.ignore_initial_guess = int(bool(ignore_initial_guess))
+    o.compression_interval = int(compression_interval)
+    o.compression = int(bool(compression))
+    o.shift_kind = int(shift_kind)
+    o.n_history = int(n_history)
+    o.compress_tolfac = float(compress_tolfac)
+    keep = None
+    if shift_kind == 0:
+        sh = np.asarray(list(shifts), dtype=np.complex128)
+        re = np.ascontiguousarray(sh.real)
+        im = np.ascontiguousarray(sh.imag)
+        o.nshifts = len(sh)
+        o.shifts_re = _dptr(re)
+        o.shifts_im = _dptr(im)
+        keep = (re, im)
+    return o, keep

@@ -1,0 +1,171 @@
+/* libdre_hip — C ABI of the MI355X-native low-rank Rosenbrock/ADI engine.
+ *
+ * Drop-in boundary for the hot path of mpimd-csc/DifferentialRiccatiEquations.jl v0.5.5
+ *   solve(GDREProblem{<:LDLᵀ}, Ros1/Ros2(ADI(...)))  and everything below it.
+ * The reference has no FFI of its own (pure Julia, multiple dispatch); each entry point cites the
+ * reference method it replaces (paths relative to the reference tree).  The Julia shim that binds
+ * these symbols with `ccall` is differentialriccatiequations.jl_amd/julia/DREHip.jl; the ctypes
+ * binding used by the tests is differentialriccatiequations.jl_amd/_lib.py.  See INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns an int32 status: 0 ok, <0 error (dre_last_error(ctx) has the text);
+ *    no exception crosses the boundary;
+ *  - dense matrices are column-major Float64 (Julia `Matrix{Float64}`), sparse matrices are passed
+ *    as the three arrays of a Julia `SparseMatrixCSC{Float64,Int64}` (colptr, rowval, nzval; 1-based
+ *    with index_base = 1) — CSC of M is byte-for-byte CSR of M', which is what every product on
+ *    the path needs (E'V, A'L, (A'+pE')\R);
+ *  - host buffers belong to the caller, device objects to the context; every object has a *_free;
+ *  - one context per GPU / host thread; all work of a context is ordered on its private HIP stream;
+ *  - there is NO CPU fallback: without a usable HIP device dre_ctx_create fails with DRE_ERR_NODEVICE.
+ */
+#ifndef DRE_HIP_H
+#define DRE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRE_OK 0
+#define DRE_ERR_INVALID (-1)
+#define DRE_ERR_HIP (-2)
+#define DRE_ERR_ALLOC (-3)
+#define DRE_ERR_SINGULAR (-4)
+#define DRE_ERR_INTERNAL (-5)
+#define DRE_ERR_NODEVICE (-6)
+
+/* warning bits reported by ADI (AdiResult.warnings) */
+#define DRE_WARN_NOT_CONVERGED 1      /* src/lyapunov/adi.jl:125-126 */
+#define DRE_WARN_RITZ_DISCARDED 4     /* src/shifts/helpers.jl:133 */
+#define DRE_WARN_RITZ_FLIPPED 8       /* src/shifts/helpers.jl:136 */
+
+typedef struct dre_ctx dre_ctx;
+typedef struct dre_dense dre_dense;
+typedef struct dre_pencil dre_pencil;
+typedef struct dre_factor dre_factor;
+typedef struct dre_ldlt dre_ldlt;
+typedef struct dre_adi_result dre_adi_result;
+typedef struct dre_gdre_result dre_gdre_result;
+
+/* ---- context ------------------------------------------------------------------------------ */
+int dre_version(void);
+int dre_ctx_create(int device, dre_ctx** out);
+int dre_ctx_destroy(dre_ctx* ctx);
+const char* dre_last_error(dre_ctx* ctx);
+int dre_ctx_sync(dre_ctx* ctx);
+int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
+/* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
+ * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */
+int dre_prof_enable(dre_ctx* ctx, int on);
+int dre_prof_reset(dre_ctx* ctx);
+int dre_prof_count(dre_ctx* ctx, int* n);
+int dre_prof_get(dre_ctx* ctx, int i, char* name, int name_len, double* ms, int64_t* launches, double* bytes, double* flops);
+
+/* ---- dense matrices (array backend: similar/adapt/copyto!) ------------------- */
+int dre_dense_upload(dre_ctx* ctx, int rows, int cols, const double* host, int ld, dre_dense** out);
+int dre_dense_create(dre_ctx* ctx, int rows, int cols, dre_dense** out);            /* zero-filled */
+int dre_dense_download(dre_ctx* ctx, const dre_dense* a, double* host, int ld);
+int dre_dense_shape(const dre_dense* a, int* rows, int* cols);
+int dre_dense_free(dre_ctx* ctx, dre_dense* a);
+
+/* ---- the pencil (E, A): union pattern, nested-dissection ordering, symbolic multifrontal analysis,
+ *      done once per problem because the pattern of A' + pE' never changes
+ *      (replaces the per-step `factorize` analysis of src/blocklinear/backslash.jl:13) --------- */
+int dre_pencil_create(dre_ctx* ctx, int n, const int64_t* E_colptr, const int64_t* E_rowval, const double* E_nzval,
+                      const int64_t* A_colptr, const int64_t* A_rowval, const double* A_nzval, int index_base,
+                      int leaf_size, dre_pencil** out);
+/* host-only variant (no GPU touched): symbolic analysis for inspection / CPU tests */
+int dre_pencil_create_host(int n, const int64_t* E_colptr, const int64_t* E_rowval, const double* E_nzval,
+                           const int64_t* A_colptr, const int64_t* A_rowval, const double* A_nzval, int index_base,
+                           int leaf_size, dre_pencil** out);
+int dre_pencil_free(dre_pencil* p);
+/* info: [0]=n [1]=nnz(union) [2]=tree nodes [3]=levels [4]=max front [5]=max separator [6]=factor nnz [7]=fronts slab entries */
+int dre_pencil_info(const dre_pencil* p, int64_t* info);
+/* integer arrays of the symbolic structure by name ("perm","iperm","ptr","idx","first","size","parent","level",
+ * "child_ptr","child_idx","bptr","bidx","cmap_ptr","cmap","front_off","inv_off","upd_off","asm_dest","lvl_ptr","lvl_nodes") */
+int dre_pencil_get_array(const dre_pencil* p, const char* name, int64_t* out, int64_t cap, int64_t* len);
+int dre_pencil_get_values(const dre_pencil* p, int which /*0 = E', 1 = A'*/, double* out, int64_t cap);
+
+/* ---- kernels exposed one by one (extension points of SURVEY.md §8b; parity tests call these) -- */
+/* C = alpha*op(A)*op(B) + beta*C on the f64 MFMA path (LinearAlgebra.mul!) */
+int dre_gemm(dre_ctx* ctx, int transA, int transB, double alpha, const dre_dense* A, const dre_dense* B, double beta, dre_dense* C);
+/* Y = alpha*M'*X + beta*Y, M = E (which=0) or A (which=1): mul!(R, E', V, a, b) src/lyapunov/adi.jl:171,217 */
+int dre_spmm(dre_ctx* ctx, const dre_pencil* p, int which, double alpha, const dre_dense* X, double beta, dre_dense* Y);
+/* orthf(L) -> Q, R  (src/LDLt.jl:237-245) */
+int dre_orthf(dre_ctx* ctx, const dre_dense* L, dre_dense** Q, dre_dense** R);
+/* eigen(Symmetric(S)) with early-terminating tridiagonalisation (src/LDLt.jl:214); returns the j computed
+ * eigenpairs (all those above tolfac*eps*||S||_F in magnitude), values ascending */
+int dre_sym_eig(dre_ctx* ctx, const dre_dense* S, double tolfac, dre_dense** values, dre_dense** vectors);
+/* factorize(cA*A' + (cE_re + i cE_im)*E')  (src/blocklinear/backslash.jl:8-15); complex iff cE_im != 0 */
+int dre_shift_factor(dre_ctx* ctx, const dre_pencil* p, double cA, double cE_re, double cE_im, dre_factor** out);
+/* X = F \ B  (src/blocklinear/backslash.jl:17-21); X_im may be NULL for a real factor */
+int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_dense** X_re, dre_dense** X_im);
+int dre_factor_free(dre_ctx* ctx, dre_factor* f);
+
+/* ---- LDLᵀ objects (src/LDLt.jl) ------------------------------------------------------------ */
+/* lowrank(L, D) scaled by alpha; rows are permuted to the pencil's ordering when p != NULL */
+int dre_ldlt_create(dre_ctx* ctx, const dre_pencil* p, const dre_dense* L, const dre_dense* D, double alpha, dre_ldlt** out);
+int dre_ldlt_zero(dre_ctx* ctx, const dre_pencil* p, int n, dre_ldlt** out);
+int dre_ldlt_free(dre_ctx* ctx, dre_ldlt* x);
+int dre_ldlt_info(const dre_ldlt* x, int* n, int* rank, int* nblocks);
+int dre_ldlt_add(dre_ctx* ctx, const dre_ldlt* a, const dre_ldlt* b, dre_ldlt** out);          /* LDLt.jl:131-148 */
+int dre_ldlt_scale(dre_ctx* ctx, const dre_ldlt* a, double alpha, dre_ldlt** out);             /* LDLt.jl:156-159 */
+int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x);                                           /* LDLt.jl:174-191 */
+int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x);                                              /* LDLt.jl:204-225 */
+int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out);                                     /* LDLt.jl:77-89 */
+/* alpha, L, D = X  (LDLt.jl:54-60; compresses when more than one component); pass NULL buffers to query sizes */
+int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* L_host, int ldl, double* D_host, int ldd);
+
+/* ---- GALE / ADI (src/lyapunov/types.jl:10-32, adi.jl:29-225) --------------------------------- */
+typedef struct dre_adi_options {
+    int32_t maxiters;              /* 100 */
+    double reltol;                 /* < 0 = nothing -> n*eps */
+    double abstol;                 /* < 0 = nothing -> reltol*norm(C) */
+    int32_t ignore_initial_guess;  /* 0 */
+    int32_t compression_interval;  /* 10 */
+    int32_t compression;           /* 1 */
+    int32_t shift_kind;            /* 0 = Cyclic(values), 1 = Projection(n_history) */
+    int32_t n_history;             /* 2 */
+    int32_t nshifts;               /* Cyclic: number of values (conjugate pairs adjacent) */
+    const double* shifts_re;
+    const double* shifts_im;       /* may be NULL (all real) */
+    double compress_tolfac;        /* <= 0 -> 4 */
+} dre_adi_options;
+int dre_adi_default_options(dre_adi_options* opt);
+
+/* solve(GALEProblem(E, F, C), ADI(...); initial_guess) with F = cA*A + cE*E + inv(lr_alpha)*U*V
+ * (LowRankUpdate, src/LowRankUpdate.jl:18-39).  U is n x m, Vt = V' is n x m; both NULL for a plain sparse F. */
+int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
+                   const dre_dense* Vt, dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_result** out);
+/* residual(GALEProblem, X)  (src/lyapunov/residual.jl:3-31) */
+int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
+                      const dre_dense* Vt, dre_ldlt* C, dre_ldlt* X, dre_ldlt** out);
+/* info: [0]=iters [1]=converged [2]=warnings [3]=number of recorded norms [4]=rhs columns;  dinfo: [0]=res_norm [1]=abstol [2]=initial norm */
+int dre_adi_result_info(const dre_adi_result* r, int64_t* info, double* dinfo);
+int dre_adi_result_history(const dre_adi_result* r, double* norms, int32_t* norm_iters, double* shifts_re, double* shifts_im);
+int dre_adi_result_take_x(dre_adi_result* r, dre_ldlt** X);            /* observe_gale_done!(…, X, …) */
+int dre_adi_result_take_residual(dre_adi_result* r, dre_ldlt** R);
+int dre_adi_result_free(dre_adi_result* r);
+
+/* ---- GDRE (src/riccati/lowrank_ros1.jl:3-66, lowrank_ros2.jl:3-89) ---------------------------- */
+/* solve(GDREProblem(E, A, B, C, X0, (t0, tf)), Ros<order>(ADI(opt)); dt, save_state).  B is n x m, C is q x n. */
+int dre_gdre_solve(dre_ctx* ctx, const dre_pencil* p, const dre_dense* B, const dre_dense* C, dre_ldlt* X0, double t0,
+                   double tf, double dt, int order, int save_state, const dre_adi_options* opt, dre_gdre_result** out);
+/* info: [0]=time points [1]=stored states [2]=total ADI iterations [3]=sparse factorisations [4]=Lyapunov solves [5]=m [6]=n */
+int dre_gdre_result_info(const dre_gdre_result* r, int64_t* info);
+int dre_gdre_result_times(const dre_gdre_result* r, double* t);
+int dre_gdre_result_K(dre_ctx* ctx, const dre_gdre_result* r, int i, double* K_host /* m x n */, int ld);
+int dre_gdre_result_X(const dre_gdre_result* r, int i, dre_ldlt** X);   /* shares the factors (sol.X[1] === prob.X0) */
+/* per Lyapunov solve j: iinfo [0]=iters [1]=converged [2]=warnings [3]=rhs columns; dinfo [0]=res_norm [1]=abstol */
+int dre_gdre_result_gale(const dre_gdre_result* r, int j, int64_t* iinfo, double* dinfo);
+int dre_gdre_result_free(dre_gdre_result* r);
+
+/* ---- host helpers exposed for CPU tests of the Projection shift pipeline ---------------------- */
+int dre_host_eigvals(int n, const double* A, double* wr, double* wi);
+int dre_host_gen_eigvals(int n, const double* A, const double* E, double* wr, double* wi);
+int dre_host_svd_left(int p, int w, const double* R, double* U, double* sv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
