@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ADI iterations/sec + GDRE wall-clock, SteelProfile Ros1 LRSIF (BASELINE.json).
+
+One "step" = one complete low-rank Rosenbrock-1 solve of the generalized differential Riccati equation on the
+SteelProfile(n) surrogate: tspan = (4500, 0), dt = -100 (45 time steps), X0 = L(0.01 I)L', ADI with
+Cyclic real shifts (real parts of Heuristic(10,20,20), tests/golden/heuristic_shifts_<n>.npy), all inputs
+resident in HBM before the timed region starts.  N > 1: one process per GPU (torchrun), every rank solves an
+independent replica (time steps are sequentially dependent) and the K(t) feedback
+trajectories are gathered over RCCL/xGMI inside the timed region (weak scaling).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=371, help="SteelProfile size (371 = the configuration the metric is quoted on)")
+    ap.add_argument("--nsteps", type=int, default=45, help="Rosenbrock time steps per solve")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2, help="Rosenbrock time steps of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import dre_amd as D
+
+    n = args.n
+    d = D.steel_profile(n)
+    L, Dm = D.initial_value(d)
+    shifts = np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy"))
+    t0, dt = 4500.0, -100.0
+    tf = t0 + dt * args.nsteps
+
+    ctx = D.Context(local_rank)
+    lib = ctx.lib
+    pencil = D.Pencil(d.E, d.A, ctx)
+    # independent replicas: rank r starts from a slightly different X0 (0.01 * (1 + r/8) * L L')
+    Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
+    X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm * (1.0 + rank / 8.0), 1.0)
+    opt, keep = D.device.make_adi_options(shift_kind=0, shifts=list(shifts))
+    m = d.B.shape[1]
+    nt = args.nsteps + 1
+    Kdev = torch.empty((nt, n, m), dtype=torch.float64, device="cuda")       # nt blocks of m x n column-major
+    Kall = [torch.empty_like(Kdev) for _ in range(world)] if world > 1 else None
+
+    def one_solve(gather=True):
+        r = C.c_void_p()
+        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, tf, dt, 1, 0, C.byref(opt), C.byref(r)))
+        ii = (C.c_int64 * 7)()
+        lib.dre_gdre_result_info(r, ii)
+        ctx.chk(lib.dre_gdre_result_K_device(ctx.ptr, r, C.c_void_p(Kdev.data_ptr())))
+        ngale = ii[4]
+        nconv = 0
+        for j in range(ngale):
+            gi = (C.c_int64 * 4)(); gd = (C.c_double * 2)()
+            lib.dre_gdre_result_gale(r, j, gi, gd)
+            nconv += int(gi[1])
+        lib.dre_gdre_result_free(r)
+        if world > 1 and gather:
+            dist.all_gather(Kall, Kdev)          # RCCL over xGMI: the K(t) feedback trajectories of all replicas
+        return int(ii[2]), int(ii[3]), nconv, ngale
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_solve()
+    barrier()
+    t_start = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        it, nfac, nconv, ngale = one_solve()
+        iters += it
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    el_t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    it_t = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+    elapsed = float(el_t.item())
+    total_iters = float(it_t.item())
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: one extra identical solve with per-kernel HIP-event timing on the library stream
+        ctx.prof_reset()
+        ctx.prof_enable(True)
+        one_solve(gather=False)      # collectives stay matched across ranks: the profiled solve does not gather
+        stats = ctx.prof_stats()
+        ctx.prof_enable(False)
+        roof = None
+        if stats:
+            name, s = max(stats.items(), key=lambda kv: kv[1]["ms"])
+            total_ms = sum(v["ms"] for v in stats.values())
+            avg_s = s["ms"] * 1e-3 / max(s["launches"], 1)
+            if s["flops"] > 0 and s["bytes"] > 0 and s["flops"] / s["bytes"] > 12.0:
+                ach = s["flops"] / max(s["launches"], 1) / avg_s / 1e12
+                roof = dict(bound="mfma", kernel=name, achieved=ach, peak=78.6, unit="TFLOP/s", frac=ach / 78.6, traffic=None)
+            else:
+                ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
+                roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
+            roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
+                        measured_on="one extra profiled solve after the timed region (HIP events on the library stream)")
+            roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample
+        cpu = None
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import warnings
+            import dre_oracle as o
+            warnings.simplefilter("ignore")
+            st = []
+            tfc = t0 + dt * args.cpu_steps
+            tc = time.perf_counter()
+            o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm), (t0, tfc)), o.Ros1(o.ADI(shifts=o.Cyclic(list(shifts)))), dt=dt, stats=st)
+            tc = time.perf_counter() - tc
+            cpu_it = sum(s["iters"] for s in st)
+            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=os.cpu_count(), kind="port",
+                       sample=f"first {args.cpu_steps} of {args.nsteps} Rosenbrock steps of the same workload ({cpu_it} ADI iterations, {tc:.1f} s), "
+                              f"NumPy/SciPy oracle (OpenBLAS threads = all cores, SuperLU refactorised every ADI step like the reference)")
+        out = {
+            "metric": "ADI iterations/sec (GDRE Ros1 LRSIF, SteelProfile surrogate)",
+            "value": total_iters / elapsed,
+            "unit": "ADI iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "gdre_wall_clock_s": elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"SteelProfile({n}) surrogate, Ros1 LRSIF (LDL' X0), Cyclic real shifts (10 heuristic values), "
+                                   f"tspan=(4500,{tf:g}), dt=-100, {args.nsteps} time steps",
+                       "adi_iterations_per_solve": total_iters / (args.steps * world),
+                       "lyapunov_solves_converged": f"{nconv}/{ngale}",
+                       "sparse_factorizations_per_solve": nfac,
+                       "parallelism": f"replicas x{world}" + (" + RCCL all_gather of K(t)" if world > 1 else "")},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,7 @@ class AdiOptionsC(C.Structure):
         ("shifts_re", C.POINTER(C.c_double)),
         ("shifts_im", C.POINTER(C.c_double)),
         ("compress_tolfac", C.c_double),
+        ("compress_exact", C.c_int32),
     ]
 
 
@@ -82,6 +83,7 @@ PROTOTYPES = {
     "dre_ldlt_concatenate": (C.c_int, [_vp, _vp]),
     "dre_ldlt_compress": (C.c_int, [_vp, _vp]),
     "dre_ldlt_norm": (C.c_int, [_vp, _vp, _pd]),
+    "dre_ldlt_canonicalize": (C.c_int, [_vp, _vp]),
     "dre_ldlt_destructure": (C.c_int, [_vp, _vp, _pd, _pd, C.c_int, _pd, C.c_int]),
     "dre_adi_default_options": (C.c_int, [C.POINTER(AdiOptionsC)]),
     "dre_gale_solve": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
@@ -95,6 +97,7 @@ PROTOTYPES = {
     "dre_gdre_result_info": (C.c_int, [_vp, _pi64]),
     "dre_gdre_result_times": (C.c_int, [_vp, _pd]),
     "dre_gdre_result_K": (C.c_int, [_vp, _vp, C.c_int, _pd, C.c_int]),
+    "dre_gdre_result_K_device": (C.c_int, [_vp, _vp, _vp]),
     "dre_gdre_result_X": (C.c_int, [_vp, C.c_int, _pvp]),
     "dre_gdre_result_gale": (C.c_int, [_vp, C.c_int, _pi64, _pd]),
     "dre_gdre_result_free": (C.c_int, [_vp]),

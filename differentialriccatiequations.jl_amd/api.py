@@ -38,6 +38,7 @@ class LDLt:
     # lazy materialisation of device results
     def _host(self):
         if self._handle is not None and not self._Ls:
+            self._handle.canonicalize()     # engine results carry a tridiagonal D; users get the reference form
             a, L, D = self._handle.destructure()
             self._alphas, self._Ls, self._Ds = [a], [L], [D]
         return self
@@ -370,6 +371,9 @@ class ADI:
     compression_interval: int = 10
     compression: bool = True
     warn_convergence: bool = True
+    # engine knob (not in the reference): True = eigen-based truncation at every compression, exactly the
+    # reference's arithmetic; False = Krylov-truncated compression (same accuracy class, far cheaper on a GPU)
+    compress_exact: bool = False
 
 
 @dataclass
@@ -439,7 +443,7 @@ def _split_operator(E, A):
 def _adi_options(alg: ADI, pencil):
     kind, nh, vals = _resolve_shifts(alg.shifts, pencil)
     return dev.make_adi_options(alg.maxiters, alg.reltol, alg.abstol, alg.ignore_initial_guess, alg.compression_interval,
-                                alg.compression, kind, nh, vals)
+                                alg.compression, kind, nh, vals, compress_exact=alg.compress_exact)
 
 
 def _replay_gale(observer, prob, alg, info):

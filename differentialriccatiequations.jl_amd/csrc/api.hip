@@ -387,6 +387,12 @@ int dre_ldlt_scale(dre_ctx* ctx, const dre_ldlt* a, double alpha, dre_ldlt** out
 }
 int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldlt_concatenate(&ctx->c, *x->x); }); }
 int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldlt_compress(&ctx->c, *x->x); }); }
+int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x) {
+    return guarded(ctx, [&] {
+        LDLt& X = *x->x;
+        if (X.blocks.size() > 1 || (X.blocks.size() == 1 && !X.blocks[0].diag && X.blocks[0].L.cols > 0)) ldlt_compress(&ctx->c, X, 4.0, true);
+    });
+}
 int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out) { return guarded(ctx, [&] { *out = ldlt_norm(&ctx->c, *x->x); }); }
 int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* Lh, int ldl, double* Dh, int ldd) {
     return guarded(ctx, [&] {
@@ -405,6 +411,7 @@ int dre_adi_default_options(dre_adi_options* o) {
     o->maxiters = 100; o->reltol = -1.0; o->abstol = -1.0; o->ignore_initial_guess = 0; o->compression_interval = 10;
     o->compression = 1; o->shift_kind = 1; o->n_history = 2; o->nshifts = 0; o->shifts_re = nullptr; o->shifts_im = nullptr;
     o->compress_tolfac = 4.0;
+    o->compress_exact = 0;
     return DRE_OK;
 }
 static AdiOptions convert_options(const dre_adi_options* o) {
@@ -413,6 +420,7 @@ static AdiOptions convert_options(const dre_adi_options* o) {
     a.maxiters = o->maxiters; a.reltol = o->reltol; a.abstol = o->abstol; a.ignore_initial_guess = o->ignore_initial_guess != 0;
     a.compression_interval = o->compression_interval; a.compression = o->compression != 0;
     a.compress_tolfac = o->compress_tolfac > 0 ? o->compress_tolfac : 4.0;
+    a.compress_exact = o->compress_exact != 0;
     if (o->shift_kind == 0) {
         a.shifts.kind = ShiftSpec::CYCLIC;
         DRE_REQUIRE(o->nshifts > 0 && o->shifts_re, "Cyclic shifts need at least one value");
@@ -524,6 +532,19 @@ int dre_gdre_result_K(dre_ctx* ctx, const dre_gdre_result* r, int i, double* K_h
         Mat K(c, Ktu.cols, Ktu.rows);
         transpose_mat(c, Ktu, K);
         download_mat(c, K, K_host, ld);
+    });
+}
+int dre_gdre_result_K_device(dre_ctx* ctx, const dre_gdre_result* r, double* K_dev) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        const int nt = (int)r->r.Kt.size();
+        for (int i = 0; i < nt; ++i) {
+            Mat Ktu = to_user_order(c, r->pen, r->r.Kt[i]);      // n x m
+            Mat K;
+            K.p = K_dev + (size_t)i * Ktu.rows * Ktu.cols; K.rows = Ktu.cols; K.cols = Ktu.rows; K.ld = Ktu.cols;
+            transpose_mat(c, Ktu, K);
+        }
+        c->sync();
     });
 }
 int dre_gdre_result_X(const dre_gdre_result* r, int i, dre_ldlt** X) {

@@ -331,16 +331,45 @@ __global__ __launch_bounds__(1024) void k_ldlt_norm(int k, const double* __restr
         }
     }
 }
+// s = sum_ij M_ij M_ji  for M = T G given explicitly
+__global__ __launch_bounds__(1024) void k_trace_sq(int k, const double* __restrict__ M, int ldm, double alpha, AdiState* st, int iters_after, double* out) {
+    __shared__ double red[17];
+    if (st && st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    double s = 0.0;
+    for (int c = wave; c < k; c += nw)
+        for (int r = lane; r < k; r += 64) s += M[r + (size_t)c * ldm] * M[c + (size_t)r * ldm];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        if (out) out[0] = nrm;
+        if (st) {
+            st->res_norm = nrm;
+            st->iters = iters_after;
+            if (iters_after < 512) st->norms[iters_after] = nrm;
+            if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+        }
+    }
+}
 void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
-    TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
-    hipLaunchKernelGGL(k_ldlt_norm, dim3(1), dim3(1024), 0, ctx->stream, G.rows, G.p, G.ld, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after, (double*)nullptr);
+    if (tdiag) {
+        TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
+        hipLaunchKernelGGL(k_ldlt_norm, dim3(1), dim3(1024), 0, ctx->stream, G.rows, G.p, G.ld, T.p, T.ld, 1, alpha, st, iters_after, (double*)nullptr);
+    } else {
+        Mat TG(ctx, G.rows, G.cols);
+        gemm(ctx, false, false, 1.0, T, G, 0.0, TG, st, "gemm_norm");
+        TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
+        hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, st, iters_after, (double*)nullptr);
+    }
 }
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
     if (L.cols == 0) return 0.0;
     Mat G(ctx, L.cols, L.cols);
     gemm(ctx, true, false, 1.0, L, L, 0.0, G, nullptr, "gemm_gram");
     DevArr<double> out(ctx, 1);
-    hipLaunchKernelGGL(k_ldlt_norm, dim3(1), dim3(1024), 0, ctx->stream, G.rows, G.p, G.ld, D.p, D.ld, 0, alpha, (AdiState*)nullptr, 0, out.p);
+    Mat TG(ctx, G.rows, G.cols);
+    gemm(ctx, false, false, 1.0, D, G, 0.0, TG, nullptr, "gemm_norm");
+    hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, (AdiState*)nullptr, 0, out.p);
     return read_scalar(ctx, out.p);
 }
 
@@ -550,14 +579,20 @@ __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S,
             for (int r = tid; r < nr; r += blockDim.x) w[r] += K * v[r];
             __syncthreads();
         }
-        // S22 -= v w' + w v'  and  ||S22||_F^2 for the next termination test
+        // S22 -= v w' + w v'  and  ||S22||_F^2 for the next termination test (one wave per column, rows on lanes)
         double acc2 = 0.0;
-        for (size_t idx = tid; idx < (size_t)nr * nr; idx += blockDim.x) {
-            const int r = idx % nr, c = idx / nr;
-            double* p = S + (size_t)(j + 1 + c) * lds_ + (j + 1 + r);
-            double x = *p;
-            if (tau != 0.0) { x -= v[r] * w[c] + w[r] * v[c]; *p = x; }
-            acc2 += x * x;
+        for (int c = wave; c < nr; c += nw) {
+            double* pc = S + (size_t)(j + 1 + c) * lds_ + (j + 1);
+            if (tau != 0.0) {
+                const double wc = w[c], vc = v[c];
+                for (int r = lane; r < nr; r += 64) {
+                    const double x = pc[r] - (v[r] * wc + w[r] * vc);
+                    pc[r] = x;
+                    acc2 += x * x;
+                }
+            } else {
+                for (int r = lane; r < nr; r += 64) { const double x = pc[r]; acc2 += x * x; }
+            }
         }
         rem2 = block_sum(acc2, red);
     }
@@ -565,78 +600,116 @@ __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S,
 }
 
 // Implicit QL with Wilkinson shift on (d, e) of order n; Z (n x n, identity on entry) accumulates the
-// rotations.  Thread 0 generates each sweep's rotation chain, all threads apply it to their rows of Z.
-__global__ __launch_bounds__(256) void k_tql(int n, double* __restrict__ dg, double* __restrict__ eg, double* __restrict__ Z, int ldz,
+// rotations.  Lane 0 of wave 0 generates the rotation chain of sweep t+1 (a strictly sequential scalar
+// recurrence, kept in registers with the next d/e prefetched) while waves 1.. apply the chain of sweep t
+// to their rows of Z, so the O(n^3) accumulation hides behind the O(n^2) scalar chase.
+// ZLDS: Z lives in LDS (n <= 128) and is written back at the end.
+template <bool ZLDS>
+__global__ __launch_bounds__(256) void k_tql(int n, double* __restrict__ dg, double* __restrict__ eg, double* __restrict__ Zg, int ldzg,
                                              double anorm, int* fail) {
     extern __shared__ double sm[];
-    double* d = sm;            // n
-    double* e = sm + n;        // n
-    double* cs = sm + 2 * n;   // n
-    double* sn = sm + 3 * n;   // n
-    __shared__ int ctl[3];     // m, ilo, stop
+    double* d = sm;                 // n
+    double* e = sm + n;             // n
+    double* csb = sm + 2 * n;       // 2 x n
+    double* snb = sm + 4 * n;       // 2 x n
+    double* Z = ZLDS ? sm + 6 * n : Zg;
+    const int ldz = ZLDS ? n : ldzg;
+    __shared__ int ctl_has[2], ctl_m[2], ctl_ilo[2];
+    __shared__ int fin;
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += blockDim.x) { d[i] = dg[i]; e[i] = (i < n - 1) ? eg[i] : 0.0; }
+    if (ZLDS) for (int i = tid; i < n * n; i += blockDim.x) Z[i] = (i % n == i / n) ? 1.0 : 0.0;
+    if (tid == 0) fin = 0;
     __syncthreads();
     const double eps = 2.220446049250313e-16;
     const double abstiny = 1e-3 * eps * anorm;
-    for (int l = 0; l < n; ++l) {
-        int iter = 0;
-        while (true) {
-            if (tid == 0) {
+    int l = 0, iter = 0, cur = 0;       // generator state (meaningful in thread 0)
+    bool have_prev = false;
+    int pm = 0, pilo = 0;
+    const int nappl = blockDim.x - 64;
+    while (true) {
+        if (tid == 0) {
+            bool produced = false;
+            double* cs = csb + cur * n;
+            double* sn = snb + cur * n;
+            while (!produced && l < n) {
                 int m = l;
                 for (; m < n - 1; ++m) {
-                    double dd = fabs(d[m]) + fabs(d[m + 1]);
-                    if (fabs(e[m]) <= eps * dd || fabs(e[m]) <= abstiny) break;
+                    const double em = fabs(e[m]);
+                    if (em <= eps * (fabs(d[m]) + fabs(d[m + 1])) || em <= abstiny) break;
                 }
-                int ilo = l;
-                if (m != l) {
-                    double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                    double r = sqrt(g * g + 1.0);
-                    g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
-                    double s = 1.0, c = 1.0, p = 0.0;
-                    int i;
-                    bool broke = false;
-                    for (i = m - 1; i >= l; --i) {
-                        double f = s * e[i], b = c * e[i];
-                        r = sqrt(f * f + g * g);
-                        e[i + 1] = r;
-                        if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; broke = true; break; }
-                        s = f / r; c = g / r;
-                        g = d[i + 1] - p;
-                        r = (d[i] - g) * s + 2.0 * c * b;
-                        p = s * r;
-                        d[i + 1] = g + p;
-                        g = c * r - b;
-                        cs[i] = c; sn[i] = s;
-                    }
-                    if (broke) ilo = i + 1;
-                    else { d[l] -= p; e[l] = g; e[m] = 0.0; }
+                if (m == l) { ++l; iter = 0; continue; }
+                if (iter >= 80) { *fail = 1; l = n; break; }
+                ++iter;
+                const double dl = d[l], el = e[l];
+                double g = (d[l + 1] - dl) / (2.0 * el);
+                double r = sqrt(g * g + 1.0);
+                g = d[m] - dl + el / (g + (g >= 0.0 ? r : -r));
+                double s = 1.0, c = 1.0, p = 0.0;
+                double ei = e[m - 1], di = d[m - 1], di1 = d[m];
+                int i, ilo = l;
+                bool broke = false;
+                for (i = m - 1; i >= l; --i) {
+                    const double e_next = (i > l) ? e[i - 1] : 0.0;     // prefetch: independent of the chain below
+                    const double d_next = (i > l) ? d[i - 1] : 0.0;
+                    const double f = s * ei, b = c * ei;
+                    const double h = f * f + g * g;
+                    if (h == 0.0) { e[i + 1] = 0.0; d[i + 1] = di1 - p; e[m] = 0.0; broke = true; break; }
+                    const double rinv = rsqrt(h);
+                    e[i + 1] = h * rinv;
+                    s = f * rinv; c = g * rinv;
+                    g = di1 - p;
+                    r = (di - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                    cs[i] = c; sn[i] = s;
+                    di1 = di; di = d_next; ei = e_next;
                 }
-                ctl[0] = m; ctl[1] = ilo; ctl[2] = (m != l && iter >= 80) ? 1 : 0;
+                if (broke) ilo = i + 1;
+                else { d[l] -= p; e[l] = g; e[m] = 0.0; }
+                ctl_m[cur] = m; ctl_ilo[cur] = ilo;
+                produced = true;
             }
-            __syncthreads();
-            const int m = ctl[0], ilo = ctl[1];
-            if (ctl[2]) { if (tid == 0) *fail = 1; break; }
-            if (m == l) break;
-            for (int k = tid; k < n; k += blockDim.x) {
-                double zi1 = Z[k + (size_t)m * ldz];
-                for (int i = m - 1; i >= ilo; --i) {
+            ctl_has[cur] = produced ? 1 : 0;
+            if (!produced) fin = 1;
+        } else if (tid >= 64 && have_prev) {
+            const double* cs = csb + (cur ^ 1) * n;
+            const double* sn = snb + (cur ^ 1) * n;
+            for (int k = tid - 64; k < n; k += nappl) {
+                double zi1 = Z[k + (size_t)pm * ldz];
+                for (int i = pm - 1; i >= pilo; --i) {
                     const double zi = Z[k + (size_t)i * ldz];
                     const double c = cs[i], s = sn[i];
                     Z[k + (size_t)(i + 1) * ldz] = s * zi + c * zi1;
                     zi1 = c * zi - s * zi1;
                 }
-                Z[k + (size_t)ilo * ldz] = zi1;
+                Z[k + (size_t)pilo * ldz] = zi1;
             }
-            ++iter;
-            __syncthreads();
         }
         __syncthreads();
+        have_prev = ctl_has[cur] != 0; pm = ctl_m[cur]; pilo = ctl_ilo[cur];
+        const int f = fin;
+        cur ^= 1;
+        __syncthreads();
+        if (!have_prev && f) break;
     }
     for (int i = tid; i < n; i += blockDim.x) dg[i] = d[i];
+    if (ZLDS) for (int i = tid; i < n * n; i += blockDim.x) Zg[i % n + (size_t)(i / n) * ldzg] = Z[i];
 }
 
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac) {
+__global__ void k_tri_to_dense(int n, const double* __restrict__ d, const double* __restrict__ e, double* __restrict__ A, int lda) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int r = idx % n, c = idx / n;
+    double v = 0.0;
+    if (r == c) v = d[r];
+    else if (r == c + 1) v = e[c];
+    else if (c == r + 1) v = e[r];
+    A[r + (size_t)c * lda] = v;
+}
+
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig) {
     DRE_REQUIRE(S.rows == S.cols, "sym_eig: square matrix expected");
     SymEig out;
     const int q = S.rows;
@@ -646,32 +719,49 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac) {
     out.V = Mat(ctx, q, q);
     fill_mat(ctx, out.V, 0.0);
     out.tau = DevArr<double>(ctx, q);
-    DevArr<double> d(ctx, q), e(ctx, q);
+    out.d = DevArr<double>(ctx, q); out.e = DevArr<double>(ctx, q);
+    DevArr<double>& d = out.d; DevArr<double>& e = out.e;
     DevArr<TridiagInfo> info(ctx, 1);
     DRE_HIP(hipMemsetAsync(out.tau.p, 0, q * sizeof(double), ctx->stream));
     {
         TimedScope ts(ctx, "sym_tridiag", 0, 0);
         size_t shm = 2 * (size_t)q * sizeof(double);
+        if (shm > 60 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr_set = true; }
+        }
         hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, info.p);
     }
     TridiagInfo hi;
     DRE_HIP(hipMemcpyAsync(&hi, info.p, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipStreamSynchronize(ctx->stream));
     out.j = hi.jdim;
-    if (out.j == 0) return out;
+    out.nref = hi.nref;
+    out.snorm = hi.snorm;
+    if (out.j == 0 || !want_eig) return out;
     const int j = out.j;
     out.Z = Mat(ctx, j, j);
-    set_identity(ctx, out.Z, 1.0);
     DevArr<int> fail(ctx, 1);
     DRE_HIP(hipMemsetAsync(fail.p, 0, sizeof(int), ctx->stream));
+    DevArr<double> dw(ctx, j), ew(ctx, j);     // QL works on copies; out.d / out.e keep T_j
+    DRE_HIP(hipMemcpyAsync(dw.p, d.p, j * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    DRE_HIP(hipMemcpyAsync(ew.p, e.p, j * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     {
-        TimedScope ts(ctx, "sym_tql", 0, 0);
-        size_t shm = 4 * (size_t)j * sizeof(double);
-        hipLaunchKernelGGL(k_tql, dim3(1), dim3(256), shm, ctx->stream, j, d.p, e.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
+        TimedScope ts(ctx, "sym_tql", 16.0 * j * j, 6.0 * 1.7 * (double)j * j * j);
+        if (j <= 128) {
+            size_t shm = (6 * (size_t)j + (size_t)j * j) * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_tql<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+            hipLaunchKernelGGL((k_tql<true>), dim3(1), dim3(256), shm, ctx->stream, j, dw.p, ew.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
+        } else {
+            set_identity(ctx, out.Z, 1.0);
+            size_t shm = 6 * (size_t)j * sizeof(double);
+            hipLaunchKernelGGL((k_tql<false>), dim3(1), dim3(256), shm, ctx->stream, j, dw.p, ew.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
+        }
     }
     out.w.resize(j);
     int hfail = 0;
-    DRE_HIP(hipMemcpyAsync(out.w.data(), d.p, j * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipMemcpyAsync(out.w.data(), dw.p, j * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipMemcpyAsync(&hfail, fail.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipStreamSynchronize(ctx->stream));
     if (hfail) throw Error(ERR_INTERNAL, "sym_eig: QL iteration did not converge");
@@ -687,8 +777,13 @@ __global__ __launch_bounds__(256) void k_backtransform(int q, int j, int nref, c
     const int c = blockIdx.x * 4 + wave;
     if (c >= ncols) return;
     double* b = B + (size_t)c * ldb;
-    const double* z = Z + (size_t)ids[c] * ldz;
-    for (int r = lane; r < q; r += 64) b[r] = (r < j) ? z[r] : 0.0;
+    if (Z) {
+        const double* z = Z + (size_t)ids[c] * ldz;
+        for (int r = lane; r < q; r += 64) b[r] = (r < j) ? z[r] : 0.0;
+    } else {
+        const int one = ids[c];
+        for (int r = lane; r < q; r += 64) b[r] = (r == one) ? 1.0 : 0.0;
+    }
     for (int i = nref - 1; i >= 0; --i) {
         const double t = tau[i];
         if (t == 0.0) continue;
@@ -700,6 +795,13 @@ __global__ __launch_bounds__(256) void k_backtransform(int q, int j, int nref, c
     }
 }
 
+Mat sym_tridiag_dense(Ctx* ctx, const SymEig& e) {
+    Mat T(ctx, e.j, e.j);
+    size_t tot = (size_t)e.j * e.j;
+    if (tot) hipLaunchKernelGGL(k_tri_to_dense, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, e.j, e.d.p, e.e.p, T.p, T.ld);
+    return T;
+}
+
 Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids) {
     const int r = (int)ids.size();
     Mat B(ctx, e.q, r);
@@ -708,8 +810,121 @@ Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids
     dids.upload(ctx, ids);
     TimedScope ts(ctx, "sym_backtransform", 0, 0);
     hipLaunchKernelGGL(k_backtransform, dim3(ceil_div(r, 4)), dim3(256), 0, ctx->stream, e.q, e.j, e.nref, e.V.p, e.V.ld,
-                       e.tau.p, e.Z.p, e.Z.ld, dids.p, r, B.p, B.ld);
+                       e.tau.p, e.Z.p, e.Z.p ? e.Z.ld : 0, dids.p, r, B.p, B.ld);
     DRE_HIP(hipGetLastError());
+    return B;
+}
+
+// =============================================================================================
+// Blocked band reduction
+// =============================================================================================
+// rem2 = ||S[k:, k:]||_F^2 + 2 * ||triu(S[k:k+b, k-b:k])||_F^2   (the second term couples the kept part to the rest)
+__global__ __launch_bounds__(1024) void k_band_rem(int q, int k, int b, const double* __restrict__ S, int ld, double* out) {
+    __shared__ double red[17];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    double s = 0.0;
+    for (int c = k + wave; c < q; c += nw)
+        for (int r = k + lane; r < q; r += 64) { const double x = S[r + (size_t)c * ld]; s += x * x; }
+    if (k >= b) {
+        for (int c = wave; c < b; c += nw)
+            for (int r = lane; r <= c && r < q - k; r += 64) { const double x = S[(k + r) + (size_t)(k - b + c) * ld]; s += 2.0 * x * x; }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+// D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
+__global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)J * J) return;
+    int i = idx % J, j = idx / J;
+    const bool swap = i < j;
+    if (swap) { int t = i; i = j; j = t; }
+    const int k = (j / b) * b;
+    double v;
+    if (i < k + b || j >= kred) v = S[i + (size_t)j * ld];   // diagonal block, or a column that was never reduced
+    else { const int r = i - k - b, c = j - k; v = (r <= c) ? S[i + (size_t)j * ld] : 0.0; }
+    const int oi = swap ? j : i, oj = swap ? i : j;
+    D[oi + (size_t)oj * ldd] = v;
+}
+__global__ void k_axpy_mat(int rows, int cols, double a, const double* __restrict__ X, int ldx, double* __restrict__ Y, int ldy) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r = idx % rows, c = idx / rows;
+    Y[r + (size_t)c * ldy] += a * X[r + (size_t)c * ldx];
+}
+
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
+    DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
+    SymBand out;
+    const int q = S.rows, b = QR_NB;
+    out.q = q; out.nb = b;
+    if (q == 0) return out;
+    out.V = Mat(ctx, q, q);
+    out.T = Mat(ctx, b, q);
+    fill_mat(ctx, out.V, 0.0);
+    DevArr<double> rem(ctx, 1);
+    double snorm2 = -1.0;
+    int k = 0, np = 0;
+    int J = q;
+    while (k < q) {
+        {
+            TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
+            hipLaunchKernelGGL(k_band_rem, dim3(1), dim3(1024), 0, ctx->stream, q, k, b, S.p, S.ld, rem.p);
+        }
+        const double r2 = read_scalar(ctx, rem.p);
+        if (snorm2 < 0.0) snorm2 = r2;
+        const double tol = abs_tol > 0.0 ? abs_tol : tolfac * 2.220446049250313e-16 * std::sqrt(snorm2);
+        if (r2 <= tol * tol) { J = k; break; }
+        const int m = q - k - b;            // rows below the diagonal block of this panel
+        if (m < b) break;                   // the last few rows stay unreduced: D is stored dense, band form is not required
+        const int jb = b;
+        {
+            TimedScope ts(ctx, "qr_panel", 8.0 * m * b * (b + 2), 2.0 * m * b * b);
+            hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(1024), 0, ctx->stream, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, jb,
+                               out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld);
+        }
+        // two-sided update of the trailing block S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,
+        // Z = S22 V T,  N = T' (V' Z)
+        Mat S22 = S.view(k + b, k + b, m, m);
+        Mat Vp = out.V.view(k + b, k, m, jb);
+        Mat Tp = out.T.view(0, k, jb, jb);
+        Mat Y(ctx, m, jb), Z(ctx, m, jb), M(ctx, jb, jb), N(ctx, jb, jb);
+        gemm(ctx, false, false, 1.0, S22, Vp, 0.0, Y, nullptr, "gemm_band");
+        gemm(ctx, false, false, 1.0, Y, Tp, 0.0, Z, nullptr, "gemm_band");
+        gemm(ctx, true, false, 1.0, Vp, Z, 0.0, M, nullptr, "gemm_band");
+        gemm(ctx, true, false, 1.0, Tp, M, 0.0, N, nullptr, "gemm_band");
+        gemm(ctx, false, false, -0.5, Vp, N, 1.0, Z, nullptr, "gemm_band");        // Z <- W
+        gemm(ctx, false, true, -1.0, Z, Vp, 1.0, S22, nullptr, "gemm_band");
+        gemm(ctx, false, true, -1.0, Vp, Z, 1.0, S22, nullptr, "gemm_band");
+        // the panel columns right of the current one inside the diagonal-block row, i.e. S[k:k+b, k+b:], must mirror
+        // the transformed coupling block: S[k:k+b, k+b:] = (Q_p' S[k+b:, k:k+b])' = [R_p; 0]'.  Only the lower triangle
+        // (column block) is read afterwards, so nothing to do here.
+        k += b; ++np;
+    }
+    out.J = J; out.npanels = np;
+    out.D = Mat(ctx, J, J);
+    size_t tot = (size_t)J * J;
+    if (tot) hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, J, b, np * b, S.p, S.ld, out.D.p, out.D.ld);
+    DRE_HIP(hipGetLastError());
+    return out;
+}
+
+Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
+    Mat B(ctx, sb.q, sb.J);
+    set_identity(ctx, B, 1.0);
+    const int b = sb.nb;
+    // Qb = Q_0 Q_1 ... Q_{np-1};  Qb * [I; 0]: apply the last panel first
+    for (int p = sb.npanels - 1; p >= 0; --p) {
+        const int k = p * b, m = sb.q - k - b, jb = std::min(b, m);
+        if (m <= 0) continue;
+        Mat Vp = sb.V.view(k + b, k, m, jb);
+        Mat Tp = sb.T.view(0, k, jb, jb);
+        Mat B2 = B.view(k + b, 0, m, sb.J);
+        Mat W(ctx, jb, sb.J), W2(ctx, jb, sb.J);
+        gemm(ctx, true, false, 1.0, Vp, B2, 0.0, W, nullptr, "gemm_band");
+        gemm(ctx, false, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_band");
+        gemm(ctx, false, false, -1.0, Vp, W2, 1.0, B2, nullptr, "gemm_band");
+    }
     return B;
 }
 

@@ -68,11 +68,28 @@ struct SymEig {
     Mat Z;           // j x j eigenvectors of the tridiagonal matrix (device)
     Mat V;           // q x q Householder vectors of the reduction (device, column i = reflector i)
     DevArr<double> tau;
+    DevArr<double> d, e;   // the tridiagonal matrix T_j (device)
+    double snorm = 0.0;    // ||S||_F
 };
 // Householder tridiagonalisation of S (q x q, full symmetric storage, destroyed) that stops as soon as
 // the not-yet-reduced trailing block is below tolfac*eps*||S||_F, then implicit QL on the tridiagonal.
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0);
-// B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host)
+// want_eig = false stops after the reduction: S ~ Q_h(:,1:j) T_j Q_h(:,1:j)' with T_j = tridiag(d, e).
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true);
+Mat sym_tridiag_dense(Ctx* ctx, const SymEig& e);    // T_j as a dense j x j matrix
+// B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host); with an empty Z the identity is used
 Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids);
+
+// --- blocked two-sided Householder band reduction with early termination (multi-CU, GEMM-rich) ------------
+// S ~ Qb(:,1:J) * Dband * Qb(:,1:J)'  with Dband the leading J x J block (band width nb) of Qb' S Qb; the reduction
+// stops at the first panel boundary J where everything not yet reduced is below tolfac*eps*||S||_F.
+struct SymBand {
+    int q = 0, J = 0, nb = 16, npanels = 0;
+    Mat V;      // q x q explicit reflectors; panel p occupies columns [p*nb, ...) and rows >= (p+1)*nb
+    Mat T;      // nb x q block-reflector factors
+    Mat D;      // J x J symmetric band matrix (dense storage)
+};
+// abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0);
+Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 
 }  // namespace dre

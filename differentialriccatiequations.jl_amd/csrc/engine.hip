@@ -106,7 +106,7 @@ static void mul_blockdiag(Ctx* ctx, const Mat& M, const LDLt& X, Mat& out) {
 static CompressStats g_cstats;
 CompressStats& compress_stats() { return g_cstats; }
 
-void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac) {
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol) {
     const int n = X.n, c = X.rank();
     auto set_empty = [&]() {
         X.blocks.clear();
@@ -133,20 +133,37 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac) {
         gemm(ctx, false, true, 1.0, RD, qr.R, 0.0, S, nullptr, "gemm_compress");
     }
     symmetrize(ctx, S);
-    SymEig e = sym_eig(ctx, S, tolfac);
-    g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
-    if (e.j == 0) { set_empty(); return; }
-    double wmax = 0.0;
-    for (double w : e.w) wmax = std::max(wmax, std::fabs(w));
-    const double thr = 100.0 * wmax * EPS;
-    std::vector<int> ids;
-    for (int i = 0; i < e.j; ++i)
-        if (std::fabs(e.w[i]) >= thr && wmax > 0.0) ids.push_back(i);
-    std::sort(ids.begin(), ids.end(), [&](int a, int b) { return e.w[a] < e.w[b]; });
-    const int r = (int)ids.size();
-    g_cstats.rank_out += r;
-    if (r == 0) { set_empty(); return; }
-    Mat B = sym_eig_backtransform(ctx, e, ids);
+    Mat B, Dnew;
+    int r = 0;
+    if (exact) {
+        SymEig e = sym_eig(ctx, S, tolfac, true);
+        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
+        if (e.j == 0) { set_empty(); return; }
+        double wmax = 0.0;
+        for (double w : e.w) wmax = std::max(wmax, std::fabs(w));
+        const double thr = 100.0 * wmax * EPS;
+        std::vector<int> ids;
+        for (int i = 0; i < e.j; ++i)
+            if (std::fabs(e.w[i]) >= thr && wmax > 0.0) ids.push_back(i);
+        std::sort(ids.begin(), ids.end(), [&](int a, int b) { return e.w[a] < e.w[b]; });
+        r = (int)ids.size();
+        g_cstats.rank_out += r;
+        if (r == 0) { set_empty(); return; }
+        B = sym_eig_backtransform(ctx, e, ids);
+        std::vector<double> hd((size_t)r * r, 0.0);
+        for (int i = 0; i < r; ++i) hd[i + (size_t)i * r] = e.w[ids[i]];
+        Dnew = Mat(ctx, r, r);
+        DRE_HIP(hipMemcpyAsync(Dnew.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
+        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += sb.J;
+        r = sb.J;
+        g_cstats.rank_out += r;
+        if (r == 0) { set_empty(); return; }
+        B = sym_band_basis(ctx, sb);
+        Dnew = sb.D;
+    }
     Mat Lnew;
     if (wide) {
         Lnew = B;
@@ -157,17 +174,12 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac) {
         copy_mat(ctx, B, top);
         qr_apply_q(ctx, qr, Lnew, false);
     }
-    std::vector<double> hd((size_t)r * r, 0.0);
-    for (int i = 0; i < r; ++i) hd[i + (size_t)i * r] = e.w[ids[i]];
-    Mat Dnew(ctx, r, r);
-    DRE_HIP(hipMemcpyAsync(Dnew.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    DRE_HIP(hipStreamSynchronize(ctx->stream));
     X.blocks.clear();
-    X.blocks.push_back({Lnew, Dnew, 1.0, true});
+    X.blocks.push_back({Lnew, Dnew, 1.0, exact});
 }
 
-void ldlt_destructure(Ctx* ctx, LDLt& X) {
-    if (X.blocks.size() > 1) ldlt_compress(ctx, X);
+void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac, bool exact) {
+    if (X.blocks.size() > 1) ldlt_compress(ctx, X, tolfac, exact);
     if (X.blocks.empty()) X.blocks.push_back({Mat(ctx, X.n, 0), Mat(ctx, 0, 0), 1.0, true});
 }
 
@@ -426,12 +438,12 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
 // =============================================================================================
 // GALE residual (/root/reference/src/lyapunov/residual.jl:3-31)
 // =============================================================================================
-LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X) {
+LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol) {
     auto Cp = std::make_shared<LDLt>(C);
     if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
     const Pencil& P = *op.P;
-    ldlt_destructure(ctx, C);
-    ldlt_destructure(ctx, *X);
+    ldlt_destructure(ctx, C, tolfac, exact);
+    ldlt_destructure(ctx, *X, tolfac, exact);
     const LBlock& cb = C.blocks[0];
     const LBlock& xb = X->blocks[0];
     const int nG = cb.L.cols, n0 = xb.L.cols, dim = nG + 2 * n0;
@@ -445,7 +457,7 @@ LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X) {
     { Mat d = T.view(nG, nG + n0, n0, n0); copy_mat(ctx, xb.D, d, xb.alpha); }
     { Mat d = T.view(nG + n0, nG, n0, n0); copy_mat(ctx, xb.D, d, xb.alpha); }
     LDLtP res = ldlt_make(ctx, P.n, R, T, 1.0, false);
-    ldlt_compress(ctx, *res);
+    ldlt_compress(ctx, *res, tolfac, exact, abs_tol);
     return res;
 }
 
@@ -477,13 +489,16 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     FactorCache local;
     if (!cache) cache = &local;
     AdiResult res;
-    ldlt_destructure(ctx, C);
+    const double ctf = opt.compress_tolfac;
+    const bool cex = opt.compress_exact;
+    ldlt_destructure(ctx, C, ctf, cex);
     const double normC = ldlt_norm(ctx, C);
     const double reltol = opt.reltol >= 0 ? opt.reltol : n * EPS;
     const double abstol = opt.abstol >= 0 ? opt.abstol : reltol * normC;
     LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
-    LDLtP resid = gale_residual(ctx, op, C, X);
-    ldlt_destructure(ctx, *resid);
+    // Krylov mode: components of the warm-start residual far below the convergence tolerance are dropped
+    LDLtP resid = gale_residual(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol);
+    ldlt_destructure(ctx, *resid, ctf, cex);
     LBlock rb = resid->blocks[0];
     Mat R = rb.L, Tm = rb.D;
     const double alpha_res = rb.alpha;
@@ -661,7 +676,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         if (h.done || recs.empty()) {
             finished = true;
         } else if (opt.compression && last_compression >= opt.compression_interval) {
-            ldlt_compress(ctx, *Xw, opt.compress_tolfac);
+            ldlt_compress(ctx, *Xw, ctf, cex);
             last_compression = 0;
         }
     }
@@ -673,7 +688,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         for (auto& f : used_real) mf_check(ctx, f->f);
         for (auto& f : used_cplx) mf_check(ctx, f->f);
     }
-    if (opt.compression && last_compression > 0) ldlt_compress(ctx, *Xw, opt.compress_tolfac);   // adi.jl:78-80
+    if (opt.compression && last_compression > 0) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
     all_shifts.resize(res.iters);
     res.shifts = all_shifts;
     res.X = Xw;
@@ -687,10 +702,10 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
 // =============================================================================================
 struct Feedback { Mat L, D, BtLD, EtL, Kt; double alpha; bool diag; };
 
-static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X) {
+static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X, double ctf, bool cex) {
     // alpha, L, D = X;  BtLD = (B'L) D [*alpha];  K = BtLD (L'E)     (lowrank_ros1.jl:25-28,53-56)
     const Pencil& P = *prob.P;
-    ldlt_destructure(ctx, X);
+    ldlt_destructure(ctx, X, ctf, cex);
     const LBlock& b = X.blocks[0];
     Feedback f;
     f.L = b.L; f.D = b.D; f.alpha = b.alpha; f.diag = b.diag;
@@ -724,7 +739,9 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     for (int i = 0; i <= nsteps; ++i) out.t.push_back(prob.t0 + i * dt);
     LDLtP X = prob.X0;
     out.X.push_back(X);
-    Feedback fb = feedback(ctx, prob, *X);
+    const double ctf = adi.compress_tolfac;
+    const bool cex = adi.compress_exact;
+    Feedback fb = feedback(ctx, prob, *X, ctf, cex);
     out.Kt.push_back(fb.Kt);
     FactorCache cache;
     std::map<uint64_t, DevArr<double>> valF_by_tau;
@@ -762,7 +779,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
             }
             LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
-            ldlt_compress(ctx, *rhs, adi.compress_tolfac);
+            ldlt_compress(ctx, *rhs, ctf, cex);
             AdiResult ar = adi_solve(ctx, op, *rhs, X, adi, &cache);
             X = ar.X;
             out.adi_iters += ar.iters;
@@ -786,11 +803,11 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 Mat d33 = S.view(q + r, q + r, r, r); gemm(ctx, true, false, -1.0, fb.BtLD, fb.BtLD, 0.0, d33);
             }
             LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);
-            ldlt_compress(ctx, *R1, adi.compress_tolfac);
+            ldlt_compress(ctx, *R1, ctf, cex);
             AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
             LDLtP K1 = a1.X;
             // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)
-            ldlt_destructure(ctx, *K1);
+            ldlt_destructure(ctx, *K1, ctf, cex);
             const LBlock kb = K1->blocks[0];
             const int r1 = kb.L.cols;
             Mat BtT1(ctx, m, r1), BtT1D1(ctx, m, r1);
@@ -813,7 +830,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             out.gale.push_back(std::move(a2));
         }
         if (save_state) out.X.push_back(X);
-        fb = feedback(ctx, prob, *X);
+        fb = feedback(ctx, prob, *X, ctf, cex);
         out.Kt.push_back(fb.Kt);
     }
     if (!save_state) out.X.push_back(X);

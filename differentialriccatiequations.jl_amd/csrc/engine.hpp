@@ -36,9 +36,12 @@ LDLtP ldlt_add(const LDLtP& a, const LDLtP& b);                 // LDLt.jl:131-1
 LDLtP ldlt_scale(const LDLtP& a, double alpha);                  // LDLt.jl:156-159
 LDLtP ldlt_deepcopy(Ctx* ctx, const LDLtP& a);
 void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-191
-void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0);      // LDLt.jl:204-225
+// LDLt.jl:204-225.  exact = true: eigen-decomposition + threshold 100*eps*max|lambda| exactly as the reference.
+// exact = false (engine default): the early-terminated Householder reduction alone, D := T_j (tridiagonal); the
+// dropped part is below tolfac*eps*||S||_F, i.e. not larger than what the reference's threshold discards.
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 double ldlt_norm(Ctx* ctx, LDLt& X);                             // LDLt.jl:77-89 (concatenates, synchronises)
-void ldlt_destructure(Ctx* ctx, LDLt& X);                        // LDLt.jl:54-60: compress iff more than one block
+void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true);   // LDLt.jl:54-60: compress iff more than one block
 
 struct CompressStats { long calls = 0; long cols_in = 0; long order = 0; long tri_steps = 0; long rank_out = 0; };
 CompressStats& compress_stats();
@@ -78,7 +81,9 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     int compression_interval = 10;
     bool compression = true;
     ShiftSpec shifts;
-    double compress_tolfac = 4.0;
+    double compress_tolfac = 4.0;    // Krylov-truncated compression inside the engine: remainder <= tolfac*eps*||X||_F
+    double residual_abs_frac = 0.05; // the warm-start residual is truncated at this fraction of abstol (Krylov mode only)
+    bool compress_exact = false;     // true: eigen-based truncation at every compression (reference arithmetic)
 };
 struct AdiResult {
     LDLtP X;
@@ -95,7 +100,7 @@ struct AdiResult {
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
                     FactorCache* cache);
 // residual of A'XE + E'XA + C for an LDL' iterate (/root/reference/src/lyapunov/residual.jl:3-31)
-LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X);
+LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 
 // ---- Rosenbrock drivers (/root/reference/src/riccati/lowrank_ros1.jl, lowrank_ros2.jl) -------------------
 struct GdreProblem {

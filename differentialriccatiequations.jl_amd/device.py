@@ -236,6 +236,9 @@ class DeviceLDLt:
     def compress(self):
         self.ctx.chk(self.ctx.lib.dre_ldlt_compress(self.ctx.ptr, self.ptr))
 
+    def canonicalize(self):
+        self.ctx.chk(self.ctx.lib.dre_ldlt_canonicalize(self.ctx.ptr, self.ptr))
+
     def norm(self):
         out = C.c_double()
         self.ctx.chk(self.ctx.lib.dre_ldlt_norm(self.ctx.ptr, self.ptr, C.byref(out)))
@@ -253,7 +256,7 @@ class DeviceLDLt:
 
 
 def make_adi_options(maxiters=100, reltol=None, abstol=None, ignore_initial_guess=False, compression_interval=10,
-                     compression=True, shift_kind=1, n_history=2, shifts=None, compress_tolfac=4.0):
+                     compression=True, shift_kind=1, n_history=2, shifts=None, compress_tolfac=4.0, compress_exact=False):
     o = AdiOptionsC()
     _lib.load().dre_adi_default_options(C.byref(o))
     o.maxiters = int(maxiters)
@@ -265,6 +268,7 @@ def make_adi_options(maxiters=100, reltol=None, abstol=None, ignore_initial_gues
     o.shift_kind = int(shift_kind)
     o.n_history = int(n_history)
     o.compress_tolfac = float(compress_tolfac)
+    o.compress_exact = int(bool(compress_exact))
     keep = None
     if shift_kind == 0:
         sh = np.asarray(list(shifts), dtype=np.complex128)

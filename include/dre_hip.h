@@ -113,6 +113,8 @@ int dre_ldlt_scale(dre_ctx* ctx, const dre_ldlt* a, double alpha, dre_ldlt** out
 int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x);                                           /* LDLt.jl:174-191 */
 int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x);                                              /* LDLt.jl:204-225 */
 int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out);                                     /* LDLt.jl:77-89 */
+/* bring an engine result to the reference's canonical form: one component, D = diag(eigenvalues), |lambda| >= 100 eps max|lambda| */
+int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x);
 /* alpha, L, D = X  (LDLt.jl:54-60; compresses when more than one component); pass NULL buffers to query sizes */
 int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* L_host, int ldl, double* D_host, int ldd);
 
@@ -129,7 +131,9 @@ typedef struct dre_adi_options {
     int32_t nshifts;               /* Cyclic: number of values (conjugate pairs adjacent) */
     const double* shifts_re;
     const double* shifts_im;       /* may be NULL (all real) */
-    double compress_tolfac;        /* <= 0 -> 4 */
+    double compress_tolfac;        /* <= 0 -> 4: the engine's compressions drop what lies below tolfac*eps*||S||_F */
+    int32_t compress_exact;        /* 1: eigen-decomposition + 100*eps*max|lambda| threshold at every compression (reference arithmetic);
+                                      0 (default): Krylov-truncated compression, D stays tridiagonal inside the engine */
 } dre_adi_options;
 int dre_adi_default_options(dre_adi_options* opt);
 
@@ -155,6 +159,9 @@ int dre_gdre_solve(dre_ctx* ctx, const dre_pencil* p, const dre_dense* B, const 
 int dre_gdre_result_info(const dre_gdre_result* r, int64_t* info);
 int dre_gdre_result_times(const dre_gdre_result* r, double* t);
 int dre_gdre_result_K(dre_ctx* ctx, const dre_gdre_result* r, int i, double* K_host /* m x n */, int ld);
+/* whole trajectory K(t_0..t_end) as nt consecutive m x n column-major blocks written to DEVICE memory owned by the
+ * caller (e.g. a torch tensor's data_ptr) so that it can be handed to RCCL without a host round trip */
+int dre_gdre_result_K_device(dre_ctx* ctx, const dre_gdre_result* r, double* K_dev);
 int dre_gdre_result_X(const dre_gdre_result* r, int i, dre_ldlt** X);   /* shares the factors (sol.X[1] === prob.X0) */
 /* per Lyapunov solve j: iinfo [0]=iters [1]=converged [2]=warnings [3]=rhs columns; dinfo [0]=res_norm [1]=abstol */
 int dre_gdre_result_gale(const dre_gdre_result* r, int j, int64_t* iinfo, double* dinfo);
