@@ -51,6 +51,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import dre_amd as D
+    from dre_amd.replicas import gather_trajectories, reduce_timing
 
     n = args.n
     d = D.steel_profile(n)
@@ -69,7 +70,6 @@ def main():
     m = d.B.shape[1]
     nt = args.nsteps + 1
     Kdev = torch.empty((nt, n, m), dtype=torch.float64, device="cuda")       # nt blocks of m x n column-major
-    Kall = [torch.empty_like(Kdev) for _ in range(world)] if world > 1 else None
 
     def one_solve(gather=True):
         r = C.c_void_p()
@@ -85,7 +85,7 @@ def main():
             nconv += int(gi[1])
         lib.dre_gdre_result_free(r)
         if world > 1 and gather:
-            dist.all_gather(Kall, Kdev)          # RCCL over xGMI: the K(t) feedback trajectories of all replicas
+            gather_trajectories(Kdev, world)     # RCCL over xGMI: the K(t) feedback trajectories of all replicas
         return int(ii[2]), int(ii[3]), nconv, ngale
 
     def barrier():
@@ -104,13 +104,7 @@ def main():
         iters += it
     barrier()
     elapsed = time.perf_counter() - t_start
-    el_t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    it_t = torch.tensor([float(iters)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
-    elapsed = float(el_t.item())
-    total_iters = float(it_t.item())
+    elapsed, total_iters = reduce_timing(elapsed, float(iters), torch.device('cuda', local_rank), world)
 
     out = None
     if rank == 0:

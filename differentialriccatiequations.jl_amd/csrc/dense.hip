@@ -511,7 +511,7 @@ struct TridiagInfo { int jdim; int nref; double snorm; };
 // V(:, j) receives reflector j (v[j+1] = 1, zeros above; V pre-zeroed), d/e the tridiagonal.
 __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S, int lds_, double* __restrict__ V, int ldv,
                                                   double* __restrict__ tau_out, double* __restrict__ d, double* __restrict__ e,
-                                                  double tolfac, TridiagInfo* info) {
+                                                  double tolfac, double abs_tol, TridiagInfo* info) {
     extern __shared__ double sm[];
     double* v = sm;          // q
     double* w = sm + q;      // q
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S,
     }
     double rem2 = block_sum(s, red);          // ||S[j:, j:]||_F^2 for j = 0
     const double snorm = sqrt(rem2);
-    const double tol = tolfac * 2.220446049250313e-16 * snorm;
+    const double tol = abs_tol > 0.0 ? abs_tol : tolfac * 2.220446049250313e-16 * snorm;
     const double tol2 = tol * tol;
     int jdim = q, nref = 0;
     double eprev = 0.0;
@@ -709,7 +709,7 @@ __global__ void k_tri_to_dense(int n, const double* __restrict__ d, const double
     A[r + (size_t)c * lda] = v;
 }
 
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig) {
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol) {
     DRE_REQUIRE(S.rows == S.cols, "sym_eig: square matrix expected");
     SymEig out;
     const int q = S.rows;
@@ -730,7 +730,7 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig) {
             static bool attr_set = false;
             if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr_set = true; }
         }
-        hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, info.p);
+        hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, abs_tol, info.p);
     }
     TridiagInfo hi;
     DRE_HIP(hipMemcpyAsync(&hi, info.p, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));

@@ -74,7 +74,7 @@ struct SymEig {
 // Householder tridiagonalisation of S (q x q, full symmetric storage, destroyed) that stops as soon as
 // the not-yet-reduced trailing block is below tolfac*eps*||S||_F, then implicit QL on the tridiagonal.
 // want_eig = false stops after the reduction: S ~ Q_h(:,1:j) T_j Q_h(:,1:j)' with T_j = tridiag(d, e).
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true);
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true, double abs_tol = -1.0);
 Mat sym_tridiag_dense(Ctx* ctx, const SymEig& e);    // T_j as a dense j x j matrix
 // B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host); with an empty Z the identity is used
 Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids);

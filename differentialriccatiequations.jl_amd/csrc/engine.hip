@@ -156,13 +156,27 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         DRE_HIP(hipMemcpyAsync(Dnew.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
     } else {
-        SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
-        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += sb.J;
-        r = sb.J;
-        g_cstats.rank_out += r;
-        if (r == 0) { set_empty(); return; }
-        B = sym_band_basis(ctx, sb);
-        Dnew = sb.D;
+        if (S.rows <= 64) {
+            // small problems: unblocked reduction with per-column termination gives the exact truncation rank
+            // (the blocked variant can only stop at multiples of the panel width)
+            SymEig e = sym_eig(ctx, S, tolfac, false, abs_tol);
+            g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
+            r = e.j;
+            g_cstats.rank_out += r;
+            if (r == 0) { set_empty(); return; }
+            std::vector<int> ids(r);
+            for (int i = 0; i < r; ++i) ids[i] = i;
+            B = sym_eig_backtransform(ctx, e, ids);
+            Dnew = sym_tridiag_dense(ctx, e);
+        } else {
+            SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
+            g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += sb.J;
+            r = sb.J;
+            g_cstats.rank_out += r;
+            if (r == 0) { set_empty(); return; }
+            B = sym_band_basis(ctx, sb);
+            Dnew = sb.D;
+        }
     }
     Mat Lnew;
     if (wide) {

@@ -45,9 +45,10 @@ class LDLt:
     """Lazy  sum_i alpha_i * L_i * D_i * L_i'   (src/LDLt.jl:29-33)."""
 
     def __init__(self, alphas, Ls, Ds):
-        self.alphas = list(alphas)
-        self.Ls = list(Ls)
-        self.Ds = list(Ds)
+        # the lists are stored as given: `2X` shares X.Ls / X.Ds exactly like the reference (LDLt.jl:156-159, test/LDLt.jl:57-58)
+        self.alphas = alphas
+        self.Ls = Ls
+        self.Ds = Ds
 
     # -- essentials (LDLt.jl:37-63,112-121)
     @property
@@ -77,7 +78,7 @@ class LDLt:
             return other
         if other.iszero():
             return self
-        return LDLt(self.alphas + other.alphas, self.Ls + other.Ls, self.Ds + other.Ds)
+        return LDLt(list(self.alphas) + list(other.alphas), list(self.Ls) + list(other.Ls), list(self.Ds) + list(other.Ds))
 
     def __neg__(self):
         return LDLt([-a for a in self.alphas], self.Ls, self.Ds)

@@ -1,0 +1,115 @@
+"""Kernel-level parity (through the C ABI) against NumPy/SciPy on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import dre_amd as D
+
+pytestmark = pytest.mark.gpu
+
+
+def _gemm(ctx, tA, tB, alpha, A, B, beta, Cm):
+    Ad, Bd, Cd = ctx.upload(A), ctx.upload(B), ctx.upload(Cm)
+    ctx.chk(ctx.lib.dre_gemm(ctx.ptr, int(tA), int(tB), alpha, Ad.ptr, Bd.ptr, beta, Cd.ptr))
+    return Cd.numpy()
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 4), (64, 64, 16), (37, 53, 29), (7, 110, 371), (130, 130, 2000), (371, 371, 1279), (1, 1, 1), (200, 3, 5)])
+def test_gemm_f64_mfma_all_transposes(ctx, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M * N + K)
+    for tA in (0, 1):
+        for tB in (0, 1):
+            A = rng.standard_normal((K, M) if tA else (M, K))      # asymmetric operands catch swapped C/D lane maps
+            B = rng.standard_normal((N, K) if tB else (K, N))
+            Cm = rng.standard_normal((M, N))
+            ref = 0.7 * (A.T if tA else A) @ (B.T if tB else B) - 0.3 * Cm
+            out = _gemm(ctx, tA, tB, 0.7, A, B, -0.3, Cm)
+            assert np.abs(out - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max()) * max(1, K) ** 0.5
+
+
+@pytest.fixture(scope="module")
+def pencil371(ctx):
+    d = D.steel_profile(371)
+    return d, D.Pencil(d.E, d.A, ctx)
+
+
+def test_spmm_axpby(ctx, pencil371):
+    d, P = pencil371
+    rng = np.random.default_rng(0)
+    for k in (1, 7, 13, 120):
+        X, Y = rng.standard_normal((371, k)), rng.standard_normal((371, k))
+        for which, M in ((0, d.E), (1, d.A)):
+            out = P.spmm(which, X, alpha=-1.3, beta=0.4, Y=Y).numpy()
+            ref = -1.3 * (M.T @ X) + 0.4 * Y
+            assert np.abs(out - ref).max() < 1e-14 * np.abs(ref).max() * 10
+
+
+@pytest.mark.parametrize("cA,cE", [(1.0, -0.5), (1.0, -0.0034), (1.0, -13.98), (1.0, -0.3 + 0.7j), (0.0, 1.0), (170.7, -0.5 - 3j)])
+def test_shifted_multifrontal_solve(ctx, pencil371, cA, cE):
+    d, P = pencil371
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((371, 19))
+    X = P.factor(cA, cE).solve(B)
+    ref = spla.splu((cA * d.A.T + cE * d.E.T).tocsc()).solve(B.astype(X.dtype))
+    assert np.linalg.norm(X - ref) / np.linalg.norm(ref) < 1e-12
+
+
+def test_shifted_solve_nonsymmetric_and_empty_rhs(ctx):
+    rng = np.random.default_rng(2)
+    n = 90
+    E = (sp.random(n, n, density=2 / n, random_state=rng) + n * sp.identity(n)).tocsc()
+    A = (sp.random(n, n, density=2 / n, random_state=rng) - n * sp.identity(n)).tocsc()
+    P = D.Pencil(E, A, ctx, leaf_size=6)
+    B = rng.standard_normal((n, 5))
+    X = P.factor(1.0, -2.0).solve(B)
+    assert np.linalg.norm((A.T - 2 * E.T) @ X - B) < 1e-11
+    assert P.factor(1.0, -2.0).solve(np.zeros((n, 0))).shape == (n, 0)
+
+
+@pytest.mark.parametrize("m,n", [(371, 115), (371, 311), (50, 7), (40, 40), (100, 17), (30, 45), (5, 1)])
+def test_orthf(ctx, m, n):
+    rng = np.random.default_rng(m + n)
+    L = rng.standard_normal((m, n))
+    if n > 5:
+        L[:, 4] = L[:, 3]                       # exactly dependent columns are routine on this path
+    Q, R = D.orthf(L)
+    k = min(m, n)
+    assert Q.shape == (m, k) and R.shape == (k, n)
+    assert np.abs(Q @ R - L).max() < 1e-12 and np.abs(Q.T @ Q - np.eye(k)).max() < 1e-13
+
+
+def _sym_eig(ctx, S, tolfac=4.0):
+    Sd = ctx.upload(S)
+    w, v = C.c_void_p(), C.c_void_p()
+    ctx.chk(ctx.lib.dre_sym_eig(ctx.ptr, Sd.ptr, tolfac, C.byref(w), C.byref(v)))
+    return D.DenseMatrix(ctx, w).numpy().ravel(), D.DenseMatrix(ctx, v).numpy()
+
+
+@pytest.mark.parametrize("q", [1, 2, 5, 33, 120, 200])
+def test_sym_eig_full_rank(ctx, q):
+    rng = np.random.default_rng(q)
+    A = rng.standard_normal((q, q)); S = A + A.T
+    w, V = _sym_eig(ctx, S)
+    ref = np.linalg.eigvalsh(S)
+    assert len(w) == q
+    sc = np.abs(ref).max()
+    assert np.abs(w - ref).max() < 1e-12 * sc and np.abs(V.T @ V - np.eye(q)).max() < 1e-12 and np.abs(S @ V - V * w).max() < 1e-12 * sc
+
+
+def test_sym_eig_early_termination_on_low_rank_indefinite(ctx):
+    rng = np.random.default_rng(7)
+    q = 371
+    Qm, _ = np.linalg.qr(rng.standard_normal((q, q)))
+    lam = np.zeros(q); lam[:110] = (0.75 ** np.arange(110)) * np.where(np.arange(110) % 3 == 0, -1, 1)
+    S = (Qm * lam) @ Qm.T; S = 0.5 * (S + S.T)
+    w, V = _sym_eig(ctx, S)
+    assert len(w) < 140                           # the reduction stopped long before q
+    keep = np.abs(w) >= 100 * np.abs(w).max() * np.finfo(float).eps
+    assert abs(int(keep.sum()) - 110) <= 2
+    assert np.linalg.norm((V[:, keep] * w[keep]) @ V[:, keep].T - S) < 1e-13 * np.linalg.norm(S)
+    w0, _ = _sym_eig(ctx, np.zeros((6, 6)))
+    assert len(w0) == 0

@@ -1,0 +1,128 @@
+"""The reference's known-answer tests for LDLᵀ / residual / ADI / Projection shifts, run through the HIP path."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dre_amd as D
+import dre_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ldlt_norm_compress_known_answers(ctx):       # test/LDLt.jl:54-89
+    rng = np.random.default_rng(1)
+    n, k = 10, 2
+    U = rng.standard_normal((n, k)); S = rng.standard_normal((k, k)); S = S + S.T
+    X = D.lowrank(U, S)
+    M = X.dense()
+    assert abs(D.norm(X) - np.linalg.norm(M)) < 1e-13 * np.linalg.norm(M)
+    assert abs(D.norm(2 * X) - 2 * D.norm(X)) < 1e-13 * np.linalg.norm(M)
+    Y = D.compress_(X + X)
+    assert Y.rank() == k and np.abs(Y.dense() - 2 * M).max() < 1e-13 * np.abs(M).max()
+    alpha, L, Dd = Y
+    assert alpha == 1.0 and np.abs(Dd - np.diag(np.diag(Dd))).max() == 0      # D = diagm(lambda) like the reference
+    S1 = np.zeros((k, k)); S1[0, 0] = 13
+    assert D.compress_(D.lowrank(U.copy(), S1)).rank() == 1
+    Z = D.lowrank(np.zeros((n, 3)), np.eye(3))
+    assert D.compress_(Z).rank() == 0 and D.norm(Z) == 0.0
+
+
+@pytest.mark.parametrize("c", [12, 115, 311, 700])
+def test_compress_tall_and_wide_panels(ctx, c):
+    rng = np.random.default_rng(c)
+    L = rng.standard_normal((371, 40)) @ rng.standard_normal((40, c))
+    Dm = np.diag(rng.standard_normal(c))
+    X = D.lowrank(L, Dm)
+    M = X.dense()
+    assert abs(D.norm(X) - np.linalg.norm(M)) < 1e-11 * np.linalg.norm(M)
+    D.compress_(X)
+    assert X.rank() <= min(40, c) and np.linalg.norm(X.dense() - M) < 1e-13 * np.linalg.norm(M)
+
+
+def _rand_pencil(rng, n, symE, symA):
+    sprand = lambda: sp.random(n, n, density=1 / n, random_state=rng, format="csc")
+    E = sprand(); E = (E + E.T + n * sp.identity(n)) if symE else (E + n * sp.identity(n))
+    A = sprand(); A = (A + A.T - n * sp.identity(n)) if symA else (A - n * sp.identity(n))
+    return E.tocsc(), A.tocsc()
+
+
+def test_residual_known_answers(ctx):                  # test/residual.jl:7-29
+    rng = np.random.default_rng(2)
+    n = 20
+    E, A = _rand_pencil(rng, n, True, False)
+    Cl = D.lowrank(rng.standard_normal((n, 3)), np.eye(3))
+    prob = D.GALEProblem(E, A, Cl)
+    r0 = D.residual(prob, Cl.zero())
+    assert r0 is not Cl and np.allclose(r0.dense(), Cl.dense())
+    for Dd in (np.diag([1.0, 2.0]), np.diag([1.0, -2.0]), 3.0 * np.diag([1.0, -2.0])):
+        X = D.lowrank(rng.standard_normal((n, 2)), Dd)
+        rd = Cl.dense() + A.T @ X.dense() @ E + E.T @ X.dense() @ A
+        assert abs(D.norm(D.residual(prob, X)) - np.linalg.norm(rd)) < 1e-12 * np.linalg.norm(rd)
+
+
+@pytest.mark.parametrize("symE,symA", [(True, True), (True, False), (False, True), (False, False)])
+def test_adi_vs_dense_lyapunov(ctx, symE, symA):       # test/tiny_random.jl:25-46 (default ADI: Projection(2), real + complex shifts)
+    rng = np.random.default_rng(10 * symE + symA)
+    n, g = 50, 4
+    E, A = _rand_pencil(rng, n, symE, symA)
+    Cl = (-2) * D.lowrank(rng.random((n, g)), -np.eye(g))
+    prob = D.GALEProblem(E, A, Cl)
+    X, info = D.solve_gale(prob, D.ADI(), return_info=True)
+    Xref = o.lyap_dense(A, E, Cl.dense())
+    assert info["converged"] and 1 <= info["iters"] <= 100
+    assert D.norm(D.residual(prob, X)) / D.norm(Cl) < 1e-10
+    assert D.delta(X.dense(), Xref) < 1e-10
+    # the oracle, given the same problem, agrees too (complex double steps are exercised for nonsymmetric E)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xo = o.adi_solve(o.GALEProblem(E, A, (-2) * o.lowrank(Cl.Ls[0], -np.eye(g))), o.ADI())
+    assert D.delta(X.dense(), Xo.dense()) < 1e-10
+
+
+def test_adi_with_explicit_conjugate_pair_shifts(ctx):  # helpers.jl:91-93 + adi.jl:181-225 (perform_double_step!)
+    rng = np.random.default_rng(5)
+    n = 60
+    E, A = _rand_pencil(rng, n, True, False)
+    Cl = D.lowrank(rng.random((n, 3)), np.diag([1.0, -1.0, 2.0]))
+    shifts = [-1 + 0.5j, -1 - 0.5j, -2.0, -0.8 + 0.1j, -0.8 - 0.1j, -1.3]      # the pencil's spectrum clusters around -1
+    prob = D.GALEProblem(E, A, Cl)
+    X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=60), return_info=True)
+    assert np.any(info["shifts"].imag != 0)
+    Xref = o.lyap_dense(A, E, Cl.dense())
+    assert D.delta(X.dense(), Xref) < 1e-10
+    with pytest.raises(D.DREError):                     # adi.jl:190: pairs must be adjacent conjugates
+        D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic([-1 + 0.5j, -2.0]), maxiters=4, warn_convergence=False))
+
+
+def test_projection_shift_known_answer(ctx):            # test/Shifts.jl:165-183: first Projection shift is -5/6
+    E = sp.identity(3, format="csc")
+    A = sp.lil_matrix((3, 3)); A[0:2, 0:2] = np.array([[-1.0, 1.0], [-1.0, -1.0]]); A[2, 2] = -0.5
+    Cl = D.lowrank(np.ones((3, 1)), np.eye(1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, info = D.solve_gale(D.GALEProblem(E, A.tocsc(), Cl), D.ADI(maxiters=1, warn_convergence=False), return_info=True)
+    assert info["iters"] == 1 and abs(info["shifts"][0] - (-5 / 6)) < 1e-13
+
+
+def test_observer_replay_and_nonconvergence_warning(ctx):
+    rng = np.random.default_rng(3)
+    E, A = _rand_pencil(rng, 50, True, True)
+    Cl = D.lowrank(rng.random((50, 2)), np.eye(2))
+
+    class Obs:
+        def __init__(self): self.steps, self.meta, self.done, self.failed = [], [], [], 0
+        def observe_gale_step(self, i, X, res, nrm): self.steps.append((i, nrm))
+        def observe_gale_metadata(self, desc, mu): self.meta.append((desc, mu))
+        def observe_gale_done(self, iters, X, res, nrm): self.done.append(iters)
+        def observe_gale_failed(self): self.failed += 1
+
+    ob = Obs()
+    D.solve_gale(D.GALEProblem(E, A, Cl), D.ADI(), observer=ob)
+    assert ob.steps[0][0] == 0 and [s[0] for s in ob.steps] == sorted(s[0] for s in ob.steps)
+    assert len(ob.meta) == ob.done[0] == ob.steps[-1][0] and ob.failed == 0 and all(m[0] == "ADI shifts" for m in ob.meta)
+    ob = Obs()
+    with pytest.warns(UserWarning, match="ADI did not converge"):
+        D.solve_gale(D.GALEProblem(E, A, Cl), D.ADI(maxiters=1), observer=ob)
+    assert ob.failed == 1 and ob.done == [1]

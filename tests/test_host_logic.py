@@ -1,0 +1,104 @@
+"""Host logic that needs no GPU: dense host LA behind the Projection shifts, the surrogate data, the Python mirror's
+LDLᵀ algebra and shift helpers, the replica gather over gloo (world_size 2)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+import dre_amd as D
+import dre_oracle as o
+from conftest import ROOT
+
+pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 40, 150])
+def test_host_eigvals_match_lapack(n):
+    lib = D._lib.load()
+    rng = np.random.default_rng(n)
+    A = np.asfortranarray(rng.standard_normal((n, n)))
+    E = np.asfortranarray(rng.standard_normal((n, n)) + n * np.eye(n))
+    wr, wi = np.zeros(n), np.zeros(n)
+    assert lib.dre_host_eigvals(n, pd(A), pd(wr), pd(wi)) == 0
+    ref = np.linalg.eigvals(A)
+    assert np.abs((wr + 1j * wi)[:, None] - ref[None, :]).min(axis=1).max() < 1e-10
+    assert lib.dre_host_gen_eigvals(n, pd(A), pd(E), pd(wr), pd(wi)) == 0
+    ref = sla.eigvals(A, E)
+    d = np.abs((wr + 1j * wi)[:, None] - ref[None, :])
+    assert d.min(axis=1).max() < 1e-10 and d.min(axis=0).max() < 1e-10
+
+
+@pytest.mark.parametrize("p,w", [(5, 8), (30, 50), (20, 20), (12, 7)])
+def test_host_svd_left(p, w):
+    lib = D._lib.load()
+    rng = np.random.default_rng(p * w)
+    R = np.asfortranarray(rng.standard_normal((p, w)))
+    if w > 3:
+        R[:, 3] = R[:, 2]
+    U, sv = np.zeros((p, p), order="F"), np.zeros(p)
+    assert lib.dre_host_svd_left(p, w, pd(R), pd(U), pd(sv)) == 0
+    ref = np.linalg.svd(R, compute_uv=False)
+    assert np.abs(np.sort(sv)[::-1][:len(ref)] - ref).max() < 1e-12
+    assert np.abs(U.T @ U - np.eye(p)).max() < 1e-13
+    assert np.abs((U * sv ** 2) @ U.T - R @ R.T).max() < 1e-11
+
+
+@pytest.mark.parametrize("n", D.SIZES)
+def test_surrogate_has_the_reference_shape(n):
+    d = D.steel_profile(n)
+    assert d.E.shape == (n, n) and d.A.shape == (n, n) and d.B.shape == (n, 7) and d.C.shape == (6, n)
+    assert abs(d.E - d.E.T).max() == 0 and abs(d.A - d.A.T).max() == 0
+    assert np.diff(d.E.indptr).max() <= 7                       # 7-point pattern
+    if n <= 1357:
+        assert np.linalg.eigvalsh(d.E.toarray()).min() > 0 and np.linalg.eigvalsh(d.A.toarray()).max() < 0
+    d2 = D.steel_profile.__wrapped__(n) if hasattr(D.steel_profile, "__wrapped__") else d
+    assert (d2.E != d.E).nnz == 0                                # deterministic
+
+
+def test_python_mirror_ldlt_algebra_without_gpu():
+    rng = np.random.default_rng(0)
+    U = rng.standard_normal((10, 2)); S = rng.standard_normal((2, 2)); S = S + S.T
+    X = D.lowrank(U, S)
+    assert X.size() == (10, 10) and X.rank() == 2 and not X.iszero()
+    a, L, Dd = X                                                 # single component: no compression, identity preserved
+    assert a == 1.0 and L is X.Ls[0] and Dd is X.Ds[0]
+    Y = 2 * X
+    assert Y.Ls is X.Ls and Y.Ds is X.Ds and Y.alphas == [2.0]
+    assert np.allclose((2 * X + 3 * X).dense(), 5 * X.dense())
+    Z = X.zero()
+    assert Z.rank() == 0 and Z.iszero() and (X + Z) is X and (Z + X) is X
+    assert np.allclose((X - X).dense(), 0)
+    with pytest.raises(ValueError):
+        X + D.lowrank(np.zeros((9, 1)))
+
+
+def test_python_mirror_shift_helpers_match_the_oracle():
+    S = D.Shifts
+    with pytest.raises(ValueError):
+        S.Projection(1)
+    vals = [complex(-np.exp(1j * a)) for a in range(-3, 4, 2)]
+    assert S.safe_sort(vals) == o.safe_sort(vals)
+    with pytest.warns(UserWarning, match="Discarding unstable"):
+        assert S.stabilize_ritz_values([1.0, -2.0], "t") == [-2.0]
+    with pytest.warns(UserWarning, match="flipping"):
+        assert S.stabilize_ritz_values([1.0, 2 + 1j], "t") == [-1.0, -2 + 1j]
+    R = [-0.1, -1.0, -10.0, -0.5 + 2j, -0.5 - 2j, -100.0]
+    assert S.heuristic(R, 4) == o.heuristic(R, 4)
+    with pytest.raises(TypeError):
+        D.solve_gdre(D.GDREProblem(None, None, None, None, np.eye(3), (0, 1)), D.Ros1(), dt=1.0)
+
+
+def test_replica_gather_over_gloo_world_size_2():
+    """bench.py's multi-GPU path (replicas + all_gather of the K(t) trajectories, MAX of wall-clock, SUM of iterations)
+    exercised with two CPU processes over gloo."""
+    script = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", script], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GLOO_OK world=2" in r.stdout

@@ -1,0 +1,141 @@
+"""Pins the CPU oracle (oracle/dre_oracle.py) to every closed-form known answer the reference's own tests hold
+for the hot path.  Paths are relative to /root/reference."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dre_oracle as o
+
+penzl = lambda p: np.array([[-1.0, p], [-p, -1.0]])
+
+
+def _pencil3():
+    E = sp.identity(3, format="csc")
+    A = sp.lil_matrix((3, 3))
+    A[0:2, 0:2] = penzl(1)
+    A[2, 2] = -0.5
+    return E, A.tocsc()
+
+
+def test_helpers_isstable_flip():                     # test/Shifts.jl:22-29
+    assert not o.isstable(0) and not o.isstable(1j) and o.isstable(-1) and o.isstable(-1 - 2j)
+    assert o.flip(1) == -1 and o.flip(1.0) == -1.0 and o.flip(2 + 1j) == -2 + 1j
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_stabilize_ritz_values(cplx):                 # test/Shifts.jl:30-67
+    rng = np.random.default_rng(0)
+    n = 3
+    v = list(rng.random(n) + (1j * rng.random(n) if cplx else 0))
+    with pytest.warns(UserWarning, match="All Ritz values of test are unstable"):
+        w = o.stabilize_ritz_values(v, "test")
+    assert len(w) == n and np.allclose(np.real(np.array(w) + np.array(v)), 0) and all(o.isstable(x) for x in w)
+    v2 = list(v); v2[0] = -v2[0]
+    with pytest.warns(UserWarning, match="Discarding unstable Ritz values of test"):
+        w = o.stabilize_ritz_values(v2, "test")
+    assert len(w) == 1 and all(o.isstable(x) for x in w)
+    v3 = [-x for x in v]
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        w = o.stabilize_ritz_values(v3, "test")
+    assert len(w) == n
+
+
+def test_cyclic_wraps_and_preserves_type():           # test/Shifts.jl:98-115
+    it = o.shifts_init(o.Cyclic(range(1, 4)), None, None)
+    assert [it.take() for _ in range(4)] == [1, 2, 3, 1]
+    for values in ((1.0, 2.0), [1 + 0j, 2 + 0j]):
+        it = o.shifts_init(o.Cyclic(values), None, None)
+        a, b = values
+        x, y = it.take(), it.take()
+        assert x == a and type(x) is type(a) and y == b
+
+
+def test_projection_known_answer():                   # test/Shifts.jl:165-183
+    E, A = _pencil3()
+    with pytest.raises(ValueError):
+        o.Projection(1)
+    it = o.shifts_init(o.Projection(2), E, A)
+    assert isinstance(it, o.BufferedIterator) and it.buffer == []
+    it.update(o.lowrank(np.zeros((3, 0)), np.zeros((0, 0))), np.ones((3, 1)))
+    assert it.buffer == []
+    assert abs(it.take() - (-5 / 6)) < 1e-14
+    assert it.buffer == []                             # rank-one residual -> exactly one shift
+
+
+def _preserves_pairs(vals):
+    i = 0
+    while i < len(vals):
+        v = vals[i]; i += 1
+        if v.imag != 0:
+            if i >= len(vals) or not np.isclose(vals[i], np.conj(v)):
+                return False
+            i += 1
+    return True
+
+
+@pytest.mark.parametrize("f", [lambda a: -np.exp(1j * a), lambda a: -1 - 1j * a])
+def test_safe_sort_keeps_conjugates_adjacent(f):      # test/Shifts.jl:185-212
+    vals = [complex(f(v)) for v in range(-3, 4, 2)]
+    assert not _preserves_pairs(vals)
+    assert _preserves_pairs(o.safe_sort(vals))
+
+
+def test_ldlt_algebra_and_compression():              # test/LDLt.jl:29-89
+    rng = np.random.default_rng(1)
+    n, k = 10, 2
+    U = rng.standard_normal((n, k)); S = rng.standard_normal((k, k)); S = S + S.T
+    X = o.lowrank(U, S)
+    a, Z1, Y = X.destructure()
+    assert a == 1.0 and Z1 is X.Ls[0] and Y is X.Ds[0]
+    Y2 = 2 * X
+    assert Y2.Ls is X.Ls and Y2.Ds is X.Ds and Y2.alphas == [2.0]
+    M = X.dense()
+    assert np.isclose(o.norm(2 * X), 2 * o.norm(X)) and np.isclose(o.norm(X), np.linalg.norm(M))
+    assert np.allclose((2 * X + 3 * X).dense(), 5 * M)
+    assert np.linalg.norm((X - X).dense()) / np.finfo(float).eps < 10 * n * max(1.0, np.linalg.norm(M))
+    Z = X.zero()
+    assert Z.rank() == 0 and Z.iszero() and (X + Z) is X and (Z + X) is X
+    Yc = o.compress(X + X)
+    assert Yc.rank() == k and np.allclose(Yc.dense(), 2 * M)
+    S1 = np.zeros((k, k)); S1[0, 0] = 13
+    X1 = o.lowrank(U.copy(), S1)
+    assert X1.rank() == k and o.compress(X1).rank() == 1
+
+
+def test_orth_of_zero_column():                       # test/runtests.jl:12-19
+    assert o.orth(np.zeros((4, 1))).shape == (4, 0)
+    assert o.orth(sp.csc_matrix((4, 1))).shape == (4, 0)
+
+
+def test_residual_of_zero_is_a_copy():                # test/residual.jl:7-16
+    rng = np.random.default_rng(2)
+    n = 20
+    E = (sp.random(n, n, density=0.1, random_state=rng) + n * sp.identity(n)).tocsc()
+    A = (sp.random(n, n, density=0.1, random_state=rng) - n * sp.identity(n)).tocsc()
+    C = o.lowrank(rng.standard_normal((n, 3)), np.eye(3))
+    prob = o.GALEProblem(E, A, C)
+    r = o.gale_residual(prob, C.zero())
+    assert r == C and r is not C and r.Ls[0] is not C.Ls[0]
+    # low-rank residual norm equals dense residual norm (test/residual.jl:18-29)
+    X = o.lowrank(rng.standard_normal((n, 2)), np.diag([1.0, -2.0]))
+    rd = C.dense() + A.T @ X.dense() @ E + E.T @ X.dense() @ A
+    assert np.isclose(o.norm(o.gale_residual(prob, X)), np.linalg.norm(rd))
+
+
+def test_rail_setup_and_solution_shape(rail371):      # test/rail.jl:32-46
+    d, L, Dm = rail371
+    X0 = o.lowrank(L, Dm)
+    lhs = d.E @ X0.dense() @ d.E.T
+    assert np.allclose(lhs, d.C.T @ d.C / 100, rtol=1e-10, atol=1e-14)
+    prob = o.GDREProblem(d.E, d.A, d.B, d.C, X0, (4500.0, 4400.0))
+    alg = o.Ros1(o.ADI(maxiters=3, warn_convergence=False))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol = o.solve(prob, alg, dt=-100.0)
+        assert len(sol.X) == 2 and sol.X[0] is prob.X0
+        sol = o.solve(prob, alg, dt=-50.0, save_state=True)
+    assert len(sol.t) == len(sol.X) == len(sol.K) == 3
+    assert (np.diff(sol.t) < 0).all()                  # direction of time preserved
