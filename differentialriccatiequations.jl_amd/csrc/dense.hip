@@ -15,7 +15,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // =============================================================================================
 #define GB_M 64
 #define GB_N 64
-#define GB_K 16
+#define GB_K 32
 #define GB_LD 81
 
 template <bool TA, bool TB>
@@ -39,39 +39,55 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
     const int lr = lane & 15, lk = lane >> 4;
 
     for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
+        // all 16 loads of a thread are independent and issued back to back: one memory latency per K-tile
+        double ra[8], rb[8];
         if (!TA) {
             const int m = tid & 63, kq = tid >> 6, gm = m0 + m;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = kq + 4 * p, gk = k0 + k;
-                As[k][m] = (gm < M && gk < kend) ? A[gm + (size_t)gk * lda] : 0.0;
+            for (int p = 0; p < 8; ++p) {
+                const int gk = k0 + kq + 4 * p;
+                ra[p] = (gm < M && gk < kend) ? A[gm + (size_t)gk * lda] : 0.0;
             }
         } else {
-            const int k = tid & 15, mq = tid >> 4, gk = k0 + k;
+            const int k = tid & 31, mq = tid >> 5, gk = k0 + k;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int m = mq + 16 * p, gm = m0 + m;
-                As[k][m] = (gm < M && gk < kend) ? A[gk + (size_t)gm * lda] : 0.0;
+            for (int p = 0; p < 8; ++p) {
+                const int gm = m0 + mq + 8 * p;
+                ra[p] = (gm < M && gk < kend) ? A[gk + (size_t)gm * lda] : 0.0;
             }
         }
         if (!TB) {
-            const int k = tid & 15, nq = tid >> 4, gk = k0 + k;
+            const int k = tid & 31, nq = tid >> 5, gk = k0 + k;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int n = nq + 16 * p, gn = n0 + n;
-                Bs[k][n] = (gn < N && gk < kend) ? B[gk + (size_t)gn * ldb] : 0.0;
+            for (int p = 0; p < 8; ++p) {
+                const int gn = n0 + nq + 8 * p;
+                rb[p] = (gn < N && gk < kend) ? B[gk + (size_t)gn * ldb] : 0.0;
             }
         } else {
             const int n = tid & 63, kq = tid >> 6, gn = n0 + n;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int k = kq + 4 * p, gk = k0 + k;
-                Bs[k][n] = (gn < N && gk < kend) ? B[gn + (size_t)gk * ldb] : 0.0;
+            for (int p = 0; p < 8; ++p) {
+                const int gk = k0 + kq + 4 * p;
+                rb[p] = (gn < N && gk < kend) ? B[gn + (size_t)gk * ldb] : 0.0;
             }
+        }
+        if (!TA) { const int m = tid & 63, kq = tid >> 6;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) As[kq + 4 * p][m] = ra[p];
+        } else { const int k = tid & 31, mq = tid >> 5;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) As[k][mq + 8 * p] = ra[p];
+        }
+        if (!TB) { const int k = tid & 31, nq = tid >> 5;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) Bs[k][nq + 8 * p] = rb[p];
+        } else { const int n = tid & 63, kq = tid >> 6;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) Bs[kq + 4 * p][n] = rb[p];
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < GB_K / 4; ++kk) {
             const int k = kk * 4 + lk;
             const double a0 = As[k][wm + lr], a1 = As[k][wm + 16 + lr];
             const double b0 = Bs[k][wn + lr], b1 = Bs[k][wn + 16 + lr];
@@ -118,10 +134,12 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
     if (M <= 0 || N <= 0) return;
     TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
     const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
+    // These GEMMs are latency bound (one memory round trip per K-tile), so K is split until the grid fills the
+    // chip or every block is down to two K-tiles; partial slabs are reduced in a fixed order (deterministic).
     int splits = 1;
-    if (K >= 512) {
+    if (K > 2 * GB_K) {
         int want = ceil_div(2 * ctx->num_cus, tm * tn);
-        splits = std::max(1, std::min(want, K / 256));
+        splits = std::max(1, std::min(want, K / (2 * GB_K)));
     }
     int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_K) * GB_K : GB_K;
     splits = K > 0 ? ceil_div(K, kchunk) : 1;
@@ -378,25 +396,37 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
 // =============================================================================================
 #define QR_NB 16
 
-// One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed) and T are written too.
+// One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed), T and VT = V*T are written too.
+// PLDS: the panel rows j0..m live in LDS for the whole factorisation (m - j0 <= QR_LDS_ROWS), which turns the
+// ~6 dependent global round trips per column into LDS round trips.
+#define QR_LDS_ROWS 1100
+template <bool PLDS>
 __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
-                                                   double* __restrict__ V, int ldv, double* __restrict__ T, int ldt) {
+                                                   double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
+                                                   double* __restrict__ VT, int ldvt, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double psm[];
     __shared__ double red[17];
     __shared__ double Tsh[QR_NB][QR_NB + 1];
     __shared__ double z[QR_NB];
     __shared__ double sc[4];  // tau, beta, scale
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int rows = m - j0;                       // panel rows (global rows j0..m-1)
+    const int ldp = PLDS ? (rows | 1) : lda;       // odd leading dimension in LDS
+    double* Pn = PLDS ? psm : (A + (size_t)j0 * lda + j0);   // Pn[r + c*ldp] = A[j0 + r, j0 + c]
+    if (PLDS) {
+        for (int c = wave; c < jb; c += nw)
+            for (int r = lane; r < rows; r += 64) Pn[r + (size_t)c * ldp] = A[(j0 + r) + (size_t)(j0 + c) * lda];
+    }
     for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) (&Tsh[0][0])[i] = 0.0;
     __syncthreads();
     for (int jj = 0; jj < jb; ++jj) {
-        const int c = j0 + jj;
-        double* col = A + (size_t)c * lda;
-        // 1. norm of the sub-column
+        double* col = Pn + (size_t)jj * ldp;        // local column jj, pivot at local row jj
         double s = 0.0;
-        for (int i = c + 1 + tid; i < m; i += blockDim.x) s += col[i] * col[i];
+        for (int i = jj + 1 + tid; i < rows; i += blockDim.x) s += col[i] * col[i];
         s = block_sum(s, red);
         if (tid == 0) {
-            double alpha = col[c], tau = 0.0, beta = alpha, scale = 0.0;
+            double alpha = col[jj], tau = 0.0, beta = alpha, scale = 0.0;
             if (s > 0.0) {
                 double nrm = sqrt(alpha * alpha + s);
                 beta = alpha >= 0.0 ? -nrm : nrm;
@@ -407,31 +437,26 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         }
         __syncthreads();
         const double tau = sc[0], beta = sc[1], scale = sc[2];
-        // 2. scale v, write explicit V column
-        for (int i = c + 1 + tid; i < m; i += blockDim.x) {
-            double v = col[i] * scale;
-            col[i] = v;
-            V[i + (size_t)c * ldv] = v;
-        }
-        if (tid == 0) { V[c + (size_t)c * ldv] = 1.0; col[c] = beta; }
+        for (int i = jj + 1 + tid; i < rows; i += blockDim.x) col[i] *= scale;
+        if (tid == 0) col[jj] = beta;
         __syncthreads();
-        // 3. apply H to the remaining panel columns (one wave per column)
-        for (int j = c + 1 + wave; j < j0 + jb; j += nw) {
-            double* cj = A + (size_t)j * lda;
+        // apply H to the remaining panel columns (one wave per column)
+        for (int j = jj + 1 + wave; j < jb; j += nw) {
+            double* cj = Pn + (size_t)j * ldp;
             double w = 0.0;
-            for (int i = c + 1 + lane; i < m; i += 64) w += col[i] * cj[i];
-            w = wave_sum(w) + cj[c];
+            for (int i = jj + 1 + lane; i < rows; i += 64) w += col[i] * cj[i];
+            w = wave_sum(w) + cj[jj];
             const double tw = tau * w;
-            for (int i = c + 1 + lane; i < m; i += 64) cj[i] -= tw * col[i];
-            if (lane == 0) cj[c] -= tw;
+            for (int i = jj + 1 + lane; i < rows; i += 64) cj[i] -= tw * col[i];
+            if (lane == 0) cj[jj] -= tw;
         }
-        // 4. z_i = V(:, j0+i)' v  for i < jj (one wave per i)
+        // z_i = V(:, i)' v  for i < jj (one wave per i)
         for (int i = wave; i < jj; i += nw) {
-            const double* vi = A + (size_t)(j0 + i) * lda;   // reflector i stored below its diagonal
+            const double* vi = Pn + (size_t)i * ldp;
             double w = 0.0;
-            for (int r = c + 1 + lane; r < m; r += 64) w += vi[r] * col[r];
+            for (int r = jj + 1 + lane; r < rows; r += 64) w += vi[r] * col[r];
             w = wave_sum(w);
-            if (lane == 0) z[i] = w + vi[c];   // vi[c] * v[c], v[c] = 1 (c > j0+i so vi[c] is a stored entry)
+            if (lane == 0) z[i] = w + vi[jj];
         }
         __syncthreads();
         if (tid < jj) {
@@ -442,9 +467,44 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         if (tid == 0) Tsh[jj][jj] = tau;
         __syncthreads();
     }
+    // write back: R part + reflectors into A, explicit V, T, and VT = V * T
+    for (int c = wave; c < jb; c += nw) {
+        const double* pc = Pn + (size_t)c * ldp;
+        for (int r = lane; r < rows; r += 64) {
+            const double x = pc[r];
+            if (PLDS) A[(j0 + r) + (size_t)(j0 + c) * lda] = x;
+            V[(j0 + r) + (size_t)(j0 + c) * ldv] = (r > c) ? x : (r == c ? 1.0 : 0.0);
+        }
+    }
     for (int i = tid; i < QR_NB * jb; i += blockDim.x) {
         int r = i % QR_NB, cc = i / QR_NB;
         T[r + (size_t)(j0 + cc) * ldt] = Tsh[r][cc];
+    }
+    if (VT) {
+        // VT(r, c) = sum_{l <= c} V(r, l) T(l, c)
+        for (int c = wave; c < jb; c += nw)
+            for (int r = lane; r < rows; r += 64) {
+                double acc = 0.0;
+                for (int l = 0; l <= c; ++l) {
+                    const double v = (r > l) ? Pn[r + (size_t)l * ldp] : (r == l ? 1.0 : 0.0);
+                    acc += v * Tsh[l][c];
+                }
+                VT[(j0 + r) + (size_t)(j0 + c) * ldvt] = acc;
+            }
+    }
+}
+
+static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
+                            double* VT, int ldvt, const AdiState* st) {
+    const int rows = m - j0;
+    TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
+    if (rows <= QR_LDS_ROWS) {
+        const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+        hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st);
+    } else {
+        hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st);
     }
 }
 
@@ -459,24 +519,23 @@ QRFact qr_factor(Ctx* ctx, Mat& A) {
     QRFact f;
     f.m = A.rows; f.n = A.cols; f.kq = std::min(A.rows, A.cols); f.nb = QR_NB;
     f.V = Mat(ctx, f.m, f.kq);
+    f.VT = Mat(ctx, f.m, f.kq);
     f.T = Mat(ctx, QR_NB, std::max(f.kq, 1));
     f.R = Mat(ctx, f.kq, f.n);
     fill_mat(ctx, f.V, 0.0);
+    fill_mat(ctx, f.VT, 0.0);
     for (int j0 = 0; j0 < f.kq; j0 += QR_NB) {
         const int jb = std::min(QR_NB, f.kq - j0);
-        {
-            TimedScope ts(ctx, "qr_panel", 8.0 * (f.m - j0) * jb * (jb + 2), 2.0 * (f.m - j0) * jb * jb);
-            hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(1024), 0, ctx->stream, A.p, A.ld, f.m, j0, jb, f.V.p, f.V.ld, f.T.p, f.T.ld);
-        }
+        launch_qr_panel(ctx, A.p, A.ld, f.m, j0, jb, f.V.p, f.V.ld, f.T.p, f.T.ld, f.VT.p, f.VT.ld, nullptr);
         const int n2 = f.n - j0 - jb;
         if (n2 > 0) {
+            // A2 <- Q_p' A2 = A2 - V (V T)' A2
             Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
+            Mat VTp = f.VT.view(j0, j0, f.m - j0, jb);
             Mat A2 = A.view(j0, j0 + jb, f.m - j0, n2);
-            Mat Tp = f.T.view(0, j0, jb, jb);
-            Mat W(ctx, jb, n2), W2(ctx, jb, n2);
-            gemm(ctx, true, false, 1.0, Vp, A2, 0.0, W, nullptr, "gemm_qr");
-            gemm(ctx, true, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_qr");   // T' W   (Q' = I - V T' V')
-            gemm(ctx, false, false, -1.0, Vp, W2, 1.0, A2, nullptr, "gemm_qr");
+            Mat W(ctx, jb, n2);
+            gemm(ctx, true, false, 1.0, VTp, A2, 0.0, W, nullptr, "gemm_qr");
+            gemm(ctx, false, false, -1.0, Vp, W, 1.0, A2, nullptr, "gemm_qr");
         }
     }
     size_t tot = (size_t)f.kq * f.n;
@@ -493,12 +552,16 @@ void qr_apply_q(Ctx* ctx, const QRFact& f, Mat& B, bool transpose) {
         const int p = transpose ? pp : np - 1 - pp;
         const int j0 = p * QR_NB, jb = std::min(QR_NB, f.kq - j0);
         Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
+        Mat VTp = f.VT.view(j0, j0, f.m - j0, jb);
         Mat B2 = B.view(j0, 0, f.m - j0, B.cols);
-        Mat Tp = f.T.view(0, j0, jb, jb);
-        Mat W(ctx, jb, B.cols), W2(ctx, jb, B.cols);
-        gemm(ctx, true, false, 1.0, Vp, B2, 0.0, W, nullptr, "gemm_qr");
-        gemm(ctx, transpose, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_qr");
-        gemm(ctx, false, false, -1.0, Vp, W2, 1.0, B2, nullptr, "gemm_qr");
+        Mat W(ctx, jb, B.cols);
+        if (!transpose) {   // Q_p B = B - (V T)(V' B)
+            gemm(ctx, true, false, 1.0, Vp, B2, 0.0, W, nullptr, "gemm_qr");
+            gemm(ctx, false, false, -1.0, VTp, W, 1.0, B2, nullptr, "gemm_qr");
+        } else {            // Q_p' B = B - V (V T)' B
+            gemm(ctx, true, false, 1.0, VTp, B2, 0.0, W, nullptr, "gemm_qr");
+            gemm(ctx, false, false, -1.0, Vp, W, 1.0, B2, nullptr, "gemm_qr");
+        }
     }
 }
 
@@ -818,19 +881,73 @@ Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids
 // =============================================================================================
 // Blocked band reduction
 // =============================================================================================
-// rem2 = ||S[k:, k:]||_F^2 + 2 * ||triu(S[k:k+b, k-b:k])||_F^2   (the second term couples the kept part to the rest)
-__global__ __launch_bounds__(1024) void k_band_rem(int q, int k, int b, const double* __restrict__ S, int ld, double* out) {
+// partial sums of  ||S[k:, k:]||_F^2 + 2 * ||triu(S[k:k+b, k-b:k])||_F^2  (the second term couples the kept part
+// to the rest); one partial per workgroup, reduced in fixed order by k_band_decide
+#define BAND_REM_BLOCKS 64
+__global__ __launch_bounds__(256) void k_band_rem(int q, int k, int b, const double* __restrict__ S, int ld, double* __restrict__ part,
+                                                  const AdiState* st) {
+    if (st->done) return;
     __shared__ double red[17];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     double s = 0.0;
-    for (int c = k + wave; c < q; c += nw)
+    for (int c = k + blockIdx.x * nw + wave; c < q; c += nw * gridDim.x)
         for (int r = k + lane; r < q; r += 64) { const double x = S[r + (size_t)c * ld]; s += x * x; }
-    if (k >= b) {
+    if (k >= b && blockIdx.x == 0) {
         for (int c = wave; c < b; c += nw)
             for (int r = lane; r <= c && r < q - k; r += 64) { const double x = S[(k + r) + (size_t)(k - b + c) * ld]; s += 2.0 * x * x; }
     }
     s = block_sum(s, red);
-    if (threadIdx.x == 0) out[0] = s;
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// st->res_norm holds ||S||_F^2 (set at k = 0), st->abstol the absolute tolerance (<= 0: relative tolfac*eps*||S||_F),
+// st->iters the panel boundary J at which the reduction stopped
+__global__ void k_band_decide(int k, int nparts, const double* __restrict__ part, double tolfac, AdiState* st) {
+    if (st->done) return;
+    double r2 = 0.0;
+    for (int i = 0; i < nparts; ++i) r2 += part[i];
+    if (k == 0) st->res_norm = r2;
+    const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(st->res_norm);
+    if (r2 <= tol * tol) { st->done = 1; st->iters = k; }
+}
+// Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup
+__global__ __launch_bounds__(1024) void k_band_w(int m, int b, const double* __restrict__ Z, int ldz, const double* __restrict__ Vp, int ldv,
+                                                 const double* __restrict__ Tp, int ldt, double* __restrict__ P1, double* __restrict__ P2,
+                                                 int ldp, const AdiState* st) {
+    if (st->done) return;
+    __shared__ double Msh[QR_NB][QR_NB + 1], Nsh[QR_NB][QR_NB + 1];
+    __shared__ double redw[16][QR_NB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    // M = V' Z  (b x b): wave w accumulates a slice of rows for all (i, j); 256 entries -> loop
+    for (int e = 0; e < b * b; e += 1) {
+        // handled below in a tiled way
+        break;
+    }
+    for (int i = 0; i < b; ++i) {
+        // column i of V against all columns of Z: each wave takes columns j = wave, wave + nw, ...
+        for (int j = wave; j < b; j += nw) {
+            double acc = 0.0;
+            for (int r = lane; r < m; r += 64) acc += Vp[r + (size_t)i * ldv] * Z[r + (size_t)j * ldz];
+            acc = wave_sum(acc);
+            if (lane == 0) Msh[i][j] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid < b * b) {
+        const int i = tid % b, j = tid / b;      // N = T' M
+        double acc = 0.0;
+        for (int l = 0; l <= i; ++l) acc += Tp[l + (size_t)i * ldt] * Msh[l][j];
+        Nsh[i][j] = acc;
+    }
+    __syncthreads();
+    for (int c = wave; c < b; c += nw)
+        for (int r = lane; r < m; r += 64) {
+            double acc = Z[r + (size_t)c * ldz];
+            for (int l = 0; l < b; ++l) acc -= 0.5 * Vp[r + (size_t)l * ldv] * Nsh[l][c];
+            const double v = Vp[r + (size_t)c * ldv];
+            P1[r + (size_t)c * ldp] = acc;       P1[r + (size_t)(b + c) * ldp] = v;
+            P2[r + (size_t)c * ldp] = v;         P2[r + (size_t)(b + c) * ldp] = acc;
+        }
+    (void)redw;
 }
 // D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
 __global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
@@ -846,12 +963,6 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
     const int oi = swap ? j : i, oj = swap ? i : j;
     D[oi + (size_t)oj * ldd] = v;
 }
-__global__ void k_axpy_mat(int rows, int cols, double a, const double* __restrict__ X, int ldx, double* __restrict__ Y, int ldy) {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * cols) return;
-    int r = idx % rows, c = idx / rows;
-    Y[r + (size_t)c * ldy] += a * X[r + (size_t)c * ldx];
-}
 
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
@@ -860,46 +971,54 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     out.q = q; out.nb = b;
     if (q == 0) return out;
     out.V = Mat(ctx, q, q);
+    out.VT = Mat(ctx, q, q);
     out.T = Mat(ctx, b, q);
     fill_mat(ctx, out.V, 0.0);
-    DevArr<double> rem(ctx, 1);
-    double snorm2 = -1.0;
-    int k = 0, np = 0;
-    int J = q;
-    while (k < q) {
-        {
-            TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
-            hipLaunchKernelGGL(k_band_rem, dim3(1), dim3(1024), 0, ctx->stream, q, k, b, S.p, S.ld, rem.p);
+    DevArr<double> part(ctx, BAND_REM_BLOCKS);
+    DevArr<AdiState> st(ctx, 1);
+    {
+        AdiState h;
+        std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
+        h.abstol = abs_tol;
+        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
+    }
+    // Panels are enqueued speculatively: every kernel returns at once after the device-side decision `done`, and the
+    // host looks at the flag only every few panels.
+    int k = 0, np = 0, J = q;
+    bool finished = false;
+    const int chunk = 4;
+    while (!finished) {
+        int issued = 0;
+        while (issued < chunk && k < q) {
+            {
+                TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
+                hipLaunchKernelGGL(k_band_rem, dim3(BAND_REM_BLOCKS), dim3(256), 0, ctx->stream, q, k, b, S.p, S.ld, part.p, st.p);
+                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, BAND_REM_BLOCKS, part.p, tolfac, st.p);
+            }
+            const int m = q - k - b;            // rows below the diagonal block of this panel
+            if (m < b) { k = q; break; }        // the last rows stay unreduced: D is stored dense, band form is not required
+            launch_qr_panel(ctx, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, b,
+                            out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld,
+                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p);
+            // two-sided update of S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,  Z = S22 (V T),  N = T' (V' Z)
+            Mat S22 = S.view(k + b, k + b, m, m);
+            Mat Vp = out.V.view(k + b, k, m, b);
+            Mat VTp = out.VT.view(k + b, k, m, b);
+            Mat Tp = out.T.view(0, k, b, b);
+            Mat Z(ctx, m, b), P1(ctx, m, 2 * b), P2(ctx, m, 2 * b);
+            gemm(ctx, false, false, 1.0, S22, VTp, 0.0, Z, st.p, "gemm_band");
+            {
+                TimedScope ts(ctx, "band_w", 8.0 * m * b * 6.0, 2.0 * m * b * b * 2.0);
+                hipLaunchKernelGGL(k_band_w, dim3(1), dim3(1024), 0, ctx->stream, m, b, Z.p, Z.ld, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+            }
+            gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band");    // S22 -= [W V] [V W]'
+            k += b; ++np; ++issued;
         }
-        const double r2 = read_scalar(ctx, rem.p);
-        if (snorm2 < 0.0) snorm2 = r2;
-        const double tol = abs_tol > 0.0 ? abs_tol : tolfac * 2.220446049250313e-16 * std::sqrt(snorm2);
-        if (r2 <= tol * tol) { J = k; break; }
-        const int m = q - k - b;            // rows below the diagonal block of this panel
-        if (m < b) break;                   // the last few rows stay unreduced: D is stored dense, band form is not required
-        const int jb = b;
-        {
-            TimedScope ts(ctx, "qr_panel", 8.0 * m * b * (b + 2), 2.0 * m * b * b);
-            hipLaunchKernelGGL(k_qr_panel, dim3(1), dim3(1024), 0, ctx->stream, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, jb,
-                               out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld);
-        }
-        // two-sided update of the trailing block S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,
-        // Z = S22 V T,  N = T' (V' Z)
-        Mat S22 = S.view(k + b, k + b, m, m);
-        Mat Vp = out.V.view(k + b, k, m, jb);
-        Mat Tp = out.T.view(0, k, jb, jb);
-        Mat Y(ctx, m, jb), Z(ctx, m, jb), M(ctx, jb, jb), N(ctx, jb, jb);
-        gemm(ctx, false, false, 1.0, S22, Vp, 0.0, Y, nullptr, "gemm_band");
-        gemm(ctx, false, false, 1.0, Y, Tp, 0.0, Z, nullptr, "gemm_band");
-        gemm(ctx, true, false, 1.0, Vp, Z, 0.0, M, nullptr, "gemm_band");
-        gemm(ctx, true, false, 1.0, Tp, M, 0.0, N, nullptr, "gemm_band");
-        gemm(ctx, false, false, -0.5, Vp, N, 1.0, Z, nullptr, "gemm_band");        // Z <- W
-        gemm(ctx, false, true, -1.0, Z, Vp, 1.0, S22, nullptr, "gemm_band");
-        gemm(ctx, false, true, -1.0, Vp, Z, 1.0, S22, nullptr, "gemm_band");
-        // the panel columns right of the current one inside the diagonal-block row, i.e. S[k:k+b, k+b:], must mirror
-        // the transformed coupling block: S[k:k+b, k+b:] = (Q_p' S[k+b:, k:k+b])' = [R_p; 0]'.  Only the lower triangle
-        // (column block) is read afterwards, so nothing to do here.
-        k += b; ++np;
+        AdiState h;
+        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (h.done) { J = h.iters; np = J / b; finished = true; }
+        else if (k >= q) { J = q; finished = true; }
     }
     out.J = J; out.npanels = np;
     out.D = Mat(ctx, J, J);
@@ -913,17 +1032,16 @@ Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
     Mat B(ctx, sb.q, sb.J);
     set_identity(ctx, B, 1.0);
     const int b = sb.nb;
-    // Qb = Q_0 Q_1 ... Q_{np-1};  Qb * [I; 0]: apply the last panel first
+    // Qb = Q_0 Q_1 ... Q_{np-1};  Qb * [I; 0]: apply the last panel first;  Q_p B = B - (V T)(V' B)
     for (int p = sb.npanels - 1; p >= 0; --p) {
-        const int k = p * b, m = sb.q - k - b, jb = std::min(b, m);
-        if (m <= 0) continue;
-        Mat Vp = sb.V.view(k + b, k, m, jb);
-        Mat Tp = sb.T.view(0, k, jb, jb);
+        const int k = p * b, m = sb.q - k - b;
+        if (m < b) continue;
+        Mat Vp = sb.V.view(k + b, k, m, b);
+        Mat VTp = sb.VT.view(k + b, k, m, b);
         Mat B2 = B.view(k + b, 0, m, sb.J);
-        Mat W(ctx, jb, sb.J), W2(ctx, jb, sb.J);
+        Mat W(ctx, b, sb.J);
         gemm(ctx, true, false, 1.0, Vp, B2, 0.0, W, nullptr, "gemm_band");
-        gemm(ctx, false, false, 1.0, Tp, W, 0.0, W2, nullptr, "gemm_band");
-        gemm(ctx, false, false, -1.0, Vp, W2, 1.0, B2, nullptr, "gemm_band");
+        gemm(ctx, false, false, -1.0, VTp, W, 1.0, B2, nullptr, "gemm_band");
     }
     return B;
 }

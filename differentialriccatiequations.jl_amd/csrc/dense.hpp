@@ -50,6 +50,7 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // s
 struct QRFact {
     int m = 0, n = 0, kq = 0, nb = 16;
     Mat V;   // m x kq, explicit unit-lower-trapezoidal reflectors (zeros above the diagonal)
+    Mat VT;  // m x kq, V_p * T_p per panel (so that Q_p = I - VT_p V_p')
     Mat T;   // nb x kq, upper-triangular block-reflector factors per panel
     Mat R;   // kq x n upper trapezoid
 };
@@ -85,6 +86,7 @@ Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids
 struct SymBand {
     int q = 0, J = 0, nb = 16, npanels = 0;
     Mat V;      // q x q explicit reflectors; panel p occupies columns [p*nb, ...) and rows >= (p+1)*nb
+    Mat VT;     // V_p * T_p per panel
     Mat T;      // nb x q block-reflector factors
     Mat D;      // J x J symmetric band matrix (dense storage)
 };
