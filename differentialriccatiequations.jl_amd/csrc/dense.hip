@@ -419,13 +419,20 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
             for (int r = lane; r < rows; r += 64) Pn[r + (size_t)c * ldp] = A[(j0 + r) + (size_t)(j0 + c) * lda];
     }
     for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) (&Tsh[0][0])[i] = 0.0;
+    __shared__ double nrm2_next;     // ||P[jj+1:, jj+1]||^2 after the update with reflector jj (lookahead)
+    __shared__ double scl[QR_NB];    // deferred scaling: v_jj = x_jj * scl[jj] below the diagonal
+    __syncthreads();                 // the LDS copy of the panel is complete
+    {
+        double s0 = 0.0;
+        for (int i = 1 + tid; i < rows; i += blockDim.x) s0 += Pn[i] * Pn[i];
+        s0 = block_sum(s0, red);
+        if (tid == 0) nrm2_next = s0;
+    }
     __syncthreads();
     for (int jj = 0; jj < jb; ++jj) {
-        double* col = Pn + (size_t)jj * ldp;        // local column jj, pivot at local row jj
-        double s = 0.0;
-        for (int i = jj + 1 + tid; i < rows; i += blockDim.x) s += col[i] * col[i];
-        s = block_sum(s, red);
+        double* col = Pn + (size_t)jj * ldp;        // local column jj, pivot at local row jj (entries below are UNSCALED x)
         if (tid == 0) {
+            const double s = nrm2_next;
             double alpha = col[jj], tau = 0.0, beta = alpha, scale = 0.0;
             if (s > 0.0) {
                 double nrm = sqrt(alpha * alpha + s);
@@ -434,29 +441,36 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
                 scale = 1.0 / (alpha - beta);
             }
             sc[0] = tau; sc[1] = beta; sc[2] = scale;
+            scl[jj] = scale;
+            col[jj] = beta;
         }
         __syncthreads();
-        const double tau = sc[0], beta = sc[1], scale = sc[2];
-        for (int i = jj + 1 + tid; i < rows; i += blockDim.x) col[i] *= scale;
-        if (tid == 0) col[jj] = beta;
-        __syncthreads();
-        // apply H to the remaining panel columns (one wave per column)
-        for (int j = jj + 1 + wave; j < jb; j += nw) {
-            double* cj = Pn + (size_t)j * ldp;
-            double w = 0.0;
-            for (int i = jj + 1 + lane; i < rows; i += 64) w += col[i] * cj[i];
-            w = wave_sum(w) + cj[jj];
-            const double tw = tau * w;
-            for (int i = jj + 1 + lane; i < rows; i += 64) cj[i] -= tw * col[i];
-            if (lane == 0) cj[jj] -= tw;
-        }
-        // z_i = V(:, i)' v  for i < jj (one wave per i)
-        for (int i = wave; i < jj; i += nw) {
-            const double* vi = Pn + (size_t)i * ldp;
-            double w = 0.0;
-            for (int r = jj + 1 + lane; r < rows; r += 64) w += vi[r] * col[r];
-            w = wave_sum(w);
-            if (lane == 0) z[i] = w + vi[jj];
+        const double tau = sc[0], scale = sc[2];
+        // waves jj+1.. : apply H to the later panel columns (the wave of column jj+1 also accumulates its next norm);
+        // waves 0..jj-1 : z_i = V(:, i)' v for the T factor.  v = scale * x below the pivot, 1 at the pivot.
+        for (int j = wave; j < jb; j += nw) {
+            if (j > jj) {
+                double* cj = Pn + (size_t)j * ldp;
+                const double cjj = cj[jj];           // entry in the pivot row, read before anybody overwrites it
+                double w = 0.0;
+                for (int i = jj + 1 + lane; i < rows; i += 64) w += col[i] * cj[i];
+                w = wave_sum(w) * scale + cjj;
+                const double tw = tau * w, tws = tw * scale;
+                double nn = 0.0;
+                for (int i = jj + 1 + lane; i < rows; i += 64) {
+                    const double x = cj[i] - tws * col[i];
+                    cj[i] = x;
+                    if (i > jj + 1) nn += x * x;
+                }
+                if (lane == 0) cj[jj] = cjj - tw;
+                if (j == jj + 1) { nn = wave_sum(nn); if (lane == 0) nrm2_next = nn; }
+            } else if (j < jj) {
+                const double* vi = Pn + (size_t)j * ldp;   // reflector j: unscaled below its pivot, scale scl[j]
+                double w = 0.0;
+                for (int r = jj + 1 + lane; r < rows; r += 64) w += vi[r] * col[r];
+                w = wave_sum(w) * scl[j] * scale;
+                if (lane == 0) z[j] = w + vi[jj] * scl[j];
+            }
         }
         __syncthreads();
         if (tid < jj) {
@@ -467,6 +481,13 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         if (tid == 0) Tsh[jj][jj] = tau;
         __syncthreads();
     }
+    // apply the deferred scaling: below-diagonal entries become the reflector vectors
+    for (int c = wave; c < jb; c += nw) {
+        double* pc = Pn + (size_t)c * ldp;
+        const double sv = scl[c];
+        for (int r = c + 1 + lane; r < rows; r += 64) pc[r] *= sv;
+    }
+    __syncthreads();
     // write back: R part + reflectors into A, explicit V, T, and VT = V * T
     for (int c = wave; c < jb; c += nw) {
         const double* pc = Pn + (size_t)c * ldp;
@@ -909,31 +930,29 @@ __global__ void k_band_decide(int k, int nparts, const double* __restrict__ part
     const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(st->res_norm);
     if (r2 <= tol * tol) { st->done = 1; st->iters = k; }
 }
-// Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup
+// Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup.
+// Wave j owns column j of Z / Wm and keeps b independent accumulators, so the global loads of a row chunk overlap.
 __global__ __launch_bounds__(1024) void k_band_w(int m, int b, const double* __restrict__ Z, int ldz, const double* __restrict__ Vp, int ldv,
                                                  const double* __restrict__ Tp, int ldt, double* __restrict__ P1, double* __restrict__ P2,
                                                  int ldp, const AdiState* st) {
     if (st->done) return;
     __shared__ double Msh[QR_NB][QR_NB + 1], Nsh[QR_NB][QR_NB + 1];
-    __shared__ double redw[16][QR_NB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    // M = V' Z  (b x b): wave w accumulates a slice of rows for all (i, j); 256 entries -> loop
-    for (int e = 0; e < b * b; e += 1) {
-        // handled below in a tiled way
-        break;
-    }
-    for (int i = 0; i < b; ++i) {
-        // column i of V against all columns of Z: each wave takes columns j = wave, wave + nw, ...
-        for (int j = wave; j < b; j += nw) {
-            double acc = 0.0;
-            for (int r = lane; r < m; r += 64) acc += Vp[r + (size_t)i * ldv] * Z[r + (size_t)j * ldz];
-            acc = wave_sum(acc);
-            if (lane == 0) Msh[i][j] = acc;
+    for (int j = wave; j < b; j += nw) {                    // M(:, j) = V' Z(:, j)
+        double acc[QR_NB];
+#pragma unroll
+        for (int i = 0; i < QR_NB; ++i) acc[i] = 0.0;
+        for (int r = lane; r < m; r += 64) {
+            const double zj = Z[r + (size_t)j * ldz];
+#pragma unroll
+            for (int i = 0; i < QR_NB; ++i) acc[i] += Vp[r + (size_t)i * ldv] * zj;
         }
+#pragma unroll
+        for (int i = 0; i < QR_NB; ++i) { const double t = wave_sum(acc[i]); if (lane == 0) Msh[i][j] = t; }
     }
     __syncthreads();
     if (tid < b * b) {
-        const int i = tid % b, j = tid / b;      // N = T' M
+        const int i = tid % b, j = tid / b;                 // N = T' M
         double acc = 0.0;
         for (int l = 0; l <= i; ++l) acc += Tp[l + (size_t)i * ldt] * Msh[l][j];
         Nsh[i][j] = acc;
@@ -941,13 +960,17 @@ __global__ __launch_bounds__(1024) void k_band_w(int m, int b, const double* __r
     __syncthreads();
     for (int c = wave; c < b; c += nw)
         for (int r = lane; r < m; r += 64) {
-            double acc = Z[r + (size_t)c * ldz];
-            for (int l = 0; l < b; ++l) acc -= 0.5 * Vp[r + (size_t)l * ldv] * Nsh[l][c];
+            double a0 = Z[r + (size_t)c * ldz], a1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < QR_NB; l += 2) {
+                a0 -= 0.5 * Vp[r + (size_t)l * ldv] * Nsh[l][c];
+                a1 -= 0.5 * Vp[r + (size_t)(l + 1) * ldv] * Nsh[l + 1][c];
+            }
+            const double acc = a0 + a1;
             const double v = Vp[r + (size_t)c * ldv];
             P1[r + (size_t)c * ldp] = acc;       P1[r + (size_t)(b + c) * ldp] = v;
             P2[r + (size_t)c * ldp] = v;         P2[r + (size_t)(b + c) * ldp] = acc;
         }
-    (void)redw;
 }
 // D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
 __global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
