@@ -795,7 +795,10 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
             }
             LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
-            ldlt_compress(ctx, *rhs, ctf, cex);
+            // The reference compresses the right-hand side here (lowrank_ros1.jl:44) and again, together with the warm start,
+            // inside residual() (lyapunov/residual.jl:30).  In Krylov mode the second compression truncates at a fraction of
+            // abstol, which also removes what the first one would have filtered, so the first is skipped for warm starts.
+            if (cex || adi.ignore_initial_guess || X->iszero()) ldlt_compress(ctx, *rhs, ctf, cex);
             AdiResult ar = adi_solve(ctx, op, *rhs, X, adi, &cache);
             X = ar.X;
             out.adi_iters += ar.iters;

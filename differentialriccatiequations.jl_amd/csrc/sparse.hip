@@ -4,6 +4,7 @@
 #include "profiling.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace dre {
 
@@ -33,6 +34,7 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
         }
     }
     int leaf = leaf_size > 0 ? leaf_size : (n <= 2000 ? 24 : 32);
+    if (leaf_size <= 0) if (const char* e = std::getenv("DRE_LEAF_SIZE")) leaf = std::max(1, atoi(e));   // tuning knob
     P->sym = symbolic_analyze(n, uptr, uidx, leaf);
     const Symbolic& S = P->sym;
     P->nnz = (int)S.idx.size();
