@@ -161,6 +161,30 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
     DRE_HIP(hipGetLastError());
 }
 
+BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                   int* splits_out, const AdiState* st, const char* tag) {
+    TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
+    const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
+    int splits = 1;
+    if (K > 2 * GB_K) {
+        int want = ceil_div(2 * ctx->num_cus, tm * tn);
+        splits = std::max(1, std::min(want, K / (2 * GB_K)));
+    }
+    int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_K) * GB_K : GB_K;
+    splits = K > 0 ? ceil_div(K, kchunk) : 1;
+    dim3 grid(tm, tn, splits), block(256);
+    auto pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
+    double* partial = (double*)pb->p;
+    double* none = nullptr;
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
+    DRE_HIP(hipGetLastError());
+    *splits_out = splits;
+    return pb;
+}
+
 // =============================================================================================
 // small helpers
 // =============================================================================================
@@ -380,6 +404,69 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
         hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, st, iters_after, (double*)nullptr);
     }
 }
+// One workgroup: G = sum of split-K slabs (fixed order), M = T G (or diag(T) G), nrm = |alpha| sqrt(sum_ij M_ij M_ji),
+// then the convergence decision of adi.jl:115-123 on the device.  G and T live in LDS (k <= 88).
+__global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const double* __restrict__ part, const double* __restrict__ T, int ldt,
+                                                    int tdiag, double alpha, AdiState* st, int iters_after) {
+    if (st->done) return;
+    extern __shared__ double gsm[];
+    double* G = gsm;                 // k x k, ld k
+    double* Ts = gsm + (size_t)k * k;  // k x k (or k diagonal entries)
+    __shared__ double red[17];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int idx = tid; idx < k * k; idx += blockDim.x) {
+        double s = 0.0;
+        for (int z = 0; z < splits; ++z) s += part[(size_t)z * k * k + idx];
+        G[idx] = s;
+        if (!tdiag) Ts[idx] = T[idx % k + (size_t)(idx / k) * ldt];
+    }
+    if (tdiag) for (int i = tid; i < k; i += blockDim.x) Ts[i] = T[i + (size_t)i * ldt];
+    __syncthreads();
+    double s = 0.0;
+    if (tdiag) {
+        for (int c = wave; c < k; c += nw)
+            for (int r = lane; r < k; r += 64) { const double g = G[r + c * k]; s += Ts[r] * Ts[c] * g * g; }
+    } else {
+        // M_ij M_ji with M = T G, G symmetric:  M_ij = sum_l T_il G_lj,  M_ji = sum_l T_jl G_li
+        for (int c = wave; c < k; c += nw)
+            for (int r = lane; r < k; r += 64) {
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                int l = 0;
+                for (; l + 1 < k; l += 2) {
+                    // G is symmetric: G_li is read as G[r + l*k] so that the lanes (r) touch consecutive LDS words
+                    a0 += Ts[r + l * k] * G[l + c * k];        a1 += Ts[r + (l + 1) * k] * G[l + 1 + c * k];
+                    b0 += Ts[c + l * k] * G[r + l * k];        b1 += Ts[c + (l + 1) * k] * G[r + (l + 1) * k];
+                }
+                if (l < k) { a0 += Ts[r + l * k] * G[l + c * k]; b0 += Ts[c + l * k] * G[r + l * k]; }
+                s += (a0 + a1) * (b0 + b1);
+            }
+    }
+    s = block_sum(s, red);
+    if (tid == 0) {
+        const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        st->res_norm = nrm;
+        st->iters = iters_after;
+        if (iters_after < 512) st->norms[iters_after] = nrm;
+        if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+    }
+}
+void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
+    const int k = R.cols;
+    if (k > 88) {
+        Mat G(ctx, k, k);
+        gemm(ctx, true, false, 1.0, R, R, 0.0, G, st, "gemm_gram");
+        ldlt_norm_update_state(ctx, G, T, tdiag, alpha, st, iters_after);
+        return;
+    }
+    int splits = 1;
+    BufP part = gemm_partials(ctx, true, false, k, k, R.rows, R.p, R.ld, R.p, R.ld, &splits, st, "gemm_gram");
+    TimedScope ts(ctx, "ldlt_norm", 8.0 * splits * k * k, 4.0 * (double)k * k * k);
+    const size_t shm = 2 * (size_t)k * k * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, splits, (const double*)part->p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
+}
+
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
     if (L.cols == 0) return 0.0;
     Mat G(ctx, L.cols, L.cols);
@@ -403,8 +490,24 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
 template <bool PLDS>
 __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
                                                    double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
-                                                   double* __restrict__ VT, int ldvt, const AdiState* st) {
+                                                   double* __restrict__ VT, int ldvt, AdiState* st,
+                                                   const double* __restrict__ part, int nparts, int kpanel, double tolfac) {
     if (st && st->done) return;
+    if (part) {
+        // fused termination test of the band reduction (was a kernel of its own): the previous launch left `nparts`
+        // partial sums of the not-yet-reduced norm; every thread evaluates the same fixed-order sum.
+        double r2 = 0.0;
+        for (int i = 0; i < nparts; ++i) r2 += part[i];
+        const double base = (kpanel == 0) ? r2 : st->res_norm;
+        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const bool stop = r2 <= tol * tol;
+        __syncthreads();          // everybody has read res_norm / done before thread 0 updates them
+        if (threadIdx.x == 0) {
+            if (kpanel == 0) st->res_norm = r2;
+            if (stop) { st->done = 1; st->iters = kpanel; }
+        }
+        if (stop) return;
+    }
     extern __shared__ double psm[];
     __shared__ double red[17];
     __shared__ double Tsh[QR_NB][QR_NB + 1];
@@ -516,16 +619,17 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
 }
 
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
-                            double* VT, int ldvt, const AdiState* st) {
+                            double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
+                            double tolfac = 0.0) {
     const int rows = m - j0;
     TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
     if (rows <= QR_LDS_ROWS) {
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st);
+        hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
     } else {
-        hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st);
+        hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
     }
 }
 
@@ -931,21 +1035,36 @@ __global__ void k_band_decide(int k, int nparts, const double* __restrict__ part
     if (r2 <= tol * tol) { st->done = 1; st->iters = k; }
 }
 // Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup.
-// Wave j owns column j of Z / Wm and keeps b independent accumulators, so the global loads of a row chunk overlap.
-__global__ __launch_bounds__(1024) void k_band_w(int m, int b, const double* __restrict__ Z, int ldz, const double* __restrict__ Vp, int ldv,
+// Z arrives as `splits` split-K slabs (m x b, ld m) that are summed here in a fixed order (no separate reduce launch);
+// ZLDS: Z and V are staged in LDS (m <= 540).  Wave j owns column j and keeps b independent accumulators.
+template <bool ZLDS>
+__global__ __launch_bounds__(1024) void k_band_w(int m, int b, int splits, const double* __restrict__ Zpart, const double* __restrict__ Vp, int ldv,
                                                  const double* __restrict__ Tp, int ldt, double* __restrict__ P1, double* __restrict__ P2,
                                                  int ldp, const AdiState* st) {
     if (st->done) return;
+    extern __shared__ double wsm[];
     __shared__ double Msh[QR_NB][QR_NB + 1], Nsh[QR_NB][QR_NB + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int ldz = ZLDS ? (m | 1) : ldp;
+    double* Zs = ZLDS ? wsm : P1;                          // without LDS staging Z is parked in P1's first b columns
+    const double* Vs = ZLDS ? wsm + (size_t)ldz * b : Vp;
+    const int ldvs = ZLDS ? ldz : ldv;
+    for (int c = wave; c < b; c += nw)
+        for (int r = lane; r < m; r += 64) {
+            double z = 0.0;
+            for (int sidx = 0; sidx < splits; ++sidx) z += Zpart[(size_t)sidx * m * b + r + (size_t)c * m];
+            Zs[r + (size_t)c * ldz] = z;
+            if (ZLDS) wsm[(size_t)ldz * b + r + (size_t)c * ldz] = Vp[r + (size_t)c * ldv];
+        }
+    __syncthreads();
     for (int j = wave; j < b; j += nw) {                    // M(:, j) = V' Z(:, j)
         double acc[QR_NB];
 #pragma unroll
         for (int i = 0; i < QR_NB; ++i) acc[i] = 0.0;
         for (int r = lane; r < m; r += 64) {
-            const double zj = Z[r + (size_t)j * ldz];
+            const double zj = Zs[r + (size_t)j * ldz];
 #pragma unroll
-            for (int i = 0; i < QR_NB; ++i) acc[i] += Vp[r + (size_t)i * ldv] * zj;
+            for (int i = 0; i < QR_NB; ++i) acc[i] += Vs[r + (size_t)i * ldvs] * zj;
         }
 #pragma unroll
         for (int i = 0; i < QR_NB; ++i) { const double t = wave_sum(acc[i]); if (lane == 0) Msh[i][j] = t; }
@@ -960,14 +1079,14 @@ __global__ __launch_bounds__(1024) void k_band_w(int m, int b, const double* __r
     __syncthreads();
     for (int c = wave; c < b; c += nw)
         for (int r = lane; r < m; r += 64) {
-            double a0 = Z[r + (size_t)c * ldz], a1 = 0.0;
+            double a0 = Zs[r + (size_t)c * ldz], a1 = 0.0;
 #pragma unroll
             for (int l = 0; l < QR_NB; l += 2) {
-                a0 -= 0.5 * Vp[r + (size_t)l * ldv] * Nsh[l][c];
-                a1 -= 0.5 * Vp[r + (size_t)(l + 1) * ldv] * Nsh[l + 1][c];
+                a0 -= 0.5 * Vs[r + (size_t)l * ldvs] * Nsh[l][c];
+                a1 -= 0.5 * Vs[r + (size_t)(l + 1) * ldvs] * Nsh[l + 1][c];
             }
             const double acc = a0 + a1;
-            const double v = Vp[r + (size_t)c * ldv];
+            const double v = Vs[r + (size_t)c * ldvs];
             P1[r + (size_t)c * ldp] = acc;       P1[r + (size_t)(b + c) * ldp] = v;
             P2[r + (size_t)c * ldp] = v;         P2[r + (size_t)(b + c) * ldp] = acc;
         }
@@ -1016,23 +1135,35 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
             {
                 TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
                 hipLaunchKernelGGL(k_band_rem, dim3(BAND_REM_BLOCKS), dim3(256), 0, ctx->stream, q, k, b, S.p, S.ld, part.p, st.p);
-                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, BAND_REM_BLOCKS, part.p, tolfac, st.p);
             }
             const int m = q - k - b;            // rows below the diagonal block of this panel
-            if (m < b) { k = q; break; }        // the last rows stay unreduced: D is stored dense, band form is not required
+            if (m < b) {                        // the last rows stay unreduced: D is stored dense, band form is not required
+                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, BAND_REM_BLOCKS, part.p, tolfac, st.p);
+                k = q;
+                break;
+            }
+            // the panel kernel evaluates the termination test in its prologue
             launch_qr_panel(ctx, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, b,
                             out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld,
-                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p);
+                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p, part.p, BAND_REM_BLOCKS, k, tolfac);
             // two-sided update of S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,  Z = S22 (V T),  N = T' (V' Z)
             Mat S22 = S.view(k + b, k + b, m, m);
             Mat Vp = out.V.view(k + b, k, m, b);
             Mat VTp = out.VT.view(k + b, k, m, b);
             Mat Tp = out.T.view(0, k, b, b);
-            Mat Z(ctx, m, b), P1(ctx, m, 2 * b), P2(ctx, m, 2 * b);
-            gemm(ctx, false, false, 1.0, S22, VTp, 0.0, Z, st.p, "gemm_band");
+            Mat P1(ctx, m, 2 * b), P2(ctx, m, 2 * b);
+            int zs = 1;
+            BufP zpart = gemm_partials(ctx, false, false, m, b, m, S22.p, S22.ld, VTp.p, VTp.ld, &zs, st.p, "gemm_band");
             {
-                TimedScope ts(ctx, "band_w", 8.0 * m * b * 6.0, 2.0 * m * b * b * 2.0);
-                hipLaunchKernelGGL(k_band_w, dim3(1), dim3(1024), 0, ctx->stream, m, b, Z.p, Z.ld, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+                TimedScope ts(ctx, "band_w", 8.0 * m * b * (zs + 5.0), 2.0 * m * b * b * 2.0);
+                if (m <= 540) {
+                    const size_t shm = 2 * (size_t)(m | 1) * b * sizeof(double);
+                    static bool attr_set = false;
+                    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_band_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+                    hipLaunchKernelGGL((k_band_w<true>), dim3(1), dim3(1024), shm, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+                } else {
+                    hipLaunchKernelGGL((k_band_w<false>), dim3(1), dim3(1024), 0, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+                }
             }
             gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band");    // S22 -= [W V] [V W]'
             k += b; ++np; ++issued;

@@ -30,6 +30,10 @@ inline void gemm(Ctx* ctx, bool tA, bool tB, double alpha, const Mat& A, const M
     gemm(ctx, tA, tB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, st, tag);
 }
 
+// Split-K GEMM that leaves the per-split partial slabs (each M x N, leading dimension M) unreduced for a consumer kernel
+// that sums them in a fixed order while doing its own work; returns the slab buffer, *splits_out slabs.
+BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
+                   int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma");
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src
 void fill_mat(Ctx* ctx, Mat& dst, double v);
 void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
@@ -44,6 +48,9 @@ bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (s
 // (/root/reference/src/LDLt.jl:77-89, evaluated through the Gram matrix instead of a pivoted QR).
 // Writes st->res_norm, st->norms[st->iters], and sets st->done on convergence / maxiters.
 void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
+// The whole residual-norm step  G = R'R,  nrm = |alpha| sqrt(tr((T G)^2)),  convergence decision  in two launches:
+// the split-K Gram GEMM and one workgroup that reduces the partial slabs, forms T G in LDS and decides (k <= 88).
+void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

@@ -664,9 +664,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                 oracle->update(R, {V1, V2});
             }
             // residual norm through the Gram matrix, convergence decision on the device
-            Mat G(ctx, k, k);
-            gemm(ctx, true, false, 1.0, R, R, 0.0, G, dst, "gemm_gram");
-            ldlt_norm_update_state(ctx, G, Tm, tdiag, alpha_res, st.p, iters_host);
+            residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
             ++since_sync;
             if (opt.compression && last_compression >= opt.compression_interval) break;
