@@ -483,47 +483,27 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
 // =============================================================================================
 #define QR_NB 16
 
-// One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed), T and VT = V*T are written too.
-// PLDS: the panel rows j0..m live in LDS for the whole factorisation (m - j0 <= QR_LDS_ROWS), which turns the
-// ~6 dependent global round trips per column into LDS round trips.
-#define QR_LDS_ROWS 1100
-template <bool PLDS>
-__global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
-                                                   double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
-                                                   double* __restrict__ VT, int ldvt, AdiState* st,
-                                                   const double* __restrict__ part, int nparts, int kpanel, double tolfac) {
-    if (st && st->done) return;
-    if (part) {
-        // fused termination test of the band reduction (was a kernel of its own): the previous launch left `nparts`
-        // partial sums of the not-yet-reduced norm; every thread evaluates the same fixed-order sum.
-        double r2 = 0.0;
-        for (int i = 0; i < nparts; ++i) r2 += part[i];
-        const double base = (kpanel == 0) ? r2 : st->res_norm;
-        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
-        const bool stop = r2 <= tol * tol;
-        __syncthreads();          // everybody has read res_norm / done before thread 0 updates them
-        if (threadIdx.x == 0) {
-            if (kpanel == 0) st->res_norm = r2;
-            if (stop) { st->done = 1; st->iters = kpanel; }
-        }
-        if (stop) return;
-    }
-    extern __shared__ double psm[];
-    __shared__ double red[17];
-    __shared__ double Tsh[QR_NB][QR_NB + 1];
-    __shared__ double z[QR_NB];
-    __shared__ double sc[4];  // tau, beta, scale
+__global__ void k_band_decide(int k, int nparts, const double* __restrict__ part, double tolfac, AdiState* st);
+
+struct PanelShared {
+    double red[17];
+    double Tsh[QR_NB][QR_NB + 1];
+    double z[QR_NB];
+    double sc[4];              // tau, beta, scale
+    double scl[QR_NB];         // deferred scaling: v_jj = x_jj * scl[jj] below the diagonal
+    double nrm2_next;          // ||P[jj+1:, jj+1]||^2 after the update with reflector jj (lookahead)
+};
+
+// Householder QR of the rows x jb panel Pn (leading dimension ldp) by one workgroup, in place: on exit the upper triangle
+// holds R, the entries below the diagonal the reflector vectors and sh.Tsh the block-reflector factor T.
+// Per column: one scalar section, one fused pass (apply H to the later columns with a lookahead of the next column's
+// norm || dot products for T), deferred scaling of the reflectors.
+__device__ void hh_panel_core(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const int rows = m - j0;                       // panel rows (global rows j0..m-1)
-    const int ldp = PLDS ? (rows | 1) : lda;       // odd leading dimension in LDS
-    double* Pn = PLDS ? psm : (A + (size_t)j0 * lda + j0);   // Pn[r + c*ldp] = A[j0 + r, j0 + c]
-    if (PLDS) {
-        for (int c = wave; c < jb; c += nw)
-            for (int r = lane; r < rows; r += 64) Pn[r + (size_t)c * ldp] = A[(j0 + r) + (size_t)(j0 + c) * lda];
-    }
+    double (*Tsh)[QR_NB + 1] = sh.Tsh;
+    double* z = sh.z; double* sc = sh.sc; double* scl = sh.scl; double* red = sh.red;
+    double& nrm2_next = sh.nrm2_next;
     for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) (&Tsh[0][0])[i] = 0.0;
-    __shared__ double nrm2_next;     // ||P[jj+1:, jj+1]||^2 after the update with reflector jj (lookahead)
-    __shared__ double scl[QR_NB];    // deferred scaling: v_jj = x_jj * scl[jj] below the diagonal
     __syncthreads();                 // the LDS copy of the panel is complete
     {
         double s0 = 0.0;
@@ -591,6 +571,45 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         for (int r = c + 1 + lane; r < rows; r += 64) pc[r] *= sv;
     }
     __syncthreads();
+}
+
+// One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed), T and VT = V*T are written too.
+// PLDS: the panel rows j0..m live in LDS for the whole factorisation (m - j0 <= QR_LDS_ROWS), which turns the
+// ~6 dependent global round trips per column into LDS round trips.
+#define QR_LDS_ROWS 1100
+template <bool PLDS>
+__global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
+                                                   double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
+                                                   double* __restrict__ VT, int ldvt, AdiState* st,
+                                                   const double* __restrict__ part, int nparts, int kpanel, double tolfac) {
+    if (st && st->done) return;
+    if (part) {
+        // fused termination test of the band reduction (was a kernel of its own): the previous launch left `nparts`
+        // partial sums of the not-yet-reduced norm; every thread evaluates the same fixed-order sum.
+        double r2 = 0.0;
+        for (int i = 0; i < nparts; ++i) r2 += part[i];
+        const double base = (kpanel == 0) ? r2 : st->res_norm;
+        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const bool stop = r2 <= tol * tol;
+        __syncthreads();          // everybody has read res_norm / done before thread 0 updates them
+        if (threadIdx.x == 0) {
+            if (kpanel == 0) st->res_norm = r2;
+            if (stop) { st->done = 1; st->iters = kpanel; }
+        }
+        if (stop) return;
+    }
+    extern __shared__ double psm[];
+    __shared__ PanelShared sh;
+    double (*Tsh)[QR_NB + 1] = sh.Tsh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int rows = m - j0;                       // panel rows (global rows j0..m-1)
+    const int ldp = PLDS ? (rows | 1) : lda;       // odd leading dimension in LDS
+    double* Pn = PLDS ? psm : (A + (size_t)j0 * lda + j0);   // Pn[r + c*ldp] = A[j0 + r, j0 + c]
+    if (PLDS) {
+        for (int c = wave; c < jb; c += nw)
+            for (int r = lane; r < rows; r += 64) Pn[r + (size_t)c * ldp] = A[(j0 + r) + (size_t)(j0 + c) * lda];
+    }
+    hh_panel_core(Pn, ldp, rows, jb, sh);
     // write back: R part + reflectors into A, explicit V, T, and VT = V * T
     for (int c = wave; c < jb; c += nw) {
         const double* pc = Pn + (size_t)c * ldp;
@@ -618,6 +637,227 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tall panels (rows > QR_LDS_ROWS): TSQR with Householder reconstruction (Ballard, Demmel, Grigori, Jacquelin, Knight,
+// Nguyen 2014).  The panel is cut into row chunks that fit LDS; every chunk is factored by one workgroup on its own
+// CU (k_tsqr_local), the stacked R factors by one workgroup (k_tsqr_top), the thin orthonormal Q is formed chunk-wise
+// (k_tsqr_formq), and one LU of [I;0] - Q S (sign matrix S chosen for unit-size pivots) turns it back into the compact
+// WY form (V, T) that the trailing updates use (k_hr_small, k_tsqr_finish).  Unconditionally stable like Householder QR.
+// ---------------------------------------------------------------------------------------------
+struct TsqrPlan { int P; int base; int rem; };     // chunk c has base + (c < rem) rows and starts at c*base + min(c, rem)
+__device__ __host__ inline int chunk_start(const TsqrPlan& p, int c) { return c * p.base + (c < p.rem ? c : p.rem); }
+__device__ __host__ inline int chunk_rows(const TsqrPlan& p, int c) { return p.base + (c < p.rem ? 1 : 0); }
+
+__global__ __launch_bounds__(1024) void k_tsqr_local(const double* __restrict__ A, int lda, int jb, TsqrPlan plan, double* __restrict__ Vloc, int ldvl,
+                                                     double* __restrict__ Tloc, double* __restrict__ Rstack, int ldrs, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double psm[];
+    __shared__ PanelShared sh;
+    const int c = blockIdx.x, r0 = chunk_start(plan, c), rows = chunk_rows(plan, c);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int ldp = rows | 1;
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rows; r += 64) psm[r + (size_t)j * ldp] = A[(r0 + r) + (size_t)j * lda];
+    hh_panel_core(psm, ldp, rows, jb, sh);
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rows; r += 64) {
+            const double x = psm[r + (size_t)j * ldp];
+            Vloc[(r0 + r) + (size_t)j * ldvl] = (r > j) ? x : (r == j ? 1.0 : 0.0);
+            if (r < jb) Rstack[(c * jb + r) + (size_t)j * ldrs] = (r <= j) ? x : 0.0;
+        }
+    for (int i = tid; i < jb * jb; i += blockDim.x) Tloc[(size_t)c * QR_NB * QR_NB + i % jb + (i / jb) * QR_NB] = sh.Tsh[i % jb][i / jb];
+}
+
+// QR of the stacked R factors (P*jb x jb) and the leading jb columns Qt of its orthogonal factor
+__global__ __launch_bounds__(1024) void k_tsqr_top(double* __restrict__ Rstack, int ldrs, int rowsR, int jb, double* __restrict__ Rfin,
+                                                   double* __restrict__ Qt, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double psm[];
+    __shared__ PanelShared sh;
+    __shared__ double Msh[QR_NB][QR_NB + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int ldp = rowsR | 1;
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rowsR; r += 64) psm[r + (size_t)j * ldp] = Rstack[r + (size_t)j * ldrs];
+    hh_panel_core(psm, ldp, rowsR, jb, sh);
+    for (int i = tid; i < jb * jb; i += blockDim.x) {
+        const int r = i % jb, j = i / jb;
+        Rfin[r + j * QR_NB] = (r <= j) ? psm[r + (size_t)j * ldp] : 0.0;
+        // M = T * V1'  with V1 the unit lower triangular top block:  M(r, j) = sum_{l >= r, l <= j} T(r,l) V1(j,l)
+        double acc = 0.0;
+        for (int l = r; l <= j; ++l) acc += sh.Tsh[r][l] * (l == j ? 1.0 : psm[j + (size_t)l * ldp]);
+        Msh[r][j] = acc;
+    }
+    __syncthreads();
+    // Qt = [I; 0] - V M
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rowsR; r += 64) {
+            double acc = (r == j) ? 1.0 : 0.0;
+            for (int l = 0; l < jb; ++l) {
+                const double v = (r > l) ? psm[r + (size_t)l * ldp] : (r == l ? 1.0 : 0.0);
+                acc -= v * Msh[l][j];
+            }
+            Qt[r + (size_t)j * ldrs] = acc;
+        }
+}
+
+// Q(chunk) = (I - V_c T_c V_c')[Qt_c; 0]
+__global__ __launch_bounds__(1024) void k_tsqr_formq(int jb, TsqrPlan plan, const double* __restrict__ Vloc, int ldvl, const double* __restrict__ Tloc,
+                                                     const double* __restrict__ Qt, int ldrs, double* __restrict__ Q, int ldq, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double Nsh[QR_NB][QR_NB + 1], Msh[QR_NB][QR_NB + 1], Qts[QR_NB][QR_NB + 1];
+    const int c = blockIdx.x, r0 = chunk_start(plan, c), rows = chunk_rows(plan, c);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const double* Vc = Vloc + r0;
+    const double* Tc = Tloc + (size_t)c * QR_NB * QR_NB;
+    if (tid < jb * jb) Qts[tid % jb][tid / jb] = Qt[(c * jb + tid % jb) + (size_t)(tid / jb) * ldrs];
+    __syncthreads();
+    if (tid < jb * jb) {            // N = V1' Qt_c  (V1 = top jb x jb block of V_c, unit lower triangular)
+        const int i = tid % jb, j = tid / jb;
+        double acc = Qts[i][j];
+        for (int l = i + 1; l < jb; ++l) acc += Vc[l + (size_t)i * ldvl] * Qts[l][j];
+        Nsh[i][j] = acc;
+    }
+    __syncthreads();
+    if (tid < jb * jb) {            // M = T_c N
+        const int i = tid % jb, j = tid / jb;
+        double acc = 0.0;
+        for (int l = i; l < jb; ++l) acc += Tc[i + l * QR_NB] * Nsh[l][j];
+        Msh[i][j] = acc;
+    }
+    __syncthreads();
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rows; r += 64) {
+            double acc = (r < jb) ? Qts[r][j] : 0.0;
+            for (int l = 0; l < jb; ++l) acc -= Vc[r + (size_t)l * ldvl] * Msh[l][j];
+            Q[(r0 + r) + (size_t)j * ldq] = acc;
+        }
+}
+
+// Householder reconstruction on the top jb x jb block Q1 of the thin Q:  [I;0] - Q S = V U  with S = diag(sgn) chosen so
+// that every pivot is 1 + |q~_jj| >= 1.  Outputs: sgn, Uinv, T = U V1^-T, V1 (unit lower), and R <- S R.  One wave.
+__global__ __launch_bounds__(64) void k_hr_small(int jb, const double* __restrict__ Q, int ldq, double* __restrict__ Rfin, double* __restrict__ hr,
+                                                 const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double W[QR_NB][QR_NB + 1], U[QR_NB][QR_NB + 1], V1[QR_NB][QR_NB + 1], Ui[QR_NB][QR_NB + 1], Vi[QR_NB][QR_NB + 1];
+    __shared__ double sg[QR_NB];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < QR_NB * (QR_NB + 1); i += 64) { (&U[0][0])[i] = 0.0; (&V1[0][0])[i] = 0.0; (&Ui[0][0])[i] = 0.0; (&Vi[0][0])[i] = 0.0; }
+    for (int i = tid; i < jb * jb; i += 64) W[i % jb][i / jb] = Q[i % jb + (size_t)(i / jb) * ldq];
+    __syncthreads();
+    for (int j = 0; j < jb; ++j) {
+        const double s = (W[j][j] >= 0.0) ? -1.0 : 1.0;       // s'_j = -sgn(q~_jj)
+        const double piv = 1.0 - s * W[j][j];
+        if (tid == 0) { sg[j] = s; U[j][j] = piv; V1[j][j] = 1.0; }
+        if (tid < j) U[tid][j] = -s * W[tid][j];
+        if (tid > j && tid < jb) V1[tid][j] = -s * W[tid][j] / piv;
+        __syncthreads();
+        // eliminate column j from the later columns of the Q block
+        for (int id = tid; id < jb * jb; id += 64) {
+            const int i = id % jb, c = id / jb;
+            if (i > j && c > j) W[i][c] -= V1[i][j] * W[j][c];
+        }
+        __syncthreads();
+    }
+    // Uinv (upper) and V1inv (unit lower), one column per lane
+    if (tid < jb) {
+        const int j = tid;
+        Ui[j][j] = 1.0 / U[j][j];
+        for (int i = j - 1; i >= 0; --i) {
+            double acc = 0.0;
+            for (int k = i + 1; k <= j; ++k) acc += U[i][k] * Ui[k][j];
+            Ui[i][j] = -acc / U[i][i];
+        }
+        Vi[j][j] = 1.0;
+        for (int i = j + 1; i < jb; ++i) {
+            double acc = V1[i][j];
+            for (int k = j + 1; k < i; ++k) acc += V1[i][k] * Vi[k][j];
+            Vi[i][j] = -acc;
+        }
+    }
+    __syncthreads();
+    // hr layout (each block QR_NB x QR_NB, column-major): [0] sgn, [1] Uinv, [2] T, [3] V1
+    double* Uo = hr + QR_NB * QR_NB; double* To = hr + 2 * QR_NB * QR_NB; double* Vo = hr + 3 * QR_NB * QR_NB;
+    for (int id = tid; id < jb * jb; id += 64) {
+        const int i = id % jb, j = id / jb;
+        Uo[i + j * QR_NB] = Ui[i][j];
+        Vo[i + j * QR_NB] = V1[i][j];
+        double acc = 0.0;                       // T = U * V1^-T  ->  T(i,j) = sum_k U(i,k) Vinv(j,k)
+        for (int k = 0; k < jb; ++k) acc += U[i][k] * Vi[j][k];
+        To[i + j * QR_NB] = acc;
+        Rfin[i + j * QR_NB] *= sg[i];           // A = Q R = (Q S)(S R)
+    }
+    if (tid < jb) hr[tid] = sg[tid];
+}
+
+// V = [V1; -Q2 S Uinv],  VT = V T,  and the panel of A receives R (upper triangle) and the reflectors below it
+__global__ __launch_bounds__(256) void k_tsqr_finish(int rows, int jb, const double* __restrict__ Q, int ldq, const double* __restrict__ hr,
+                                                     const double* __restrict__ Rfin, double* __restrict__ A, int lda, double* __restrict__ V, int ldv,
+                                                     double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double Us[QR_NB][QR_NB + 1], Ts[QR_NB][QR_NB + 1], sg[QR_NB];
+    const int tid = threadIdx.x;
+    for (int id = tid; id < jb * jb; id += blockDim.x) {
+        Us[id % jb][id / jb] = hr[QR_NB * QR_NB + id % jb + (id / jb) * QR_NB];
+        Ts[id % jb][id / jb] = hr[2 * QR_NB * QR_NB + id % jb + (id / jb) * QR_NB];
+    }
+    if (tid < jb) sg[tid] = hr[tid];
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + tid;
+    if (blockIdx.x == 0) for (int id = tid; id < jb * jb; id += blockDim.x) T[id % jb + (size_t)(id / jb) * ldt] = Ts[id % jb][id / jb];
+    if (r >= rows) return;
+    double v[QR_NB];
+#pragma unroll
+    for (int c = 0; c < QR_NB; ++c) {
+        double acc = 0.0;
+        if (c < jb) {
+            if (r < jb) acc = hr[3 * QR_NB * QR_NB + r + c * QR_NB];          // V1
+            else for (int l = 0; l <= c; ++l) acc -= Q[r + (size_t)l * ldq] * sg[l] * Us[l][c];
+        }
+        v[c] = acc;
+    }
+#pragma unroll
+    for (int c = 0; c < QR_NB; ++c) {
+        if (c < jb) {
+            V[r + (size_t)c * ldv] = v[c];
+            double acc = 0.0;
+#pragma unroll
+            for (int l = 0; l < QR_NB; ++l) if (l <= c && l < jb) acc += v[l] * Ts[l][c];
+            if (VT) VT[r + (size_t)c * ldvt] = acc;
+            A[r + (size_t)c * lda] = (r <= c) ? Rfin[r + c * QR_NB] : v[c];
+        }
+    }
+}
+
+#define TSQR_CHUNK 512
+static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, double* V, int ldv, double* T, int ldt, double* VT, int ldvt,
+                              const AdiState* st) {
+    // A, V, VT point at the (0,0) entry of the panel
+    TsqrPlan plan;
+    plan.P = std::max(2, rows / TSQR_CHUNK);
+    while (plan.P * jb > QR_LDS_ROWS) --plan.P;
+    plan.base = rows / plan.P; plan.rem = rows % plan.P;
+    DRE_REQUIRE(plan.base >= jb && plan.base + 1 <= QR_LDS_ROWS, "TSQR panel: chunk size out of range");
+    const int rowsR = plan.P * jb;
+    Mat Vloc(ctx, rows, jb), Q(ctx, rows, jb), Rstack(ctx, rowsR, jb), Qt(ctx, rowsR, jb);
+    DevArr<double> Tloc(ctx, (size_t)plan.P * QR_NB * QR_NB), Rfin(ctx, QR_NB * QR_NB), hr(ctx, 4 * QR_NB * QR_NB);
+    TimedScope ts(ctx, "qr_panel_tsqr", 8.0 * rows * jb * 8.0, 2.0 * rows * jb * jb * 3.0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_top, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    const size_t shm1 = (size_t)((plan.base + 1) | 1) * jb * sizeof(double);
+    hipLaunchKernelGGL(k_tsqr_local, dim3(plan.P), dim3(1024), shm1, ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
+    const size_t shm2 = (size_t)(rowsR | 1) * jb * sizeof(double);
+    hipLaunchKernelGGL(k_tsqr_top, dim3(1), dim3(1024), shm2, ctx->stream, Rstack.p, Rstack.ld, rowsR, jb, Rfin.p, Qt.p, st);
+    hipLaunchKernelGGL(k_tsqr_formq, dim3(plan.P), dim3(1024), 0, ctx->stream, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Qt.p, Qt.ld, Q.p, Q.ld, st);
+    hipLaunchKernelGGL(k_hr_small, dim3(1), dim3(64), 0, ctx->stream, jb, Q.p, Q.ld, Rfin.p, hr.p, st);
+    hipLaunchKernelGGL(k_tsqr_finish, dim3(ceil_div(rows, 256)), dim3(256), 0, ctx->stream, rows, jb, Q.p, Q.ld, hr.p, Rfin.p, A, lda, V, ldv, T, ldt, VT, ldvt, st);
+    DRE_HIP(hipGetLastError());
+}
+
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
                             double tolfac = 0.0) {
@@ -628,6 +868,11 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
         static bool attr_set = false;
         if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
         hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
+    } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2) {
+        // tall panel: TSQR + Householder reconstruction on many CUs (the termination test, if any, runs on its own)
+        if (part) hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, kpanel, nparts, part, tolfac, st);
+        launch_tsqr_panel(ctx, A + (size_t)j0 * lda + j0, lda, rows, jb, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt,
+                          VT ? VT + (size_t)j0 * ldvt + j0 : nullptr, ldvt, st);
     } else {
         hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
     }
