@@ -125,6 +125,17 @@ def main():
             else:
                 ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
                 roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))
+                sym = {"qr_panel": "k_qr_panel", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm", "gemm_gram": "k_gemm",
+                       "band_w": "k_band_w", "mf_solve_real": "k_mf_", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm"}.get(name)
+                hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
+                if hits and n == 371:
+                    tot_l = sum(h["launches"] for h in hits)
+                    roof["traffic"] = sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
+                    roof["traffic_source"] = "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated)"
+            except Exception:
+                pass
             roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
                         measured_on="one extra profiled solve after the timed region (HIP events on the library stream)")
             roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
@@ -141,9 +152,14 @@ def main():
             o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm), (t0, tfc)), o.Ros1(o.ADI(shifts=o.Cyclic(list(shifts)))), dt=dt, stats=st)
             tc = time.perf_counter() - tc
             cpu_it = sum(s["iters"] for s in st)
-            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=os.cpu_count(), kind="port",
+            try:
+                from threadpoolctl import threadpool_info
+                blas_threads = max([int(x.get("num_threads", 1)) for x in threadpool_info()] or [1])
+            except Exception:
+                blas_threads = os.cpu_count()
+            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=blas_threads, kind="port",
                        sample=f"first {args.cpu_steps} of {args.nsteps} Rosenbrock steps of the same workload ({cpu_it} ADI iterations, {tc:.1f} s), "
-                              f"NumPy/SciPy oracle (OpenBLAS threads = all cores, SuperLU refactorised every ADI step like the reference)")
+                              f"NumPy/SciPy oracle (OpenBLAS with {blas_threads} threads of {os.cpu_count()} host CPUs, SuperLU refactorised every ADI step like the reference)")
         out = {
             "metric": "ADI iterations/sec (GDRE Ros1 LRSIF, SteelProfile surrogate)",
             "value": total_iters / elapsed,

@@ -5,13 +5,13 @@
   rocprofv3 --pmc WRITE_SIZE  --output-format csv -d gpurun_out/pmc_w -- python bench.py --steps 1 --warmup 0 ...
   (+ the same two PMC passes on tools/pmc_calibrate.py -> gpurun_out/pmc_cal_f, pmc_cal_w)
 
-usage: python tools/profile_summarize.py <round-tag> <stats-dir>
+usage: python tools/profile_summarize.py <round-tag> <stats-dir> [out-dir]   (out-dir defaults to profiles/)
 """
 import collections, csv, glob, json, os, sys
 
 tag, stats_dir = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(ROOT, "profiles")
+out_dir = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
 os.makedirs(out_dir, exist_ok=True)
 
 # ---- kernel timing summary
