@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--n", type=int, default=371, help="SteelProfile size (371 = the configuration the metric is quoted on)")
     ap.add_argument("--nsteps", type=int, default=45, help="Rosenbrock time steps per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2, help="Rosenbrock time steps of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=8, help="Rosenbrock time steps of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 

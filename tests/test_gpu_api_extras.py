@@ -1,0 +1,91 @@
+"""Remaining API surface through the HIP path: Heuristic / Wrapped shifts, warm starts, save_state consistency, error behaviour."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dre_amd as D
+import dre_oracle as o
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def test_heuristic_shifts_on_device_match_the_oracle(ctx, rail371):     # shifts/heuristic.jl:39-101
+    d, L, Dm = rail371
+    P = D.Pencil(d.E, d.A, ctx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hs = D.heuristic_shifts(D.Shifts.Heuristic(10, 20, 20), P)
+    mine = np.array(sorted(v.real for v in hs))
+    gold = np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy"))
+    assert len(mine) == len(gold) and np.all(mine < 0)
+    assert np.allclose(mine, gold, rtol=1e-6)        # symmetric pencil: E'^-1 A' and E^-1 A generate the same Krylov spaces
+
+
+def test_cyclic_heuristic_and_wrapped_strategies(ctx, rail371):          # test/rail.jl:79-87 flavour, test/Shifts.jl:126-131
+    d, L, Dm = rail371
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
+    gold = np.load(os.path.join(GOLDEN, "ros1_371.npz"))
+    S = D.Shifts
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s1 = D.solve(prob, D.Ros1(D.ADI(shifts=S.Cyclic(S.Heuristic(10, 20, 20)))), dt=-100.0)
+        s2 = D.solve(prob, D.Ros1(D.ADI(shifts=S.Cyclic(S.Wrapped(lambda sh: sorted(v.real for v in sh), S.Heuristic(10, 20, 20))))), dt=-100.0)
+    assert D.delta(s1.K[-1], gold["K"][1]) < 1e-7 and D.delta(s2.K[-1], gold["K"][1]) < 1e-7
+    with pytest.raises(NotImplementedError):
+        D.solve(prob, D.Ros1(D.ADI(shifts=S.Cyclic(S.Projection(2)))), dt=-100.0)
+    with pytest.raises(ValueError):
+        D.solve(prob, D.Ros1(D.ADI(shifts=S.Cyclic([]))), dt=-100.0)
+
+
+def test_gale_warm_start_and_ignore_initial_guess(ctx):                  # adi.jl:41-46, types.jl:25
+    rng = np.random.default_rng(11)
+    n = 60
+    E = (sp.random(n, n, density=1 / n, random_state=rng) + n * sp.identity(n)).tocsc(); E = (E + E.T).tocsc()
+    A = (sp.random(n, n, density=1 / n, random_state=rng) - n * sp.identity(n)).tocsc(); A = (A + A.T).tocsc()
+    Cl = D.lowrank(rng.random((n, 3)), np.diag([1.0, 2.0, -0.5]))
+    prob = D.GALEProblem(E, A, Cl)
+    X, info = D.solve_gale(prob, D.ADI(), return_info=True)
+    # restarting from the converged solution needs no iteration and returns the guess itself (adi.jl:47,71-75)
+    X2, info2 = D.solve_gale(prob, D.ADI(), initial_guess=X, return_info=True)
+    assert info2["iters"] <= 2 and D.delta(X2.dense(), X.dense()) < 1e-12
+    # a rough guess still converges to the same solution; ignore_initial_guess reproduces the cold start exactly
+    G = D.lowrank(X.Ls[0] + 0.05 * rng.standard_normal(X.Ls[0].shape), X.Ds[0])
+    X3 = D.solve_gale(prob, D.ADI(), initial_guess=G)
+    X4, info4 = D.solve_gale(prob, D.ADI(ignore_initial_guess=True), initial_guess=G, return_info=True)
+    assert D.delta(X3.dense(), X.dense()) < 1e-10
+    assert info4["iters"] == info["iters"] and np.array_equal(X4.dense(), X.dense())
+
+
+def test_save_state_is_consistent_with_feedback(ctx, rail371):           # lowrank_ros1.jl:50-57
+    d, L, Dm = rail371
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4200.0))
+    sol = D.solve(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p))), dt=-100.0, save_state=True)
+    assert len(sol.X) == 4
+    for X, K in zip(sol.X, sol.K):
+        a, Lx, Dx = X
+        assert D.delta((d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E), K) < 1e-10
+    # resuming from a stored state continues the trajectory (SURVEY §5 "checkpoint / resume")
+    prob2 = D.GDREProblem(d.E, d.A, d.B, d.C, sol.X[2], (4300.0, 4200.0))
+    sol2 = D.solve(prob2, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p))), dt=-100.0)
+    assert D.delta(sol2.K[-1], sol.K[-1]) < 1e-9
+
+
+def test_error_behaviour(ctx, rail371):
+    d, L, Dm = rail371
+    with pytest.raises(TypeError):                          # dense X0 selects the dense path of the reference: not this engine
+        D.solve(D.GDREProblem(d.E, d.A, d.B, d.C, np.eye(371), (1.0, 0.0)), D.Ros1(), dt=-0.5)
+    with pytest.raises(D.DREError):                         # dt pointing away from tf
+        D.solve(D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0)), D.Ros1(D.ADI(shifts=D.Shifts.Cyclic([-1.0]))), dt=+100.0)
+    with pytest.raises(D.DREError) as e:                    # singular shifted operator: mu = 1 with A = -E
+        Es = sp.identity(5, format="csc")
+        D.Pencil(Es, (-Es).tocsc(), ctx).factor(1.0, 1.0)
+    assert e.value.code == -4
+    with pytest.raises(D.DREError):                         # LDLᵀ operands of different orders
+        a = D.DeviceLDLt.create(ctx, None, np.ones((4, 1)), np.eye(1))
+        b = D.DeviceLDLt.create(ctx, None, np.ones((5, 1)), np.eye(1))
+        a.add(b)
