@@ -1427,14 +1427,68 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     return out;
 }
 
+// Block reflector of ALL band panels at once.  With V = [V_0 ... V_{np-1}] and G = V'V the aggregated factor of
+// H = Q_0 Q_1 ... Q_{np-1} = I - V Tbig V' has the block inverse  Tbig^-1 = blockdiag(T_p^-1) + blockstriu(G),  so
+// M = Tbig R (R = V(1:J, :)') follows from a block back substitution that needs only the panel factors T_p themselves:
+//   M_p = T_p (R_p - sum_{l > p} G_{p,l} M_l).
+// One workgroup per 16 columns of M (they are independent); nb == 16.
+__global__ __launch_bounds__(256) void k_blocktri_apply(int nr, int J, const double* __restrict__ G, int ldg, const double* __restrict__ Tp, int ldt,
+                                                        const double* __restrict__ V, int ldv, double* __restrict__ M, int ldm) {
+    extern __shared__ double sh[];
+    double* Msh = sh;                     // nr x 17
+    double* Ysh = sh + (size_t)nr * 17;   // 16 x 17
+    const int tid = threadIdx.x, i = tid & 15, j = tid >> 4;
+    const int j0 = blockIdx.x * 16;
+    const bool colok = (j0 + j) < J;
+    for (int k = nr - 16; k >= 0; k -= 16) {
+        double a0 = colok ? V[(size_t)(j0 + j) + (size_t)(k + i) * ldv] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double* g = G + (size_t)(k + i);
+        int l = k + 16;
+        for (; l + 3 < nr; l += 4) {
+            a0 -= g[(size_t)l * ldg] * Msh[l * 17 + j];
+            a1 -= g[(size_t)(l + 1) * ldg] * Msh[(l + 1) * 17 + j];
+            a2 -= g[(size_t)(l + 2) * ldg] * Msh[(l + 2) * 17 + j];
+            a3 -= g[(size_t)(l + 3) * ldg] * Msh[(l + 3) * 17 + j];
+        }
+        for (; l < nr; ++l) a0 -= g[(size_t)l * ldg] * Msh[l * 17 + j];
+        Ysh[i * 17 + j] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        double m = 0.0;
+        for (int t = i; t < 16; ++t) m += Tp[i + (size_t)(k + t) * ldt] * Ysh[t * 17 + j];
+        Msh[(k + i) * 17 + j] = m;
+        __syncthreads();
+    }
+    if (colok)
+        for (int r = i; r < nr; r += 16) M[r + (size_t)(j0 + j) * ldm] = Msh[r * 17 + j];
+}
+
 Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
     Mat B(ctx, sb.q, sb.J);
     set_identity(ctx, B, 1.0);
     const int b = sb.nb;
+    int np = sb.npanels;
+    while (np > 0 && sb.q - (np - 1) * b - b < b) --np;        // panels that really hold reflectors
+    const int nr = np * b;
+    if (nr == 0) return B;
+    if (nr <= 512) {
+        // all panels as ONE block reflector:  Qb(:, 1:J) = [I; 0] - V (Tbig V(1:J, :)')   — 4 launches instead of 2 per panel
+        Mat Vall = sb.V.view(0, 0, sb.q, nr);
+        DRE_REQUIRE(b == 16, "sym_band_basis: panel width 16 expected");
+        Mat G(ctx, nr, nr), M(ctx, nr, sb.J);
+        gemm(ctx, true, false, 1.0, Vall, Vall, 0.0, G, nullptr, "gemm_band");
+        {
+            TimedScope ts(ctx, "blocktri", 8.0 * (nr * (double)nr / 2 + 2.0 * nr * sb.J), (double)nr * nr * sb.J);
+            const size_t shm = ((size_t)nr + 16) * 17 * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_blocktri_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set = true; }
+            hipLaunchKernelGGL(k_blocktri_apply, dim3((sb.J + 15) / 16), dim3(256), shm, ctx->stream, nr, sb.J, G.p, G.ld, sb.T.p, sb.T.ld, sb.V.p, sb.V.ld, M.p, M.ld);
+        }
+        gemm(ctx, false, false, -1.0, Vall, M, 1.0, B, nullptr, "gemm_band");
+        return B;
+    }
     // Qb = Q_0 Q_1 ... Q_{np-1};  Qb * [I; 0]: apply the last panel first;  Q_p B = B - (V T)(V' B)
-    for (int p = sb.npanels - 1; p >= 0; --p) {
+    for (int p = np - 1; p >= 0; --p) {
         const int k = p * b, m = sb.q - k - b;
-        if (m < b) continue;
         Mat Vp = sb.V.view(k + b, k, m, b);
         Mat VTp = sb.VT.view(k + b, k, m, b);
         Mat B2 = B.view(k + b, 0, m, sb.J);
