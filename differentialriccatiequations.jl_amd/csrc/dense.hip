@@ -277,9 +277,28 @@ void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double a
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, L.rows, L.cols, L.p, L.ld, D.p, D.ld, out.p, out.ld, alpha);
 }
 
+// Wave-wide sum through DPP row shifts / row broadcasts (no LDS crossbar round trips as with ds_bpermute shuffles);
+// the total lands in lane 63 and is broadcast through a scalar register.  Invalid source lanes contribute 0.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline double dpp_mov0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum(double v) {
+    v += dpp_mov0<0x111>(v);            // row_shr:1
+    v += dpp_mov0<0x112>(v);            // row_shr:2
+    v += dpp_mov0<0x114>(v);            // row_shr:4
+    v += dpp_mov0<0x118>(v);            // row_shr:8   -> lane 15 of every row holds the row total
+    v += dpp_mov0<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 // block-wide sum, result valid in every thread; blockDim.x multiple of 64, <= 1024
 __device__ inline double block_sum(double v, double* red /* >= 17 doubles */) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
@@ -291,10 +310,6 @@ __device__ inline double block_sum(double v, double* red /* >= 17 doubles */) {
     }
     __syncthreads();
     return red[16];
-}
-__device__ inline double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
 }
 
 __global__ __launch_bounds__(1024) void k_frob2(int rows, int cols, const double* __restrict__ A, int ld, double* out) {
@@ -485,85 +500,148 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
 
 __global__ void k_band_decide(int k, int nparts, const double* __restrict__ part, double tolfac, AdiState* st);
 
+#ifdef DRE_PANEL_PROBE
+__device__ long long g_probe[64];
+#define PROBE(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
+#define PROBEW(i) do { if (jj == 3 && wave == 4 && lane == 0 && blockIdx.x == 0) g_probe[i] = clock64(); } while (0)
+#else
+#define PROBE(i) do { } while (0)
+#define PROBEW(i) do { } while (0)
+#endif
+
 struct PanelShared {
     double red[17];
     double Tsh[QR_NB][QR_NB + 1];
-    double z[QR_NB];
-    double sc[4];              // tau, beta, scale
-    double scl[QR_NB];         // deferred scaling: v_jj = x_jj * scl[jj] below the diagonal
-    double nrm2_next;          // ||P[jj+1:, jj+1]||^2 after the update with reflector jj (lookahead)
+    double Zm[QR_NB][QR_NB + 1];   // Zm[i][j] = v_i' v_j  (i < j), input of the T recurrence
+    double scl[QR_NB];             // deferred scaling: v_jj = x_jj * scl[jj] below the diagonal
+    double taus[QR_NB];
+    double betas[QR_NB];
+    double nrm2[QR_NB + 1];        // nrm2[j] = ||P[j+1:, j]||^2 once reflectors 0..j-1 are applied (lookahead)
 };
 
 // Householder QR of the rows x jb panel Pn (leading dimension ldp) by one workgroup, in place: on exit the upper triangle
 // holds R, the entries below the diagonal the reflector vectors and sh.Tsh the block-reflector factor T.
-// Per column: one scalar section, one fused pass (apply H to the later columns with a lookahead of the next column's
-// norm || dot products for T), deferred scaling of the reflectors.
-__device__ void hh_panel_core(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
+// ONE barrier per column: every thread derives (tau, beta, scale) of column jj redundantly from the lookahead norm; then
+// waves jj+1.. apply H_jj to the later columns (the wave of column jj+1 also accumulates the next norm), waves 0..jj-1
+// compute the dot products v_i' v_jj for T, and the otherwise idle wave jj advances the T recurrence by one column.
+// Diagonal entries (beta) and the scaling of the reflectors are written after the loop.
+__device__ __forceinline__ void hh_panel_core(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     double (*Tsh)[QR_NB + 1] = sh.Tsh;
-    double* z = sh.z; double* sc = sh.sc; double* scl = sh.scl; double* red = sh.red;
-    double& nrm2_next = sh.nrm2_next;
-    for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) (&Tsh[0][0])[i] = 0.0;
+    double (*Zm)[QR_NB + 1] = sh.Zm;
+    double* scl = sh.scl; double* red = sh.red;
+    for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) { (&Tsh[0][0])[i] = 0.0; (&Zm[0][0])[i] = 0.0; }
     __syncthreads();                 // the LDS copy of the panel is complete
     {
         double s0 = 0.0;
         for (int i = 1 + tid; i < rows; i += blockDim.x) s0 += Pn[i] * Pn[i];
         s0 = block_sum(s0, red);
-        if (tid == 0) nrm2_next = s0;
+        if (tid == 0) sh.nrm2[0] = s0;
     }
     __syncthreads();
+    PROBE(3);
+    // T recurrence for column c (all earlier columns of T final):  T(0:c, c) = -tau_c T(0:c, 0:c) Zm(0:c, c)
+    auto t_column = [&](int c) {
+        const double tc = sh.taus[c];
+        // four independent FMA chains (the chain of the plain recurrence is the long pole of the late columns)
+        if (lane < c) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int l = lane;
+            for (; l + 3 < c; l += 4) {
+                a0 += Tsh[lane][l] * Zm[l][c];
+                a1 += Tsh[lane][l + 1] * Zm[l + 1][c];
+                a2 += Tsh[lane][l + 2] * Zm[l + 2][c];
+                a3 += Tsh[lane][l + 3] * Zm[l + 3][c];
+            }
+            for (; l < c; ++l) a0 += Tsh[lane][l] * Zm[l][c];
+            Tsh[lane][c] = -tc * ((a0 + a1) + (a2 + a3));
+        }
+        if (lane == 0) Tsh[c][c] = tc;
+    };
     for (int jj = 0; jj < jb; ++jj) {
         double* col = Pn + (size_t)jj * ldp;        // local column jj, pivot at local row jj (entries below are UNSCALED x)
-        if (tid == 0) {
-            const double s = nrm2_next;
-            double alpha = col[jj], tau = 0.0, beta = alpha, scale = 0.0;
-            if (s > 0.0) {
-                double nrm = sqrt(alpha * alpha + s);
-                beta = alpha >= 0.0 ? -nrm : nrm;
-                tau = (beta - alpha) / beta;
-                scale = 1.0 / (alpha - beta);
-            }
-            sc[0] = tau; sc[1] = beta; sc[2] = scale;
-            scl[jj] = scale;
-            col[jj] = beta;
+        PROBEW(10);
+        const double s = sh.nrm2[jj], alpha = col[jj];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (s > 0.0) {
+            const double nrm = sqrt(alpha * alpha + s);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
         }
-        __syncthreads();
-        const double tau = sc[0], scale = sc[2];
-        // waves jj+1.. : apply H to the later panel columns (the wave of column jj+1 also accumulates its next norm);
-        // waves 0..jj-1 : z_i = V(:, i)' v for the T factor.  v = scale * x below the pivot, 1 at the pivot.
+        if (tid == 0) { scl[jj] = scale; sh.taus[jj] = tau; sh.betas[jj] = beta; }
+        PROBEW(11);
         for (int j = wave; j < jb; j += nw) {
             if (j > jj) {
                 double* cj = Pn + (size_t)j * ldp;
-                const double cjj = cj[jj];           // entry in the pivot row, read before anybody overwrites it
+                const double cjj = cj[jj];           // entry in the pivot row
                 double w = 0.0;
-                for (int i = jj + 1 + lane; i < rows; i += 64) w += col[i] * cj[i];
+                {   // four row strips in flight: the loop is bound by LDS latency, not by bandwidth
+                    double w1 = 0.0, w2 = 0.0, w3 = 0.0;
+                    int i = jj + 1 + lane;
+#pragma unroll 1
+                    for (; i + 192 < rows; i += 256) {
+                        w += col[i] * cj[i]; w1 += col[i + 64] * cj[i + 64]; w2 += col[i + 128] * cj[i + 128]; w3 += col[i + 192] * cj[i + 192];
+                    }
+#pragma unroll 1
+                    for (; i < rows; i += 64) w += col[i] * cj[i];
+                    w = (w + w1) + (w2 + w3);
+                }
+                PROBEW(12);
                 w = wave_sum(w) * scale + cjj;
                 const double tw = tau * w, tws = tw * scale;
+                PROBEW(13);
                 double nn = 0.0;
-                for (int i = jj + 1 + lane; i < rows; i += 64) {
-                    const double x = cj[i] - tws * col[i];
-                    cj[i] = x;
-                    if (i > jj + 1) nn += x * x;
+                {
+                    double n1 = 0.0, n2 = 0.0, n3 = 0.0;
+                    int i = jj + 1 + lane;
+#pragma unroll 1
+                    for (; i + 192 < rows; i += 256) {
+                        const double x0 = cj[i] - tws * col[i], x1 = cj[i + 64] - tws * col[i + 64];
+                        const double x2 = cj[i + 128] - tws * col[i + 128], x3 = cj[i + 192] - tws * col[i + 192];
+                        cj[i] = x0; cj[i + 64] = x1; cj[i + 128] = x2; cj[i + 192] = x3;
+                        if (i > jj + 1) nn += x0 * x0;
+                        n1 += x1 * x1; n2 += x2 * x2; n3 += x3 * x3;
+                    }
+#pragma unroll 1
+                    for (; i < rows; i += 64) {
+                        const double x = cj[i] - tws * col[i];
+                        cj[i] = x;
+                        if (i > jj + 1) nn += x * x;
+                    }
+                    nn = (nn + n1) + (n2 + n3);
                 }
                 if (lane == 0) cj[jj] = cjj - tw;
-                if (j == jj + 1) { nn = wave_sum(nn); if (lane == 0) nrm2_next = nn; }
+                PROBEW(14);
+                if (j == jj + 1) { nn = wave_sum(nn); if (lane == 0) sh.nrm2[jj + 1] = nn; }
+                PROBEW(15);
             } else if (j < jj) {
                 const double* vi = Pn + (size_t)j * ldp;   // reflector j: unscaled below its pivot, scale scl[j]
                 double w = 0.0;
-                for (int r = jj + 1 + lane; r < rows; r += 64) w += vi[r] * col[r];
+                {
+                    double w1 = 0.0, w2 = 0.0, w3 = 0.0;
+                    int r = jj + 1 + lane;
+#pragma unroll 1
+                    for (; r + 192 < rows; r += 256) {
+                        w += vi[r] * col[r]; w1 += vi[r + 64] * col[r + 64]; w2 += vi[r + 128] * col[r + 128]; w3 += vi[r + 192] * col[r + 192];
+                    }
+#pragma unroll 1
+                    for (; r < rows; r += 64) w += vi[r] * col[r];
+                    w = (w + w1) + (w2 + w3);
+                }
                 w = wave_sum(w) * scl[j] * scale;
-                if (lane == 0) z[j] = w + vi[jj] * scl[j];
+                if (lane == 0) Zm[j][jj] = w + vi[jj] * scl[j];
+            } else if (jj > 0) {
+                t_column(jj - 1);
             }
         }
         __syncthreads();
-        if (tid < jj) {
-            double t = 0.0;
-            for (int l = tid; l < jj; ++l) t += Tsh[tid][l] * z[l];
-            Tsh[tid][jj] = -tau * t;
-        }
-        if (tid == 0) Tsh[jj][jj] = tau;
-        __syncthreads();
+        PROBEW(16);
     }
+    PROBE(4);
+    if (wave == 0) t_column(jb - 1);
+    if (tid < jb) Pn[tid + (size_t)tid * ldp] = sh.betas[tid];
+    __syncthreads();
     // apply the deferred scaling: below-diagonal entries become the reflector vectors
     for (int c = wave; c < jb; c += nw) {
         double* pc = Pn + (size_t)c * ldp;
@@ -582,14 +660,17 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
                                                    double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
                                                    double* __restrict__ VT, int ldvt, AdiState* st,
                                                    const double* __restrict__ part, int nparts, int kpanel, double tolfac) {
+    PROBE(0);
     if (st && st->done) return;
     if (part) {
         // fused termination test of the band reduction (was a kernel of its own): the previous launch left `nparts`
         // partial sums of the not-yet-reduced norm; every thread evaluates the same fixed-order sum.
+        const double resn = st->res_norm, atol = st->abstol;
         double r2 = 0.0;
-        for (int i = 0; i < nparts; ++i) r2 += part[i];
-        const double base = (kpanel == 0) ? r2 : st->res_norm;
-        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        for (int i = (threadIdx.x & 63); i < nparts; i += 64) r2 += part[i];
+        r2 = wave_sum(r2);
+        const double base = (kpanel == 0) ? r2 : resn;
+        const double tol = atol > 0.0 ? atol : tolfac * 2.220446049250313e-16 * sqrt(base);
         const bool stop = r2 <= tol * tol;
         __syncthreads();          // everybody has read res_norm / done before thread 0 updates them
         if (threadIdx.x == 0) {
@@ -598,6 +679,7 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         }
         if (stop) return;
     }
+    PROBE(1);
     extern __shared__ double psm[];
     __shared__ PanelShared sh;
     double (*Tsh)[QR_NB + 1] = sh.Tsh;
@@ -606,10 +688,24 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
     const int ldp = PLDS ? (rows | 1) : lda;       // odd leading dimension in LDS
     double* Pn = PLDS ? psm : (A + (size_t)j0 * lda + j0);   // Pn[r + c*ldp] = A[j0 + r, j0 + c]
     if (PLDS) {
-        for (int c = wave; c < jb; c += nw)
-            for (int r = lane; r < rows; r += 64) Pn[r + (size_t)c * ldp] = A[(j0 + r) + (size_t)(j0 + c) * lda];
+        // global -> LDS with four independent loads in flight per thread
+        const int tot = rows * jb, nt = blockDim.x;
+        for (int base = tid; base < tot; base += 4 * nt) {
+            double x[4]; int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int id = base + u * nt;
+                cc[u] = id / rows; rr[u] = id - cc[u] * rows;
+                x[u] = (id < tot) ? A[(j0 + rr[u]) + (size_t)(j0 + cc[u]) * lda] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * nt < tot) Pn[rr[u] + (size_t)cc[u] * ldp] = x[u];
+        }
     }
+    PROBE(2);
     hh_panel_core(Pn, ldp, rows, jb, sh);
+    PROBE(5);
     // write back: R part + reflectors into A, explicit V, T, and VT = V * T
     for (int c = wave; c < jb; c += nw) {
         const double* pc = Pn + (size_t)c * ldp;
@@ -623,6 +719,7 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         int r = i % QR_NB, cc = i / QR_NB;
         T[r + (size_t)(j0 + cc) * ldt] = Tsh[r][cc];
     }
+    PROBE(6);
     if (VT) {
         // VT(r, c) = sum_{l <= c} V(r, l) T(l, c)
         for (int c = wave; c < jb; c += nw)
@@ -635,6 +732,7 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
                 VT[(j0 + r) + (size_t)(j0 + c) * ldvt] = acc;
             }
     }
+    PROBE(7);
 }
 
 // ---------------------------------------------------------------------------------------------

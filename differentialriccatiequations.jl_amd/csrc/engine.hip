@@ -480,6 +480,15 @@ LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, d
 // =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
 // =============================================================================================
+static int dense_inverse_max_n() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("DRE_DENSE_INV_MAX_N");
+        v = e ? std::atoi(e) : 1536;
+    }
+    return v;
+}
+
 template <typename T>
 static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
                                                   std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
@@ -492,6 +501,20 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     auto fe = std::make_shared<FactorEntry<T>>();
     mf_factor<T>(ctx, *op.P, op.valFt.p, op.P->valEt.p, make_scalar<T>(1.0, 0.0), make_scalar<T>(mu.real(), mu.imag()), fe->f);
     cache->nfactor++;
+    if constexpr (sizeof(T) == sizeof(double)) {
+        const int n = op.P->n;
+        if (n <= dense_inverse_max_n()) {
+            // explicit inverse through n unit right-hand sides; kept only if the operator is well conditioned enough
+            // that inverse-times-vector is as accurate as the triangular solves for the ADI recurrences
+            Mat W(ctx, n, n);
+            set_identity(ctx, W, 1.0);
+            mf_solve<double>(ctx, *op.P, fe->f, W.p, W.ld, n, nullptr);
+            Mat fv(ctx, op.P->nnz, 1);
+            vals_axpby(ctx, op.P->nnz, 1.0, op.valFt.p, mu.real(), op.P->valEt.p, fv.p);
+            const double cond_est = frob_norm_host(ctx, fv) * frob_norm_host(ctx, W);
+            if (cond_est == cond_est && cond_est < 1e7) { fe->dinv = W; fe->dense = true; }
+        }
+    }
     if (cache->enabled) store[key] = fe;
     return fe;
 }
@@ -586,9 +609,15 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                 const bool have = op.has_lr && sc != smw_cache.end();
                 const int ncols = k + ((op.has_lr && !have) ? m : 0);
                 Mat W(ctx, n, ncols);
-                { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
-                if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
-                mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
+                if (fe->dense) {
+                    // W = inv(Fs' + mu E') [R, Vt] with the cached dense inverse: MFMA GEMMs instead of the tree sweeps
+                    { Mat d = W.colsview(0, k); gemm(ctx, false, false, 1.0, fe->dinv, R, 0.0, d, dst, "gemm_dinv"); }
+                    if (op.has_lr && !have) { Mat d = W.colsview(k, m); gemm(ctx, false, false, 1.0, fe->dinv, op.Vt, 0.0, d, dst, "gemm_dinv"); }
+                } else {
+                    { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
+                    if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
+                    mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
+                }
                 if (op.has_lr) {
                     V1 = Mat(ctx, n, k);
                     Mat small(ctx, m, ncols);

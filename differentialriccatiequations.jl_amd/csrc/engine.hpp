@@ -48,7 +48,9 @@ CompressStats& compress_stats();
 
 // ---- GALE operator  F = Fs + inv(alpha) U V  with sparse Fs on the pencil's pattern ----------------------
 // (/root/reference/src/LowRankUpdate.jl:18-26, src/lyapunov/types.jl:10-16)
-template <typename T> struct FactorEntry { Factor<T> f; };
+// `dinv` (real shifts, small n only): the explicit dense inverse of the shifted sparse operator, applied with one MFMA
+// GEMM per ADI step instead of the level-by-level triangular sweeps (which are launch-latency bound at small n).
+template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; };
 struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<double>>> real;
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
