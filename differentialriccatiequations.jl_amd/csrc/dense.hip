@@ -420,40 +420,66 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
     }
 }
 // One workgroup: G = sum of split-K slabs (fixed order), M = T G (or diag(T) G), nrm = |alpha| sqrt(sum_ij M_ij M_ji),
-// then the convergence decision of adi.jl:115-123 on the device.  G and T live in LDS (k <= 88).
+// then the convergence decision of adi.jl:115-123 on the device.  G and T live in LDS, zero-padded to a multiple of 32
+// (k <= 96).  Dense T: M = T G and N = G T' (= M') are formed 32 x 32 block-wise on the matrix cores — both in the same
+// lane layout, so tr(M M) = sum_ij M_ij N_ij needs no transposition; only blocks bi <= bj are computed (symmetry of the sum).
 __global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const double* __restrict__ part, const double* __restrict__ T, int ldt,
                                                     int tdiag, double alpha, AdiState* st, int iters_after) {
     if (st->done) return;
     extern __shared__ double gsm[];
-    double* G = gsm;                 // k x k, ld k
-    double* Ts = gsm + (size_t)k * k;  // k x k (or k diagonal entries)
+    const int kp = (k + 31) & ~31, ld = kp;
+    double* G = gsm;                        // kp x kp
+    double* Ts = gsm + (size_t)kp * kp;     // kp x kp (or k diagonal entries)
     __shared__ double red[17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    for (int idx = tid; idx < k * k; idx += blockDim.x) {
+    for (int idx = tid; idx < kp * kp; idx += blockDim.x) {
+        const int r = idx % kp, c = idx / kp;
+        const bool in = r < k && c < k;
         double s = 0.0;
-        for (int z = 0; z < splits; ++z) s += part[(size_t)z * k * k + idx];
+        if (in) for (int z = 0; z < splits; ++z) s += part[(size_t)z * k * k + r + (size_t)c * k];
         G[idx] = s;
-        if (!tdiag) Ts[idx] = T[idx % k + (size_t)(idx / k) * ldt];
+        if (!tdiag) Ts[idx] = in ? T[r + (size_t)c * ldt] : 0.0;
     }
     if (tdiag) for (int i = tid; i < k; i += blockDim.x) Ts[i] = T[i + (size_t)i * ldt];
     __syncthreads();
     double s = 0.0;
     if (tdiag) {
         for (int c = wave; c < k; c += nw)
-            for (int r = lane; r < k; r += 64) { const double g = G[r + c * k]; s += Ts[r] * Ts[c] * g * g; }
+            for (int r = lane; r < k; r += 64) { const double g = G[r + c * ld]; s += Ts[r] * Ts[c] * g * g; }
     } else {
-        // M_ij M_ji with M = T G, G symmetric:  M_ij = sum_l T_il G_lj,  M_ji = sum_l T_jl G_li
-        for (int c = wave; c < k; c += nw)
-            for (int r = lane; r < k; r += 64) {
-                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
-                int l = 0;
-                for (; l + 1 < k; l += 2) {
-                    // G is symmetric: G_li is read as G[r + l*k] so that the lanes (r) touch consecutive LDS words
-                    a0 += Ts[r + l * k] * G[l + c * k];        a1 += Ts[r + (l + 1) * k] * G[l + 1 + c * k];
-                    b0 += Ts[c + l * k] * G[r + l * k];        b1 += Ts[c + (l + 1) * k] * G[r + (l + 1) * k];
+        const int nbk = kp / 32, lr = lane & 15, lk = lane >> 4;
+        int p = 0;
+        for (int bi = 0; bi < nbk; ++bi)
+            for (int bj = bi; bj < nbk; ++bj, ++p) {
+                if (p % nw != wave) continue;
+                v4d m[2][2], nn[2][2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) { m[x][y] = (v4d){0.0, 0.0, 0.0, 0.0}; nn[x][y] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+                const double* ti = Ts + bi * 32 + lr; const double* tj = Ts + bj * 32 + lr;
+                const double* gi = G + bi * 32 + lr;  const double* gj = G + bj * 32 + lr;
+                for (int kk = 0; kk < kp / 4; ++kk) {
+                    const size_t off = (size_t)(kk * 4 + lk) * ld;
+                    const double ta0 = ti[off], ta1 = ti[off + 16], gb0 = gj[off], gb1 = gj[off + 16];
+                    const double ga0 = gi[off], ga1 = gi[off + 16], tb0 = tj[off], tb1 = tj[off + 16];
+                    m[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, gb0, m[0][0], 0, 0, 0);
+                    m[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, gb1, m[0][1], 0, 0, 0);
+                    m[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, gb0, m[1][0], 0, 0, 0);
+                    m[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, gb1, m[1][1], 0, 0, 0);
+                    nn[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga0, tb0, nn[0][0], 0, 0, 0);
+                    nn[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga0, tb1, nn[0][1], 0, 0, 0);
+                    nn[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga1, tb0, nn[1][0], 0, 0, 0);
+                    nn[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga1, tb1, nn[1][1], 0, 0, 0);
                 }
-                if (l < k) { a0 += Ts[r + l * k] * G[l + c * k]; b0 += Ts[c + l * k] * G[r + l * k]; }
-                s += (a0 + a1) * (b0 + b1);
+                double sum = 0.0;
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum += m[x][y][r] * nn[x][y][r];
+                s += (bi == bj) ? sum : 2.0 * sum;
             }
     }
     s = block_sum(s, red);
@@ -467,7 +493,7 @@ __global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const dou
 }
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
-    if (k > 88) {
+    if (k > 96) {
         Mat G(ctx, k, k);
         gemm(ctx, true, false, 1.0, R, R, 0.0, G, st, "gemm_gram");
         ldlt_norm_update_state(ctx, G, T, tdiag, alpha, st, iters_after);
@@ -476,9 +502,10 @@ void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double
     int splits = 1;
     BufP part = gemm_partials(ctx, true, false, k, k, R.rows, R.p, R.ld, R.p, R.ld, &splits, st, "gemm_gram");
     TimedScope ts(ctx, "ldlt_norm", 8.0 * splits * k * k, 4.0 * (double)k * k * k);
-    const size_t shm = 2 * (size_t)k * k * sizeof(double);
+    const int kp = (k + 31) & ~31;
+    const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
     static bool attr_set = false;
-    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 130 * 1024)); attr_set = true; }
+    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
     hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, splits, (const double*)part->p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
 }
 

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_smw_small(int n, int m, const double* _
 // Sinv = inv(alpha I + Smat) by Gauss-Jordan with partial pivoting; one workgroup, m <= 32
 template <typename T>
 __global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv,
-                                             const AdiState* st, int* err) {
+                                             const AdiState* st, int* err, T* __restrict__ WK = nullptr, int ldwk = 0, int nrows = 0) {
     if (st && st->done) return;
     __shared__ double abuf[32 * 64 * 2];
     __shared__ int piv;
@@ -296,6 +296,16 @@ __global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, 
         const int i = id % m, j = id / m;
         Sinv[i + (size_t)j * m] = A[i + (m + j) * 32];
     }
+    // optional: fold Sinv into the first nrows rows of WK (WK <- WK * Sinv), so that the apply kernel needs no inner solve
+    for (int r = tid; r < nrows; r += 64) {
+        T row[32];
+        for (int j = 0; j < m; ++j) row[j] = WK[r + (size_t)j * ldwk];
+        for (int j = 0; j < m; ++j) {
+            T acc = make_scalar<T>(0.0, 0.0);
+            for (int l = 0; l < m; ++l) acc += row[l] * A[l + (m + j) * 32];
+            WK[r + (size_t)j * ldwk] = acc;
+        }
+    }
 }
 
 #define SMW_CB 8
@@ -334,6 +344,32 @@ __global__ __launch_bounds__(256) void k_smw_apply(int n, int m, int k, const T*
             V2[i + (size_t)(c0 + c) * ldv2] = sqrt(2.0 * delta * delta + 2.0) * z.im;
         }
     }
+}
+
+// Dense-inverse ADI step (real shift).  Wst = [inv; E' inv; U' inv] * R holds W (n rows), EW = E' W (n rows) and
+// small = U' W (m rows);  WKst the same products for the low-rank factor Vt.  With y = Sinv * small:
+//   V = W - WK y,      R <- R - 2 mu E' V = R - 2 mu (EW - EWK y)          (adi.jl:166-171 with LowRankUpdate.jl:29-39)
+template <bool HAS_LR>
+__global__ __launch_bounds__(256) void k_dense_apply(int n, int m, int k, const double* __restrict__ Wst, int ldw,
+                                                     const double* __restrict__ WKS, int ldwk,
+                                                     double* __restrict__ V, int ldv, double* __restrict__ R, int ldr,
+                                                     double two_mu, const AdiState* st) {
+    if (st && st->done) return;
+    // WKS = [WK; EWK] * Sinv (folded once per shift), small = rows 2n.. of Wst:  V = W - WKS_top small,  R -= 2 mu (EW - WKS_mid small)
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= n || c >= k) return;
+    const double* wc = Wst + (size_t)c * ldw;
+    double v = wc[i], ev = wc[n + i];
+    if (HAS_LR) {
+        const double* small = wc + 2 * (size_t)n;
+        for (int j = 0; j < m; ++j) {
+            const double sj = small[j];
+            v -= WKS[i + (size_t)j * ldwk] * sj;
+            ev -= WKS[n + i + (size_t)j * ldwk] * sj;
+        }
+    }
+    V[i + (size_t)c * ldv] = v;
+    R[i + (size_t)c * ldr] -= two_mu * ev;
 }
 
 __global__ void k_real_to_cplx(int rows, int cols, const double* __restrict__ src, int lds_, cplx* __restrict__ dst, int ldd,
@@ -594,7 +630,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         std::vector<StepRec> recs;
         const size_t blocks_before = Xw->blocks.size();
         const int lc_before = last_compression;
-        int since_sync = 0;
+        int since_sync = 0, chunk_shifts = 0;
         while (iters_host < opt.maxiters) {
             std::complex<double> mu = oracle->take(&res.warnings);
             all_shifts.push_back(mu);
@@ -608,37 +644,68 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                 auto sc = smw_cache.find(key);
                 const bool have = op.has_lr && sc != smw_cache.end();
                 const int ncols = k + ((op.has_lr && !have) ? m : 0);
-                Mat W(ctx, n, ncols);
                 if (fe->dense) {
-                    // W = inv(Fs' + mu E') [R, Vt] with the cached dense inverse: MFMA GEMMs instead of the tree sweeps
-                    { Mat d = W.colsview(0, k); gemm(ctx, false, false, 1.0, fe->dinv, R, 0.0, d, dst, "gemm_dinv"); }
-                    if (op.has_lr && !have) { Mat d = W.colsview(k, m); gemm(ctx, false, false, 1.0, fe->dinv, op.Vt, 0.0, d, dst, "gemm_dinv"); }
+                    // dense-inverse step: one stacked GEMM + one fused apply (V and the residual recurrence)
+                    const int mm = op.has_lr ? m : 0;
+                    if (fe->stack.empty() || fe->stack_U != (const void*)op.U.p || fe->stack_m != mm) {
+                        Mat stk(ctx, 2 * n + mm, n);
+                        { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, fe->dinv, top); }
+                        { Mat mid = stk.view(n, 0, n, n); spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, fe->dinv, mid, 1.0, 0.0, nullptr); }
+                        if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe->dinv, 0.0, bot, nullptr, "gemm_dinv"); }
+                        fe->stack = stk; fe->stack_U = (const void*)op.U.p; fe->stack_m = mm;
+                    }
+                    const int lds_ = 2 * n + mm;
+                    Mat Wst(ctx, lds_, k);
+                    gemm(ctx, false, false, 1.0, fe->stack, R, 0.0, Wst, dst, "gemm_dinv");
+                    V1 = Mat(ctx, n, k);
+                    if (op.has_lr) {
+                        if (!have) {
+                            Mat WK(ctx, lds_, m);
+                            gemm(ctx, false, false, 1.0, fe->stack, op.Vt, 0.0, WK, dst, "gemm_dinv");
+                            SmwCacheEntry en;
+                            en.keep = WK.buf; en.WU = WK.p; en.ldwu = WK.ld;
+                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, WK.p + 2 * (size_t)n, WK.ld, op.alpha, (double*)en.sinv->p, dst, serr.p,
+                                               WK.p, WK.ld, 2 * n);
+                            sc = smw_cache.emplace(key, en).first;
+                        }
+                        TimedScope ts(ctx, "dense_apply", 8.0 * n * (4.0 * k + 2.0 * m), 4.0 * n * k * m);
+                        hipLaunchKernelGGL((k_dense_apply<true>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
+                                           n, m, k, Wst.p, Wst.ld, (const double*)sc->second.WU, sc->second.ldwu,
+                                           V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
+                    } else {
+                        TimedScope ts(ctx, "dense_apply", 8.0 * n * 4.0 * k, 2.0 * n * k);
+                        hipLaunchKernelGGL((k_dense_apply<false>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
+                                           n, 0, k, Wst.p, Wst.ld, (const double*)nullptr, 0,
+                                           V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
+                    }
                 } else {
+                    Mat W(ctx, n, ncols);
                     { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
                     if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
                     mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
-                }
-                if (op.has_lr) {
-                    V1 = Mat(ctx, n, k);
-                    Mat small(ctx, m, ncols);
-                    { TimedScope ts(ctx, "smw_small");
-                      hipLaunchKernelGGL((k_smw_small<double>), dim3(ncols), dim3(256), 0, ctx->stream, n, m, op.U.p, op.U.ld, W.p, W.ld, small.p, small.ld, dst); }
-                    if (!have) {
-                        SmwCacheEntry en;
-                        en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
-                        en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
-                        sc = smw_cache.emplace(key, en).first;
+                    if (op.has_lr) {
+                        V1 = Mat(ctx, n, k);
+                        Mat small(ctx, m, ncols);
+                        { TimedScope ts(ctx, "smw_small");
+                          hipLaunchKernelGGL((k_smw_small<double>), dim3(ncols), dim3(256), 0, ctx->stream, n, m, op.U.p, op.U.ld, W.p, W.ld, small.p, small.ld, dst); }
+                        if (!have) {
+                            SmwCacheEntry en;
+                            en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
+                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
+                            sc = smw_cache.emplace(key, en).first;
+                        }
+                        TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
+                        hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
+                                           n, m, k, W.p, W.ld, (const double*)sc->second.WU, sc->second.ldwu, (const double*)sc->second.sinv->p,
+                                           small.p, small.ld, V1.p, V1.ld, (double*)nullptr, 0, 0.0, dst);
+                    } else {
+                        V1 = W;
                     }
-                    TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
-                    hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
-                                       n, m, k, W.p, W.ld, (const double*)sc->second.WU, sc->second.ldwu, (const double*)sc->second.sinv->p,
-                                       small.p, small.ld, V1.p, V1.ld, (double*)nullptr, 0, 0.0, dst);
-                } else {
-                    V1 = W;
+                    // R <- R - 2 mu E' V   (adi.jl:171)
+                    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);
                 }
-                // R <- R - 2 mu E' V   (adi.jl:171)
-                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);
                 Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
                 iters_host += 1; last_compression += 1;
                 oracle->update(R, {V1});
@@ -695,8 +762,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             // residual norm through the Gram matrix, convergence decision on the device
             residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
-            ++since_sync;
-            if (opt.compression && last_compression >= opt.compression_interval) break;
+            ++since_sync; chunk_shifts += is_real ? 1 : 2;
+            if (opt.compression && chunk_shifts >= opt.compression_interval) break;
             if (!opt.compression && since_sync >= 10) break;
         }
         // synchronise once per chunk and find out how far the device really got
@@ -719,8 +786,14 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         if (h.done || recs.empty()) {
             finished = true;
         } else if (opt.compression && last_compression >= opt.compression_interval) {
-            ldlt_compress(ctx, *Xw, ctf, cex);
-            last_compression = 0;
+            // Small n: the compression works on the n x n matrix L D L' whatever the number of columns, and the increments
+            // never depend on X, so the intermediate compressions of adi.jl:72-76 are deferred to the final one
+            // (adi.jl:78-80) as long as the uncompressed factor stays small.
+            const bool defer = !cex && n <= 512 && Xw->rank() <= 16 * n;
+            if (!defer) {
+                ldlt_compress(ctx, *Xw, ctf, cex);
+                last_compression = 0;
+            }
         }
     }
     {

@@ -50,7 +50,9 @@ CompressStats& compress_stats();
 // (/root/reference/src/LowRankUpdate.jl:18-26, src/lyapunov/types.jl:10-16)
 // `dinv` (real shifts, small n only): the explicit dense inverse of the shifted sparse operator, applied with one MFMA
 // GEMM per ADI step instead of the level-by-level triangular sweeps (which are launch-latency bound at small n).
-template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; };
+// `stack` = [inv; E' inv; U' inv] ((2n + m) x n) for the low-rank factor U of the current operator: ONE GEMM with the residual
+// factor R then yields the plain solve, its image under E' (for the residual recurrence) and the SMW inner products.
+template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; Mat stack; const void* stack_U = nullptr; int stack_m = -1; };
 struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<double>>> real;
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
