@@ -419,24 +419,27 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
         hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, st, iters_after, (double*)nullptr);
     }
 }
-// One workgroup: G = sum of split-K slabs (fixed order), M = T G (or diag(T) G), nrm = |alpha| sqrt(sum_ij M_ij M_ji),
-// then the convergence decision of adi.jl:115-123 on the device.  G and T live in LDS, zero-padded to a multiple of 32
-// (k <= 96).  Dense T: M = T G and N = G T' (= M') are formed 32 x 32 block-wise on the matrix cores — both in the same
-// lane layout, so tr(M M) = sum_ij M_ij N_ij needs no transposition; only blocks bi <= bj are computed (symmetry of the sum).
-__global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const double* __restrict__ part, const double* __restrict__ T, int ldt,
-                                                    int tdiag, double alpha, AdiState* st, int iters_after) {
-    if (st->done) return;
-    extern __shared__ double gsm[];
+// Workgroup-wide: G = sum of `splits` k x k slabs (fixed order), M = T G (or diag(T) G), nrm = |alpha| sqrt(sum_ij M_ij M_ji),
+// then the convergence decision of adi.jl:115-123 on the device.  G and T live in LDS (gsm: 2 kp^2 doubles, kp = k rounded
+// up to 32, k <= 96).  Dense T: M = T G and N = G T' (= M') are formed 32 x 32 block-wise on the matrix cores — both in the
+// same lane layout, so tr(M M) = sum_ij M_ij N_ij needs no transposition; only blocks bi <= bj are computed.
+template <bool COHERENT>
+__device__ __forceinline__ void gram_norm_body(int k, int splits, const double* part, const double* __restrict__ T, int ldt,
+                                               int tdiag, double alpha, AdiState* st, int iters_after, double* gsm, double* red) {
     const int kp = (k + 31) & ~31, ld = kp;
     double* G = gsm;                        // kp x kp
     double* Ts = gsm + (size_t)kp * kp;     // kp x kp (or k diagonal entries)
-    __shared__ double red[17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     for (int idx = tid; idx < kp * kp; idx += blockDim.x) {
         const int r = idx % kp, c = idx / kp;
         const bool in = r < k && c < k;
         double s = 0.0;
-        if (in) for (int z = 0; z < splits; ++z) s += part[(size_t)z * k * k + r + (size_t)c * k];
+        if (in)
+            for (int z = 0; z < splits; ++z) {
+                const double* q = part + (size_t)z * k * k + r + (size_t)c * k;
+                // slabs written by other workgroups of the same launch are read past the L1 (agent-scope relaxed atomic load)
+                s += COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+            }
         G[idx] = s;
         if (!tdiag) Ts[idx] = in ? T[r + (size_t)c * ldt] : 0.0;
     }
@@ -491,6 +494,154 @@ __global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const dou
         if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
     }
 }
+__global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const double* __restrict__ part, const double* __restrict__ T, int ldt,
+                                                    int tdiag, double alpha, AdiState* st, int iters_after) {
+    if (st->done) return;
+    extern __shared__ double gsm[];
+    __shared__ double red[17];
+    gram_norm_body<false>(k, splits, part, T, ldt, tdiag, alpha, st, iters_after, gsm, red);
+}
+
+// Dense-inverse ADI step for a real shift: everything after the stacked GEMM except the final norm reduction (k <= 96):
+//   Wpart: split-K slabs of [inv; E' inv; U' inv] * R  ((2n + m) x k each);  WKS = [inv Vt; E' inv Vt] * Sinv  (2n x m)
+//   V = W - WKS_top small,   R <- R - 2 mu (EW - WKS_mid small)                 (adi.jl:166-171, LowRankUpdate.jl:29-39)
+//   Gpart[blockIdx] = R_new(rows of this workgroup)' R_new(rows)                 (Gram slabs for the residual norm)
+// One workgroup per 64 rows (grid-stride over row chunks).
+template <bool HAS_LR>
+__global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int splits, const double* __restrict__ Wpart,
+                                                     const double* __restrict__ WKS, int ldwk, double* __restrict__ V, int ldv,
+                                                     double* __restrict__ R, int ldr, double two_mu, double* __restrict__ Gpart,
+                                                     const AdiState* st) {
+    if (st->done) return;
+    extern __shared__ double dsm[];
+    const int M = 2 * n + m;
+    const size_t slab = (size_t)M * k;
+    const int kp16 = (k + 15) & ~15, ldk = kp16 + 1;
+    double* Rt = dsm;                                  // Rt[c + il * ldk] = R_new(i0 + il, c)
+    double* small = Rt + (size_t)64 * ldk;             // m x k
+    double* WKs = small + (size_t)(HAS_LR ? m : 0) * k;   // 64 x m
+    double* EWKs = WKs + (size_t)64 * (HAS_LR ? m : 0);   // 64 x m
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nt = blockDim.x, nw = nt >> 6;
+    const int nt16 = kp16 / 16, lr = lane & 15, lk = lane >> 4;
+    // Gram tiles owned by this wave (at most 3 for k <= 96 with 16 waves), accumulated over all row chunks of the workgroup
+    v4d acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (HAS_LR) {
+        for (int id = tid; id < m * k; id += nt) {
+            const int j = id % m, c = id / m;
+            double sv = 0.0;
+            for (int z = 0; z < splits; ++z) sv += Wpart[z * slab + (size_t)(2 * n + j) + (size_t)c * M];
+            small[id] = sv;
+        }
+    }
+    for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
+        if (HAS_LR) {
+            for (int id = tid; id < 64 * m; id += nt) {
+                const int il = id & 63, j = id >> 6, i = i0 + il;
+                WKs[id] = i < n ? WKS[i + (size_t)j * ldwk] : 0.0;
+                EWKs[id] = i < n ? WKS[n + i + (size_t)j * ldwk] : 0.0;
+            }
+        }
+        __syncthreads();          // small / WKs ready; previous chunk's Rt consumed
+        {
+            // every thread owns row i and the columns wave, wave + 16, ...: the slab loads of a split are independent
+            // (three columns at a time keeps the kernel inside 128 registers without spills)
+            const int il = lane, i = i0 + il;
+#pragma unroll 1
+            for (int qb = 0; qb < 6; qb += 3) {
+                if (wave + qb * 16 >= kp16) break;
+                double w[3], ew[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { w[q] = 0.0; ew[q] = 0.0; }
+#pragma unroll 1
+                for (int z = 0; z < splits; ++z) {
+                    const double* wp = Wpart + z * slab + i;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int c = wave + (qb + q) * 16;
+                        if (c < k && i < n) { w[q] += wp[(size_t)c * M]; ew[q] += wp[(size_t)c * M + n]; }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = wave + (qb + q) * 16;
+                    if (c >= kp16) continue;
+                    double rn = 0.0;
+                    if (c < k && i < n) {
+                        double wv = w[q], ev = ew[q];
+                        if (HAS_LR)
+                            for (int j = 0; j < m; ++j) {
+                                const double sj = small[j + c * m];
+                                wv -= WKs[il + j * 64] * sj;
+                                ev -= EWKs[il + j * 64] * sj;
+                            }
+                        V[i + (size_t)c * ldv] = wv;
+                        double* rp = R + i + (size_t)c * ldr;
+                        rn = *rp - two_mu * ev;
+                        *rp = rn;
+                    }
+                    Rt[c + il * ldk] = rn;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int t = wave + q * nw;
+            if (t < nt16 * nt16) {
+                const int ti = t % nt16, tj = t / nt16;
+                const double* pa = Rt + ti * 16 + lr; const double* pb = Rt + tj * 16 + lr;
+#pragma unroll 4
+                for (int l0 = 0; l0 < 64; l0 += 4) {
+                    const double a = pa[(l0 + lk) * ldk], bb = pb[(l0 + lk) * ldk];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    {
+        double* gp = Gpart + (size_t)blockIdx.x * k * k;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int t = wave + q * nw;
+            if (t < nt16 * nt16) {
+                const int ti = t % nt16, tj = t / nt16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = ti * 16 + (lane >> 4) + 4 * r, col = tj * 16 + (lane & 15);
+                    if (row < k && col < k) gp[row + (size_t)col * k] = acc[q][r];
+                }
+            }
+        }
+    }
+}
+
+void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, int* ticket) {
+    DRE_REQUIRE(k <= 96 && m <= 32, "dense_adi_step: k <= 96 and m <= 32 expected");
+    const int nblk = ceil_div(n, 64), kp16 = (k + 15) & ~15, kp32 = (k + 31) & ~31;
+    DevArr<double> gpart(ctx, (size_t)nblk * k * k);
+    const size_t step_lds = ((size_t)64 * (kp16 + 1) + (size_t)m * k + 2 * (size_t)64 * m) * sizeof(double);
+    {
+        TimedScope ts(ctx, "dense_step", 8.0 * (2.0 * n * k * splits + 3.0 * n * k + 2.0 * n * m + (double)nblk * k * k), 4.0 * n * k * m + 2.0 * n * (double)k * k);
+        if (m > 0)
+            hipLaunchKernelGGL((k_dense_step<true>), dim3(nblk), dim3(1024), step_lds, ctx->stream, n, m, k, splits, Wpart, WKS, ldwk, V.p, V.ld, R.p, R.ld,
+                               two_mu, gpart.p, (const AdiState*)st);
+        else
+            hipLaunchKernelGGL((k_dense_step<false>), dim3(nblk), dim3(1024), step_lds, ctx->stream, n, 0, k, splits, Wpart, (const double*)nullptr, 0, V.p, V.ld,
+                               R.p, R.ld, two_mu, gpart.p, (const AdiState*)st);
+    }
+    // the Gram slabs of the workgroups are summed (fixed order) by the norm kernel; a hand-over inside one launch would
+    // need agent-scope fences, which cost more than a launch on a multi-XCD part
+    TimedScope ts(ctx, "ldlt_norm", 8.0 * nblk * k * k, 4.0 * (double)k * k * k);
+    const size_t shm = 2 * (size_t)kp32 * kp32 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, nblk, (const double*)gpart.p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
+    DRE_HIP(hipGetLastError());
+}
+
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
     if (k > 96) {

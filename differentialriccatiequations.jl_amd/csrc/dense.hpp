@@ -51,6 +51,9 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 // The whole residual-norm step  G = R'R,  nrm = |alpha| sqrt(tr((T G)^2)),  convergence decision  in two launches:
 // the split-K Gram GEMM and one workgroup that reduces the partial slabs, forms T G in LDS and decides (k <= 88).
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
+// fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
+void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, int* ticket);
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

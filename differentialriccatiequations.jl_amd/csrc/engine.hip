@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_smw_small(int n, int m, const double* _
 // Sinv = inv(alpha I + Smat) by Gauss-Jordan with partial pivoting; one workgroup, m <= 32
 template <typename T>
 __global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv,
-                                             const AdiState* st, int* err, T* __restrict__ WK = nullptr, int ldwk = 0, int nrows = 0) {
+                                             const AdiState* st, int* err) {
     if (st && st->done) return;
     __shared__ double abuf[32 * 64 * 2];
     __shared__ int piv;
@@ -296,16 +296,24 @@ __global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, 
         const int i = id % m, j = id / m;
         Sinv[i + (size_t)j * m] = A[i + (m + j) * 32];
     }
-    // optional: fold Sinv into the first nrows rows of WK (WK <- WK * Sinv), so that the apply kernel needs no inner solve
-    for (int r = tid; r < nrows; r += 64) {
-        T row[32];
-        for (int j = 0; j < m; ++j) row[j] = WK[r + (size_t)j * ldwk];
-        for (int j = 0; j < m; ++j) {
-            T acc = make_scalar<T>(0.0, 0.0);
-            for (int l = 0; l < m; ++l) acc += row[l] * A[l + (m + j) * 32];
-            WK[r + (size_t)j * ldwk] = acc;
-        }
+}
+
+// WKS = WK(0:nrows, :) * Sinv  — folds the capacitance inverse into the low-rank solve products once per shift, so that the
+// per-step apply kernel needs no inner m x m solve.  One thread per output entry.
+__global__ __launch_bounds__(256) void k_fold_sinv(int nrows, int m, const double* __restrict__ WK, int ldwk, const double* __restrict__ Sinv,
+                                                   double* __restrict__ WKS, int ldo, const AdiState* st) {
+    if (st && st->done) return;
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nrows * m) return;
+    const int r = id % nrows, j = id / nrows;
+    double a0 = 0.0, a1 = 0.0;
+    int l = 0;
+    for (; l + 1 < m; l += 2) {
+        a0 += WK[r + (size_t)l * ldwk] * Sinv[l + (size_t)j * m];
+        a1 += WK[r + (size_t)(l + 1) * ldwk] * Sinv[l + 1 + (size_t)j * m];
     }
+    if (l < m) a0 += WK[r + (size_t)l * ldwk] * Sinv[l + (size_t)j * m];
+    WKS[r + (size_t)j * ldo] = a0 + a1;
 }
 
 #define SMW_CB 8
@@ -614,8 +622,9 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     const int m = op.has_lr ? op.U.cols : 0;
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
     std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
-    DevArr<int> serr(ctx, 1);
+    DevArr<int> serr(ctx, 1), ticket(ctx, 1);
     DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
+    DRE_HIP(hipMemsetAsync(ticket.p, 0, sizeof(int), ctx->stream));
 
     // the iterate: never mutate the caller's initial guess (adi.jl:174 `cache.X += increment` builds a new list)
     auto Xw = std::make_shared<LDLt>(*X);
@@ -637,6 +646,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             const bool is_real = (mu.imag() == 0.0);
             const AdiState* dst = st.p;
             Mat V1, V2;
+            bool norm_done = false;
             if (is_real) {
                 auto fe = get_factor<double>(ctx, op, cache, cache->real, mu);
                 used_real.push_back(fe);
@@ -655,29 +665,38 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         fe->stack = stk; fe->stack_U = (const void*)op.U.p; fe->stack_m = mm;
                     }
                     const int lds_ = 2 * n + mm;
-                    Mat Wst(ctx, lds_, k);
-                    gemm(ctx, false, false, 1.0, fe->stack, R, 0.0, Wst, dst, "gemm_dinv");
                     V1 = Mat(ctx, n, k);
-                    if (op.has_lr) {
-                        if (!have) {
-                            Mat WK(ctx, lds_, m);
-                            gemm(ctx, false, false, 1.0, fe->stack, op.Vt, 0.0, WK, dst, "gemm_dinv");
-                            SmwCacheEntry en;
-                            en.keep = WK.buf; en.WU = WK.p; en.ldwu = WK.ld;
-                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, WK.p + 2 * (size_t)n, WK.ld, op.alpha, (double*)en.sinv->p, dst, serr.p,
-                                               WK.p, WK.ld, 2 * n);
-                            sc = smw_cache.emplace(key, en).first;
-                        }
-                        TimedScope ts(ctx, "dense_apply", 8.0 * n * (4.0 * k + 2.0 * m), 4.0 * n * k * m);
-                        hipLaunchKernelGGL((k_dense_apply<true>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
-                                           n, m, k, Wst.p, Wst.ld, (const double*)sc->second.WU, sc->second.ldwu,
-                                           V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
+                    if (op.has_lr && !have) {
+                        Mat WK(ctx, lds_, m);
+                        gemm(ctx, false, false, 1.0, fe->stack, op.Vt, 0.0, WK, dst, "gemm_dinv");
+                        SmwCacheEntry en;
+                        Mat WKS(ctx, 2 * n, m);
+                        en.keep = WKS.buf; en.WU = WKS.p; en.ldwu = WKS.ld;
+                        en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, WK.p + 2 * (size_t)n, WK.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
+                        hipLaunchKernelGGL(k_fold_sinv, dim3(ceil_div(2 * n * m, 256)), dim3(256), 0, ctx->stream, 2 * n, m, WK.p, WK.ld,
+                                           (const double*)en.sinv->p, WKS.p, WKS.ld, dst);
+                        sc = smw_cache.emplace(key, en).first;
+                    }
+                    if (k <= 96) {
+                        // split-K slabs of the stacked GEMM are consumed directly by the fused step kernel
+                        int zs = 1;
+                        BufP wpart = gemm_partials(ctx, false, false, lds_, k, n, fe->stack.p, fe->stack.ld, R.p, R.ld, &zs, dst, "gemm_dinv");
+                        dense_adi_step(ctx, n, mm, k, zs, (const double*)wpart->p, op.has_lr ? (const double*)sc->second.WU : nullptr,
+                                       op.has_lr ? sc->second.ldwu : 0, V1, R, 2.0 * mu.real(), Tm, tdiag, alpha_res, st.p, iters_host + 1, ticket.p);
+                        norm_done = true;
                     } else {
-                        TimedScope ts(ctx, "dense_apply", 8.0 * n * 4.0 * k, 2.0 * n * k);
-                        hipLaunchKernelGGL((k_dense_apply<false>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
-                                           n, 0, k, Wst.p, Wst.ld, (const double*)nullptr, 0,
-                                           V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
+                        Mat Wst(ctx, lds_, k);
+                        gemm(ctx, false, false, 1.0, fe->stack, R, 0.0, Wst, dst, "gemm_dinv");
+                        TimedScope ts(ctx, "dense_apply", 8.0 * n * (4.0 * k + 2.0 * m), 4.0 * n * k * m);
+                        if (op.has_lr)
+                            hipLaunchKernelGGL((k_dense_apply<true>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
+                                               n, m, k, Wst.p, Wst.ld, (const double*)sc->second.WU, sc->second.ldwu,
+                                               V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
+                        else
+                            hipLaunchKernelGGL((k_dense_apply<false>), dim3(ceil_div(n, 64), ceil_div(k, 4)), dim3(256), 0, ctx->stream,
+                                               n, 0, k, Wst.p, Wst.ld, (const double*)nullptr, 0,
+                                               V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
                     }
                 } else {
                     Mat W(ctx, n, ncols);
@@ -760,7 +779,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                 oracle->update(R, {V1, V2});
             }
             // residual norm through the Gram matrix, convergence decision on the device
-            residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
+            if (!norm_done) residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
             ++since_sync; chunk_shifts += is_real ? 1 : 2;
             if (opt.compression && chunk_shifts >= opt.compression_interval) break;
