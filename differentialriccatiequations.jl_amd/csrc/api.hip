@@ -77,6 +77,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         hipDeviceProp_t prop;
         DRE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = std::getenv("DRE_DENSE_INV_MAX_N")) ctx->c.dense_inv_max_n = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
     if (rc != DRE_OK) { g_noctx_error = ctx->c.last_error; delete ctx; return rc; }
@@ -98,6 +99,13 @@ int dre_ctx_sync(dre_ctx* ctx) { return guarded(ctx, [&] { ctx->c.sync(); }); }
 int dre_ctx_info(dre_ctx* ctx, int64_t* info) {
     info[0] = ctx->c.num_cus; info[1] = (int64_t)ctx->c.pool.total_bytes();
     return DRE_OK;
+}
+int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
+    return guarded(ctx, [&] {
+        const std::string key = name ? name : "";
+        if (key == "dense_inverse_max_n") ctx->c.dense_inv_max_n = (int)value;
+        else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
+    });
 }
 int dre_prof_enable(dre_ctx* ctx, int on) {
     return guarded(ctx, [&] { ctx->c.timer->collect(&ctx->c); ctx->c.timer->enabled = on != 0; });

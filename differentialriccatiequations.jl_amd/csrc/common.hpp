@@ -110,6 +110,8 @@ struct Ctx {
     // pinned scratch for small device->host reads
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // tunables (dre_ctx_set_option): real shifts of pencils with n <= dense_inv_max_n use the cached dense inverse
+    int dense_inv_max_n = 1536;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

@@ -524,15 +524,6 @@ LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, d
 // =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
 // =============================================================================================
-static int dense_inverse_max_n() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = std::getenv("DRE_DENSE_INV_MAX_N");
-        v = e ? std::atoi(e) : 1536;
-    }
-    return v;
-}
-
 template <typename T>
 static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
                                                   std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
@@ -547,7 +538,7 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     cache->nfactor++;
     if constexpr (sizeof(T) == sizeof(double)) {
         const int n = op.P->n;
-        if (n <= dense_inverse_max_n()) {
+        if (n <= ctx->dense_inv_max_n) {
             // explicit inverse through n unit right-hand sides; kept only if the operator is well conditioned enough
             // that inverse-times-vector is as accurate as the triangular solves for the ADI recurrences
             Mat W(ctx, n, n);

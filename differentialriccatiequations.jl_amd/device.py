@@ -44,6 +44,10 @@ class Context:
         return {"cus": a[0], "pool_bytes": a[1]}
 
     # --- profiling -------------------------------------------------------------------------
+    def set_option(self, name, value):
+        """Engine tunables (dre_ctx_set_option), e.g. ``dense_inverse_max_n``."""
+        self.chk(self.lib.dre_ctx_set_option(self.ptr, name.encode(), float(value)))
+
     def prof_enable(self, on=True):
         self.chk(self.lib.dre_prof_enable(self.ptr, 1 if on else 0))
 

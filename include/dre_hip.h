@@ -54,6 +54,10 @@ int dre_ctx_destroy(dre_ctx* ctx);
 const char* dre_last_error(dre_ctx* ctx);
 int dre_ctx_sync(dre_ctx* ctx);
 int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
+/* Tunables of the engine (no counterpart in the reference; they select between device code paths that compute the same result):
+ *   "dense_inverse_max_n"  real ADI shifts on pencils with n <= value apply a cached dense inverse of A' + mu E' by MFMA GEMM
+ *                          instead of the multifrontal triangular sweeps (default 1536, or env DRE_DENSE_INV_MAX_N; 0 disables). */
+int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value);
 /* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
  * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */
 int dre_prof_enable(dre_ctx* ctx, int on);

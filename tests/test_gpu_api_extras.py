@@ -89,3 +89,28 @@ def test_error_behaviour(ctx, rail371):
         a = D.DeviceLDLt.create(ctx, None, np.ones((4, 1)), np.eye(1))
         b = D.DeviceLDLt.create(ctx, None, np.ones((5, 1)), np.eye(1))
         a.add(b)
+
+
+def test_dense_inverse_path_matches_the_multifrontal_path(ctx, rail371):
+    """Real shifts at small n apply a cached dense inverse (MFMA GEMM) instead of the multifrontal sweeps: same iterates."""
+    d, L, Dm = rail371
+    p = np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy"))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4200.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(list(p))))
+    out = {}
+    try:
+        for name, limit in (("multifrontal", 0), ("dense", 1536)):
+            ctx.set_option("dense_inverse_max_n", limit)
+            sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True, save_state=True)
+            out[name] = (sol, [g["iters"] for g in st["gales"]], [g["res_norm"] for g in st["gales"]])
+    finally:
+        ctx.set_option("dense_inverse_max_n", 1536)
+    (s0, it0, r0), (s1, it1, r1) = out["multifrontal"], out["dense"]
+    assert it0 == it1                                         # identical ADI iteration counts per Lyapunov solve
+    assert np.allclose(r0, r1, rtol=1e-3)                     # same final residual norms (they sit at ~n*eps*|C|)
+    for K0, K1 in zip(s0.K, s1.K):
+        assert D.delta(K0, K1) < 1e-10
+    a0, L0, D0 = s0.X[-1]; a1, L1, D1 = s1.X[-1]
+    assert D.delta(a0 * L0 @ D0 @ L0.T, a1 * L1 @ D1 @ L1.T) < 1e-10
+    with pytest.raises(D.DREError):
+        ctx.set_option("no_such_option", 1)
