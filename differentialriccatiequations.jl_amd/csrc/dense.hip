@@ -1161,6 +1161,47 @@ __global__ void k_extract_upper(int kq, int n, const double* __restrict__ A, int
     R[r + (size_t)c * ldr] = (r <= c) ? A[r + (size_t)c * lda] : 0.0;
 }
 
+// Aggregated block-reflector factor of nr = np*nb Householder vectors V = [V_0 ... V_{np-1}] (panel factors T_p given):
+//   H_0 H_1 ... H_{nr-1} = I - V Tg V',   Tg(0:k, k:k+nb) = -Tg(0:k, 0:k) * G(0:k, k:k+nb) * T_p,   G = V'V.
+// One workgroup (nr <= 64 here); X is an nr x nb scratch block in LDS.
+__global__ __launch_bounds__(256) void k_build_T(int nr, int nb, const double* __restrict__ G, int ldg, const double* __restrict__ Tp, int ldt,
+                                                 double* __restrict__ Tg, int ldb) {
+    __shared__ double Ts[64 * 65];
+    __shared__ double X[64 * 17];
+    const int tid = threadIdx.x;
+    for (int id = tid; id < nr * nr; id += blockDim.x) Ts[(id % nr) + (id / nr) * 65] = 0.0;
+    __syncthreads();
+    for (int k = 0; k < nr; k += nb) {
+        const int jb = min(nb, nr - k);
+        for (int id = tid; id < jb * jb; id += blockDim.x) {
+            const int i = id % jb, j = id / jb;
+            Ts[(k + i) + (k + j) * 65] = Tp[i + (size_t)(k + j) * ldt];
+        }
+        if (k > 0) {
+            for (int id = tid; id < k * jb; id += blockDim.x) {      // X = G(0:k, k:k+jb) * T_p   (T_p upper triangular)
+                const int i = id % k, j = id / k;
+                double acc = 0.0;
+                for (int l = 0; l <= j; ++l) acc += G[i + (size_t)(k + l) * ldg] * Tp[l + (size_t)(k + j) * ldt];
+                X[i + j * 64] = acc;
+            }
+            __syncthreads();
+            for (int id = tid; id < k * jb; id += blockDim.x) {      // Tg(0:k, k:k+jb) = -Tg(0:k, 0:k) * X
+                const int i = id % k, j = id / k;
+                double a0 = 0.0, a1 = 0.0;
+                int l = i;
+                for (; l + 1 < k; l += 2) { a0 += Ts[i + l * 65] * X[l + j * 64]; a1 += Ts[i + (l + 1) * 65] * X[l + 1 + j * 64]; }
+                if (l < k) a0 += Ts[i + l * 65] * X[l + j * 64];
+                Ts[i + (k + j) * 65] = -(a0 + a1);
+            }
+        }
+        __syncthreads();
+    }
+    for (int id = tid; id < nr * nr; id += blockDim.x) Tg[(id % nr) + (size_t)(id / nr) * ldb] = Ts[(id % nr) + (id / nr) * 65];
+}
+
+#define QR_GROUP 64
+#define QR_GROUP_MIN_ROWS 4096
+
 QRFact qr_factor(Ctx* ctx, Mat& A) {
     QRFact f;
     f.m = A.rows; f.n = A.cols; f.kq = std::min(A.rows, A.cols); f.nb = QR_NB;
@@ -1170,18 +1211,44 @@ QRFact qr_factor(Ctx* ctx, Mat& A) {
     f.R = Mat(ctx, f.kq, f.n);
     fill_mat(ctx, f.V, 0.0);
     fill_mat(ctx, f.VT, 0.0);
-    for (int j0 = 0; j0 < f.kq; j0 += QR_NB) {
-        const int jb = std::min(QR_NB, f.kq - j0);
-        launch_qr_panel(ctx, A.p, A.ld, f.m, j0, jb, f.V.p, f.V.ld, f.T.p, f.T.ld, f.VT.p, f.VT.ld, nullptr);
-        const int n2 = f.n - j0 - jb;
+    const bool grouped = f.m >= QR_GROUP_MIN_ROWS && f.kq > QR_NB;
+    const int GW = grouped ? QR_GROUP : QR_NB;
+    if (grouped) { f.group = GW; f.VTg = Mat(ctx, f.m, f.kq); }
+    for (int g0 = 0; g0 < f.kq; g0 += GW) {
+        const int gw = std::min(GW, f.kq - g0), gend = g0 + gw;
+        for (int j0 = g0; j0 < gend; j0 += QR_NB) {
+            const int jb = std::min(QR_NB, gend - j0);
+            launch_qr_panel(ctx, A.p, A.ld, f.m, j0, jb, f.V.p, f.V.ld, f.T.p, f.T.ld, f.VT.p, f.VT.ld, nullptr);
+            // columns up to the end of the group (all remaining columns when not grouped):  A2 <- Q_p' A2 = A2 - V (V T)' A2
+            const int n2 = (grouped ? gend : f.n) - j0 - jb;
+            if (n2 > 0) {
+                Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
+                Mat VTp = f.VT.view(j0, j0, f.m - j0, jb);
+                Mat A2 = A.view(j0, j0 + jb, f.m - j0, n2);
+                Mat W(ctx, jb, n2);
+                gemm(ctx, true, false, 1.0, VTp, A2, 0.0, W, nullptr, "gemm_qr");
+                gemm(ctx, false, false, -1.0, Vp, W, 1.0, A2, nullptr, "gemm_qr");
+            }
+        }
+        if (!grouped) continue;
+        // aggregate the group's panels:  Q_g = I - V_g T_g V_g',  VTg = V_g T_g
+        Mat Vg = f.V.view(g0, g0, f.m - g0, gw);
+        Mat VTg = f.VTg.view(g0, g0, f.m - g0, gw);
+        if (gw > QR_NB) {
+            Mat G(ctx, gw, gw), Tg(ctx, gw, gw);
+            gemm(ctx, true, false, 1.0, Vg, Vg, 0.0, G, nullptr, "gemm_qr");
+            hipLaunchKernelGGL(k_build_T, dim3(1), dim3(256), 0, ctx->stream, gw, QR_NB, G.p, G.ld, f.T.p + (size_t)g0 * f.T.ld, f.T.ld, Tg.p, Tg.ld);
+            gemm(ctx, false, false, 1.0, Vg, Tg, 0.0, VTg, nullptr, "gemm_qr");
+        } else {
+            Mat VTp = f.VT.view(g0, g0, f.m - g0, gw);
+            copy_mat(ctx, VTp, VTg);
+        }
+        const int n2 = f.n - gend;
         if (n2 > 0) {
-            // A2 <- Q_p' A2 = A2 - V (V T)' A2
-            Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
-            Mat VTp = f.VT.view(j0, j0, f.m - j0, jb);
-            Mat A2 = A.view(j0, j0 + jb, f.m - j0, n2);
-            Mat W(ctx, jb, n2);
-            gemm(ctx, true, false, 1.0, VTp, A2, 0.0, W, nullptr, "gemm_qr");
-            gemm(ctx, false, false, -1.0, Vp, W, 1.0, A2, nullptr, "gemm_qr");
+            Mat A2 = A.view(g0, gend, f.m - g0, n2);
+            Mat W(ctx, gw, n2);
+            gemm(ctx, true, false, 1.0, VTg, A2, 0.0, W, nullptr, "gemm_qr");      // W = T_g' V_g' A2
+            gemm(ctx, false, false, -1.0, Vg, W, 1.0, A2, nullptr, "gemm_qr");      // A2 <- Q_g' A2
         }
     }
     size_t tot = (size_t)f.kq * f.n;
@@ -1193,12 +1260,14 @@ QRFact qr_factor(Ctx* ctx, Mat& A) {
 void qr_apply_q(Ctx* ctx, const QRFact& f, Mat& B, bool transpose) {
     DRE_REQUIRE(B.rows == f.m, "qr_apply_q: row mismatch");
     if (B.cols == 0 || f.kq == 0) return;
-    const int np = ceil_div(f.kq, QR_NB);
+    const int GW = f.group > 0 ? f.group : QR_NB;
+    const Mat& VTall = f.group > 0 ? f.VTg : f.VT;
+    const int np = ceil_div(f.kq, GW);
     for (int pp = 0; pp < np; ++pp) {
         const int p = transpose ? pp : np - 1 - pp;
-        const int j0 = p * QR_NB, jb = std::min(QR_NB, f.kq - j0);
+        const int j0 = p * GW, jb = std::min(GW, f.kq - j0);
         Mat Vp = f.V.view(j0, j0, f.m - j0, jb);
-        Mat VTp = f.VT.view(j0, j0, f.m - j0, jb);
+        Mat VTp = VTall.view(j0, j0, f.m - j0, jb);
         Mat B2 = B.view(j0, 0, f.m - j0, B.cols);
         Mat W(ctx, jb, B.cols);
         if (!transpose) {   // Q_p B = B - (V T)(V' B)

@@ -63,6 +63,10 @@ struct QRFact {
     Mat VT;  // m x kq, V_p * T_p per panel (so that Q_p = I - VT_p V_p')
     Mat T;   // nb x kq, upper-triangular block-reflector factors per panel
     Mat R;   // kq x n upper trapezoid
+    // tall matrices: panels are aggregated in groups of `group` columns (a multiple of nb); VTg(:, group) = V_g * T_g, so
+    // that the wide trailing updates and Q applications stream the big operand once per GROUP instead of once per panel
+    int group = 0;
+    Mat VTg;
 };
 // A (m x n) is destroyed.  (/root/reference/src/LDLt.jl:237-245 `orthf`: any orthogonal-triangular
 // factorisation gives the same X up to roundoff; no pivoting is needed because rank decisions are

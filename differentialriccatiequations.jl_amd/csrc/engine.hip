@@ -697,8 +697,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                     if (op.has_lr) {
                         V1 = Mat(ctx, n, k);
                         Mat small(ctx, m, ncols);
-                        { TimedScope ts(ctx, "smw_small");
-                          hipLaunchKernelGGL((k_smw_small<double>), dim3(ncols), dim3(256), 0, ctx->stream, n, m, op.U.p, op.U.ld, W.p, W.ld, small.p, small.ld, dst); }
+                        // small = U' W: a skinny split-K MFMA GEMM (the one-workgroup-per-column kernel is latency bound at large n)
+                        gemm(ctx, true, false, 1.0, op.U, W, 0.0, small, dst, "smw_small");
                         if (!have) {
                             SmwCacheEntry en;
                             en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;

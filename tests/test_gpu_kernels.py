@@ -70,7 +70,7 @@ def test_shifted_solve_nonsymmetric_and_empty_rhs(ctx):
     assert P.factor(1.0, -2.0).solve(np.zeros((n, 0))).shape == (n, 0)
 
 
-@pytest.mark.parametrize("m,n", [(371, 115), (371, 311), (50, 7), (40, 40), (100, 17), (30, 45), (5, 1), (1357, 50), (5177, 40), (20209, 37), (2100, 300)])
+@pytest.mark.parametrize("m,n", [(371, 115), (371, 311), (50, 7), (40, 40), (100, 17), (30, 45), (5, 1), (1357, 50), (5177, 40), (20209, 37), (2100, 300), (4500, 200), (20209, 150)])
 def test_orthf(ctx, m, n):
     rng = np.random.default_rng(m + n)
     L = rng.standard_normal((m, n))
