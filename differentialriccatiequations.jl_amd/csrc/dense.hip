@@ -122,8 +122,15 @@ __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const doub
     if (st && st->done) return;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)M * N) return;
+    // fixed summation order (deterministic); four slab loads in flight at a time
+    const size_t slab = (size_t)M * N;
     double s = 0.0;
-    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * M * N + idx];   // fixed order: deterministic
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {
+        const double p0 = partial[z * slab + idx], p1 = partial[(z + 1) * slab + idx], p2 = partial[(z + 2) * slab + idx], p3 = partial[(z + 3) * slab + idx];
+        s = (((s + p0) + p1) + p2) + p3;
+    }
+    for (; z < splits; ++z) s += partial[z * slab + idx];
     int row = idx % M, col = idx / M;
     double* c = C + row + (size_t)col * ldc;
     *c = (beta == 0.0) ? alpha * s : alpha * s + beta * (*c);
@@ -1681,6 +1688,44 @@ __global__ __launch_bounds__(1024) void k_band_w(int m, int b, int splits, const
             P2[r + (size_t)c * ldp] = v;         P2[r + (size_t)(b + c) * ldp] = acc;
         }
 }
+// Large panels (m > 540): the same update row-parallel over many workgroups.  Z is already reduced (m x b), the b x b
+// matrix M = V' Z arrives as split-K slabs; every workgroup forms N = T' M redundantly and owns 256 rows.
+__global__ __launch_bounds__(256) void k_band_w_rows(int m, int splits, const double* __restrict__ Z, int ldz, const double* __restrict__ Mpart,
+                                                     const double* __restrict__ Vp, int ldv, const double* __restrict__ Tp, int ldt,
+                                                     double* __restrict__ P1, double* __restrict__ P2, int ldp, const AdiState* st) {
+    if (st->done) return;
+    constexpr int b = QR_NB;
+    __shared__ double Msh[b][b + 1], Nsh[b][b + 1];
+    const int tid = threadIdx.x;
+    {
+        const int i = tid % b, j = tid / b;
+        double acc = 0.0;
+        for (int z = 0; z < splits; ++z) acc += Mpart[(size_t)z * b * b + i + j * b];
+        Msh[i][j] = acc;
+    }
+    __syncthreads();
+    {
+        const int i = tid % b, j = tid / b;                 // N = T' M
+        double acc = 0.0;
+        for (int l = 0; l <= i; ++l) acc += Tp[l + (size_t)i * ldt] * Msh[l][j];
+        Nsh[i][j] = acc;
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= m) return;
+    double v[b], z[b];
+#pragma unroll
+    for (int l = 0; l < b; ++l) { v[l] = Vp[r + (size_t)l * ldv]; z[l] = Z[r + (size_t)l * ldz]; }
+#pragma unroll
+    for (int c = 0; c < b; ++c) {
+        double a0 = z[c], a1 = 0.0;
+#pragma unroll
+        for (int l = 0; l < b; l += 2) { a0 -= 0.5 * v[l] * Nsh[l][c]; a1 -= 0.5 * v[l + 1] * Nsh[l + 1][c]; }
+        const double acc = a0 + a1;
+        P1[r + (size_t)c * ldp] = acc;       P1[r + (size_t)(b + c) * ldp] = v[c];
+        P2[r + (size_t)c * ldp] = v[c];      P2[r + (size_t)(b + c) * ldp] = acc;
+    }
+}
 // D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
 __global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1742,6 +1787,16 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
             Mat VTp = out.VT.view(k + b, k, m, b);
             Mat Tp = out.T.view(0, k, b, b);
             Mat P1(ctx, m, 2 * b), P2(ctx, m, 2 * b);
+            if (m > 540) {
+                // row-parallel variant: Z = S22 (V T) reduced, M = V' Z as slabs, then one multi-workgroup kernel
+                Mat Z(ctx, m, b);
+                gemm(ctx, false, false, 1.0, S22, VTp, 0.0, Z, st.p, "gemm_band");
+                int ms = 1;
+                BufP mpart = gemm_partials(ctx, true, false, b, b, m, Vp.p, Vp.ld, Z.p, Z.ld, &ms, st.p, "gemm_band");
+                TimedScope ts(ctx, "band_w", 8.0 * m * b * 6.0, 2.0 * m * b * b);
+                hipLaunchKernelGGL(k_band_w_rows, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, m, ms, Z.p, Z.ld, (const double*)mpart->p,
+                                   Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+            } else {
             int zs = 1;
             BufP zpart = gemm_partials(ctx, false, false, m, b, m, S22.p, S22.ld, VTp.p, VTp.ld, &zs, st.p, "gemm_band");
             {
@@ -1754,6 +1809,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
                 } else {
                     hipLaunchKernelGGL((k_band_w<false>), dim3(1), dim3(1024), 0, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
                 }
+            }
             }
             gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band");    // S22 -= [W V] [V W]'
             k += b; ++np; ++issued;
