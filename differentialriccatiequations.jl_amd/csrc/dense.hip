@@ -702,6 +702,7 @@ struct PanelShared {
     double taus[QR_NB];
     double betas[QR_NB];
     double nrm2[QR_NB + 1];        // nrm2[j] = ||P[j+1:, j]||^2 once reflectors 0..j-1 are applied (lookahead)
+    double pv[2][1024];            // register-resident core: the current / next pivot column (double buffered)
 };
 
 // Householder QR of the rows x jb panel Pn (leading dimension ldp) by one workgroup, in place: on exit the upper triangle
@@ -836,10 +837,133 @@ __device__ __forceinline__ void hh_panel_core(double* __restrict__ Pn, int ldp, 
     __syncthreads();
 }
 
+// Register-resident variant (rows <= 64 NR <= 1024, blockDim = 1024 >= 64 jb): wave w keeps column w of the panel in NR
+// registers per lane for the whole factorisation; only the pivot column travels through LDS (published by its owner one
+// step ahead, double buffered).  Per column step the LDS traffic drops from five panel sweeps to one pivot-column read
+// per wave.  Same arithmetic as hh_panel_core; Pn is read at entry and holds R / the reflectors / sh.Tsh at exit.
+__device__ __forceinline__ double lane_bcast(double v, int srclane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane), hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+template <int NR>
+__device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double (*Tsh)[QR_NB + 1] = sh.Tsh;
+    double (*Zm)[QR_NB + 1] = sh.Zm;
+    double* scl = sh.scl;
+    for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) { (&Tsh[0][0])[i] = 0.0; (&Zm[0][0])[i] = 0.0; }
+    __syncthreads();                 // the LDS copy of the panel is complete
+    const bool own = wave < jb;
+    double x[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) { const int i = lane + 64 * u; x[u] = (own && i < rows) ? Pn[i + (size_t)wave * ldp] : 0.0; }
+    if (wave == 0) {
+        double s0 = 0.0;
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { const int i = lane + 64 * u; if (i >= 1) s0 += x[u] * x[u]; if (i < rows) sh.pv[0][i] = x[u]; }
+        s0 = wave_sum(s0);
+        if (lane == 0) sh.nrm2[0] = s0;
+    }
+    __syncthreads();
+    PROBE(3);
+    auto t_column = [&](int c) {
+        const double tc = sh.taus[c];
+        if (lane < c) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int l = lane;
+            for (; l + 3 < c; l += 4) {
+                a0 += Tsh[lane][l] * Zm[l][c];
+                a1 += Tsh[lane][l + 1] * Zm[l + 1][c];
+                a2 += Tsh[lane][l + 2] * Zm[l + 2][c];
+                a3 += Tsh[lane][l + 3] * Zm[l + 3][c];
+            }
+            for (; l < c; ++l) a0 += Tsh[lane][l] * Zm[l][c];
+            Tsh[lane][c] = -tc * ((a0 + a1) + (a2 + a3));
+        }
+        if (lane == 0) Tsh[c][c] = tc;
+    };
+    for (int jj = 0; jj < jb; ++jj) {
+        const double* pv = sh.pv[jj & 1];
+        double* pvn = sh.pv[(jj + 1) & 1];
+        const double s = sh.nrm2[jj], alpha = pv[jj];
+        double tau = 0.0, beta = alpha, scale = 0.0;
+        if (s > 0.0) {
+            const double nrm = sqrt(alpha * alpha + s);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (tid == 0) { scl[jj] = scale; sh.taus[jj] = tau; sh.betas[jj] = beta; }
+        if (own) {
+            const int ju = jj >> 6, jl = jj & 63;
+            if (wave > jj) {
+                double sel = 0.0, w = 0.0;
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int i = lane + 64 * u;
+                    if (u == ju) sel = x[u];
+                    if (i > jj && i < rows) w += pv[i] * x[u];
+                }
+                const double cjj = lane_bcast(sel, jl);          // entry of my column in the pivot row
+                w = wave_sum(w) * scale + cjj;
+                const double tw = tau * w, tws = tw * scale;
+                double nn = 0.0;
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int i = lane + 64 * u;
+                    if (i > jj && i < rows) {
+                        x[u] -= tws * pv[i];
+                        if (i > jj + 1) nn += x[u] * x[u];
+                    }
+                    if (u == ju && lane == jl) x[u] = cjj - tw;
+                }
+                if (wave == jj + 1) {
+                    nn = wave_sum(nn);
+                    if (lane == 0) sh.nrm2[jj + 1] = nn;
+#pragma unroll
+                    for (int u = 0; u < NR; ++u) { const int i = lane + 64 * u; if (i < rows) pvn[i] = x[u]; }
+                }
+            } else if (wave < jj) {
+                double sel = 0.0, w = 0.0;
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    const int i = lane + 64 * u;
+                    if (u == ju) sel = x[u];
+                    if (i > jj && i < rows) w += x[u] * pv[i];
+                }
+                const double vjj = lane_bcast(sel, jl);           // entry of reflector `wave` in row jj (unscaled)
+                w = wave_sum(w) * scl[wave] * scale;
+                if (lane == 0) Zm[wave][jj] = w + vjj * scl[wave];
+            } else if (jj > 0) {
+                t_column(jj - 1);
+            }
+        }
+        __syncthreads();
+    }
+    PROBE(4);
+    if (wave == 0) t_column(jb - 1);
+    if (own) {
+        const double sv = scl[wave], bw = sh.betas[wave];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int i = lane + 64 * u;
+            if (i < rows) Pn[i + (size_t)wave * ldp] = (i > wave) ? x[u] * sv : (i == wave ? bw : x[u]);
+        }
+    }
+    __syncthreads();
+}
+// LDS panels: dispatch on the number of rows (registers per lane)
+__device__ __forceinline__ void hh_panel_core_lds(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
+    if (rows <= 256) hh_panel_core_reg<4>(Pn, ldp, rows, jb, sh);
+    else if (rows <= 512) hh_panel_core_reg<8>(Pn, ldp, rows, jb, sh);
+    else if (rows <= 768) hh_panel_core_reg<12>(Pn, ldp, rows, jb, sh);
+    else hh_panel_core_reg<16>(Pn, ldp, rows, jb, sh);
+}
+
 // One workgroup factors the panel A[j0:m, j0:j0+jb].  V (explicit, pre-zeroed), T and VT = V*T are written too.
 // PLDS: the panel rows j0..m live in LDS for the whole factorisation (m - j0 <= QR_LDS_ROWS), which turns the
 // ~6 dependent global round trips per column into LDS round trips.
-#define QR_LDS_ROWS 1100
+#define QR_LDS_ROWS 1024
 template <bool PLDS>
 __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
                                                    double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
@@ -889,7 +1013,8 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
         }
     }
     PROBE(2);
-    hh_panel_core(Pn, ldp, rows, jb, sh);
+    if (PLDS) hh_panel_core_lds(Pn, ldp, rows, jb, sh);
+    else hh_panel_core(Pn, ldp, rows, jb, sh);
     PROBE(5);
     // write back: R part + reflectors into A, explicit V, T, and VT = V * T
     for (int c = wave; c < jb; c += nw) {
@@ -941,7 +1066,7 @@ __global__ __launch_bounds__(1024) void k_tsqr_local(const double* __restrict__ 
     const int ldp = rows | 1;
     for (int j = wave; j < jb; j += nw)
         for (int r = lane; r < rows; r += 64) psm[r + (size_t)j * ldp] = A[(r0 + r) + (size_t)j * lda];
-    hh_panel_core(psm, ldp, rows, jb, sh);
+    hh_panel_core_lds(psm, ldp, rows, jb, sh);
     for (int j = wave; j < jb; j += nw)
         for (int r = lane; r < rows; r += 64) {
             const double x = psm[r + (size_t)j * ldp];
@@ -962,7 +1087,7 @@ __global__ __launch_bounds__(1024) void k_tsqr_top(double* __restrict__ Rstack, 
     const int ldp = rowsR | 1;
     for (int j = wave; j < jb; j += nw)
         for (int r = lane; r < rowsR; r += 64) psm[r + (size_t)j * ldp] = Rstack[r + (size_t)j * ldrs];
-    hh_panel_core(psm, ldp, rowsR, jb, sh);
+    hh_panel_core_lds(psm, ldp, rowsR, jb, sh);
     for (int i = tid; i < jb * jb; i += blockDim.x) {
         const int r = i % jb, j = i / jb;
         Rfin[r + j * QR_NB] = (r <= j) ? psm[r + (size_t)j * ldp] : 0.0;
@@ -1127,8 +1252,8 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     TimedScope ts(ctx, "qr_panel_tsqr", 8.0 * rows * jb * 8.0, 2.0 * rows * jb * jb * 3.0);
     static bool attr_set = false;
     if (!attr_set) {
-        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_top, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_top, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
         attr_set = true;
     }
     const size_t shm1 = (size_t)((plan.base + 1) | 1) * jb * sizeof(double);
@@ -1149,7 +1274,7 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
     if (rows <= QR_LDS_ROWS) {
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
         static bool attr_set = false;
-        if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+        if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); attr_set = true; }
         hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
     } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2) {
         // tall panel: TSQR + Householder reconstruction on many CUs (the termination test, if any, runs on its own)

@@ -12,7 +12,7 @@ int main() {
         hipMalloc(&A, h.size() * 8); hipMalloc(&V, h.size() * 8); hipMalloc(&VT, h.size() * 8); hipMalloc(&T, b * b * 8); hipMalloc(&part, 64 * 8); hipMalloc(&st, sizeof(AdiState));
         hipMemset(V, 0, h.size() * 8); hipMemset(st, 0, sizeof(AdiState));
         std::vector<double> hp(64, 1.0); hipMemcpy(part, hp.data(), 64 * 8, hipMemcpyHostToDevice);
-        hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
         for (int withpart = 0; withpart < 2; ++withpart)
             for (int rep = 0; rep < 3; ++rep) {
                 hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice);
