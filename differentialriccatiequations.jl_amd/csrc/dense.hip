@@ -18,18 +18,35 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define GB_K 32
 #define GB_LD 81
 
+// Wave-wide sum through DPP row shifts / row broadcasts (no LDS crossbar round trips as with ds_bpermute shuffles);
+// the total lands in lane 63 and is broadcast through a scalar register.  Invalid source lanes contribute 0.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ inline double dpp_mov0(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_sum(double v) {
+    v += dpp_mov0<0x111>(v);            // row_shr:1
+    v += dpp_mov0<0x112>(v);            // row_shr:2
+    v += dpp_mov0<0x114>(v);            // row_shr:4
+    v += dpp_mov0<0x118>(v);            // row_shr:8   -> lane 15 of every row holds the row total
+    v += dpp_mov0<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+// One 64 x 64 output tile over the K range [kbeg, kend): C = alpha A B + beta C, or (partial != nullptr) the raw
+// product into the slab `partial` (M x N, ld M).
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
-                                              int lda, const double* __restrict__ B, int ldb, double beta,
-                                              double* __restrict__ C, int ldc, int kchunk,
-                                              double* __restrict__ partial, const AdiState* st) {
-    if (st && st->done) return;
+__device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, const double* __restrict__ A, int lda,
+                                          const double* __restrict__ B, int ldb, double beta, double* __restrict__ C, int ldc,
+                                          int m0, int n0, int kbeg, int kend, double* __restrict__ partial,
+                                          double* __restrict__ tile_sumsq = nullptr) {
     __shared__ double As[GB_K][GB_LD];
     __shared__ double Bs[GB_K][GB_LD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
-    const int kbeg = blockIdx.z * kchunk;
-    const int kend = min(K, kbeg + kchunk);
     v4d acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -98,6 +115,7 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
         }
         __syncthreads();
     }
+    double ssq = 0.0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -108,13 +126,65 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha,
                 const int col = n0 + wn + j * 16 + (lane & 15);
                 if (row < M && col < N) {
                     if (partial) {
-                        partial[(size_t)blockIdx.z * M * N + row + (size_t)col * M] = acc[i][j][r];
+                        partial[row + (size_t)col * M] = acc[i][j][r];
                     } else {
                         double* c = C + row + (size_t)col * ldc;
-                        *c = (beta == 0.0) ? alpha * acc[i][j][r] : alpha * acc[i][j][r] + beta * (*c);
+                        const double v = (beta == 0.0) ? alpha * acc[i][j][r] : alpha * acc[i][j][r] + beta * (*c);
+                        *c = v;
+                        ssq += v * v;
                     }
                 }
             }
+    if (tile_sumsq) {
+        // one partial per tile, summed wave by wave in a fixed order (As is free again after the last K-tile)
+        ssq = wave_sum(ssq);
+        if (lane == 0) As[0][wave] = ssq;
+        __syncthreads();
+        if (tid == 0) *tile_sumsq = (As[0][0] + As[0][1]) + (As[0][2] + As[0][3]);
+    }
+}
+
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
+                                              int lda, const double* __restrict__ B, int ldb, double beta,
+                                              double* __restrict__ C, int ldc, int kchunk,
+                                              double* __restrict__ partial, const AdiState* st, double* __restrict__ tile_sumsq) {
+    if (st && st->done) return;
+    const int kbeg = blockIdx.z * kchunk;
+    gemm_tile<TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.x * GB_M, blockIdx.y * GB_N, kbeg, min(K, kbeg + kchunk),
+                      partial ? partial + (size_t)blockIdx.z * M * N : nullptr,
+                      tile_sumsq ? tile_sumsq + blockIdx.x + (size_t)gridDim.x * blockIdx.y : nullptr);
+}
+
+// Batched NN GEMM with per-batch operands (blockIdx.z = batch): C_z = alpha_z A_z B_z; optionally A_z is also copied to
+// copy_dst_z (the column-concatenation of LDL' blocks comes for free with the product by the block-diagonal factor).
+__global__ __launch_bounds__(256) void k_gemm_batched(const GemmBatchDesc* __restrict__ descs) {
+    const GemmBatchDesc d = descs[blockIdx.z];
+    const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+    if (m0 >= d.M) return;
+    if (d.copy_dst && blockIdx.y == 0) {
+        for (int id = threadIdx.x; id < GB_M * d.K; id += blockDim.x) {
+            const int r = m0 + id % GB_M, c = id / GB_M;
+            if (r < d.M) d.copy_dst[r + (size_t)c * d.ldcopy] = d.A[r + (size_t)c * d.lda];
+        }
+    }
+    if (n0 >= d.N) return;
+    gemm_tile<false, false>(d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb, 0.0, d.C, d.ldc, m0, n0, 0, d.K, nullptr);
+}
+void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag) {
+    if (descs.empty()) return;
+    int maxM = 0, maxN = 0; double fl = 0.0, by = 0.0;
+    for (auto& d : descs) {
+        maxM = std::max(maxM, d.M); maxN = std::max(maxN, d.N);
+        fl += 2.0 * d.M * d.N * (double)d.K; by += 8.0 * ((double)d.M * d.K * (d.copy_dst ? 2.0 : 1.0) + (double)d.K * d.N + (double)d.M * d.N);
+    }
+    DevArr<GemmBatchDesc> dd(ctx, descs.size());
+    DRE_HIP(hipMemcpyAsync(dd.p, descs.data(), descs.size() * sizeof(GemmBatchDesc), hipMemcpyHostToDevice, ctx->stream));
+    TimedScope ts(ctx, tag, by, fl);
+    hipLaunchKernelGGL(k_gemm_batched, dim3(ceil_div(maxM, GB_M), std::max(1, ceil_div(maxN, GB_N)), (unsigned)descs.size()), dim3(256), 0, ctx->stream,
+                       (const GemmBatchDesc*)dd.p);
+    DRE_HIP(hipGetLastError());
 }
 
 __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const double* __restrict__ partial,
@@ -137,12 +207,13 @@ __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const doub
 }
 
 void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
-          int ldb, double beta, double* C, int ldc, const AdiState* st, const char* tag) {
+          int ldb, double beta, double* C, int ldc, const AdiState* st, const char* tag, double* tile_sumsq) {
     if (M <= 0 || N <= 0) return;
     TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
     const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
     // These GEMMs are latency bound (one memory round trip per K-tile), so K is split until the grid fills the
     // chip or every block is down to two K-tiles; partial slabs are reduced in a fixed order (deterministic).
+    DRE_REQUIRE(!tile_sumsq || K <= 2 * GB_K, "gemm: tile_sumsq needs an unsplit K");
     int splits = 1;
     if (K > 2 * GB_K) {
         int want = ceil_div(2 * ctx->num_cus, tm * tn);
@@ -157,10 +228,10 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
         pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
         partial = (double*)pb->p;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
     if (splits > 1) {
         size_t tot = (size_t)M * N;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, M, N, splits, alpha, partial, beta, C, ldc, st);
@@ -183,10 +254,10 @@ BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double
     auto pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
     double* partial = (double*)pb->p;
     double* none = nullptr;
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
     DRE_HIP(hipGetLastError());
     *splits_out = splits;
     return pb;
@@ -284,25 +355,6 @@ void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double a
     hipLaunchKernelGGL(k_scale_cols, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, L.rows, L.cols, L.p, L.ld, D.p, D.ld, out.p, out.ld, alpha);
 }
 
-// Wave-wide sum through DPP row shifts / row broadcasts (no LDS crossbar round trips as with ds_bpermute shuffles);
-// the total lands in lane 63 and is broadcast through a scalar register.  Invalid source lanes contribute 0.
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ inline double dpp_mov0(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ inline double wave_sum(double v) {
-    v += dpp_mov0<0x111>(v);            // row_shr:1
-    v += dpp_mov0<0x112>(v);            // row_shr:2
-    v += dpp_mov0<0x114>(v);            // row_shr:4
-    v += dpp_mov0<0x118>(v);            // row_shr:8   -> lane 15 of every row holds the row total
-    v += dpp_mov0<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
-    v += dpp_mov0<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
 // block-wide sum, result valid in every thread; blockDim.x multiple of 64, <= 1024
 __device__ inline double block_sum(double v, double* red /* >= 17 doubles */) {
     v = wave_sum(v);
@@ -968,7 +1020,8 @@ template <bool PLDS>
 __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int lda, int m, int j0, int jb,
                                                    double* __restrict__ V, int ldv, double* __restrict__ T, int ldt,
                                                    double* __restrict__ VT, int ldvt, AdiState* st,
-                                                   const double* __restrict__ part, int nparts, int kpanel, double tolfac) {
+                                                   const double* __restrict__ part, int nparts, int kpanel, double tolfac,
+                                                   double* __restrict__ part_out) {
     PROBE(0);
     if (st && st->done) return;
     if (part) {
@@ -1016,6 +1069,16 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
     if (PLDS) hh_panel_core_lds(Pn, ldp, rows, jb, sh);
     else hh_panel_core(Pn, ldp, rows, jb, sh);
     PROBE(5);
+    if (part_out && wave == 0) {
+        // coupling term of the NEXT termination test: 2 ||triu(R)||_F^2 of this panel (see k_band_rem)
+        double c2 = 0.0;
+        for (int id = lane; id < jb * jb; id += 64) {
+            const int r = id % jb, c = id / jb;
+            if (r <= c && r < rows) { const double x = Pn[r + (size_t)c * ldp]; c2 += 2.0 * x * x; }
+        }
+        c2 = wave_sum(c2);
+        if (lane == 0) part_out[0] = c2;
+    }
     // write back: R part + reflectors into A, explicit V, T, and VT = V * T
     for (int c = wave; c < jb; c += nw) {
         const double* pc = Pn + (size_t)c * ldp;
@@ -1268,21 +1331,21 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
 
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
-                            double tolfac = 0.0) {
+                            double tolfac = 0.0, double* part_out = nullptr) {
     const int rows = m - j0;
     TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
     if (rows <= QR_LDS_ROWS) {
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
+        hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
     } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2) {
         // tall panel: TSQR + Householder reconstruction on many CUs (the termination test, if any, runs on its own)
         if (part) hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, kpanel, nparts, part, tolfac, st);
         launch_tsqr_panel(ctx, A + (size_t)j0 * lda + j0, lda, rows, jb, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt,
                           VT ? VT + (size_t)j0 * ldvt + j0 : nullptr, ldvt, st);
     } else {
-        hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac);
+        hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
     }
 }
 
@@ -1876,7 +1939,11 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     out.VT = Mat(ctx, q, q);
     out.T = Mat(ctx, b, q);
     fill_mat(ctx, out.V, 0.0);
-    DevArr<double> part(ctx, BAND_REM_BLOCKS);
+    // all panels factored by the LDS panel kernel: the termination norm of the next panel is assembled from the update
+    // GEMM's per-tile sums of squares plus the coupling term written by the panel kernel — no separate norm launch
+    const bool fused_rem = q - b <= QR_LDS_ROWS;
+    DevArr<double> part(ctx, (size_t)std::max(BAND_REM_BLOCKS, 1 + gemm_num_tiles(q, q)));
+    int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
     {
         AdiState h;
@@ -1892,20 +1959,22 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     while (!finished) {
         int issued = 0;
         while (issued < chunk && k < q) {
-            {
+            if (!fused_rem || k == 0) {
                 TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
                 hipLaunchKernelGGL(k_band_rem, dim3(BAND_REM_BLOCKS), dim3(256), 0, ctx->stream, q, k, b, S.p, S.ld, part.p, st.p);
+                nparts = BAND_REM_BLOCKS;
             }
             const int m = q - k - b;            // rows below the diagonal block of this panel
             if (m < b) {                        // the last rows stay unreduced: D is stored dense, band form is not required
-                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, BAND_REM_BLOCKS, part.p, tolfac, st.p);
+                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, nparts, part.p, tolfac, st.p);
                 k = q;
                 break;
             }
             // the panel kernel evaluates the termination test in its prologue
             launch_qr_panel(ctx, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, b,
                             out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld,
-                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p, part.p, BAND_REM_BLOCKS, k, tolfac);
+                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p, part.p, nparts, k, tolfac,
+                            fused_rem ? part.p : nullptr);
             // two-sided update of S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,  Z = S22 (V T),  N = T' (V' Z)
             Mat S22 = S.view(k + b, k + b, m, m);
             Mat Vp = out.V.view(k + b, k, m, b);
@@ -1936,7 +2005,8 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
                 }
             }
             }
-            gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band");    // S22 -= [W V] [V W]'
+            gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band", fused_rem ? part.p + 1 : nullptr);    // S22 -= [W V] [V W]'
+            if (fused_rem) nparts = 1 + gemm_num_tiles(m, m);
             k += b; ++np; ++issued;
         }
         AdiState h;

@@ -21,17 +21,27 @@ struct AdiState {
 // C = alpha*op(A)*op(B) + beta*C   (M x N, inner K).  `st` may be null.
 void gemm(Ctx* ctx, bool transA, bool transB, int M, int N, int K, double alpha, const double* A, int lda,
           const double* B, int ldb, double beta, double* C, int ldc, const AdiState* st = nullptr,
-          const char* tag = "gemm_f64_mfma");
+          const char* tag = "gemm_f64_mfma", double* tile_sumsq = nullptr);
+// tile_sumsq (optional, K <= 64 only): receives one partial sum of squares of the updated C per 64 x 64 tile
+// (gemm_num_tiles(M, N) entries) — the band reduction's termination norm comes out of the update GEMM's epilogue.
+inline int gemm_num_tiles(int M, int N) { return ((M + 63) / 64) * ((N + 63) / 64); }
 inline void gemm(Ctx* ctx, bool tA, bool tB, double alpha, const Mat& A, const Mat& B, double beta, Mat& C,
-                 const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma") {
+                 const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma", double* tile_sumsq = nullptr) {
     int M = tA ? A.cols : A.rows, K = tA ? A.rows : A.cols, N = tB ? B.rows : B.cols;
     int K2 = tB ? B.cols : B.rows;
     DRE_REQUIRE(K == K2 && C.rows == M && C.cols == N, "gemm: shape mismatch");
-    gemm(ctx, tA, tB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, st, tag);
+    gemm(ctx, tA, tB, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, st, tag, tile_sumsq);
 }
 
 // Split-K GEMM that leaves the per-split partial slabs (each M x N, leading dimension M) unreduced for a consumer kernel
 // that sums them in a fixed order while doing its own work; returns the slab buffer, *splits_out slabs.
+// Batched C_z = alpha_z A_z B_z (no transposes, no split-K) in one launch; copy_dst_z (optional) also receives A_z.
+struct GemmBatchDesc {
+    const double* A; const double* B; double* C; double* copy_dst;
+    double alpha;
+    int M, N, K, lda, ldb, ldc, ldcopy;
+};
+void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag = "gemm_batched");
 BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                    int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma");
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src

@@ -90,17 +90,31 @@ void ldlt_concatenate(Ctx* ctx, LDLt& X) {
     X.blocks.push_back({L, D, 1.0, diag});
 }
 
-// out(:, blk) = alpha_blk * M(:, blk) * D_blk  for every block of X (M has X.rank() columns)
+// out(:, blk) = alpha_blk * M(:, blk) * D_blk  for every block of X (M has X.rank() columns): one batched launch
 static void mul_blockdiag(Ctx* ctx, const Mat& M, const LDLt& X, Mat& out) {
+    std::vector<GemmBatchDesc> descs;
     int off = 0;
     for (auto& b : X.blocks) {
         const int k = b.L.cols;
         if (k == 0) continue;
         Mat src = M.colsview(off, k), dst = out.colsview(off, k);
-        if (b.diag) scale_cols_by_diag(ctx, src, b.D, dst, b.alpha);
-        else gemm(ctx, false, false, b.alpha, src, b.D, 0.0, dst, nullptr, "gemm_compress");
+        descs.push_back({src.p, b.D.p, dst.p, nullptr, b.alpha, M.rows, k, k, src.ld, b.D.ld, dst.ld, 0});
         off += k;
     }
+    gemm_batched(ctx, descs, "gemm_compress");
+}
+// Lcat = [L_1 ... L_p] and LD(:, blk) = alpha_blk L_blk D_blk in one batched launch (the copy rides on the product)
+static void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD) {
+    std::vector<GemmBatchDesc> descs;
+    int off = 0;
+    for (auto& b : X.blocks) {
+        const int k = b.L.cols;
+        if (k == 0) continue;
+        Mat dl = Lcat.colsview(off, k), dd = LD.colsview(off, k);
+        descs.push_back({b.L.p, b.D.p, dd.p, dl.p, b.alpha, X.n, k, k, b.L.ld, b.D.ld, dd.ld, dl.ld});
+        off += k;
+    }
+    gemm_batched(ctx, descs, "gemm_compress");
 }
 
 static CompressStats g_cstats;
@@ -113,19 +127,20 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true});
     };
     if (c == 0) { set_empty(); return; }
-    Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
-    Mat S;
-    QRFact qr;
     // Q = I is admissible whenever the n x n matrix S = L D L' is affordable; for small n this skips the whole QR
     // (two thirds of all panel factorisations at n = 371) at the price of one GEMM.
     const bool wide = c >= n || (n <= 512 && !exact);
+    Mat Lcat, S;
+    QRFact qr;
     if (wide) {
         // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
         Mat LD(ctx, n, c);
-        mul_blockdiag(ctx, Lcat, X, LD);
+        if (X.blocks.size() == 1) { Lcat = X.blocks[0].L; mul_blockdiag(ctx, Lcat, X, LD); }
+        else { Lcat = Mat(ctx, n, c); hcat_scale_blocks(ctx, X, Lcat, LD); }
         S = Mat(ctx, n, n);
         gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
     } else {
+        Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
         Mat A(ctx, n, c);
         copy_mat(ctx, Lcat, A);
         qr = qr_factor(ctx, A);

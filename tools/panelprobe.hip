@@ -19,7 +19,7 @@ int main() {
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 hipEventRecord(e0, 0);
                 hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), (size_t)(m | 1) * b * 8, 0, A, m, m, 0, b, V, m, T, b, VT, m, st,
-                                   withpart ? part : (const double*)nullptr, 64, 0, 4.0);
+                                   withpart ? part : (const double*)nullptr, 64, 0, 4.0, (double*)nullptr);
                 hipEventRecord(e1, 0);
                 hipDeviceSynchronize();
                 float ms; hipEventElapsedTime(&ms, e0, e1);
