@@ -2030,30 +2030,56 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
 // One workgroup per 16 columns of M (they are independent); nb == 16.
 __global__ __launch_bounds__(256) void k_blocktri_apply(int nr, int J, const double* __restrict__ G, int ldg, const double* __restrict__ Tp, int ldt,
                                                         const double* __restrict__ V, int ldv, double* __restrict__ M, int ldm) {
+    // Every operand of a panel step (the 16 x (nr-k-16) block row of G, the panel factor T_p, the right-hand-side entry) is
+    // prefetched into registers one step ahead and handed over through LDS: the recurrence itself never waits for L2.
     extern __shared__ double sh[];
-    double* Msh = sh;                     // nr x 17
-    double* Ysh = sh + (size_t)nr * 17;   // 16 x 17
+    double* Msh = sh;                          // nr x 17
+    double* Gs = sh + (size_t)nr * 17;         // 16 x (nr - 16), ld 17:  Gs[i + l * 17] = G(k + i, k + 16 + l)
+    double* Ysh = Gs + (size_t)nr * 17;        // 16 x 17
+    double* Tsm2 = Ysh + 16 * 17;              // 2 x (16 x 17): the panel factor, double buffered (read after the second barrier)
     const int tid = threadIdx.x, i = tid & 15, j = tid >> 4;
     const int j0 = blockIdx.x * 16;
     const bool colok = (j0 + j) < J;
-    for (int k = nr - 16; k >= 0; k -= 16) {
-        double a0 = colok ? V[(size_t)(j0 + j) + (size_t)(k + i) * ldv] : 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const double* g = G + (size_t)(k + i);
-        int l = k + 16;
-        for (; l + 3 < nr; l += 4) {
-            a0 -= g[(size_t)l * ldg] * Msh[l * 17 + j];
-            a1 -= g[(size_t)(l + 1) * ldg] * Msh[(l + 1) * 17 + j];
-            a2 -= g[(size_t)(l + 2) * ldg] * Msh[(l + 2) * 17 + j];
-            a3 -= g[(size_t)(l + 3) * ldg] * Msh[(l + 3) * 17 + j];
+    constexpr int NPRE = 16;                   // 16 * (nr - 16) / 256 <= 16  for nr <= 272
+    double pre[NPRE], tpre, rpre;
+    auto prefetch = [&](int k) {
+        const int ncols = nr - k - 16;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int id = tid + q * 256;
+            pre[q] = (id < 16 * ncols) ? G[(size_t)(k + (id & 15)) + (size_t)(k + 16 + (id >> 4)) * ldg] : 0.0;
         }
-        for (; l < nr; ++l) a0 -= g[(size_t)l * ldg] * Msh[l * 17 + j];
+        tpre = Tp[i + (size_t)(k + j) * ldt];
+        rpre = colok ? V[(size_t)(j0 + j) + (size_t)(k + i) * ldv] : 0.0;
+    };
+    prefetch(nr - 16);
+    for (int k = nr - 16; k >= 0; k -= 16) {
+        const int ncols = nr - k - 16;
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int id = tid + q * 256;
+            if (id < 16 * ncols) Gs[(id & 15) + (id >> 4) * 17] = pre[q];
+        }
+        double* Tsm = Tsm2 + ((k >> 4) & 1) * 16 * 17;
+        Tsm[i + j * 17] = tpre;
+        double a0 = rpre, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        __syncthreads();
+        if (k >= 16) prefetch(k - 16);
+        int l = 0;
+        for (; l + 3 < ncols; l += 4) {
+            a0 -= Gs[i + l * 17] * Msh[(k + 16 + l) * 17 + j];
+            a1 -= Gs[i + (l + 1) * 17] * Msh[(k + 17 + l) * 17 + j];
+            a2 -= Gs[i + (l + 2) * 17] * Msh[(k + 18 + l) * 17 + j];
+            a3 -= Gs[i + (l + 3) * 17] * Msh[(k + 19 + l) * 17 + j];
+        }
+        for (; l < ncols; ++l) a0 -= Gs[i + l * 17] * Msh[(k + 16 + l) * 17 + j];
         Ysh[i * 17 + j] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         double m = 0.0;
-        for (int t = i; t < 16; ++t) m += Tp[i + (size_t)(k + t) * ldt] * Ysh[t * 17 + j];
+        for (int t = i; t < 16; ++t) m += Tsm[i + t * 17] * Ysh[t * 17 + j];
         Msh[(k + i) * 17 + j] = m;
-        __syncthreads();
     }
+    __syncthreads();
     if (colok)
         for (int r = i; r < nr; r += 16) M[r + (size_t)(j0 + j) * ldm] = Msh[r * 17 + j];
 }
@@ -2066,7 +2092,7 @@ Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
     while (np > 0 && sb.q - (np - 1) * b - b < b) --np;        // panels that really hold reflectors
     const int nr = np * b;
     if (nr == 0) return B;
-    if (nr <= 512) {
+    if (nr <= 272) {
         // all panels as ONE block reflector:  Qb(:, 1:J) = [I; 0] - V (Tbig V(1:J, :)')   — 4 launches instead of 2 per panel
         Mat Vall = sb.V.view(0, 0, sb.q, nr);
         DRE_REQUIRE(b == 16, "sym_band_basis: panel width 16 expected");
@@ -2074,7 +2100,7 @@ Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
         gemm(ctx, true, false, 1.0, Vall, Vall, 0.0, G, nullptr, "gemm_band");
         {
             TimedScope ts(ctx, "blocktri", 8.0 * (nr * (double)nr / 2 + 2.0 * nr * sb.J), (double)nr * nr * sb.J);
-            const size_t shm = ((size_t)nr + 16) * 17 * sizeof(double);
+            const size_t shm = ((size_t)2 * nr + 48) * 17 * sizeof(double);
             static bool attr_set = false;
             if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_blocktri_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set = true; }
             hipLaunchKernelGGL(k_blocktri_apply, dim3((sb.J + 15) / 16), dim3(256), shm, ctx->stream, nr, sb.J, G.p, G.ld, sb.T.p, sb.T.ld, sb.V.p, sb.V.ld, M.p, M.ld);
