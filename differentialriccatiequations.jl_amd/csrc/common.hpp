@@ -112,6 +112,8 @@ struct Ctx {
     size_t pinned_bytes = 0;
     // tunables (dre_ctx_set_option): real shifts of pencils with n <= dense_inv_max_n use the cached dense inverse
     int dense_inv_max_n = 1536;
+    // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
+    std::map<long, int> band_hint;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

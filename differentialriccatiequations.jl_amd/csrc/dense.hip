@@ -493,12 +493,19 @@ __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* 
         const int r = idx % kp, c = idx / kp;
         const bool in = r < k && c < k;
         double s = 0.0;
-        if (in)
-            for (int z = 0; z < splits; ++z) {
-                const double* q = part + (size_t)z * k * k + r + (size_t)c * k;
-                // slabs written by other workgroups of the same launch are read past the L1 (agent-scope relaxed atomic load)
-                s += COHERENT ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-            }
+        if (in) {
+            // fixed summation order; up to four slab loads in flight
+            const double* q = part + r + (size_t)c * k;
+            const size_t sl = (size_t)k * k;
+            int z = 0;
+            if (!COHERENT)
+                for (; z + 3 < splits; z += 4) {
+                    const double p0 = q[z * sl], p1 = q[(z + 1) * sl], p2 = q[(z + 2) * sl], p3 = q[(z + 3) * sl];
+                    s = (((s + p0) + p1) + p2) + p3;
+                }
+            for (; z < splits; ++z)   // COHERENT: slabs written by other workgroups of the same launch are read past the L1
+                s += COHERENT ? __hip_atomic_load(q + z * sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : q[z * sl];
+        }
         G[idx] = s;
         if (!tdiag) Ts[idx] = in ? T[r + (size_t)c * ldt] : 0.0;
     }
@@ -590,7 +597,13 @@ __global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int sp
         for (int id = tid; id < m * k; id += nt) {
             const int j = id % m, c = id / m;
             double sv = 0.0;
-            for (int z = 0; z < splits; ++z) sv += Wpart[z * slab + (size_t)(2 * n + j) + (size_t)c * M];
+            const double* wp = Wpart + (size_t)(2 * n + j) + (size_t)c * M;
+            int z = 0;
+            for (; z + 3 < splits; z += 4) {
+                const double p0 = wp[z * slab], p1 = wp[(z + 1) * slab], p2 = wp[(z + 2) * slab], p3 = wp[(z + 3) * slab];
+                sv = (((sv + p0) + p1) + p2) + p3;
+            }
+            for (; z < splits; ++z) sv += wp[z * slab];
             small[id] = sv;
         }
     }
@@ -1837,7 +1850,16 @@ __global__ __launch_bounds__(1024) void k_band_w(int m, int b, int splits, const
     for (int c = wave; c < b; c += nw)
         for (int r = lane; r < m; r += 64) {
             double z = 0.0;
-            for (int sidx = 0; sidx < splits; ++sidx) z += Zpart[(size_t)sidx * m * b + r + (size_t)c * m];
+            {
+                const double* zp = Zpart + r + (size_t)c * m;
+                const size_t sl = (size_t)m * b;
+                int sidx = 0;
+                for (; sidx + 3 < splits; sidx += 4) {
+                    const double p0 = zp[sidx * sl], p1 = zp[(sidx + 1) * sl], p2 = zp[(sidx + 2) * sl], p3 = zp[(sidx + 3) * sl];
+                    z = (((z + p0) + p1) + p2) + p3;
+                }
+                for (; sidx < splits; ++sidx) z += zp[sidx * sl];
+            }
             Zs[r + (size_t)c * ldz] = z;
             if (ZLDS) wsm[(size_t)ldz * b + r + (size_t)c * ldz] = Vp[r + (size_t)c * ldv];
         }
@@ -1955,7 +1977,11 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     // host looks at the flag only every few panels.
     int k = 0, np = 0, J = q;
     bool finished = false;
-    const int chunk = 4;
+    // speculation depth: the previous reduction of the same kind (same order, same tolerance mode) needed `hint` panels; the
+    // panel after the last one is the one whose prologue detects termination
+    const long hkey = (long)q * 2 + (abs_tol > 0.0 ? 1 : 0);
+    auto hit = ctx->band_hint.find(hkey);
+    int chunk = hit != ctx->band_hint.end() ? std::max(4, hit->second + 1) : 4;
     while (!finished) {
         int issued = 0;
         while (issued < chunk && k < q) {
@@ -2014,7 +2040,9 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         if (h.done) { J = h.iters; np = J / b; finished = true; }
         else if (k >= q) { J = q; finished = true; }
+        chunk = 4;
     }
+    ctx->band_hint[hkey] = np;
     out.J = J; out.npanels = np;
     out.D = Mat(ctx, J, J);
     size_t tot = (size_t)J * J;
