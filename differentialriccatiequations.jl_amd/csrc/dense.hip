@@ -1346,8 +1346,8 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
                             double tolfac = 0.0, double* part_out = nullptr) {
     const int rows = m - j0;
-    TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
     if (rows <= QR_LDS_ROWS) {
+        TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
         static bool attr_set = false;
         if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); attr_set = true; }
@@ -1358,6 +1358,7 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
         launch_tsqr_panel(ctx, A + (size_t)j0 * lda + j0, lda, rows, jb, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt,
                           VT ? VT + (size_t)j0 * ldvt + j0 : nullptr, ldvt, st);
     } else {
+        TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), 0, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
     }
 }
