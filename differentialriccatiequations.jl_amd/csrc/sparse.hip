@@ -58,7 +58,11 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
     if (hostE) *hostE = vE;
     if (hostA) *hostA = vA;
     P->lvl_maxfront.assign(S.nlevels, 0);
-    for (int t = 0; t < S.nnodes; ++t) P->lvl_maxfront[S.level[t]] = std::max(P->lvl_maxfront[S.level[t]], S.fsize(t));
+    P->lvl_maxsep.assign(S.nlevels, 0);
+    for (int t = 0; t < S.nnodes; ++t) {
+        P->lvl_maxfront[S.level[t]] = std::max(P->lvl_maxfront[S.level[t]], S.fsize(t));
+        P->lvl_maxsep[S.level[t]] = std::max(P->lvl_maxsep[S.level[t]], S.size[t]);
+    }
     if (!upload) return P;
 
     auto up_i = [&](DevArr<int>& d, const std::vector<int>& h) { d = DevArr<int>(ctx, std::max<size_t>(h.size(), 1)); d.upload(ctx, h); };
@@ -210,6 +214,132 @@ __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, 
     }
 }
 
+// Blocked variant: panels of 16 pivot columns.  The column panel (f-kb) x 16 and the row panel 16 x (f-kb-16) live in LDS,
+// so the trailing matrix in global memory is read and written once per PANEL (not once per pivot) and the per-pivot work
+// runs at LDS latency.  The inverses of the triangular diagonal blocks are formed in LDS as well when s^2 entries fit
+// (inv_lds).  Same arithmetic (right-looking LU without pivoting), same outputs as k_front_factor.
+#define FF_NB 16
+template <typename T>
+__global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv,
+                                                               int* __restrict__ err, int inv_lds) {
+    extern __shared__ double ffraw[];
+    T* sm = reinterpret_cast<T*>(ffraw);
+    __shared__ int bad;
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    T* F = fronts + a.front_off[t];
+    if (tid == 0) bad = 0;
+    for (int ci = a.child_ptr[t]; ci < a.child_ptr[t + 1]; ++ci) {
+        const int c = a.child_idx[ci];
+        const int sc = a.size[c], bc = a.bptr[c + 1] - a.bptr[c], fc = sc + bc;
+        const T* Fc = fronts + a.front_off[c];
+        const int* map = a.cmap + a.cmap_ptr[c];
+        for (int id = tid; id < bc * bc; id += nt) {
+            const int i = id % bc, j = id / bc;
+            F[map[i] + (size_t)map[j] * f] += Fc[(sc + i) + (size_t)(sc + j) * fc];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int kb = 0; kb < s; kb += FF_NB) {
+        const int jb = min(FF_NB, s - kb), rows = f - kb, nc = f - kb - jb;     // panel rows, trailing columns
+        T* Pn = sm;                                  // rows x jb, ld rows:  F[kb + r, kb + c]
+        T* U = sm + (size_t)rows * FF_NB;            // jb x nc, ld FF_NB:   F[kb + l, kb + jb + c]
+        for (int id = tid; id < rows * jb; id += nt) { const int r = id % rows, c = id / rows; Pn[r + c * rows] = F[(kb + r) + (size_t)(kb + c) * f]; }
+        for (int id = tid; id < jb * nc; id += nt) { const int l = id % jb, c = id / jb; U[l + c * FF_NB] = F[(kb + l) + (size_t)(kb + jb + c) * f]; }
+        __syncthreads();
+        // unblocked LU of the column panel
+        for (int c = 0; c < jb; ++c) {
+            const T piv = Pn[c + c * rows];
+            if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) bad = 1;      // every thread sees the same value
+            const T rp = recip(piv);
+            __syncthreads();
+            for (int r = c + 1 + tid; r < rows; r += nt) Pn[r + c * rows] *= rp;
+            __syncthreads();
+            const int nr = rows - c - 1, ncc = jb - c - 1;
+            for (int id = tid; id < nr * ncc; id += nt) {
+                const int r = c + 1 + id % nr, c2 = c + 1 + id / nr;
+                Pn[r + c2 * rows] -= Pn[r + c * rows] * Pn[c + c2 * rows];
+            }
+            __syncthreads();
+        }
+        if (bad) { if (tid == 0) *err = 1; return; }
+        // row panel: U12 = inv(L11) A12, one thread per column
+        for (int c = tid; c < nc; c += nt) {
+            T* u = U + c * FF_NB;
+            for (int l = 1; l < jb; ++l) {
+                T acc = u[l];
+                for (int q = 0; q < l; ++q) acc -= Pn[l + q * rows] * u[q];
+                u[l] = acc;
+            }
+        }
+        __syncthreads();
+        // write back the panel and the row panel, update the trailing matrix once
+        for (int id = tid; id < rows * jb; id += nt) { const int r = id % rows, c = id / rows; F[(kb + r) + (size_t)(kb + c) * f] = Pn[r + c * rows]; }
+        for (int id = tid; id < jb * nc; id += nt) { const int l = id % jb, c = id / jb; F[(kb + l) + (size_t)(kb + jb + c) * f] = U[l + c * FF_NB]; }
+        for (int id = tid; id < nc * nc; id += nt) {
+            const int r = id % nc, c = id / nc;
+            T* dst = F + (size_t)(kb + jb + r) + (size_t)(kb + jb + c) * f;
+            T a0 = *dst, a1 = make_scalar<T>(0.0, 0.0);
+            const T* lrow = Pn + (jb + r);
+            const T* ucol = U + c * FF_NB;
+            int l = 0;
+            for (; l + 1 < jb; l += 2) { a0 -= lrow[l * rows] * ucol[l]; a1 -= lrow[(l + 1) * rows] * ucol[l + 1]; }
+            if (l < jb) a0 -= lrow[l * rows] * ucol[l];
+            *dst = a0 + a1;
+        }
+        __syncthreads();
+    }
+    T* Ti = inv + a.inv_off[t];
+    if (inv_lds) {
+        // both triangular inverses from an LDS copy of F11 (L\U), one thread per column, results straight to global
+        T* A11 = sm;                                   // s x s, ld s
+        T* X = sm + (size_t)s * s;                     // s x s scratch for the inverse being built
+        for (int id = tid; id < s * s; id += nt) A11[id] = F[(id % s) + (size_t)(id / s) * f];
+        __syncthreads();
+        for (int j = tid; j < s; j += nt) {            // column j of inv(L11) (unit lower), stored strictly below the diagonal
+            for (int i = j + 1; i < s; ++i) {
+                T acc = A11[i + j * s];
+                for (int k = j + 1; k < i; ++k) acc += A11[i + k * s] * X[k + j * s];
+                X[i + j * s] = -acc;
+                Ti[i + (size_t)j * s] = -acc;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < s; j += nt) {            // column j of inv(U11), stored on and above the diagonal
+            const T dj = recip(A11[j + j * s]);
+            X[j + j * s] = dj;
+            Ti[j + (size_t)j * s] = dj;
+            for (int i = j - 1; i >= 0; --i) {
+                T acc = make_scalar<T>(0.0, 0.0);
+                for (int k = i + 1; k <= j; ++k) acc += A11[i + k * s] * X[k + j * s];
+                const T v = -(acc * recip(A11[i + i * s]));
+                X[i + j * s] = v;
+                Ti[i + (size_t)j * s] = v;
+            }
+        }
+        return;
+    }
+    for (int j = tid; j < s; j += nt) {
+        for (int i = j + 1; i < s; ++i) {
+            T acc = F[i + (size_t)j * f];
+            for (int k = j + 1; k < i; ++k) acc += F[i + (size_t)k * f] * Ti[k + (size_t)j * s];
+            Ti[i + (size_t)j * s] = -acc;
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < s; j += nt) {
+        T dj = recip(F[j + (size_t)j * f]);
+        Ti[j + (size_t)j * s] = dj;
+        for (int i = j - 1; i >= 0; --i) {
+            T acc = make_scalar<T>(0.0, 0.0);
+            for (int k = i + 1; k <= j; ++k) acc += F[i + (size_t)k * f] * Ti[k + (size_t)j * s];
+            Ti[i + (size_t)j * s] = -(acc * recip(F[i + (size_t)i * f]));
+        }
+    }
+}
+
 static MfArgs mf_args(const Pencil& P) {
     MfArgs a;
     a.first = P.dev.first.p; a.size = P.dev.size.p; a.bptr = P.dev.bptr.p; a.bidx = P.dev.bidx.p;
@@ -234,7 +364,22 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
         const int nt = P.lvl_maxfront[l] > 96 ? 1024 : 256;
-        hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p);
+        const int fmax = P.lvl_maxfront[l], smax = P.lvl_maxsep[l];
+        const size_t panel_b = (size_t)2 * fmax * FF_NB * sizeof(T), inv_b = (size_t)2 * smax * smax * sizeof(T);
+        const size_t lim = 150 * 1024;
+        if (panel_b <= lim) {
+            const int inv_lds = inv_b <= lim ? 1 : 0;
+            const size_t shm = std::max(panel_b, inv_lds ? inv_b : (size_t)0);
+            static bool attr_set = false;
+            if (!attr_set) {
+                DRE_HIP(hipFuncSetAttribute((const void*)k_front_factor_blocked<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                DRE_HIP(hipFuncSetAttribute((const void*)k_front_factor_blocked<cplx>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds);
+        } else {
+            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p);
+        }
     }
     DRE_HIP(hipGetLastError());
 }

@@ -50,6 +50,7 @@ struct Pencil {
     DevArr<double> valEt, valAt;    // values of E' and A' on that pattern
     DevArr<int> perm, iperm;        // device copies (perm[new] = old)
     std::vector<int> lvl_maxfront;  // per level: largest front
+    std::vector<int> lvl_maxsep;    // per level: largest number of pivot columns
     bool has_device = false;
 };
 
