@@ -1152,82 +1152,18 @@ __global__ __launch_bounds__(1024) void k_tsqr_local(const double* __restrict__ 
     for (int i = tid; i < jb * jb; i += blockDim.x) Tloc[(size_t)c * QR_NB * QR_NB + i % jb + (i / jb) * QR_NB] = sh.Tsh[i % jb][i / jb];
 }
 
-// QR of the stacked R factors (P*jb x jb) and the leading jb columns Qt of its orthogonal factor
-__global__ __launch_bounds__(1024) void k_tsqr_top(double* __restrict__ Rstack, int ldrs, int rowsR, int jb, double* __restrict__ Rfin,
-                                                   double* __restrict__ Qt, const AdiState* st) {
-    if (st && st->done) return;
-    extern __shared__ double psm[];
-    __shared__ PanelShared sh;
-    __shared__ double Msh[QR_NB][QR_NB + 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const int ldp = rowsR | 1;
-    for (int j = wave; j < jb; j += nw)
-        for (int r = lane; r < rowsR; r += 64) psm[r + (size_t)j * ldp] = Rstack[r + (size_t)j * ldrs];
-    hh_panel_core_lds(psm, ldp, rowsR, jb, sh);
-    for (int i = tid; i < jb * jb; i += blockDim.x) {
-        const int r = i % jb, j = i / jb;
-        Rfin[r + j * QR_NB] = (r <= j) ? psm[r + (size_t)j * ldp] : 0.0;
-        // M = T * V1'  with V1 the unit lower triangular top block:  M(r, j) = sum_{l >= r, l <= j} T(r,l) V1(j,l)
-        double acc = 0.0;
-        for (int l = r; l <= j; ++l) acc += sh.Tsh[r][l] * (l == j ? 1.0 : psm[j + (size_t)l * ldp]);
-        Msh[r][j] = acc;
-    }
-    __syncthreads();
-    // Qt = [I; 0] - V M
-    for (int j = wave; j < jb; j += nw)
-        for (int r = lane; r < rowsR; r += 64) {
-            double acc = (r == j) ? 1.0 : 0.0;
-            for (int l = 0; l < jb; ++l) {
-                const double v = (r > l) ? psm[r + (size_t)l * ldp] : (r == l ? 1.0 : 0.0);
-                acc -= v * Msh[l][j];
-            }
-            Qt[r + (size_t)j * ldrs] = acc;
-        }
-}
-
-// Q(chunk) = (I - V_c T_c V_c')[Qt_c; 0]
-__global__ __launch_bounds__(1024) void k_tsqr_formq(int jb, TsqrPlan plan, const double* __restrict__ Vloc, int ldvl, const double* __restrict__ Tloc,
-                                                     const double* __restrict__ Qt, int ldrs, double* __restrict__ Q, int ldq, const AdiState* st) {
-    if (st && st->done) return;
-    __shared__ double Nsh[QR_NB][QR_NB + 1], Msh[QR_NB][QR_NB + 1], Qts[QR_NB][QR_NB + 1];
-    const int c = blockIdx.x, r0 = chunk_start(plan, c), rows = chunk_rows(plan, c);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const double* Vc = Vloc + r0;
-    const double* Tc = Tloc + (size_t)c * QR_NB * QR_NB;
-    if (tid < jb * jb) Qts[tid % jb][tid / jb] = Qt[(c * jb + tid % jb) + (size_t)(tid / jb) * ldrs];
-    __syncthreads();
-    if (tid < jb * jb) {            // N = V1' Qt_c  (V1 = top jb x jb block of V_c, unit lower triangular)
-        const int i = tid % jb, j = tid / jb;
-        double acc = Qts[i][j];
-        for (int l = i + 1; l < jb; ++l) acc += Vc[l + (size_t)i * ldvl] * Qts[l][j];
-        Nsh[i][j] = acc;
-    }
-    __syncthreads();
-    if (tid < jb * jb) {            // M = T_c N
-        const int i = tid % jb, j = tid / jb;
-        double acc = 0.0;
-        for (int l = i; l < jb; ++l) acc += Tc[i + l * QR_NB] * Nsh[l][j];
-        Msh[i][j] = acc;
-    }
-    __syncthreads();
-    for (int j = wave; j < jb; j += nw)
-        for (int r = lane; r < rows; r += 64) {
-            double acc = (r < jb) ? Qts[r][j] : 0.0;
-            for (int l = 0; l < jb; ++l) acc -= Vc[r + (size_t)l * ldvl] * Msh[l][j];
-            Q[(r0 + r) + (size_t)j * ldq] = acc;
-        }
-}
-
 // Householder reconstruction on the top jb x jb block Q1 of the thin Q:  [I;0] - Q S = V U  with S = diag(sgn) chosen so
-// that every pivot is 1 + |q~_jj| >= 1.  Outputs: sgn, Uinv, T = U V1^-T, V1 (unit lower), and R <- S R.  One wave.
-__global__ __launch_bounds__(64) void k_hr_small(int jb, const double* __restrict__ Q, int ldq, double* __restrict__ Rfin, double* __restrict__ hr,
-                                                 const AdiState* st) {
-    if (st && st->done) return;
-    __shared__ double W[QR_NB][QR_NB + 1], U[QR_NB][QR_NB + 1], V1[QR_NB][QR_NB + 1], Ui[QR_NB][QR_NB + 1], Vi[QR_NB][QR_NB + 1];
-    __shared__ double sg[QR_NB];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < QR_NB * (QR_NB + 1); i += 64) { (&U[0][0])[i] = 0.0; (&V1[0][0])[i] = 0.0; (&Ui[0][0])[i] = 0.0; (&Vi[0][0])[i] = 0.0; }
-    for (int i = tid; i < jb * jb; i += 64) W[i % jb][i / jb] = Q[i % jb + (size_t)(i / jb) * ldq];
+// that every pivot is 1 + |q~_jj| >= 1.  Outputs: sgn, Uinv, T = U V1^-T, V1 (unit lower), and R <- S R.
+struct HrShared {
+    double W[QR_NB][QR_NB + 1], U[QR_NB][QR_NB + 1], V1[QR_NB][QR_NB + 1], Ui[QR_NB][QR_NB + 1], Vi[QR_NB][QR_NB + 1];
+    double sg[QR_NB];
+};
+// Workgroup-wide (only the first 64 threads do arithmetic, everybody takes the barriers); h.W holds Q1 on entry.
+__device__ __forceinline__ void hr_small_body(int jb, HrShared& h, double* __restrict__ Rfin, double* __restrict__ hr) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double (*W)[QR_NB + 1] = h.W; double (*U)[QR_NB + 1] = h.U; double (*V1)[QR_NB + 1] = h.V1;
+    double (*Ui)[QR_NB + 1] = h.Ui; double (*Vi)[QR_NB + 1] = h.Vi; double* sg = h.sg;
+    for (int i = tid; i < QR_NB * (QR_NB + 1); i += nt) { (&U[0][0])[i] = 0.0; (&V1[0][0])[i] = 0.0; (&Ui[0][0])[i] = 0.0; (&Vi[0][0])[i] = 0.0; }
     __syncthreads();
     for (int j = 0; j < jb; ++j) {
         const double s = (W[j][j] >= 0.0) ? -1.0 : 1.0;       // s'_j = -sgn(q~_jj)
@@ -1237,7 +1173,7 @@ __global__ __launch_bounds__(64) void k_hr_small(int jb, const double* __restric
         if (tid > j && tid < jb) V1[tid][j] = -s * W[tid][j] / piv;
         __syncthreads();
         // eliminate column j from the later columns of the Q block
-        for (int id = tid; id < jb * jb; id += 64) {
+        for (int id = tid; id < jb * jb; id += nt) {
             const int i = id % jb, c = id / jb;
             if (i > j && c > j) W[i][c] -= V1[i][j] * W[j][c];
         }
@@ -1262,7 +1198,7 @@ __global__ __launch_bounds__(64) void k_hr_small(int jb, const double* __restric
     __syncthreads();
     // hr layout (each block QR_NB x QR_NB, column-major): [0] sgn, [1] Uinv, [2] T, [3] V1
     double* Uo = hr + QR_NB * QR_NB; double* To = hr + 2 * QR_NB * QR_NB; double* Vo = hr + 3 * QR_NB * QR_NB;
-    for (int id = tid; id < jb * jb; id += 64) {
+    for (int id = tid; id < jb * jb; id += nt) {
         const int i = id % jb, j = id / jb;
         Uo[i + j * QR_NB] = Ui[i][j];
         Vo[i + j * QR_NB] = V1[i][j];
@@ -1274,42 +1210,142 @@ __global__ __launch_bounds__(64) void k_hr_small(int jb, const double* __restric
     if (tid < jb) hr[tid] = sg[tid];
 }
 
-// V = [V1; -Q2 S Uinv],  VT = V T,  and the panel of A receives R (upper triangle) and the reflectors below it
-__global__ __launch_bounds__(256) void k_tsqr_finish(int rows, int jb, const double* __restrict__ Q, int ldq, const double* __restrict__ hr,
-                                                     const double* __restrict__ Rfin, double* __restrict__ A, int lda, double* __restrict__ V, int ldv,
-                                                     double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, const AdiState* st) {
+// QR of the stacked R factors (P*jb x jb) and the leading jb columns Qt of its orthogonal factor
+__global__ __launch_bounds__(1024) void k_tsqr_top(double* __restrict__ Rstack, int ldrs, int rowsR, int jb, double* __restrict__ Rfin,
+                                                   double* __restrict__ Qt, const AdiState* st, const double* __restrict__ Vloc0, int ldvl,
+                                                   const double* __restrict__ Tloc0, double* __restrict__ hr) {
     if (st && st->done) return;
-    __shared__ double Us[QR_NB][QR_NB + 1], Ts[QR_NB][QR_NB + 1], sg[QR_NB];
-    const int tid = threadIdx.x;
-    for (int id = tid; id < jb * jb; id += blockDim.x) {
-        Us[id % jb][id / jb] = hr[QR_NB * QR_NB + id % jb + (id / jb) * QR_NB];
-        Ts[id % jb][id / jb] = hr[2 * QR_NB * QR_NB + id % jb + (id / jb) * QR_NB];
-    }
-    if (tid < jb) sg[tid] = hr[tid];
-    __syncthreads();
-    const int r = blockIdx.x * blockDim.x + tid;
-    if (blockIdx.x == 0) for (int id = tid; id < jb * jb; id += blockDim.x) T[id % jb + (size_t)(id / jb) * ldt] = Ts[id % jb][id / jb];
-    if (r >= rows) return;
-    double v[QR_NB];
-#pragma unroll
-    for (int c = 0; c < QR_NB; ++c) {
+    extern __shared__ double psm[];
+    __shared__ PanelShared sh;
+    __shared__ double Msh[QR_NB][QR_NB + 1];
+    static_assert(sizeof(HrShared) <= sizeof(((PanelShared*)nullptr)->pv), "HrShared must fit the pivot buffers");
+    HrShared& hs = *reinterpret_cast<HrShared*>(&sh.pv[0][0]);     // the pivot buffers are free once the panel is factored
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int ldp = rowsR | 1;
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rowsR; r += 64) psm[r + (size_t)j * ldp] = Rstack[r + (size_t)j * ldrs];
+    hh_panel_core_lds(psm, ldp, rowsR, jb, sh);
+    for (int i = tid; i < jb * jb; i += blockDim.x) {
+        const int r = i % jb, j = i / jb;
+        Rfin[r + j * QR_NB] = (r <= j) ? psm[r + (size_t)j * ldp] : 0.0;
+        // M = T * V1'  with V1 the unit lower triangular top block:  M(r, j) = sum_{l >= r, l <= j} T(r,l) V1(j,l)
         double acc = 0.0;
-        if (c < jb) {
-            if (r < jb) acc = hr[3 * QR_NB * QR_NB + r + c * QR_NB];          // V1
-            else for (int l = 0; l <= c; ++l) acc -= Q[r + (size_t)l * ldq] * sg[l] * Us[l][c];
-        }
-        v[c] = acc;
+        for (int l = r; l <= j; ++l) acc += sh.Tsh[r][l] * (l == j ? 1.0 : psm[j + (size_t)l * ldp]);
+        Msh[r][j] = acc;
     }
-#pragma unroll
-    for (int c = 0; c < QR_NB; ++c) {
-        if (c < jb) {
-            V[r + (size_t)c * ldv] = v[c];
-            double acc = 0.0;
-#pragma unroll
-            for (int l = 0; l < QR_NB; ++l) if (l <= c && l < jb) acc += v[l] * Ts[l][c];
-            if (VT) VT[r + (size_t)c * ldvt] = acc;
-            A[r + (size_t)c * lda] = (r <= c) ? Rfin[r + c * QR_NB] : v[c];
+    __syncthreads();
+    // Qt = [I; 0] - V M
+    for (int j = wave; j < jb; j += nw)
+        for (int r = lane; r < rowsR; r += 64) {
+            double acc = (r == j) ? 1.0 : 0.0;
+            for (int l = 0; l < jb; ++l) {
+                const double v = (r > l) ? psm[r + (size_t)l * ldp] : (r == l ? 1.0 : 0.0);
+                acc -= v * Msh[l][j];
+            }
+            Qt[r + (size_t)j * ldrs] = acc;
+            if (r < jb) hs.W[r][j] = acc;            // Qt block of chunk 0, reused below
         }
+    __syncthreads();
+    // Q1 = top jb x jb block of the thin Q = Qt_0 - V1_0 (T_0 (V1_0' Qt_0))  (chunk 0's local reflectors), then the
+    // Householder reconstruction on it — all on 16 x 16 blocks, no launch of its own
+    if (tid < jb * jb) {
+        const int i = tid % jb, j = tid / jb;
+        double acc = hs.W[i][j];
+        for (int l = i + 1; l < jb; ++l) acc += Vloc0[l + (size_t)i * ldvl] * hs.W[l][j];
+        hs.U[i][j] = acc;                             // N = V1' Qt_0   (U, Ui are scratch here)
+    }
+    __syncthreads();
+    if (tid < jb * jb) {
+        const int i = tid % jb, j = tid / jb;
+        double acc = 0.0;
+        for (int l = i; l < jb; ++l) acc += Tloc0[i + l * QR_NB] * hs.U[l][j];
+        hs.Ui[i][j] = acc;                            // M = T_0 N
+    }
+    __syncthreads();
+    if (tid < jb * jb) {
+        const int r = tid % jb, j = tid / jb;
+        double acc = hs.W[r][j];
+        for (int l = 0; l <= r && l < jb; ++l) acc -= Vloc0[r + (size_t)l * ldvl] * hs.Ui[l][j];   // V1 is unit lower triangular (explicit)
+        hs.Vi[r][j] = acc;
+    }
+    __syncthreads();
+    if (tid < jb * jb) hs.W[tid % jb][tid / jb] = hs.Vi[tid % jb][tid / jb];
+    __syncthreads();
+    hr_small_body(jb, hs, Rfin, hr);
+}
+
+// Fused per chunk: thin Q rows (never stored), V = [V1; -Q2 S Uinv], VT = V T, and the panel of A receives R / the reflectors.
+// With M = T_c V1_c' Qt_c the rows of the thin Q are q = [Qt_c; 0] - V_c M, hence
+//   v  = -q (S Uinv) = vloc (M SU) - [Qt_c SU; 0],      vt = v T = vloc (M SU T) - [Qt_c SU T; 0]
+// i.e. two 16-wide mat-vecs per row against 16 x 16 matrices that are formed once per workgroup in LDS.  One thread per row.
+__global__ __launch_bounds__(256) void k_tsqr_formq_finish(int jb, TsqrPlan plan, const double* __restrict__ Vloc, int ldvl,
+                                                           const double* __restrict__ Tloc, const double* __restrict__ Qt, int ldrs,
+                                                           const double* __restrict__ hr, const double* __restrict__ Rfin,
+                                                           double* __restrict__ A, int lda, double* __restrict__ V, int ldv,
+                                                           double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, const AdiState* st) {
+    if (st && st->done) return;
+    constexpr int B = QR_NB;
+    __shared__ double Qts[B][B + 1], Nsh[B][B + 1], Msh[B][B + 1], SU[B][B + 1], Ts[B][B + 1];
+    __shared__ double MU[B][B + 1], QU[B][B + 1], MUT[B][B + 1], QUT[B][B + 1];
+    const int c = blockIdx.x, r0 = chunk_start(plan, c), rows = chunk_rows(plan, c);
+    const int tid = threadIdx.x, i = tid % B, j = tid / B;          // blockDim.x == 256 == B*B
+    const bool in = i < jb && j < jb;
+    const double* Vc = Vloc + r0;
+    const double* Tc = Tloc + (size_t)c * B * B;
+    Qts[i][j] = in ? Qt[(c * jb + i) + (size_t)j * ldrs] : 0.0;
+    SU[i][j] = in ? hr[i] * hr[B * B + i + j * B] : 0.0;            // S * Uinv
+    Ts[i][j] = (in && i <= j) ? hr[2 * B * B + i + j * B] : 0.0;      // upper triangular
+    __syncthreads();
+    {   // N = V1' Qt_c  (V1 = top jb x jb block of V_c, unit lower triangular)
+        double acc = Qts[i][j];
+        if (in) for (int l = i + 1; l < jb; ++l) acc += Vc[l + (size_t)i * ldvl] * Qts[l][j];
+        Nsh[i][j] = in ? acc : 0.0;
+    }
+    __syncthreads();
+    {   // M = T_c N
+        double acc = 0.0;
+        if (in) for (int l = i; l < jb; ++l) acc += Tc[i + l * B] * Nsh[l][j];
+        Msh[i][j] = acc;
+    }
+    __syncthreads();
+    {
+        double a = 0.0, q = 0.0;
+        for (int l = 0; l < B; ++l) { a += Msh[i][l] * SU[l][j]; q += Qts[i][l] * SU[l][j]; }
+        MU[i][j] = a; QU[i][j] = q;
+    }
+    __syncthreads();
+    {
+        double a = 0.0, q = 0.0;
+        for (int l = 0; l < B; ++l) { a += MU[i][l] * Ts[l][j]; q += QU[i][l] * Ts[l][j]; }
+        MUT[i][j] = a; QUT[i][j] = q;
+    }
+    __syncthreads();
+    if (c == 0 && blockIdx.y == 0 && in) T[i + (size_t)j * ldt] = Ts[i][j];
+    const int rl = blockIdx.y * blockDim.x + tid;
+    if (rl >= rows) return;
+    const int r = r0 + rl;                              // row of the panel
+    double vrow[B];
+#pragma unroll
+    for (int l = 0; l < B; ++l) vrow[l] = (l < jb) ? Vc[rl + (size_t)l * ldvl] : 0.0;
+    const bool top = r < jb;                            // the first jb rows of the panel: V1 from the reconstruction
+#pragma unroll
+    for (int cc = 0; cc < B; ++cc) {
+        if (cc >= jb) break;
+        double v, vt;
+        if (top) {
+            v = hr[3 * B * B + r + cc * B];
+            vt = 0.0;
+            for (int l = 0; l <= cc; ++l) vt += hr[3 * B * B + r + l * B] * Ts[l][cc];
+        } else {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int l = 0; l < B; ++l) { a0 += vrow[l] * MU[l][cc]; a1 += vrow[l] * MUT[l][cc]; }
+            v = a0 - (rl < jb ? QU[rl][cc] : 0.0);
+            vt = a1 - (rl < jb ? QUT[rl][cc] : 0.0);
+        }
+        V[r + (size_t)cc * ldv] = v;
+        if (VT) VT[r + (size_t)cc * ldvt] = vt;
+        A[r + (size_t)cc * lda] = (r <= cc) ? Rfin[r + cc * B] : v;
     }
 }
 
@@ -1323,7 +1359,7 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     plan.base = rows / plan.P; plan.rem = rows % plan.P;
     DRE_REQUIRE(plan.base >= jb && plan.base + 1 <= QR_LDS_ROWS, "TSQR panel: chunk size out of range");
     const int rowsR = plan.P * jb;
-    Mat Vloc(ctx, rows, jb), Q(ctx, rows, jb), Rstack(ctx, rowsR, jb), Qt(ctx, rowsR, jb);
+    Mat Vloc(ctx, rows, jb), Rstack(ctx, rowsR, jb), Qt(ctx, rowsR, jb);
     DevArr<double> Tloc(ctx, (size_t)plan.P * QR_NB * QR_NB), Rfin(ctx, QR_NB * QR_NB), hr(ctx, 4 * QR_NB * QR_NB);
     TimedScope ts(ctx, "qr_panel_tsqr", 8.0 * rows * jb * 8.0, 2.0 * rows * jb * jb * 3.0);
     static bool attr_set = false;
@@ -1335,10 +1371,10 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     const size_t shm1 = (size_t)((plan.base + 1) | 1) * jb * sizeof(double);
     hipLaunchKernelGGL(k_tsqr_local, dim3(plan.P), dim3(1024), shm1, ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
     const size_t shm2 = (size_t)(rowsR | 1) * jb * sizeof(double);
-    hipLaunchKernelGGL(k_tsqr_top, dim3(1), dim3(1024), shm2, ctx->stream, Rstack.p, Rstack.ld, rowsR, jb, Rfin.p, Qt.p, st);
-    hipLaunchKernelGGL(k_tsqr_formq, dim3(plan.P), dim3(1024), 0, ctx->stream, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Qt.p, Qt.ld, Q.p, Q.ld, st);
-    hipLaunchKernelGGL(k_hr_small, dim3(1), dim3(64), 0, ctx->stream, jb, Q.p, Q.ld, Rfin.p, hr.p, st);
-    hipLaunchKernelGGL(k_tsqr_finish, dim3(ceil_div(rows, 256)), dim3(256), 0, ctx->stream, rows, jb, Q.p, Q.ld, hr.p, Rfin.p, A, lda, V, ldv, T, ldt, VT, ldvt, st);
+    hipLaunchKernelGGL(k_tsqr_top, dim3(1), dim3(1024), shm2, ctx->stream, Rstack.p, Rstack.ld, rowsR, jb, Rfin.p, Qt.p, st,
+                       (const double*)Vloc.p, Vloc.ld, (const double*)Tloc.p, hr.p);
+    hipLaunchKernelGGL(k_tsqr_formq_finish, dim3(plan.P, ceil_div(plan.base + 1, 256)), dim3(256), 0, ctx->stream, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Qt.p, Qt.ld, hr.p, Rfin.p,
+                       A, lda, V, ldv, T, ldt, VT, ldvt, st);
     DRE_HIP(hipGetLastError());
 }
 
