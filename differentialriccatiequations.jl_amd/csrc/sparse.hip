@@ -35,6 +35,7 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
     }
     int leaf = leaf_size > 0 ? leaf_size : (n <= 2000 ? 24 : 32);
     if (leaf_size <= 0) if (const char* e = std::getenv("DRE_LEAF_SIZE")) leaf = std::max(1, atoi(e));   // tuning knob
+    if (const char* e = std::getenv("DRE_MF_SCALAR")) P->use_mfma_sweeps = atoi(e) == 0;
     P->sym = symbolic_analyze(n, uptr, uidx, leaf);
     const Symbolic& S = P->sym;
     P->nnz = (int)S.idx.size();
@@ -514,9 +515,188 @@ __global__ __launch_bounds__(256) void k_mf_backward(MfArgs a, int lvl_begin, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Real sweeps on the matrix cores: a workgroup owns (front, 16 right-hand-side columns); every 16 x 16 output tile of
+// y = inv(L11) w_S, upd = w_B - L21 y (forward) and z = w_S - U12 x_B, x = inv(U11) z (backward) is a chain of
+// v_mfma_f64_16x16x4 with the factor entries streamed from HBM/L2 straight into the A operand (coalesced 128 B rows,
+// eight loads in flight) and the right-hand-side panel staged in LDS as the B operand.
+// ---------------------------------------------------------------------------------------------
+typedef double mf_v4d __attribute__((ext_vector_type(4)));
+#define MFM_KC 16
+
+// acc += A(rows r0.., K range [kbeg, kend)) * Bs   with A(row, k) = sign * Aglob[row + k * lda] where keep(row, k), else 0
+template <typename Keep>
+__device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restrict__ Aglob, int lda, int r0, int kbeg, int kend, double sign,
+                                               const double* __restrict__ Bs, int ldb, Keep keep) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int row = r0 + lr;
+    for (int k0 = kbeg; k0 < kend; k0 += 32) {
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + lk;
+            av[u] = (k < kend && keep(row, k)) ? sign * Aglob[row + (size_t)k * lda] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + lk;
+            if (k0 + 4 * u < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], Bs[k + lr * ldb], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+                                                          double* __restrict__ W, int ldw, int nrhs, double* __restrict__ upd, int64_t ldu,
+                                                          const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double sm[];
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
+    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int sp = (s + 15) & ~15, wr = max(s + ((b + 15) & ~15), sp) + 4, ldl = wr | 1, ldy = (sp + 4) | 1;
+    double* w = sm;                          // wr x 16 (ld ldl): rows 0..s-1 = w_S, s..f-1 = assembled w_B, rest 0
+    double* y = sm + (size_t)ldl * MFM_KC;   // (sp + 4) x 16 (ld ldy), zero padded
+    const double* F = fronts + a.front_off[t];
+    const double* Ti = inv + a.inv_off[t];
+    for (int id = tid; id < ldl * MFM_KC; id += nt) {
+        const int i = id % ldl, c = id / ldl;
+        w[id] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+    }
+    for (int id = tid; id < ldy * MFM_KC; id += nt) y[id] = 0.0;
+    __syncthreads();
+    for (int ci = a.child_ptr[t]; ci < a.child_ptr[t + 1]; ++ci) {
+        const int ch = a.child_idx[ci];
+        const int bc = a.bptr[ch + 1] - a.bptr[ch];
+        const int* map = a.cmap + a.cmap_ptr[ch];
+        const double* uc = upd + a.upd_off[ch];
+        for (int id = tid; id < bc * kc; id += nt) {
+            const int i = id % bc, c = id / bc;
+            w[map[i] + c * ldl] += uc[i + (size_t)(c0 + c) * ldu];
+        }
+        __syncthreads();
+    }
+    const int lr = lane & 15, lq = lane >> 4;
+    // y = inv(L11) w_S :  unit diagonal (accumulator starts at w), strictly lower part of Ti
+    for (int rt = wave; rt * 16 < s; rt += nw) {
+        const int r0 = rt * 16;
+        mf_v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = w[(r0 + lq + 4 * r) + lr * ldl];
+        acc = mfma_rowtile(acc, Ti, s, r0, 0, min(s, r0 + 16), 1.0, w, ldl, [s](int row, int k) { return row < s && k < row; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lq + 4 * r;
+            if (row < s) {
+                y[row + lr * ldy] = acc[r];
+                if (lr < kc) W[(first + row) + (size_t)(c0 + lr) * ldw] = acc[r];
+            }
+        }
+    }
+    __syncthreads();
+    // upd = w_B - L21 y
+    double* ut = upd + a.upd_off[t];
+    for (int rt = wave; rt * 16 < b; rt += nw) {
+        const int r0 = rt * 16;
+        mf_v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = w[(s + r0 + lq + 4 * r) + lr * ldl];
+        acc = mfma_rowtile(acc, F + s, f, r0, 0, s, -1.0, y, ldy, [b](int row, int) { return row < b; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lq + 4 * r;
+            if (row < b && lr < kc) ut[row + (size_t)(c0 + lr) * ldu] = acc[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double sm[];
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
+    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int sp = (s + 15) & ~15, ldx = (b + 36) | 1, ldz = (sp + 36) | 1;
+    double* xb = sm;                          // (b + pad) x 16: the already known ancestor unknowns, zero padded
+    double* z = sm + (size_t)ldx * MFM_KC;    // (sp + pad) x 16
+    const double* F = fronts + a.front_off[t];
+    const double* Ti = inv + a.inv_off[t];
+    const int* B = a.bidx + a.bptr[t];
+    for (int id = tid; id < ldx * MFM_KC; id += nt) {
+        const int i = id % ldx, c = id / ldx;
+        xb[id] = (i < b && c < kc) ? W[B[i] + (size_t)(c0 + c) * ldw] : 0.0;
+    }
+    for (int id = tid; id < ldz * MFM_KC; id += nt) {
+        const int i = id % ldz, c = id / ldz;
+        z[id] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+    }
+    __syncthreads();
+    const int lr = lane & 15, lq = lane >> 4;
+    // z = w_S - U12 x_B   (in place in LDS: every tile reads and writes only its own rows of z)
+    for (int rt = wave; rt * 16 < s; rt += nw) {
+        const int r0 = rt * 16;
+        mf_v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = z[(r0 + lq + 4 * r) + lr * ldz];
+        acc = mfma_rowtile(acc, F + (size_t)s * f, f, r0, 0, b, -1.0, xb, ldx, [s](int row, int) { return row < s; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z[(r0 + lq + 4 * r) + lr * ldz] = acc[r];
+    }
+    __syncthreads();
+    // x_S = inv(U11) z : upper triangle of Ti including the diagonal
+    for (int rt = wave; rt * 16 < s; rt += nw) {
+        const int r0 = rt * 16;
+        mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = mfma_rowtile(acc, Ti, s, r0, r0, s, 1.0, z, ldz, [s](int row, int k) { return row < s && k >= row; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lq + 4 * r;
+            if (row < s && lr < kc) W[(first + row) + (size_t)(c0 + lr) * ldw] = acc[r];
+        }
+    }
+}
+
+static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st) {
+    const Symbolic& S = P.sym;
+    MfArgs a = mf_args(P);
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    DevArr<double> upd(ctx, (size_t)ldu * nrhs);
+    const int ncb = ceil_div(nrhs, MFM_KC);
+    const double bytes = 2.0 * 8.0 * (double)S.factor_nnz + 4.0 * 8.0 * (double)P.n * nrhs;
+    const double flops = 2.0 * 2.0 * (double)S.factor_nnz * nrhs;
+    TimedScope ts(ctx, "mf_solve_real", bytes, flops);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DRE_HIP(hipFuncSetAttribute((const void*)k_mf_forward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_mf_backward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+        const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
+        const size_t shm = ((size_t)((std::max(fm + 16, spm) + 4) | 1) + (size_t)((spm + 4) | 1)) * MFM_KC * sizeof(double);
+        const int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
+        hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd.p, ldu, st);
+    }
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+        const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
+        const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
+        const int nthreads = sm_ > 64 ? 512 : 256;
+        hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+    }
+    DRE_HIP(hipGetLastError());
+}
+
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st) {
     if (nrhs <= 0) return;
+    if constexpr (sizeof(T) == sizeof(double)) {
+        if (P.use_mfma_sweeps) { mf_solve_mfma(ctx, P, Fc, W, ldw, nrhs, st); return; }
+    }
     const Symbolic& S = P.sym;
     MfArgs a = mf_args(P);
     const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);

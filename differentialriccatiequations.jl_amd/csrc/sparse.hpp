@@ -51,6 +51,7 @@ struct Pencil {
     DevArr<int> perm, iperm;        // device copies (perm[new] = old)
     std::vector<int> lvl_maxfront;  // per level: largest front
     std::vector<int> lvl_maxsep;    // per level: largest number of pivot columns
+    bool use_mfma_sweeps = true;    // real triangular sweeps on the matrix cores (env DRE_MF_SCALAR=1 selects the scalar kernels)
     bool has_device = false;
 };
 
