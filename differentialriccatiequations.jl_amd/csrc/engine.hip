@@ -826,8 +826,9 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
-        for (auto& f : used_real) mf_check(ctx, f->f);
-        for (auto& f : used_cplx) mf_check(ctx, f->f);
+        // every factorisation is checked once (the flag is written by the factorisation kernels only)
+        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
     }
     if (opt.compression && last_compression > 0) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
     all_shifts.resize(res.iters);

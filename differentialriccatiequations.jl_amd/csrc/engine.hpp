@@ -52,7 +52,8 @@ CompressStats& compress_stats();
 // GEMM per ADI step instead of the level-by-level triangular sweeps (which are launch-latency bound at small n).
 // `stack` = [inv; E' inv; U' inv] ((2n + m) x n) for the low-rank factor U of the current operator: ONE GEMM with the residual
 // factor R then yields the plain solve, its image under E' (for the residual recurrence) and the SMW inner products.
-template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; Mat stack; const void* stack_U = nullptr; int stack_m = -1; };
+template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; Mat stack; const void* stack_U = nullptr; int stack_m = -1;
+                                            bool checked = false; /* pivot-breakdown flag already read back */ };
 struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<double>>> real;
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
