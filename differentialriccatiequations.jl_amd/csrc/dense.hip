@@ -690,7 +690,7 @@ __global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int sp
 }
 
 void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
-                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, int* ticket) {
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     DRE_REQUIRE(k <= 96 && m <= 32, "dense_adi_step: k <= 96 and m <= 32 expected");
     const int nblk = ceil_div(n, 64), kp16 = (k + 15) & ~15, kp32 = (k + 31) & ~31;
     DevArr<double> gpart(ctx, (size_t)nblk * k * k);

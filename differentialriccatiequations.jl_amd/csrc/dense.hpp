@@ -12,7 +12,7 @@ struct AdiState {
     int done;            // 1 = converged / collapsed / maxiters reached
     int iters;           // shifts consumed so far (a complex pair counts 2)
     int maxiters;
-    int zero_increment;  // /root/reference/src/lyapunov/adi.jl:161-165,200-204
+    int smw_singular;    // set by the capacitance-matrix inversion (SMW) when a pivot vanishes; read back with the state
     double abstol;
     double res_norm;
     double norms[512];   // residual norm after iteration i (index = shifts consumed)
@@ -63,7 +63,7 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 // fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
 void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
-                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, int* ticket);
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

@@ -592,7 +592,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     Mat R = rb.L, Tm = rb.D;
     const double alpha_res = rb.alpha;
     const int k = R.cols;
-    const bool tdiag = rb.diag || is_diagonal_host(ctx, Tm);
+    const bool tdiag = rb.diag;      // a numerically diagonal T that is not flagged takes the general (dense-T) kernels: same result
     const double norm0 = ldlt_norm_host(ctx, R, Tm, alpha_res);
     res.abstol = abstol; res.initial_norm = norm0; res.rhs_cols = k;
     res.norms.push_back(norm0); res.norm_iters.push_back(0);
@@ -618,19 +618,14 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     // device-resident control block
     DevArr<AdiState> st(ctx, 1);
     if (auto* po = dynamic_cast<ProjectionOracle*>(oracle.get())) po->st_dev = st.p;
-    {
-        AdiState h;
-        std::memset(&h, 0, sizeof(h));
-        h.maxiters = opt.maxiters; h.abstol = abstol; h.res_norm = norm0; h.norms[0] = norm0;
-        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    AdiState h0;                     // stays alive until the function returns (source of an asynchronous upload)
+    std::memset(&h0, 0, sizeof(h0));
+    h0.maxiters = opt.maxiters; h0.abstol = abstol; h0.res_norm = norm0; h0.norms[0] = norm0;
+    DRE_HIP(hipMemcpyAsync(st.p, &h0, sizeof(int) * 4 + sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     const int m = op.has_lr ? op.U.cols : 0;
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
     std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
-    DevArr<int> serr(ctx, 1), ticket(ctx, 1);
-    DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
-    DRE_HIP(hipMemsetAsync(ticket.p, 0, sizeof(int), ctx->stream));
+    int* const serr = &st.p->smw_singular;     // lives in the control block: comes back with every chunk synchronisation
 
     // the iterate: never mutate the caller's initial guess (adi.jl:174 `cache.X += increment` builds a new list)
     auto Xw = std::make_shared<LDLt>(*X);
@@ -679,7 +674,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         Mat WKS(ctx, 2 * n, m);
                         en.keep = WKS.buf; en.WU = WKS.p; en.ldwu = WKS.ld;
                         en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, WK.p + 2 * (size_t)n, WK.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
+                        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, WK.p + 2 * (size_t)n, WK.ld, op.alpha, (double*)en.sinv->p, dst, serr);
                         hipLaunchKernelGGL(k_fold_sinv, dim3(ceil_div(2 * n * m, 256)), dim3(256), 0, ctx->stream, 2 * n, m, WK.p, WK.ld,
                                            (const double*)en.sinv->p, WKS.p, WKS.ld, dst);
                         sc = smw_cache.emplace(key, en).first;
@@ -689,7 +684,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         int zs = 1;
                         BufP wpart = gemm_partials(ctx, false, false, lds_, k, n, fe->stack.p, fe->stack.ld, R.p, R.ld, &zs, dst, "gemm_dinv");
                         dense_adi_step(ctx, n, mm, k, zs, (const double*)wpart->p, op.has_lr ? (const double*)sc->second.WU : nullptr,
-                                       op.has_lr ? sc->second.ldwu : 0, V1, R, 2.0 * mu.real(), Tm, tdiag, alpha_res, st.p, iters_host + 1, ticket.p);
+                                       op.has_lr ? sc->second.ldwu : 0, V1, R, 2.0 * mu.real(), Tm, tdiag, alpha_res, st.p, iters_host + 1);
                         norm_done = true;
                     } else {
                         Mat Wst(ctx, lds_, k);
@@ -718,7 +713,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                             SmwCacheEntry en;
                             en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
                             en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr.p);
+                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr);
                             sc = smw_cache.emplace(key, en).first;
                         }
                         TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
@@ -766,7 +761,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         SmwCacheEntry en;
                         en.keep = Wb; en.WU = W + (size_t)k * n; en.ldwu = n;
                         en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(cplx));
-                        hipLaunchKernelGGL((k_sinv<cplx>), dim3(1), dim3(64), 0, ctx->stream, m, small + (size_t)k * m, m, op.alpha, (cplx*)en.sinv->p, dst, serr.p);
+                        hipLaunchKernelGGL((k_sinv<cplx>), dim3(1), dim3(64), 0, ctx->stream, m, small + (size_t)k * m, m, op.alpha, (cplx*)en.sinv->p, dst, serr);
                         sc = smw_cache.emplace(key, en).first;
                     }
                     hipLaunchKernelGGL((k_smw_apply<cplx, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
@@ -808,6 +803,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         last_compression = lc;
         res.iters = h.iters;
         res.res_norm = h.res_norm;
+        if (h.smw_singular) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
         if (h.done || recs.empty()) {
             finished = true;
         } else if (opt.compression && last_compression >= opt.compression_interval) {
@@ -822,10 +818,6 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         }
     }
     {
-        int herr = 0;
-        DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
-        if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
         // every factorisation is checked once (the flag is written by the factorisation kernels only)
         for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
         for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
