@@ -267,9 +267,7 @@ __global__ __launch_bounds__(256) void k_smw_small(int n, int m, const double* _
 
 // Sinv = inv(alpha I + Smat) by Gauss-Jordan with partial pivoting; one workgroup, m <= 32
 template <typename T>
-__global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv,
-                                             const AdiState* st, int* err) {
-    if (st && st->done) return;
+__device__ __forceinline__ void sinv_body(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv, int* err) {
     __shared__ double abuf[32 * 64 * 2];
     __shared__ int piv;
     __shared__ double colkbuf[32 * 2];
@@ -311,6 +309,34 @@ __global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, 
         const int i = id % m, j = id / m;
         Sinv[i + (size_t)j * m] = A[i + (m + j) * 32];
     }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_sinv(int m, const T* __restrict__ Smat, int lds_, double alpha, T* __restrict__ Sinv,
+                                             const AdiState* st, int* err) {
+    if (st && st->done) return;
+    sinv_body<T>(m, Smat, lds_, alpha, Sinv, err);
+}
+// All shifts of a Cyclic list at once (dense-inverse path): blockIdx.x = shift.  WK_j = [inv; E'inv; U'inv]_j * Vt is (2n+m) x m.
+struct SmwBatch { const double* WK; double* Sinv; double* WKS; };
+__global__ __launch_bounds__(64) void k_sinv_batched(int n, int m, int ldwk, double alpha, const SmwBatch* __restrict__ bt, const AdiState* st, int* err) {
+    if (st && st->done) return;
+    const SmwBatch b = bt[blockIdx.x];
+    sinv_body<double>(m, b.WK + 2 * (size_t)n, ldwk, alpha, b.Sinv, err);
+}
+__global__ __launch_bounds__(256) void k_fold_sinv_batched(int nrows, int m, int ldwk, const SmwBatch* __restrict__ bt, const AdiState* st) {
+    if (st && st->done) return;
+    const SmwBatch b = bt[blockIdx.y];
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nrows * m) return;
+    const int r = id % nrows, j = id / nrows;
+    double a0 = 0.0, a1 = 0.0;
+    int l = 0;
+    for (; l + 1 < m; l += 2) {
+        a0 += b.WK[r + (size_t)l * ldwk] * b.Sinv[l + (size_t)j * m];
+        a1 += b.WK[r + (size_t)(l + 1) * ldwk] * b.Sinv[l + 1 + (size_t)j * m];
+    }
+    if (l < m) a0 += b.WK[r + (size_t)l * ldwk] * b.Sinv[l + (size_t)j * m];
+    b.WKS[r + (size_t)j * nrows] = a0 + a1;
 }
 
 // WKS = WK(0:nrows, :) * Sinv  — folds the capacitance inverse into the low-rank solve products once per shift, so that the
@@ -569,7 +595,7 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     return fe;
 }
 
-struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; };
+struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; BufP keep2; };
 
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
                     FactorCache* cache) {
@@ -626,6 +652,42 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
     std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
     int* const serr = &st.p->smw_singular;     // lives in the control block: comes back with every chunk synchronisation
+    if (op.has_lr && opt.shifts.kind == ShiftSpec::CYCLIC) {
+        // Dense-inverse path: the SMW products of ALL shifts of the cycle whose stacked inverses already exist (i.e. from the
+        // second time step on) are formed up front — one batched GEMM, one batched capacitance inversion, one batched fold —
+        // instead of three launches per shift inside the loop.
+        std::vector<GemmBatchDesc> descs;
+        std::vector<SmwBatch> hb;
+        std::vector<std::pair<double, SmwCacheEntry>> pending;
+        for (auto& mu : opt.shifts.values) {
+            if (mu.imag() != 0.0 || smw_cache.count({mu.real(), 0.0})) continue;
+            bool dup = false;
+            for (auto& pe : pending) dup = dup || pe.first == mu.real();
+            if (dup) continue;
+            auto it = cache->real.find(std::make_tuple(op.tag, mu.real(), 0.0));
+            if (it == cache->real.end()) continue;
+            auto& fe = it->second;
+            if (!fe->dense || fe->stack.empty() || fe->stack_U != (const void*)op.U.p || fe->stack_m != m) continue;
+            Mat WK(ctx, 2 * n + m, m), WKS(ctx, 2 * n, m);
+            SmwCacheEntry en;
+            en.keep = WKS.buf; en.WU = WKS.p; en.ldwu = WKS.ld;
+            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+            en.keep2 = WK.buf;
+            descs.push_back({fe->stack.p, op.Vt.p, WK.p, nullptr, 1.0, 2 * n + m, m, n, fe->stack.ld, op.Vt.ld, WK.ld, 0});
+            hb.push_back({WK.p, (double*)en.sinv->p, WKS.p});
+            pending.push_back({mu.real(), en});
+        }
+        if (!descs.empty()) {
+            gemm_batched(ctx, descs, "gemm_dinv");
+            DevArr<SmwBatch> db(ctx, hb.size());
+            DRE_HIP(hipMemcpyAsync(db.p, hb.data(), hb.size() * sizeof(SmwBatch), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_sinv_batched, dim3((unsigned)hb.size()), dim3(64), 0, ctx->stream, n, m, 2 * n + m, op.alpha, (const SmwBatch*)db.p,
+                               (const AdiState*)st.p, serr);
+            hipLaunchKernelGGL(k_fold_sinv_batched, dim3(ceil_div(2 * n * m, 256), (unsigned)hb.size()), dim3(256), 0, ctx->stream, 2 * n, m, 2 * n + m,
+                               (const SmwBatch*)db.p, (const AdiState*)st.p);
+            for (auto& pe : pending) smw_cache.emplace(std::make_pair(pe.first, 0.0), pe.second);
+        }
+    }
 
     // the iterate: never mutate the caller's initial guess (adi.jl:174 `cache.X += increment` builds a new list)
     auto Xw = std::make_shared<LDLt>(*X);
