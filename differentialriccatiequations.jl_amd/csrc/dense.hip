@@ -55,9 +55,10 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
     const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
     const int lr = lane & 15, lk = lane >> 4;
 
-    for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
-        // all 16 loads of a thread are independent and issued back to back: one memory latency per K-tile
-        double ra[8], rb[8];
+    // Software pipeline: the 16 global loads of K-tile t+1 are issued right after tile t went to LDS, so their latency
+    // overlaps the MFMAs of tile t (these GEMMs are bound by the memory round trip per K-tile, not by the matrix cores).
+    double ra[8], rb[8];
+    auto load_tile = [&](int k0) {
         if (!TA) {
             const int m = tid & 63, kq = tid >> 6, gm = m0 + m;
 #pragma unroll
@@ -88,6 +89,9 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
                 rb[p] = (gn < N && gk < kend) ? B[gn + (size_t)gk * ldb] : 0.0;
             }
         }
+    };
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
         if (!TA) { const int m = tid & 63, kq = tid >> 6;
 #pragma unroll
             for (int p = 0; p < 8; ++p) As[kq + 4 * p][m] = ra[p];
@@ -103,6 +107,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
             for (int p = 0; p < 8; ++p) Bs[kq + 4 * p][n] = rb[p];
         }
         __syncthreads();
+        if (k0 + GB_K < kend) load_tile(k0 + GB_K);
 #pragma unroll
         for (int kk = 0; kk < GB_K / 4; ++kk) {
             const int k = kk * 4 + lk;
