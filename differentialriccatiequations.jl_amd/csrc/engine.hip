@@ -568,7 +568,7 @@ LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, d
 template <typename T>
 static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
                                                   std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
-                                                  std::complex<double> mu) {
+                                                  std::complex<double> mu, bool want_dense = true) {
     auto key = std::make_tuple(op.tag, mu.real(), mu.imag());
     if (cache->enabled) {
         auto it = store.find(key);
@@ -579,7 +579,7 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     cache->nfactor++;
     if constexpr (sizeof(T) == sizeof(double)) {
         const int n = op.P->n;
-        if (n <= ctx->dense_inv_max_n) {
+        if (want_dense && n <= ctx->dense_inv_max_n) {      // only for shifts that will be reused (Cyclic): the inverse costs n solves
             // explicit inverse through n unit right-hand sides; kept only if the operator is well conditioned enough
             // that inverse-times-vector is as accurate as the triangular solves for the ADI recurrences
             Mat W(ctx, n, n);
@@ -711,7 +711,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             Mat V1, V2;
             bool norm_done = false;
             if (is_real) {
-                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu);
+                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt.shifts.kind == ShiftSpec::CYCLIC);
                 used_real.push_back(fe);
                 auto key = std::make_pair(mu.real(), 0.0);
                 auto sc = smw_cache.find(key);
