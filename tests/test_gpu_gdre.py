@@ -105,7 +105,7 @@ def test_observer_sees_every_time_step(ctx, rail371):
     assert ob.t == [4500.0, 4400.0, 4300.0] and ob.done == 1 and ob.iters == st["adi_iters"]   # the metric's numerator
 
 
-@pytest.mark.parametrize("n", [1357, 5177])
+@pytest.mark.parametrize("n", [1357, 5177, 20209])
 def test_full_size_properties(ctx, n):
     """BASELINE sizes where the dense oracle is too expensive: size-independent properties of one Rosenbrock step —
     every Lyapunov solve converges, the independently evaluated GALE residual of the returned X is at the tolerance,
