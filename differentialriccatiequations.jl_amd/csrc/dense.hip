@@ -201,6 +201,13 @@ __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const doub
     const size_t slab = (size_t)M * N;
     double s = 0.0;
     int z = 0;
+    for (; z + 7 < splits; z += 8) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = partial[(z + u) * slab + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += q[u];
+    }
     for (; z + 3 < splits; z += 4) {
         const double p0 = partial[z * slab + idx], p1 = partial[(z + 1) * slab + idx], p2 = partial[(z + 2) * slab + idx], p3 = partial[(z + 3) * slab + idx];
         s = (((s + p0) + p1) + p2) + p3;
@@ -1184,8 +1191,27 @@ __device__ __forceinline__ void hr_small_body(int jb, HrShared& h, double* __res
         }
         __syncthreads();
     }
-    // Uinv (upper) and V1inv (unit lower), one column per lane
-    if (tid < jb) {
+    // Uinv (upper) and V1inv (unit lower): one column per 16-lane group, the dot product of each substitution step spread over
+    // the 16 lanes (DPP row reduction) — the recurrences are 16 steps long instead of 136 dependent multiply-adds
+    if (nt >= 512) {
+        const int j = tid >> 4, l = tid & 15;            // tid < 256: Uinv column j;  256 <= tid < 512: V1inv column j - 16
+        if (j < jb) {
+            if (l == 0) Ui[j][j] = 1.0 / U[j][j];
+            for (int i = j - 1; i >= 0; --i) {
+                double p = (l > i && l <= j) ? U[i][l] * Ui[l][j] : 0.0;
+                p += dpp_mov0<0x111>(p); p += dpp_mov0<0x112>(p); p += dpp_mov0<0x114>(p); p += dpp_mov0<0x118>(p);   // lane 15 of the row: total
+                if (l == 15) Ui[i][j] = -p / U[i][i];
+            }
+        } else if (j >= 16 && j - 16 < jb) {
+            const int c = j - 16;
+            if (l == 0) Vi[c][c] = 1.0;
+            for (int i = c + 1; i < jb; ++i) {
+                double p = (l > c && l < i) ? V1[i][l] * Vi[l][c] : 0.0;
+                p += dpp_mov0<0x111>(p); p += dpp_mov0<0x112>(p); p += dpp_mov0<0x114>(p); p += dpp_mov0<0x118>(p);
+                if (l == 15) Vi[i][c] = -(p + V1[i][c]);
+            }
+        }
+    } else if (tid < jb) {
         const int j = tid;
         Ui[j][j] = 1.0 / U[j][j];
         for (int i = j - 1; i >= 0; --i) {
