@@ -923,13 +923,16 @@ __device__ __forceinline__ double lane_bcast(double v, int srclane) {
     return __hiloint2double(hi, lo);
 }
 template <int NR>
-__device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh) {
+__device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int ldp, int rows, int jb, PanelShared& sh,
+                                                  double* __restrict__ pvext = nullptr, int pvld = 1024) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double (*Tsh)[QR_NB + 1] = sh.Tsh;
     double (*Zm)[QR_NB + 1] = sh.Zm;
     double* scl = sh.scl;
     for (int i = tid; i < QR_NB * (QR_NB + 1); i += blockDim.x) { (&Tsh[0][0])[i] = 0.0; (&Zm[0][0])[i] = 0.0; }
     __syncthreads();                 // the LDS copy of the panel is complete
+    double* const pvb = pvext ? pvext : &sh.pv[0][0];     // two pivot-column buffers of pvld doubles each
+    if (!pvext) pvld = 1024;
     const bool own = wave < jb;
     double x[NR];
 #pragma unroll
@@ -937,7 +940,7 @@ __device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int l
     if (wave == 0) {
         double s0 = 0.0;
 #pragma unroll
-        for (int u = 0; u < NR; ++u) { const int i = lane + 64 * u; if (i >= 1) s0 += x[u] * x[u]; if (i < rows) sh.pv[0][i] = x[u]; }
+        for (int u = 0; u < NR; ++u) { const int i = lane + 64 * u; if (i >= 1) s0 += x[u] * x[u]; if (i < rows) pvb[i] = x[u]; }
         s0 = wave_sum(s0);
         if (lane == 0) sh.nrm2[0] = s0;
     }
@@ -960,8 +963,8 @@ __device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int l
         if (lane == 0) Tsh[c][c] = tc;
     };
     for (int jj = 0; jj < jb; ++jj) {
-        const double* pv = sh.pv[jj & 1];
-        double* pvn = sh.pv[(jj + 1) & 1];
+        const double* pv = pvb + (size_t)(jj & 1) * pvld;
+        double* pvn = pvb + (size_t)((jj + 1) & 1) * pvld;
         const double s = sh.nrm2[jj], alpha = pv[jj];
         double tau = 0.0, beta = alpha, scale = 0.0;
         if (s > 0.0) {
@@ -980,6 +983,7 @@ __device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int l
                     const int i = lane + 64 * u;
                     if (u == ju) sel = x[u];
                     if (i > jj && i < rows) w += pv[i] * x[u];
+                    if (NR > 16 && (u & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the number of pivot entries in flight
                 }
                 const double cjj = lane_bcast(sel, jl);          // entry of my column in the pivot row
                 w = wave_sum(w) * scale + cjj;
@@ -993,6 +997,7 @@ __device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int l
                         if (i > jj + 1) nn += x[u] * x[u];
                     }
                     if (u == ju && lane == jl) x[u] = cjj - tw;
+                    if (NR > 16 && (u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (wave == jj + 1) {
                     nn = wave_sum(nn);
@@ -1007,6 +1012,7 @@ __device__ __forceinline__ void hh_panel_core_reg(double* __restrict__ Pn, int l
                     const int i = lane + 64 * u;
                     if (u == ju) sel = x[u];
                     if (i > jj && i < rows) w += x[u] * pv[i];
+                    if (NR > 16 && (u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
                 const double vjj = lane_bcast(sel, jl);           // entry of reflector `wave` in row jj (unscaled)
                 w = wave_sum(w) * scl[wave] * scale;
@@ -1092,7 +1098,11 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
     }
     PROBE(2);
     if (PLDS) hh_panel_core_lds(Pn, ldp, rows, jb, sh);
-    else hh_panel_core(Pn, ldp, rows, jb, sh);
+    else if (rows <= 1536) {
+        // medium panels (1024 < rows <= 1536): no LDS copy at all — the register-resident core reads its columns straight
+        // from global memory and writes them back; only the two pivot-column buffers live in (dynamic) LDS
+        hh_panel_core_reg<24>(Pn, ldp, rows, jb, sh, psm, 2048);
+    } else hh_panel_core(Pn, ldp, rows, jb, sh);
     PROBE(5);
     if (part_out && wave == 0) {
         // coupling term of the NEXT termination test: 2 ||triu(R)||_F^2 of this panel (see k_band_rem)
@@ -1419,6 +1429,15 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
         static bool attr_set = false;
         if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); attr_set = true; }
         hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
+    } else if (rows <= 1536) {
+        {
+            TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
+            hipLaunchKernelGGL((k_qr_panel<false>), dim3(1), dim3(1024), (size_t)2 * 2048 * sizeof(double), ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt,
+                               (double*)nullptr, 0, st, part, nparts, kpanel, tolfac, part_out);
+        }
+        // V T as a (multi-workgroup) GEMM: inside the single-workgroup kernel it would re-read the panel 8.5 times from L2
+        if (VT) gemm(ctx, false, false, rows, jb, jb, 1.0, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt, 0.0,
+                     VT + (size_t)j0 * ldvt + j0, ldvt, st, "gemm_qr");
     } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2) {
         // tall panel: TSQR + Householder reconstruction on many CUs (the termination test, if any, runs on its own)
         if (part) hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, kpanel, nparts, part, tolfac, st);
