@@ -215,6 +215,16 @@ __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, 
     }
 }
 
+// sum over the 16 consecutive lanes of a group (result in every lane of the group)
+template <typename T> __device__ __forceinline__ T group16_sum(T v);
+template <> __device__ __forceinline__ double group16_sum<double>(double v) {
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+template <> __device__ __forceinline__ cplx group16_sum<cplx>(cplx v) {
+    for (int o = 8; o > 0; o >>= 1) { v.re += __shfl_xor(v.re, o, 16); v.im += __shfl_xor(v.im, o, 16); }
+    return v;
+}
 // Blocked variant: panels of 16 pivot columns.  The column panel (f-kb) x 16 and the row panel 16 x (f-kb-16) live in LDS,
 // so the trailing matrix in global memory is read and written once per PANEL (not once per pivot) and the per-pivot work
 // runs at LDS latency.  The inverses of the triangular diagonal blocks are formed in LDS as well when s^2 entries fit
@@ -299,25 +309,38 @@ __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl
         T* X = sm + (size_t)s * s;                     // s x s scratch for the inverse being built
         for (int id = tid; id < s * s; id += nt) A11[id] = F[(id % s) + (size_t)(id / s) * f];
         __syncthreads();
-        for (int j = tid; j < s; j += nt) {            // column j of inv(L11) (unit lower), stored strictly below the diagonal
+        // One column of an inverse per 16-lane group; the dot product of every substitution step is spread over the 16 lanes
+        // (strided over k) and reduced with __shfl_xor inside the group, so a column costs s short steps instead of s^2/2
+        // dependent multiply-adds of a single thread.
+        const int grp = tid >> 4, l = tid & 15, ngrp = nt >> 4;
+        for (int j = grp; j < s; j += ngrp) {          // column j of inv(L11) (unit lower), stored strictly below the diagonal
             for (int i = j + 1; i < s; ++i) {
-                T acc = A11[i + j * s];
-                for (int k = j + 1; k < i; ++k) acc += A11[i + k * s] * X[k + j * s];
-                X[i + j * s] = -acc;
-                Ti[i + (size_t)j * s] = -acc;
+                T acc = make_scalar<T>(0.0, 0.0);
+                for (int k = j + 1 + l; k < i; k += 16) acc += A11[i + k * s] * X[k + j * s];
+                acc = group16_sum<T>(acc);
+                if (l == 0) {
+                    const T v = -(acc + A11[i + j * s]);
+                    X[i + j * s] = v;
+                    Ti[i + (size_t)j * s] = v;
+                }
             }
         }
         __syncthreads();
-        for (int j = tid; j < s; j += nt) {            // column j of inv(U11), stored on and above the diagonal
-            const T dj = recip(A11[j + j * s]);
-            X[j + j * s] = dj;
-            Ti[j + (size_t)j * s] = dj;
+        for (int j = grp; j < s; j += ngrp) {          // column j of inv(U11), stored on and above the diagonal
+            if (l == 0) {
+                const T dj = recip(A11[j + j * s]);
+                X[j + j * s] = dj;
+                Ti[j + (size_t)j * s] = dj;
+            }
             for (int i = j - 1; i >= 0; --i) {
                 T acc = make_scalar<T>(0.0, 0.0);
-                for (int k = i + 1; k <= j; ++k) acc += A11[i + k * s] * X[k + j * s];
-                const T v = -(acc * recip(A11[i + i * s]));
-                X[i + j * s] = v;
-                Ti[i + (size_t)j * s] = v;
+                for (int k = i + 1 + l; k <= j; k += 16) acc += A11[i + k * s] * X[k + j * s];
+                acc = group16_sum<T>(acc);
+                if (l == 0) {
+                    const T v = -(acc * recip(A11[i + i * s]));
+                    X[i + j * s] = v;
+                    Ti[i + (size_t)j * s] = v;
+                }
             }
         }
         return;
