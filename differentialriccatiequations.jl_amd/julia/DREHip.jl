@@ -34,6 +34,10 @@ function chk(ctx::Context, rc)
     throw(DREError(rc, unsafe_string(ccall((:dre_last_error, LIB), Cstring, (Ptr{Cvoid},), ctx.ptr))))
 end
 
+# engine tunables (include/dre_hip.h: dre_ctx_set_option), e.g. set_option!(ctx, "dense_inverse_max_n", 0) forces the multifrontal sweeps
+set_option!(ctx::Context, name::AbstractString, value::Real) =
+    chk(ctx, ccall((:dre_ctx_set_option, LIB), Cint, (Ptr{Cvoid}, Cstring, Cdouble), ctx.ptr, name, Float64(value)))
+
 const DEFAULT = Ref{Union{Nothing,Context}}(nothing)
 default_context() = something(DEFAULT[], (DEFAULT[] = Context(0)))
 
