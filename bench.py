@@ -158,7 +158,15 @@ def main():
                 blas_threads = max([int(x.get("num_threads", 1)) for x in threadpool_info()] or [1])
             except Exception:
                 blas_threads = os.cpu_count()
-            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=blas_threads, kind="port",
+            # "fair" variant: the same oracle, but sparse factorisations cached per (operator, shift) like the engine
+            st2 = []
+            tc2 = time.perf_counter()
+            o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm), (t0, tfc)),
+                    o.Ros1(o.ADI(shifts=o.Cyclic(list(shifts)), factor_cache=o.FactorCache(reuse=True))), dt=dt, stats=st2)
+            tc2 = time.perf_counter() - tc2
+            fair = dict(value=sum(s["iters"] for s in st2) / tc2, unit="ADI iterations/s",
+                        note="same sample, sparse LU factors reused per shift (the reference refactorises every ADI step)")
+            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=blas_threads, kind="port", factor_caching_variant=fair,
                        sample=f"first {args.cpu_steps} of {args.nsteps} Rosenbrock steps of the same workload ({cpu_it} ADI iterations, {tc:.1f} s), "
                               f"NumPy/SciPy oracle (OpenBLAS with {blas_threads} threads of {os.cpu_count()} host CPUs, SuperLU refactorised every ADI step like the reference)")
         out = {
