@@ -1542,8 +1542,8 @@ QRFact qr_factor(Ctx* ctx, Mat& A) {
         if (n2 > 0) {
             Mat A2 = A.view(g0, gend, f.m - g0, n2);
             Mat W(ctx, gw, n2);
-            gemm(ctx, true, false, 1.0, VTg, A2, 0.0, W, nullptr, "gemm_qr");      // W = T_g' V_g' A2
-            gemm(ctx, false, false, -1.0, Vg, W, 1.0, A2, nullptr, "gemm_qr");      // A2 <- Q_g' A2
+            gemm(ctx, true, false, 1.0, VTg, A2, 0.0, W, nullptr, "gemm_qr_wide_tn");      // W = T_g' V_g' A2
+            gemm(ctx, false, false, -1.0, Vg, W, 1.0, A2, nullptr, "gemm_qr_wide_nn");      // A2 <- Q_g' A2
         }
     }
     size_t tot = (size_t)f.kq * f.n;
