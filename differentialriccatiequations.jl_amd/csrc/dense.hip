@@ -91,6 +91,20 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
         }
     };
     if (kbeg < kend) load_tile(kbeg);
+    // beta != 0: the old C tile is requested now, its latency hides behind the K loop
+    double cpre[2][2][4];
+    const bool want_c = !partial && beta != 0.0;
+    if (want_c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm + i * 16 + (lane >> 4) + 4 * r, col = n0 + wn + j * 16 + (lane & 15);
+                    cpre[i][j][r] = (row < M && col < N) ? C[row + (size_t)col * ldc] : 0.0;
+                }
+    }
     for (int k0 = kbeg; k0 < kend; k0 += GB_K) {
         if (!TA) { const int m = tid & 63, kq = tid >> 6;
 #pragma unroll
@@ -134,7 +148,7 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
                         partial[row + (size_t)col * M] = acc[i][j][r];
                     } else {
                         double* c = C + row + (size_t)col * ldc;
-                        const double v = (beta == 0.0) ? alpha * acc[i][j][r] : alpha * acc[i][j][r] + beta * (*c);
+                        const double v = (beta == 0.0) ? alpha * acc[i][j][r] : alpha * acc[i][j][r] + beta * cpre[i][j][r];
                         *c = v;
                         ssq += v * v;
                     }
