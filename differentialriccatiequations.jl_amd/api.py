@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import warnings
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Any, Optional
 
@@ -504,8 +505,10 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
     return (X, info) if return_info else X
 
 
-def residual(prob: GALEProblem, X: LDLt, ctx=None) -> LDLt:
-    """residual(::GALEProblem{<:LDLᵀ}, ::LDLᵀ)  (lyapunov/residual.jl:3-31)"""
+def residual(prob, X: LDLt, ctx=None) -> LDLt:
+    """residual(::GALEProblem{<:LDLᵀ}, ::LDLᵀ)  (lyapunov/residual.jl:3-31);  residual(::GAREProblem, ::LDLᵀ)  (riccati/residual.jl:5-52)"""
+    if isinstance(prob, GAREProblem):
+        return gare_residual(prob, X, ctx)
     ctx = ctx or dev.default_context()
     A0, lr = _split_operator(prob.E, prob.A)
     pencil = _pencil_for(prob.E, A0, ctx)
@@ -584,10 +587,151 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     return sol
 
 
+# ------------------------------------------------------------------------------------------------
+# Algebraic Riccati equation: Kleinman-Newton with the device ADI as inner solver     
+# src/riccati/types.jl:41-107, src/riccati/newton.jl:3-172, src/riccati/residual.jl:5-52
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class GAREProblem:
+    """Q + A'XE + E'XA − E'XGXE = 0 with G = lowrank(B, I), Q = lowrank(C', I) (riccati/types.jl:41-52)."""
+    E: Any
+    A: Any
+    G: LDLt
+    Q: LDLt
+
+
+def quadratic_forcing(_, residual_norm):          # newton.jl:164-172
+    return min(0.1, 0.9 * residual_norm)
+
+
+def superlinear_forcing(i, _):                    # newton.jl:150-157
+    return 1.0 / (i ** 3 + 1)
+
+
+@dataclass
+class Newton:
+    """Kleinman-Newton options (riccati/types.jl:96-107)."""
+    inner_alg: Optional[ADI] = None
+    maxiters: int = 5
+    reltol: Optional[float] = None
+    abstol: Optional[float] = None
+    inexact: bool = True
+    inexact_hybrid: bool = True
+    inexact_forcing: Any = quadratic_forcing
+    linesearch: bool = True
+
+
+def _spT_mul(M, L):
+    return np.asarray(M.T @ L) if sp.issparse(M) else np.asarray(M).T @ L
+
+
+def gare_residual(prob: GAREProblem, X: LDLt, ctx=None) -> LDLt:
+    """residual(::GAREProblem, ::LDLᵀ)  (riccati/residual.jl:5-52): the factors R = [C', A'L, E'L] and the small T are assembled on
+    the host (n x (h + 2 z) doubles), the compression — the expensive part — runs on the device."""
+    if X.iszero():
+        g, Ct, S = prob.Q
+        return g * lowrank(Ct.copy(), np.array(S, dtype=float))
+    gamma, Ct, S = prob.Q
+    beta, B, Rinv = prob.G
+    alpha, L, D = X
+    h, z = Ct.shape[1], L.shape[1]
+    BtLD = (B.T @ L) @ D * (alpha * beta)
+    R = np.hstack([Ct, _spT_mul(prob.A, L), _spT_mul(prob.E, L)])
+    T = np.zeros((h + 2 * z, h + 2 * z))
+    T[:h, :h] = gamma * np.asarray(S)
+    T[h:h + z, h + z:] = alpha * D
+    T[h + z:, h:h + z] = alpha * D
+    T[h + z:, h + z:] = -(BtLD.T @ np.asarray(Rinv) @ BtLD)
+    ctx = ctx or dev.default_context()
+    _pencil_for(prob.E, prob.A, ctx)                 # (keeps the symbolic analysis of (E, A) cached for the Lyapunov solves)
+    return compress_(lowrank(R, T))
+
+
+def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_info=False):
+    """solve(::GAREProblem, ::Newton; observer)  (riccati/newton.jl:3-147).  The Newton loop, the forcing terms and the Armijo line search
+    are host logic exactly as in the reference; every Newton step is one device-resident LDLᵀ-ADI solve of
+    (A − BK)'XE + E'X(A − BK) = −[C', E'XB][C', E'XB]' with the previous iterate as initial guess."""
+    inner = alg.inner_alg if alg.inner_alg is not None else ADI()
+    a_g, B, Dg = prob.G
+    a_q, Ct, Dq = prob.Q
+    if not (a_g == 1 and a_q == 1 and np.array_equal(Dg, np.eye(Dg.shape[0])) and np.array_equal(Dq, np.eye(Dq.shape[0]))):
+        raise NotImplementedError("G and Q must be unscaled with identity inner matrices (newton.jl:8-9,15-17)")
+    _call(observer, "observe_gare_start", prob, alg)
+    n = prob.A.shape[0]
+    res_norm = norm(prob.Q)
+    reltol = alg.reltol if alg.reltol is not None else n * np.finfo(float).eps
+    abstol = alg.abstol if alg.abstol is not None else reltol * res_norm
+    inner_reltol = inner.reltol if inner.reltol is not None else reltol / 10
+    X = lowrank(np.zeros((n, 0)), np.zeros((0, 0)))
+    X_prev = None
+    history, adi_iters, i = [], 0, 0
+
+    def aux(Xc):
+        alpha, L, D = Xc
+        EtL = _spT_mul(prob.E, L)
+        BtLD = (B.T @ L) @ D * alpha
+        return EtL, BtLD, BtLD @ EtL.T
+
+    while True:
+        EtL, BtLD, K = aux(X)
+        res = gare_residual(prob, X, ctx)
+        res_norm_prev, res_norm = res_norm, norm(res)
+        if i > 0 and alg.linesearch and res_norm > (1 - 0.1) * res_norm_prev:      # Armijo, newton.jl:50-92
+            Xt, lam = X, 0.5
+            while True:
+                X = (1 - lam) * X_prev + lam * Xt
+                res = gare_residual(prob, X, ctx)
+                res_norm = norm(res)
+                if res_norm < (1 - lam * 0.1) * res_norm_prev:
+                    EtL, BtLD, K = aux(X)
+                    break
+                lam *= 0.5
+                if lam < np.finfo(float).eps:
+                    warnings.warn("Line search failed; using un-modified iterate")
+                    X, lam = Xt, 1.0
+                    EtL, BtLD, K = aux(X)
+                    break
+            _call(observer, "observe_gare_metadata", "line search", lam)
+        _call(observer, "observe_gare_step", i, X, res, res_norm)
+        history.append(res_norm)
+        if res_norm <= abstol:
+            break
+        if i >= alg.maxiters:
+            _call(observer, "observe_gare_failed")
+            warnings.warn(f"Newton method did not converge: residual={res_norm} abstol={abstol} maxiters={alg.maxiters}")
+            break
+        i += 1
+        F = lr_update(prob.A, -1.0, B, K)                                        # newton.jl:104
+        G = np.hstack([Ct, EtL @ BtLD.T])                                        # newton.jl:107-112
+        lyap = GALEProblem(prob.E, F, lowrank(G, np.eye(G.shape[1])))
+        if alg.inexact:                                                          # newton.jl:116-133
+            inner_abstol = alg.inexact_forcing(i, res_norm) * res_norm
+            if alg.inexact_hybrid:
+                classical = inner_reltol * norm(lyap.C)
+                switch_back = classical > inner_abstol
+                _call(observer, "observe_gare_metadata", "inexact", not switch_back)
+                if switch_back:
+                    inner_abstol = classical
+            else:
+                _call(observer, "observe_gare_metadata", "inexact", True)
+        else:
+            inner_abstol = inner_reltol * norm(lyap.C)
+        X_prev = X
+        X, info = solve_gale(lyap, dataclasses.replace(inner, abstol=float(inner_abstol)), initial_guess=X_prev, observer=observer,
+                             ctx=ctx, return_info=True)
+        adi_iters += info["iters"]
+    _call(observer, "observe_gare_done", i, X, res, res_norm)
+    if return_info:
+        return X, dict(newton_steps=i, residual_norms=history, abstol=abstol, adi_iters=adi_iters, converged=res_norm <= abstol)
+    return X
+
+
 def solve(prob, alg, **kw):
     """CommonSolve.solve for the problems of this path."""
     if isinstance(prob, GDREProblem):
         return solve_gdre(prob, alg, **kw)
     if isinstance(prob, GALEProblem):
         return solve_gale(prob, alg, **kw)
+    if isinstance(prob, GAREProblem):
+        return solve_gare(prob, alg, **kw)
     raise TypeError(f"unsupported problem type {type(prob).__name__}")

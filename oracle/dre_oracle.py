@@ -896,6 +896,135 @@ def solve_dense_ros2(prob: GDREProblem, dt, save_state=False):
     return DRESolution(Xs, Ks, tstops)
 
 
+# --------------------------------------------------------------------------------------------
+# Algebraic Riccati equation: Kleinman-Newton with low-rank ADI
+# --------------------------------------------------------------------------------------------
+@dataclass
+class GAREProblem:
+    """Q + A'XE + E'XA - E'XGXE = 0 with G = B B' and Q = C'C given as LDLt (riccati/types.jl:41-52)."""
+    E: Any
+    A: Any
+    G: LDLt
+    Q: LDLt
+
+
+def quadratic_forcing(_, residual_norm):      # riccati/newton.jl:164-172
+    return min(0.1, 0.9 * residual_norm)
+
+
+def superlinear_forcing(i, _):                # riccati/newton.jl:150-157
+    return 1.0 / (i ** 3 + 1)
+
+
+@dataclass
+class Newton:
+    """riccati/types.jl:96-107"""
+    inner_alg: Any = None
+    maxiters: int = 5
+    reltol: Optional[float] = None
+    abstol: Optional[float] = None
+    inexact: bool = True
+    inexact_hybrid: bool = True
+    inexact_forcing: Callable = quadratic_forcing
+    linesearch: bool = True
+
+
+def gare_residual(prob: GAREProblem, X: LDLt) -> LDLt:
+    """residual(::GAREProblem, ::LDLt)  (riccati/residual.jl:5-52): R = [C', A'L, E'L], T = [gS 0 0; 0 0 aD; 0 aD -(B'LD)'R^-1(B'LD)]."""
+    if X.iszero():
+        return prob.Q.copy()
+    gamma, Ct, S = prob.Q.destructure()
+    beta, B, Rinv = prob.G.destructure()
+    alpha, L, D = X.destructure()
+    h, z = Ct.shape[1], L.shape[1]
+    BtLD = (B.T @ L) @ D * (alpha * beta)
+    DLGLD = BtLD.T @ Rinv @ BtLD
+    R = np.hstack([Ct, _At_mul(prob.A, L), _At_mul(prob.E, L)])
+    T = np.zeros((h + 2 * z, h + 2 * z))
+    T[:h, :h] = gamma * S
+    T[h:h + z, h + z:] = alpha * D
+    T[h + z:, h:h + z] = alpha * D
+    T[h + z:, h + z:] = -DLGLD
+    return compress(lowrank(R, T))
+
+
+def gare_residual_dense(prob: GAREProblem, X):
+    """riccati/residual.jl:54-66"""
+    Ed = prob.E.toarray() if sp.issparse(prob.E) else np.asarray(prob.E)
+    Ad = prob.A.toarray() if sp.issparse(prob.A) else np.asarray(prob.A)
+    BtXE = (prob.G.Ls[0].T @ X) @ Ed
+    return prob.Q.dense() + Ad.T @ X @ Ed + Ed.T @ X @ Ad - BtXE.T @ (prob.G.alphas[0] * prob.G.Ds[0]) @ BtXE
+
+
+def solve_newton(prob: GAREProblem, alg: Newton, observer=None, stats=None) -> LDLt:
+    """solve(::GAREProblem, ::Newton)  (riccati/newton.jl:3-147): Kleinman-Newton, inexact inner tolerances
+    (Dembo/Eisenstat/Steihaug forcing), Armijo line search (Benner et al. 2015)."""
+    inner = alg.inner_alg if alg.inner_alg is not None else ADI()
+    E, A = prob.E, prob.A
+    a_g, B, Dg = prob.G.destructure()
+    a_q, Ct, Dq = prob.Q.destructure()
+    if not (np.array_equal(Dg, np.eye(Dg.shape[0])) and np.array_equal(Dq, np.eye(Dq.shape[0])) and a_g == 1 and a_q == 1):
+        raise NotImplementedError("G and Q must be unscaled with identity inner matrices (newton.jl:8-9,15-17)")
+    n = A.shape[0]
+    res_norm = norm(prob.Q)
+    reltol = alg.reltol if alg.reltol is not None else n * EPS
+    abstol = alg.abstol if alg.abstol is not None else reltol * res_norm
+    inner_reltol = inner.reltol if inner.reltol is not None else reltol / 10
+    X = lowrank(np.zeros((n, 0)), np.zeros((0, 0)))
+    X_prev = None
+    i = 0
+    while True:
+        alpha, L, D = X.destructure()
+        EtL = _At_mul(E, L)
+        BtLD = (B.T @ L) @ D * alpha
+        K = BtLD @ EtL.T
+        res = gare_residual(prob, X)
+        res_norm_prev, res_norm = res_norm, norm(res)
+        if i > 0 and alg.linesearch and res_norm > (1 - 0.1) * res_norm_prev:
+            Xt, lam = X, 0.5
+            while True:
+                X = (1 - lam) * X_prev + lam * Xt
+                res = gare_residual(prob, X)
+                res_norm = norm(res)
+                if res_norm < (1 - lam * 0.1) * res_norm_prev:
+                    alpha, L, D = X.destructure()
+                    EtL = _At_mul(E, L)
+                    BtLD = (B.T @ L) @ D * alpha
+                    K = BtLD @ EtL.T
+                    break
+                lam *= 0.5
+                if lam < EPS:
+                    warnings.warn("Line search failed; using un-modified iterate")
+                    X = Xt
+                    break
+            _call(observer, "observe_gare_metadata", "line search", lam)
+        _call(observer, "observe_gare_step", i, X, res, res_norm)
+        if stats is not None:
+            stats.append(dict(newton=i, res=res_norm, rank=X.rank()))
+        if res_norm <= abstol:
+            break
+        if i >= alg.maxiters:
+            _call(observer, "observe_gare_failed")
+            warnings.warn(f"Newton method did not converge: residual={res_norm} abstol={abstol} maxiters={alg.maxiters}")
+            break
+        i += 1
+        F = lr_update(A, -1.0, B, K)
+        G = np.hstack([Ct, EtL @ BtLD.T])
+        lyap = GALEProblem(E, F, lowrank(G, np.eye(G.shape[1])))
+        if alg.inexact:
+            inner_abstol = alg.inexact_forcing(i, res_norm) * res_norm
+            if alg.inexact_hybrid:
+                classical = inner_reltol * norm(lyap.C)
+                if classical > inner_abstol:
+                    inner_abstol = classical
+        else:
+            inner_abstol = inner_reltol * norm(lyap.C)
+        X_prev = X
+        X = adi_solve(lyap, inner, abstol=inner_abstol, initial_guess=X_prev, observer=observer)
+    _call(observer, "observe_gare_done", i, X, res, res_norm)
+    return X
+
+
 def solve(prob: GDREProblem, alg, dt, save_state=False, observer=None, stats=None):
     """DifferentialRiccatiEquations.jl:78-94: dispatch on the type of X0."""
     if isinstance(prob.X0, LDLt):

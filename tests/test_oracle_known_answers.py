@@ -139,3 +139,28 @@ def test_rail_setup_and_solution_shape(rail371):      # test/rail.jl:32-46
         sol = o.solve(prob, alg, dt=-50.0, save_state=True)
     assert len(sol.t) == len(sol.X) == len(sol.K) == 3
     assert (np.diff(sol.t) < 0).all()                  # direction of time preserved
+
+
+def test_oracle_newton_kleinman_matches_dense_are():        # riccati/newton.jl:3-147; criterion of test/rail.jl:86
+    import scipy.linalg as sla
+    import scipy.sparse as sp
+    import warnings
+    rng = np.random.default_rng(3)
+    n = 40
+    A = sp.csc_matrix(-2.0 * np.eye(n) + 0.3 * rng.standard_normal((n, n)) / np.sqrt(n))
+    E = sp.identity(n, format="csc") + sp.csc_matrix(0.05 * np.diag(rng.random(n)))
+    B, Cm = rng.standard_normal((n, 2)), rng.standard_normal((3, n))
+    prob = o.GAREProblem(E, A, o.lowrank(B), o.lowrank(Cm.T))
+    Xref = sla.solve_continuous_are(A.toarray(), B, Cm.T @ Cm, np.eye(2), e=E.toarray())
+    for kw in (dict(), dict(inexact=False), dict(inexact_forcing=o.superlinear_forcing), dict(linesearch=False)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            st = []
+            X = o.solve_newton(prob, o.Newton(o.ADI(ignore_initial_guess=True), maxiters=12, reltol=1e-10, **kw), stats=st)
+        assert o.norm(o.gare_residual(prob, X)) < 1e-10 * o.norm(prob.Q)
+        assert abs(o.norm(o.gare_residual(prob, X)) - np.linalg.norm(o.gare_residual_dense(prob, X.dense()))) < 1e-11 * o.norm(prob.Q)
+        assert o.delta(X.dense(), Xref) < 1e-8
+        res = [s["res"] for s in st]
+        assert res[-1] < res[0] and len(res) <= 13
+    assert o.gare_residual(prob, prob.Q.zero()) == prob.Q          # riccati/residual.jl:15
+    assert o.quadratic_forcing(3, 0.05) == 0.9 * 0.05 and o.quadratic_forcing(1, 7.0) == 0.1 and o.superlinear_forcing(2, None) == 1 / 9
