@@ -588,6 +588,121 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
 
 
 # ------------------------------------------------------------------------------------------------
+# Low-rank FGMRES with (optional) ADI preconditioner                                   
+# src/lyapunov/gmres.jl:7-134, src/lyapunov/types.jl:44-52, dot: src/LDLt.jl:91-108
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class GMRES:
+    """Flexible GMRES options (lyapunov/types.jl:44-52)."""
+    maxiters: int = 3            # per restart
+    maxrestarts: int = 0
+    reltol: Optional[float] = None
+    abstol: Optional[float] = None
+    ignore_initial_guess: bool = False
+    compression: bool = True
+    preconditioner: Any = None
+    warn_convergence: bool = True
+
+
+def dot(X1: LDLt, X2: LDLt) -> float:
+    """dot(::LDLᵀ, ::LDLᵀ) = <X1, X2>_F  (LDLt.jl:91-108); small host GEMMs on the factors."""
+    a, A, Bm = X1
+    b, Cm, Dm = X2
+    M = A.T @ Cm
+    return float(a * b * np.sum((Bm @ M @ Dm) * M))
+
+
+def _opT_mul(A, Z):
+    """A' Z for a sparse matrix or a LowRankUpdate  A0 + inv(alpha) U V  (LowRankUpdate.jl:51-54,82-85)."""
+    if isinstance(A, LowRankUpdate):
+        return _spT_mul(A.A, Z) + np.asarray(A.V).T @ (np.asarray(A.U).T @ Z) / A.alpha
+    return _spT_mul(A, Z)
+
+
+def lyapunov_apply(E, A, X: LDLt) -> LDLt:
+    """LyapunovOperator(E, A) * X = A'XE + E'XA = a [E'Z, A'Z] [0 Y; Y 0] [E'Z, A'Z]'  (gmres.jl:108-120)."""
+    a, Z, Y = X
+    O = np.zeros_like(Y)
+    return a * lowrank(np.hstack([_spT_mul(E, Z), _opT_mul(A, Z)]), np.block([[O, Y], [Y, O]]))
+
+
+def _specialize(alg, prob, ctx):
+    """gmres.jl:122-134: the Heuristic shifts of a preconditioner are computed once per problem, not once per inner solve."""
+    if isinstance(alg, ADI) and isinstance(alg.shifts, Shifts.Cyclic) and isinstance(alg.shifts.inner, Shifts.Heuristic):
+        A0, _ = _split_operator(prob.E, prob.A)
+        return dataclasses.replace(alg, shifts=Shifts.Cyclic(heuristic_shifts(alg.shifts.inner, _pencil_for(prob.E, A0, ctx))))
+    if isinstance(alg, GMRES):
+        return dataclasses.replace(alg, preconditioner=_specialize(alg.preconditioner, prob, ctx))
+    return alg
+
+
+def solve_gmres(prob: GALEProblem, alg: GMRES, initial_guess: LDLt | None = None, abstol=None, observer=None, ctx=None, return_info=False):
+    """solve(::GALEProblem, ::GMRES; initial_guess, abstol, observer)  (lyapunov/gmres.jl:7-106): flexible GMRES (Saad 1993, Alg. 2.2) on
+    low-rank iterates.  The Arnoldi bookkeeping is host logic as in the reference; residuals, compressions, norms and the ADI
+    preconditioner solves run on the device."""
+    ctx = ctx or dev.default_context()
+    _call(observer, "observe_gale_start", prob, alg)
+    E, A, Cl = prob.E, prob.A, prob.C
+    X = Cl.zero() if (alg.ignore_initial_guess or initial_guess is None) else initial_guess
+    reltol = alg.reltol if alg.reltol is not None else Cl.n * np.finfo(float).eps
+    if abstol is None:
+        abstol = alg.abstol if alg.abstol is not None else reltol * norm(Cl)
+    pre = _specialize(alg.preconditioner, prob, ctx)
+    mmax = alg.maxiters
+    H, bvec = np.zeros((mmax + 1, mmax)), np.zeros(mmax + 1)
+    residual_norm, m, restarts = math.inf, 0, 0
+    for restarts in range(alg.maxrestarts + 1):
+        m = 0
+        R0 = residual(prob, X, ctx)
+        beta = residual_norm = norm(R0)
+        _call(observer, "observe_gale_step", 0, X, R0, beta)
+        if beta <= abstol:
+            break
+        V, Zs = [R0 / beta], []
+        H[:] = 0.0; bvec[:] = 0.0; bvec[0] = beta
+        y = np.zeros(0)
+        for j in range(mmax):
+            if pre is None:
+                Zs.append(V[j])
+            else:
+                sub = GALEProblem(E, A, V[j])
+                Zs.append(solve_gale(sub, pre, observer=observer, ctx=ctx) if isinstance(pre, ADI) else solve_gmres(sub, pre, observer=observer, ctx=ctx))
+            W = lyapunov_apply(E, A, Zs[j])
+            if alg.compression:
+                compress_(W)
+            for i in range(j + 1):
+                H[i, j] = dot(V[i], W)
+                W = W - H[i, j] * V[i]
+            H[j + 1, j] = norm(W)
+            V.append(W / H[j + 1, j])
+            m = j + 1
+            Hm, bm = H[:m + 1, :m], bvec[:m + 1]
+            y = np.linalg.lstsq(Hm, bm, rcond=None)[0]
+            residual_norm = float(np.linalg.norm(bm - Hm @ y))
+            if residual_norm <= abstol:
+                break
+            _call(observer, "observe_gale_step", m, None, None, residual_norm)
+            if alg.compression:
+                compress_(V[j + 1])
+        for j in range(m):
+            X = X + (-y[j]) * Zs[j]
+        if alg.compression:
+            compress_(X)
+        _call(observer, "observe_gale_step", m, X, None, residual_norm)
+        if residual_norm <= abstol:
+            break
+    iters = restarts * alg.maxiters + m
+    if residual_norm > abstol:
+        _call(observer, "observe_gale_failed")
+        if alg.warn_convergence:
+            warnings.warn(f"GMRES did not converge: residual={residual_norm} abstol={abstol} maxrestarts={alg.maxrestarts} maxiters={alg.maxiters}")
+    _call(observer, "observe_gale_done", iters, X, None, residual_norm)
+    if return_info:
+        return X, dict(iters=iters, res_norm=residual_norm, abstol=abstol, converged=residual_norm <= abstol)
+    return X
+
+
+# ------------------------------------------------------------------------------------------------
 # Algebraic Riccati equation: Kleinman-Newton with the device ADI as inner solver     (SURVEY §8f item 1)
 # src/riccati/types.jl:41-107, src/riccati/newton.jl:3-172, src/riccati/residual.jl:5-52
 # ------------------------------------------------------------------------------------------------
@@ -717,8 +832,11 @@ def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_i
         else:
             inner_abstol = inner_reltol * norm(lyap.C)
         X_prev = X
-        X, info = solve_gale(lyap, dataclasses.replace(inner, abstol=float(inner_abstol)), initial_guess=X_prev, observer=observer,
-                             ctx=ctx, return_info=True)
+        if isinstance(inner, GMRES):
+            X, info = solve_gmres(lyap, inner, initial_guess=X_prev, abstol=float(inner_abstol), observer=observer, ctx=ctx, return_info=True)
+        else:
+            X, info = solve_gale(lyap, dataclasses.replace(inner, abstol=float(inner_abstol)), initial_guess=X_prev, observer=observer,
+                                 ctx=ctx, return_info=True)
         adi_iters += info["iters"]
     _call(observer, "observe_gare_done", i, X, res, res_norm)
     if return_info:
@@ -731,7 +849,7 @@ def solve(prob, alg, **kw):
     if isinstance(prob, GDREProblem):
         return solve_gdre(prob, alg, **kw)
     if isinstance(prob, GALEProblem):
-        return solve_gale(prob, alg, **kw)
+        return solve_gmres(prob, alg, **kw) if isinstance(alg, GMRES) else solve_gale(prob, alg, **kw)
     if isinstance(prob, GAREProblem):
         return solve_gare(prob, alg, **kw)
     raise TypeError(f"unsupported problem type {type(prob).__name__}")

@@ -401,7 +401,7 @@ int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x) {
         if (X.blocks.size() > 1 || (X.blocks.size() == 1 && !X.blocks[0].diag && X.blocks[0].L.cols > 0)) ldlt_compress(&ctx->c, X, 4.0, true);
     });
 }
-int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out) { return guarded(ctx, [&] { *out = ldlt_norm(&ctx->c, *x->x); }); }
+int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out) { return guarded(ctx, [&] { *out = ldlt_norm_accurate(&ctx->c, *x->x); }); }
 int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* Lh, int ldl, double* Dh, int ldd) {
     return guarded(ctx, [&] {
         Ctx* c = &ctx->c;

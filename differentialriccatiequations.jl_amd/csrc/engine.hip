@@ -221,6 +221,19 @@ double ldlt_norm(Ctx* ctx, LDLt& X) {
     return ldlt_norm_host(ctx, b.L, b.D, b.alpha);
 }
 
+// norm(::LDLt) as the reference defines it (LDLt.jl:77-89: through an orthogonal-triangular factorisation of L): accurate
+// relative to the RESULT even when the terms of X cancel.  The Gram form used inside the ADI loop is only accurate relative to
+// the largest term (error ~ sqrt(eps) ||L||^2 ||D|| under cancellation), which is harmless there but not for user-level sums
+// such as the Arnoldi vectors of the low-rank GMRES.  X itself is left untouched (the compression works on a shallow copy).
+double ldlt_norm_accurate(Ctx* ctx, const LDLt& X) {
+    if (X.rank() == 0) return 0.0;
+    LDLt Y = X;
+    ldlt_compress(ctx, Y, 4.0, false);
+    if (Y.rank() == 0) return 0.0;
+    auto& b = Y.blocks[0];
+    return ldlt_norm_host(ctx, b.L, b.D, b.alpha);
+}
+
 // =============================================================================================
 // Sherman-Morrison-Woodbury pieces (/root/reference/src/blocklinear/sherman-morrison-woodbury.jl:10-45)
 // with  F' + mu E' = M + inv(alpha) Vt U'  :  W = M^-1 [R, Vt];  S = alpha I + U' W_U;  X = W_R - W_U S^-1 (U' W_R)

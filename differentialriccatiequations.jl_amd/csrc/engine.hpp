@@ -41,6 +41,7 @@ void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-
 // dropped part is below tolfac*eps*||S||_F, i.e. not larger than what the reference's threshold discards.
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 double ldlt_norm(Ctx* ctx, LDLt& X);                             // LDLt.jl:77-89 (concatenates, synchronises)
+double ldlt_norm_accurate(Ctx* ctx, const LDLt& X);   // QR/compression based like LDLt.jl:77-89 (robust to cancellation); X unchanged
 void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true);   // LDLt.jl:54-60: compress iff more than one block
 
 struct CompressStats { long calls = 0; long cols_in = 0; long order = 0; long tri_steps = 0; long rank_out = 0; };

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import math
 import warnings
+import dataclasses
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
@@ -894,6 +895,109 @@ def solve_dense_ros2(prob: GDREProblem, dt, save_state=False):
     if not save_state:
         Xs.append(X)
     return DRESolution(Xs, Ks, tstops)
+
+
+# --------------------------------------------------------------------------------------------
+# Low-rank FGMRES with (optional) ADI preconditioner
+# --------------------------------------------------------------------------------------------
+@dataclass
+class GMRES:
+    """lyapunov/types.jl:44-52"""
+    maxiters: int = 3            # per restart
+    maxrestarts: int = 0
+    reltol: Optional[float] = None
+    abstol: Optional[float] = None
+    ignore_initial_guess: bool = False
+    compression: bool = True
+    preconditioner: Any = None
+
+
+def ldlt_dot(X1: LDLt, X2: LDLt) -> float:
+    """dot(::LDLt, ::LDLt) = <X1, X2>_F  (LDLt.jl:91-108):  alpha beta tr(B (A'C) D (A'C)')."""
+    X1, X2 = concatenate(X1), concatenate(X2)
+    a, A, B = X1.alphas[0], X1.Ls[0], X1.Ds[0]
+    b, C, D = X2.alphas[0], X2.Ls[0], X2.Ds[0]
+    M = A.T @ C
+    return float(a * b * np.sum((B @ M @ D) * M))
+
+
+def lyapunov_apply(E, A, X: LDLt) -> LDLt:
+    """LyapunovOperator * X = A'XE + E'XA as  a [E'Z, A'Z] [0 Y; Y 0] [E'Z, A'Z]'  (gmres.jl:108-120)."""
+    a, Z, Y = X.destructure()
+    O = np.zeros_like(Y)
+    return a * lowrank(np.hstack([_At_mul(E, Z), _At_mul(A, Z)]), np.block([[O, Y], [Y, O]]))
+
+
+def _specialize(alg, E, A):
+    """gmres.jl:122-134: Heuristic shifts of a preconditioner are computed once per problem."""
+    if isinstance(alg, ADI) and isinstance(alg.shifts, Cyclic) and isinstance(alg.shifts.inner, Heuristic):
+        return dataclasses.replace(alg, shifts=Cyclic(heuristic_shifts(alg.shifts.inner, E, A)))
+    if isinstance(alg, GMRES):
+        return dataclasses.replace(alg, preconditioner=_specialize(alg.preconditioner, E, A))
+    return alg
+
+
+def gmres_solve(prob: GALEProblem, alg: GMRES, initial_guess=None, abstol=None, observer=None, stats=None) -> LDLt:
+    """solve(::GALEProblem, ::GMRES)  (lyapunov/gmres.jl:7-106): flexible GMRES (Saad 1993, Alg. 2.2) on low-rank iterates."""
+    _call(observer, "observe_gale_start", prob, alg)
+    E, A, C = prob.E, prob.A, prob.C
+    X = C.zero() if (alg.ignore_initial_guess or initial_guess is None) else initial_guess
+    reltol = alg.reltol if alg.reltol is not None else A.shape[0] * EPS
+    if abstol is None:
+        abstol = alg.abstol if alg.abstol is not None else reltol * norm(C)
+    pre = _specialize(alg.preconditioner, E, A)
+    m_, H, bvec = alg.maxiters, np.zeros((alg.maxiters + 1, alg.maxiters)), np.zeros(alg.maxiters + 1)
+    residual_norm, m, restarts = np.inf, 0, 0
+    for restarts in range(alg.maxrestarts + 1):
+        m = 0
+        R0 = gale_residual(prob, X)
+        beta = residual_norm = norm(R0)
+        _call(observer, "observe_gale_step", 0, X, R0, beta)
+        if beta <= abstol:
+            break
+        V, Zs = [R0 / beta], []
+        H[:] = 0.0; bvec[:] = 0.0; bvec[0] = beta
+        y = np.zeros(0)
+        for j in range(m_):
+            if pre is None:
+                Zs.append(V[j])
+            else:
+                with warnings.catch_warnings():
+                    if not getattr(pre, "warn_convergence", True):
+                        warnings.simplefilter("ignore")
+                    Zs.append(adi_solve(GALEProblem(E, A, V[j]), pre, observer=observer) if isinstance(pre, ADI)
+                              else gmres_solve(GALEProblem(E, A, V[j]), pre, observer=observer))
+            W = lyapunov_apply(E, A, Zs[j])
+            if alg.compression:
+                W = compress(W)
+            for i in range(j + 1):
+                H[i, j] = ldlt_dot(V[i], W)
+                W = W - H[i, j] * V[i]
+            H[j + 1, j] = norm(W)
+            V.append(W / H[j + 1, j])
+            m = j + 1
+            Hm, bm = H[:m + 1, :m], bvec[:m + 1]
+            y = np.linalg.lstsq(Hm, bm, rcond=None)[0]
+            residual_norm = float(np.linalg.norm(bm - Hm @ y))
+            if residual_norm <= abstol:
+                break
+            _call(observer, "observe_gale_step", m, None, None, residual_norm)
+            if alg.compression:
+                V[j + 1] = compress(V[j + 1])
+        for j in range(m):
+            X = X + (-y[j]) * Zs[j]
+        if alg.compression:
+            X = compress(X)
+        _call(observer, "observe_gale_step", m, X, None, residual_norm)
+        if residual_norm <= abstol:
+            break
+    if residual_norm > abstol:
+        _call(observer, "observe_gale_failed")
+        warnings.warn(f"GMRES did not converge: residual={residual_norm} abstol={abstol}")
+    if stats is not None:
+        stats.append(dict(iters=restarts * alg.maxiters + m, res=residual_norm, abstol=abstol))
+    _call(observer, "observe_gale_done", restarts * alg.maxiters + m, X, None, residual_norm)
+    return X
 
 
 # --------------------------------------------------------------------------------------------

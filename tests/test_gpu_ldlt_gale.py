@@ -126,3 +126,19 @@ def test_observer_replay_and_nonconvergence_warning(ctx):
     with pytest.warns(UserWarning, match="ADI did not converge"):
         D.solve_gale(D.GALEProblem(E, A, Cl), D.ADI(maxiters=1), observer=ob)
     assert ob.failed == 1 and ob.done == [1]
+
+
+def test_norm_is_accurate_when_terms_cancel(ctx):
+    """norm(::LDLᵀ) goes through an orthogonal-triangular factorisation in the reference (LDLt.jl:77-89), so it is accurate relative to
+    the result even for sums whose terms cancel (the Arnoldi vectors of the low-rank GMRES rely on it); a Gram-matrix formula would
+    only be accurate to sqrt(eps) times the largest term."""
+    rng = np.random.default_rng(4)
+    n = 80
+    L = rng.standard_normal((n, 5)); Dd = np.diag([1.0, -2.0, 0.5, 3.0, -1.0])
+    X = D.lowrank(L, Dd)
+    for eps_rel in (1e-6, 1e-10, 1e-13):
+        Lp = L + eps_rel * rng.standard_normal((n, 5))
+        Y = X - D.lowrank(Lp, Dd)                                  # two blocks that cancel to eps_rel
+        ref = np.linalg.norm(X.dense() - Lp @ Dd @ Lp.T)
+        assert abs(D.norm(Y) - ref) < 1e-2 * ref + 1e-14 * np.linalg.norm(X.dense())
+    assert D.norm(X - X) < 1e-14 * D.norm(X)

@@ -164,3 +164,28 @@ def test_oracle_newton_kleinman_matches_dense_are():        # riccati/newton.jl:
         assert res[-1] < res[0] and len(res) <= 13
     assert o.gare_residual(prob, prob.Q.zero()) == prob.Q          # riccati/residual.jl:15
     assert o.quadratic_forcing(3, 0.05) == 0.9 * 0.05 and o.quadratic_forcing(1, 7.0) == 0.1 and o.superlinear_forcing(2, None) == 1 / 9
+
+
+def test_oracle_gmres_and_fgmres_match_dense_lyapunov():      # test/tiny_random.jl:25-45 (GMRES / FGMRES legs); lyapunov/gmres.jl:7-106
+    import scipy.sparse as sp
+    import warnings
+    rng = np.random.default_rng(1)
+    n, g = 50, 4
+    E = sp.random(n, n, density=1 / n, random_state=rng).tocsc(); E = (E + E.T + n * sp.identity(n)).tocsc()
+    A = sp.random(n, n, density=1 / n, random_state=rng).tocsc(); A = (A + A.T - n * sp.identity(n)).tocsc()
+    C = (-2) * o.lowrank(rng.random((n, g)), -np.eye(g))
+    prob = o.GALEProblem(E, A, C)
+    res0 = o.norm(C)
+    Xref = o.lyap_dense(A, E, C.dense())
+    Xg = o.gmres_solve(prob, o.GMRES(maxiters=5, reltol=1e-8))
+    assert o.norm(o.gale_residual(prob, Xg)) / res0 < 1e-8 and o.delta(Xg.dense(), Xref) < 1e-8
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xf = o.gmres_solve(prob, o.GMRES(maxiters=3, maxrestarts=0, reltol=1e-10,
+                                         preconditioner=o.ADI(maxiters=10, shifts=o.Cyclic(o.Heuristic(10, 10, 10)), compression_interval=20)))
+    assert o.norm(o.gale_residual(prob, Xf)) / res0 < 1e-10 and o.delta(Xf.dense(), Xref) < 1e-10
+    # dot(::LDLt, ::LDLt) is the Frobenius inner product (LDLt.jl:91-108); LyapunovOperator * X (gmres.jl:113-120)
+    X1, X2 = o.lowrank(rng.random((n, 3)), np.diag([1.0, -2.0, 0.5])), 0.7 * o.lowrank(rng.random((n, 2)))
+    assert abs(o.ldlt_dot(X1, X2) - np.sum(X1.dense() * X2.dense())) < 1e-12 * abs(np.sum(X1.dense() * X2.dense()))
+    LX = o.lyapunov_apply(E, A, X1).dense()
+    assert np.allclose(LX, A.T @ X1.dense() @ E + E.T @ X1.dense() @ A, rtol=1e-13, atol=1e-10)
