@@ -313,19 +313,34 @@ def _arnoldi_ritz(op, b0, k, desc):
     return Shifts.stabilize_ritz_values(list(np.linalg.eigvals(H[:k, :k])), desc)
 
 
-def heuristic_shifts(strategy: "Shifts.Heuristic", pencil: dev.Pencil):
+def heuristic_shifts(strategy: "Shifts.Heuristic", pencil: dev.Pencil, lr=None):
     """Shifts.init(::Heuristic, prob) (shifts/heuristic.jl:39-66).  The device holds E' and A', so the Arnoldi
-    processes run with E'^-1 A' and A'^-1 E', which have the same spectra as E^-1 A and A^-1 E."""
+    processes run with E'^-1 F' and F'^-1 E', which have the same spectra as E^-1 F and F^-1 E.  `lr = (alpha, U, V)` is the
+    low-rank part of F = A + inv(alpha) U V (LowRankUpdate): products add V'(U'x)/alpha, solves go through
+    Sherman-Morrison-Woodbury exactly like the reference's inner solvers (heuristic.jl:51-60)."""
     n = pencil.n
     b0 = np.ones(n)
     fE = pencil.factor(0.0, 1.0)
-    Rp = _arnoldi_ritz(lambda x: fE.solve(pencil.spmm(1, x.reshape(-1, 1)).numpy()), b0, strategy.k_plus, "E⁻¹A")
     fA = pencil.factor(1.0, 0.0)
-    Rm = _arnoldi_ritz(lambda x: fA.solve(pencil.spmm(0, x.reshape(-1, 1)).numpy()), b0, strategy.k_minus, "A⁻¹E")
+    if lr is None:
+        mulF = lambda x: pencil.spmm(1, x.reshape(-1, 1)).numpy()
+        solveF = lambda y: fA.solve(y)
+    else:
+        alpha, U, V = lr
+        U, Vt = np.asarray(U, dtype=float), np.asarray(V, dtype=float).T
+        W = np.asarray(fA.solve(Vt))                                  # A0'^-1 V'   (n x m)
+        Sm = alpha * np.eye(U.shape[1]) + U.T @ W
+        mulF = lambda x: pencil.spmm(1, x.reshape(-1, 1)).numpy() + (Vt @ (U.T @ x.reshape(-1, 1))) / alpha
+
+        def solveF(y):
+            z = np.asarray(fA.solve(y)).reshape(n, -1)
+            return z - W @ np.linalg.solve(Sm, U.T @ z)
+    Rp = _arnoldi_ritz(lambda x: fE.solve(mulF(x)), b0, strategy.k_plus, "E⁻¹A")
+    Rm = _arnoldi_ritz(lambda x: solveF(pencil.spmm(0, x.reshape(-1, 1)).numpy()), b0, strategy.k_minus, "A⁻¹E")
     return Shifts.heuristic(list(Rp) + [1.0 / v for v in Rm], strategy.nshifts)
 
 
-def _resolve_shifts(strategy, pencil):
+def _resolve_shifts(strategy, pencil, lr=None):
     """Map a strategy object to (shift_kind, n_history, values) of the C ABI."""
     S = Shifts
     if isinstance(strategy, S.Projection):
@@ -333,11 +348,11 @@ def _resolve_shifts(strategy, pencil):
     if isinstance(strategy, S.Cyclic):
         inner = strategy.inner
         if isinstance(inner, S.Heuristic):
-            vals = heuristic_shifts(inner, pencil)
+            vals = heuristic_shifts(inner, pencil, lr)
         elif isinstance(inner, S.Wrapped):
             if not isinstance(inner.inner, S.Heuristic):
                 raise NotImplementedError("Cyclic(Wrapped(f, s)) is supported for s = Heuristic only")
-            vals = list(inner.func(heuristic_shifts(inner.inner, pencil)))
+            vals = list(inner.func(heuristic_shifts(inner.inner, pencil, lr)))
         elif isinstance(inner, S.Strategy):
             raise NotImplementedError(f"Cyclic({type(inner).__name__}) is not supported")
         else:
@@ -441,8 +456,8 @@ def _split_operator(E, A):
     return A, None
 
 
-def _adi_options(alg: ADI, pencil):
-    kind, nh, vals = _resolve_shifts(alg.shifts, pencil)
+def _adi_options(alg: ADI, pencil, lr=None):
+    kind, nh, vals = _resolve_shifts(alg.shifts, pencil, lr)
     return dev.make_adi_options(alg.maxiters, alg.reltol, alg.abstol, alg.ignore_initial_guess, alg.compression_interval,
                                 alg.compression, kind, nh, vals, compress_exact=alg.compress_exact)
 
@@ -480,7 +495,7 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
     ctx = ctx or dev.default_context()
     A0, lr = _split_operator(prob.E, prob.A)
     pencil = _pencil_for(prob.E, A0, ctx)
-    opt, keep = _adi_options(alg, pencil)
+    opt, keep = _adi_options(alg, pencil, lr)
     Cd = prob.C._to_device(ctx, pencil)
     X0d = initial_guess._to_device(ctx, pencil) if initial_guess is not None else None
     U = Vt = None
@@ -629,8 +644,8 @@ def lyapunov_apply(E, A, X: LDLt) -> LDLt:
 def _specialize(alg, prob, ctx):
     """gmres.jl:122-134: the Heuristic shifts of a preconditioner are computed once per problem, not once per inner solve."""
     if isinstance(alg, ADI) and isinstance(alg.shifts, Shifts.Cyclic) and isinstance(alg.shifts.inner, Shifts.Heuristic):
-        A0, _ = _split_operator(prob.E, prob.A)
-        return dataclasses.replace(alg, shifts=Shifts.Cyclic(heuristic_shifts(alg.shifts.inner, _pencil_for(prob.E, A0, ctx))))
+        A0, lr = _split_operator(prob.E, prob.A)
+        return dataclasses.replace(alg, shifts=Shifts.Cyclic(heuristic_shifts(alg.shifts.inner, _pencil_for(prob.E, A0, ctx), lr)))
     if isinstance(alg, GMRES):
         return dataclasses.replace(alg, preconditioner=_specialize(alg.preconditioner, prob, ctx))
     return alg
