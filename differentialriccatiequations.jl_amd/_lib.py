@@ -83,6 +83,7 @@ PROTOTYPES = {
     "dre_ldlt_scale": (C.c_int, [_vp, _vp, C.c_double, _pvp]),
     "dre_ldlt_concatenate": (C.c_int, [_vp, _vp]),
     "dre_ldlt_compress": (C.c_int, [_vp, _vp]),
+    "dre_ldlt_compress_tol": (C.c_int, [_vp, _vp, C.c_double]),
     "dre_ldlt_norm": (C.c_int, [_vp, _vp, _pd]),
     "dre_ldlt_canonicalize": (C.c_int, [_vp, _vp]),
     "dre_ldlt_destructure": (C.c_int, [_vp, _vp, _pd, _pd, C.c_int, _pd, C.c_int]),

@@ -44,6 +44,15 @@ class LDLt:
             self._alphas, self._Ls, self._Ds = [a], [L], [D]
         return self
 
+    def _factors_any_form(self):
+        """(alpha, L, D) of a single-block view in WHATEVER form the engine holds (D may be a band matrix): enough for products
+        such as B'LD or E'L; skips the eigen-decomposition that the reference form (`alpha, L, D = X`) costs."""
+        if self._handle is not None and not self._Ls:
+            if getattr(self, "_raw", None) is None:
+                self._raw = self._handle.destructure()
+            return self._raw
+        return tuple(self)
+
     @property
     def alphas(self):
         return self._host()._alphas
@@ -71,6 +80,8 @@ class LDLt:
         return sum(L.shape[1] for L in self._Ls)
 
     def iszero(self):                    # LDLt.jl:114
+        if self._handle is not None and not self._Ls:
+            return self.rank() == 0      # engine results: no download / canonicalisation just to look at alpha
         return self.rank() == 0 or all(a == 0 for a in self.alphas)
 
     def zero(self):                      # LDLt.jl:116-121
@@ -755,7 +766,7 @@ def _spT_mul(M, L):
     return np.asarray(M.T @ L) if sp.issparse(M) else np.asarray(M).T @ L
 
 
-def gare_residual(prob: GAREProblem, X: LDLt, ctx=None) -> LDLt:
+def gare_residual(prob: GAREProblem, X: LDLt, ctx=None, drop_below=None) -> LDLt:
     """residual(::GAREProblem, ::LDLᵀ)  (riccati/residual.jl:5-52): the factors R = [C', A'L, E'L] and the small T are assembled on
     the host (n x (h + 2 z) doubles), the compression — the expensive part — runs on the device."""
     if X.iszero():
@@ -763,7 +774,7 @@ def gare_residual(prob: GAREProblem, X: LDLt, ctx=None) -> LDLt:
         return g * lowrank(Ct.copy(), np.array(S, dtype=float))
     gamma, Ct, S = prob.Q
     beta, B, Rinv = prob.G
-    alpha, L, D = X
+    alpha, L, D = X._factors_any_form()
     h, z = Ct.shape[1], L.shape[1]
     BtLD = (B.T @ L) @ D * (alpha * beta)
     R = np.hstack([Ct, _spT_mul(prob.A, L), _spT_mul(prob.E, L)])
@@ -773,8 +784,10 @@ def gare_residual(prob: GAREProblem, X: LDLt, ctx=None) -> LDLt:
     T[h + z:, h:h + z] = alpha * D
     T[h + z:, h + z:] = -(BtLD.T @ np.asarray(Rinv) @ BtLD)
     ctx = ctx or dev.default_context()
-    _pencil_for(prob.E, prob.A, ctx)                 # (keeps the symbolic analysis of (E, A) cached for the Lyapunov solves)
-    return compress_(lowrank(R, T))
+    pencil = _pencil_for(prob.E, prob.A, ctx)
+    h = lowrank(R, T)._to_device(ctx, pencil)        # compressed on the device; the factors stay there until somebody looks at them
+    h.compress(drop_below)                           # drop_below: absolute truncation (the Newton loop passes a fraction of its tolerance)
+    return LDLt([], [], [], _handle=h)
 
 
 def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_info=False):
@@ -797,20 +810,20 @@ def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_i
     history, adi_iters, i = [], 0, 0
 
     def aux(Xc):
-        alpha, L, D = Xc
+        alpha, L, D = Xc._factors_any_form()
         EtL = _spT_mul(prob.E, L)
         BtLD = (B.T @ L) @ D * alpha
         return EtL, BtLD, BtLD @ EtL.T
 
     while True:
         EtL, BtLD, K = aux(X)
-        res = gare_residual(prob, X, ctx)
+        res = gare_residual(prob, X, ctx, drop_below=1e-3 * abstol)
         res_norm_prev, res_norm = res_norm, norm(res)
         if i > 0 and alg.linesearch and res_norm > (1 - 0.1) * res_norm_prev:      # Armijo, newton.jl:50-92
             Xt, lam = X, 0.5
             while True:
                 X = (1 - lam) * X_prev + lam * Xt
-                res = gare_residual(prob, X, ctx)
+                res = gare_residual(prob, X, ctx, drop_below=1e-3 * abstol)
                 res_norm = norm(res)
                 if res_norm < (1 - lam * 0.1) * res_norm_prev:
                     EtL, BtLD, K = aux(X)

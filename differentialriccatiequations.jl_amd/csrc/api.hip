@@ -395,6 +395,9 @@ int dre_ldlt_scale(dre_ctx* ctx, const dre_ldlt* a, double alpha, dre_ldlt** out
 }
 int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldlt_concatenate(&ctx->c, *x->x); }); }
 int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldlt_compress(&ctx->c, *x->x); }); }
+int dre_ldlt_compress_tol(dre_ctx* ctx, dre_ldlt* x, double abs_tol) {
+    return guarded(ctx, [&] { ldlt_compress(&ctx->c, *x->x, 4.0, false, abs_tol > 0.0 ? abs_tol : -1.0); });
+}
 int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x) {
     return guarded(ctx, [&] {
         LDLt& X = *x->x;

@@ -206,7 +206,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         qr_apply_q(ctx, qr, Lnew, false);
     }
     X.blocks.clear();
-    X.blocks.push_back({Lnew, Dnew, 1.0, exact});
+    X.blocks.push_back({Lnew, Dnew, 1.0, exact, true});
 }
 
 void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac, bool exact) {
@@ -227,6 +227,10 @@ double ldlt_norm(Ctx* ctx, LDLt& X) {
 // such as the Arnoldi vectors of the low-rank GMRES.  X itself is left untouched (the compression works on a shallow copy).
 double ldlt_norm_accurate(Ctx* ctx, const LDLt& X) {
     if (X.rank() == 0) return 0.0;
+    if (X.blocks.size() == 1 && X.blocks[0].ortho) {        // already compressed: L'L = I, nothing can cancel
+        auto& b0 = X.blocks[0];
+        return ldlt_norm_host(ctx, b0.L, b0.D, b0.alpha);
+    }
     LDLt Y = X;
     ldlt_compress(ctx, Y, 4.0, false);
     if (Y.rank() == 0) return 0.0;

@@ -17,6 +17,7 @@ struct LBlock {
     Mat D;          // k x k (dense storage)
     double alpha = 1.0;
     bool diag = false;   // D known to be diagonal
+    bool ortho = false;  // L has orthonormal columns (output of compress!): the Gram form of the norm is then fully accurate
 };
 struct LDLt {
     int n = 0;

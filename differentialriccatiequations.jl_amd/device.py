@@ -237,8 +237,11 @@ class DeviceLDLt:
     def concatenate(self):
         self.ctx.chk(self.ctx.lib.dre_ldlt_concatenate(self.ctx.ptr, self.ptr))
 
-    def compress(self):
-        self.ctx.chk(self.ctx.lib.dre_ldlt_compress(self.ctx.ptr, self.ptr))
+    def compress(self, abs_tol=None):
+        if abs_tol is not None and abs_tol > 0:
+            self.ctx.chk(self.ctx.lib.dre_ldlt_compress_tol(self.ctx.ptr, self.ptr, float(abs_tol)))
+        else:
+            self.ctx.chk(self.ctx.lib.dre_ldlt_compress(self.ctx.ptr, self.ptr))
 
     def canonicalize(self):
         self.ctx.chk(self.ctx.lib.dre_ldlt_canonicalize(self.ctx.ptr, self.ptr))

@@ -116,6 +116,10 @@ int dre_ldlt_add(dre_ctx* ctx, const dre_ldlt* a, const dre_ldlt* b, dre_ldlt** 
 int dre_ldlt_scale(dre_ctx* ctx, const dre_ldlt* a, double alpha, dre_ldlt** out);             /* LDLt.jl:156-159 */
 int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x);                                           /* LDLt.jl:174-191 */
 int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x);                                              /* LDLt.jl:204-225 */
+/* compress! with an ABSOLUTE truncation tolerance (Frobenius norm of what may be dropped) instead of the relative one: used where the
+ * caller only compares norm(x) with a tolerance (Riccati / Lyapunov residuals near convergence are pure cancellation noise relative to
+ * their own size, so a relative criterion keeps all of it).  abs_tol <= 0 behaves like dre_ldlt_compress. */
+int dre_ldlt_compress_tol(dre_ctx* ctx, dre_ldlt* x, double abs_tol);
 int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out);                                     /* LDLt.jl:77-89 */
 /* bring an engine result to the reference's canonical form: one component, D = diag(eigenvalues), |lambda| >= 100 eps max|lambda| */
 int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x);
