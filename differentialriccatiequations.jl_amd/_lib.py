@@ -89,6 +89,7 @@ PROTOTYPES = {
     "dre_ldlt_destructure": (C.c_int, [_vp, _vp, _pd, _pd, C.c_int, _pd, C.c_int]),
     "dre_adi_default_options": (C.c_int, [C.POINTER(AdiOptionsC)]),
     "dre_gale_solve": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
+    "dre_heuristic_ritz": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, C.c_int, C.c_int, _pd, _pd, _pd, _pd]),
     "dre_gale_residual": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _pvp]),
     "dre_adi_result_info": (C.c_int, [_vp, _pi64, _pd]),
     "dre_adi_result_history": (C.c_int, [_vp, _pd, _pi32, _pd, _pd]),

@@ -324,11 +324,31 @@ def _arnoldi_ritz(op, b0, k, desc):
     return Shifts.stabilize_ritz_values(list(np.linalg.eigvals(H[:k, :k])), desc)
 
 
-def heuristic_shifts(strategy: "Shifts.Heuristic", pencil: dev.Pencil, lr=None):
-    """Shifts.init(::Heuristic, prob) (shifts/heuristic.jl:39-66).  The device holds E' and A', so the Arnoldi
-    processes run with E'^-1 F' and F'^-1 E', which have the same spectra as E^-1 F and F^-1 E.  `lr = (alpha, U, V)` is the
-    low-rank part of F = A + inv(alpha) U V (LowRankUpdate): products add V'(U'x)/alpha, solves go through
-    Sherman-Morrison-Woodbury exactly like the reference's inner solvers (heuristic.jl:51-60)."""
+def heuristic_shifts(strategy: "Shifts.Heuristic", pencil: dev.Pencil, lr=None, on_device=True):
+    """Shifts.init(::Heuristic, prob) (shifts/heuristic.jl:39-66).  The two Arnoldi runs (Ritz values of E^-1 F and F^-1 E from
+    ones(n)) execute on the device in one call (`dre_heuristic_ritz`); `lr = (alpha, U, V)` is the low-rank part of
+    F = A + inv(alpha) U V (LowRankUpdate): products add it, solves go through Sherman-Morrison-Woodbury exactly like the reference's
+    inner solvers (heuristic.jl:51-60).  Stabilisation and the greedy min-max selection are host logic (Shifts.heuristic).
+    `on_device=False` runs the Arnoldi recurrences in NumPy with device solves/SpMMs (kept as a cross-check)."""
+    if not on_device:
+        return _heuristic_shifts_host_arnoldi(strategy, pencil, lr)
+    ctx = pencil.ctx
+    kp, km = int(strategy.k_plus), int(strategy.k_minus)
+    pr, pi_, mr, mi = np.zeros(kp), np.zeros(kp), np.zeros(km), np.zeros(km)
+    U = Vt = None
+    alpha = 1.0
+    if lr is not None:
+        alpha, Uh, Vh = lr
+        U, Vt = ctx.upload(np.asarray(Uh, dtype=float)), ctx.upload(np.ascontiguousarray(np.asarray(Vh, dtype=float).T))
+    as_pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ctx.chk(ctx.lib.dre_heuristic_ritz(ctx.ptr, pencil.ptr, 1.0, 0.0, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
+                                       kp, km, as_pd(pr), as_pd(pi_), as_pd(mr), as_pd(mi)))
+    Rp = Shifts.stabilize_ritz_values(list(pr + 1j * pi_), "E⁻¹A")
+    Rm = Shifts.stabilize_ritz_values(list(mr + 1j * mi), "A⁻¹E")
+    return Shifts.heuristic(list(Rp) + [1.0 / v for v in Rm], strategy.nshifts)
+
+
+def _heuristic_shifts_host_arnoldi(strategy, pencil, lr=None):
     n = pencil.n
     b0 = np.ones(n)
     fE = pencil.factor(0.0, 1.0)

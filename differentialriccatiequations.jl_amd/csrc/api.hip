@@ -473,6 +473,17 @@ int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, doub
         *out = r;
     });
 }
+int dre_heuristic_ritz(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                       int kplus, int kminus, double* plus_re, double* plus_im, double* minus_re, double* minus_im) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        GaleOperator op = make_operator(c, p, cA, cE, lr_alpha, U, Vt);
+        std::vector<std::complex<double>> rp, rm;
+        heuristic_ritz(c, op, kplus, kminus, rp, rm);
+        for (int i = 0; i < kplus; ++i) { plus_re[i] = rp[i].real(); plus_im[i] = rp[i].imag(); }
+        for (int i = 0; i < kminus; ++i) { minus_re[i] = rm[i].real(); minus_im[i] = rm[i].imag(); }
+    });
+}
 int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
                       dre_ldlt* C, dre_ldlt* X, dre_ldlt** out) {
     return guarded(ctx, [&] {

@@ -414,6 +414,9 @@ static double read_scalar(Ctx* ctx, const double* dev) {
     DRE_HIP(hipStreamSynchronize(ctx->stream));
     return h;
 }
+void frob2_device(Ctx* ctx, const Mat& A, double* out_dev) {
+    hipLaunchKernelGGL(k_frob2, dim3(1), dim3(1024), 0, ctx->stream, A.rows, A.cols, A.p, A.ld, out_dev);
+}
 double frob_norm_host(Ctx* ctx, const Mat& A) {
     if (A.empty()) return 0.0;
     DevArr<double> out(ctx, 1);

@@ -52,6 +52,7 @@ void add_diag(Ctx* ctx, Mat& dst, const double* diag_dev, double scale);  // dst
 void symmetrize(Ctx* ctx, Mat& S);                           // S = (S+S')/2
 void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double alpha);  // out = alpha * L * diag(D_ii)
 double frob_norm_host(Ctx* ctx, const Mat& A);               // synchronising
+void frob2_device(Ctx* ctx, const Mat& A, double* out_dev);   // ||A||_F^2 into device memory (no synchronisation)
 bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (small)
 
 // nrm = |alpha| * sqrt(trace((T*G)^2)) = |alpha| * ||R T R'||_F with G = R'R

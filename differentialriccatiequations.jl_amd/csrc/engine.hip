@@ -1,5 +1,6 @@
 // Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
 #include "engine.hpp"
+#include <functional>
 
 #include <algorithm>
 #include <numeric>
@@ -908,6 +909,93 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     res.converged = res.res_norm <= abstol;
     if (!res.converged) res.warnings |= 1;
     return res;
+}
+
+// =============================================================================================
+// Penzl's heuristic: Ritz values of E^-1 F and F^-1 E by two Arnoldi runs from ones(n), everything on the device
+// (/root/reference/src/shifts/heuristic.jl:39-66,103-130).  The engine holds the transposed operators, whose spectra are the same.
+// F' = Fs' + inv(alpha) Vt U' ; products add the rank-m term, solves go through Sherman-Morrison-Woodbury (heuristic.jl:51-60).
+// The Hessenberg matrix is accumulated on the device and downloaded once; its eigenvalues come from the host QR (hostla.hpp).
+// =============================================================================================
+__global__ void k_scale_inv_norm(int n, const double* __restrict__ w, const double* __restrict__ nrm2, double* __restrict__ out, double* __restrict__ hslot) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double nr = sqrt(nrm2[0]);
+    if (i == 0) *hslot = nr;
+    if (i < n) out[i] = w[i] / nr;
+}
+
+static std::vector<std::complex<double>> arnoldi_ritz(Ctx* ctx, int n, int k, const std::function<void(const Mat&, Mat&)>& apply) {
+    DRE_REQUIRE(k >= 1 && k < n, "heuristic shifts: Krylov dimension out of range");
+    Mat V(ctx, n, k + 1), H(ctx, k + 1, k), w(ctx, n, 1);
+    DevArr<double> nr(ctx, 1);
+    fill_mat(ctx, H, 0.0);
+    { Mat v0 = V.colsview(0, 1); fill_mat(ctx, v0, 1.0 / std::sqrt((double)n)); }         // b0 = ones(n) (heuristic.jl:68-80), normalised
+    for (int j = 0; j < k; ++j) {
+        Mat x = V.colsview(j, 1);
+        apply(x, w);
+        Mat Vj = V.colsview(0, j + 1);
+        Mat hcol = H.view(0, j, j + 1, 1);
+        gemm(ctx, true, false, 1.0, Vj, w, 0.0, hcol, nullptr, "gemm_arnoldi");           // classical Gram-Schmidt, twice
+        gemm(ctx, false, false, -1.0, Vj, hcol, 1.0, w, nullptr, "gemm_arnoldi");
+        Mat g2(ctx, j + 1, 1);
+        gemm(ctx, true, false, 1.0, Vj, w, 0.0, g2, nullptr, "gemm_arnoldi");
+        gemm(ctx, false, false, -1.0, Vj, g2, 1.0, w, nullptr, "gemm_arnoldi");
+        vals_axpby(ctx, j + 1, 1.0, hcol.p, 1.0, g2.p, hcol.p);
+        frob2_device(ctx, w, nr.p);
+        Mat vn = V.colsview(j + 1, 1);
+        hipLaunchKernelGGL(k_scale_inv_norm, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, n, w.p, nr.p, vn.p, H.p + (size_t)(j + 1) + (size_t)j * H.ld);
+    }
+    std::vector<double> hh((size_t)(k + 1) * k), hk((size_t)k * k);
+    DRE_HIP(hipMemcpyAsync(hh.data(), H.p, hh.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < k; ++c) for (int r = 0; r < k; ++r) hk[r + (size_t)c * k] = hh[r + (size_t)c * (k + 1)];
+    return host_eigvals(k, hk);
+}
+
+void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std::vector<std::complex<double>>& rplus,
+                    std::vector<std::complex<double>>& rminus) {
+    const Pencil& P = *op.P;
+    const int n = P.n, m = op.has_lr ? op.U.cols : 0;
+    Factor<double> fE, fF;
+    mf_factor<double>(ctx, P, op.valFt.p, P.valEt.p, 0.0, 1.0, fE);        // E'
+    mf_factor<double>(ctx, P, op.valFt.p, P.valEt.p, 1.0, 0.0, fF);        // Fs'
+    mf_check(ctx, fE); mf_check(ctx, fF);
+    Mat W, Sinv, t1, t2;
+    DevArr<int> serr(ctx, 1);
+    if (m) {
+        DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
+        W = Mat(ctx, n, m); copy_mat(ctx, op.Vt, W);
+        mf_solve<double>(ctx, P, fF, W.p, W.ld, m, nullptr);               // Fs'^-1 Vt
+        Mat S(ctx, m, m); Sinv = Mat(ctx, m, m); t1 = Mat(ctx, m, 1); t2 = Mat(ctx, m, 1);
+        gemm(ctx, true, false, 1.0, op.U, W, 0.0, S, nullptr, "gemm_arnoldi");
+        DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, S.p, S.ld, op.alpha, Sinv.p, (const AdiState*)nullptr, serr.p);
+    }
+    // w = E'^-1 (F' x)
+    rplus = arnoldi_ritz(ctx, n, kplus, [&](const Mat& x, Mat& w) {
+        spmm(ctx, n, P.ptr.p, P.idx.p, op.valFt.p, x, w, 1.0, 0.0, nullptr);
+        if (m) {
+            gemm(ctx, true, false, 1.0, op.U, x, 0.0, t1, nullptr, "gemm_arnoldi");
+            gemm(ctx, false, false, 1.0 / op.alpha, op.Vt, t1, 1.0, w, nullptr, "gemm_arnoldi");
+        }
+        mf_solve<double>(ctx, P, fE, w.p, w.ld, 1, nullptr);
+    });
+    // w = F'^-1 (E' x)
+    rminus = arnoldi_ritz(ctx, n, kminus, [&](const Mat& x, Mat& w) {
+        spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, x, w, 1.0, 0.0, nullptr);
+        mf_solve<double>(ctx, P, fF, w.p, w.ld, 1, nullptr);
+        if (m) {
+            gemm(ctx, true, false, 1.0, op.U, w, 0.0, t1, nullptr, "gemm_arnoldi");
+            gemm(ctx, false, false, 1.0, Sinv, t1, 0.0, t2, nullptr, "gemm_arnoldi");
+            gemm(ctx, false, false, -1.0, W, t2, 1.0, w, nullptr, "gemm_arnoldi");
+        }
+    });
+    if (m) {
+        int herr = 0;
+        DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (herr) throw Error(ERR_SINGULAR, "heuristic shifts: SMW capacitance matrix is singular");
+    }
 }
 
 // =============================================================================================

@@ -72,6 +72,9 @@ struct GaleOperator {
     Mat U;                     // n x m
     Mat Vt;                    // n x m  (V')
 };
+// Ritz values of E^-1 F (rplus) and F^-1 E (rminus), kplus / kminus Arnoldi steps from ones(n)  (shifts/heuristic.jl:39-66,103-130)
+void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std::vector<std::complex<double>>& rplus,
+                    std::vector<std::complex<double>>& rminus);
 
 // ---- shift strategies (/root/reference/src/Shifts.jl:79-116, src/shifts/*.jl) -----------------------------
 struct ShiftSpec {

@@ -149,6 +149,12 @@ int dre_adi_default_options(dre_adi_options* opt);
  * (LowRankUpdate, src/LowRankUpdate.jl:18-39).  U is n x m, Vt = V' is n x m; both NULL for a plain sparse F. */
 int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
                    const dre_dense* Vt, dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_result** out);
+/* Penzl's heuristic, device part (src/shifts/heuristic.jl:39-66,103-130): Ritz values of E^-1 F (kplus Arnoldi steps) and of F^-1 E
+ * (kminus steps), both from ones(n), for F = cA*A + cE*E + inv(lr_alpha)*U*V (products and solves see the low-rank part, the solves
+ * through Sherman-Morrison-Woodbury like heuristic.jl:51-60).  Outputs: kplus + kminus complex numbers, raw (unsorted, unstabilised);
+ * the selection `heuristic(R, nshifts)` (heuristic.jl:22-37,82-101) is host logic of the shim. */
+int dre_heuristic_ritz(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                       int kplus, int kminus, double* plus_re, double* plus_im, double* minus_re, double* minus_im);
 /* residual(GALEProblem, X)  (src/lyapunov/residual.jl:3-31) */
 int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
                       const dre_dense* Vt, dre_ldlt* C, dre_ldlt* X, dre_ldlt** out);

@@ -25,6 +25,26 @@ def test_heuristic_shifts_on_device_match_the_oracle(ctx, rail371):     # shifts
     assert np.allclose(mine, gold, rtol=1e-6)        # symmetric pencil: E'^-1 A' and E^-1 A generate the same Krylov spaces
 
 
+@pytest.mark.parametrize("n", [371, 1357])
+def test_device_arnoldi_matches_the_host_arnoldi_with_and_without_low_rank_part(ctx, n):   # heuristic.jl:39-66 with A::LowRankUpdate (:51-60)
+    d = D.steel_profile(n)
+    P = D.Pencil(d.E, d.A, ctx)
+    K = 1e-2 * np.random.default_rng(n).standard_normal((d.B.shape[1], n))
+    H = D.Shifts.Heuristic(10, 20, 20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for lr in (None, (-1.0, d.B, K)):
+            a = np.array(sorted(v.real for v in D.heuristic_shifts(H, P, lr)))
+            b = np.array(sorted(v.real for v in D.heuristic_shifts(H, P, lr, on_device=False)))
+            assert len(a) == len(b) == 10 and np.all(a < 0)
+            assert np.allclose(a, b, rtol=1e-6)
+    gold = np.load(os.path.join(GOLDEN, f"heuristic_shifts_{n}.npy"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mine = np.array(sorted(v.real for v in D.heuristic_shifts(D.Shifts.Heuristic(10, 20, 20), P)))
+    assert np.allclose(mine, gold, rtol=1e-6)
+
+
 def test_cyclic_heuristic_and_wrapped_strategies(ctx, rail371):          # test/rail.jl:79-87 flavour, test/Shifts.jl:126-131
     d, L, Dm = rail371
     prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
