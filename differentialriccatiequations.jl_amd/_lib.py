@@ -34,6 +34,8 @@ class AdiOptionsC(C.Structure):
         ("shifts_im", C.POINTER(C.c_double)),
         ("compress_tolfac", C.c_double),
         ("compress_exact", C.c_int32),
+        ("heuristic_kplus", C.c_int32),
+        ("heuristic_kminus", C.c_int32),
     ]
 
 

@@ -379,7 +379,7 @@ def _resolve_shifts(strategy, pencil, lr=None):
     if isinstance(strategy, S.Cyclic):
         inner = strategy.inner
         if isinstance(inner, S.Heuristic):
-            vals = heuristic_shifts(inner, pencil, lr)
+            return 2, 2, (inner.nshifts, inner.k_plus, inner.k_minus)       # resolved inside the engine, per Lyapunov solve (adi.jl:54)
         elif isinstance(inner, S.Wrapped):
             if not isinstance(inner.inner, S.Heuristic):
                 raise NotImplementedError("Cyclic(Wrapped(f, s)) is supported for s = Heuristic only")
@@ -490,7 +490,8 @@ def _split_operator(E, A):
 def _adi_options(alg: ADI, pencil, lr=None):
     kind, nh, vals = _resolve_shifts(alg.shifts, pencil, lr)
     return dev.make_adi_options(alg.maxiters, alg.reltol, alg.abstol, alg.ignore_initial_guess, alg.compression_interval,
-                                alg.compression, kind, nh, vals, compress_exact=alg.compress_exact)
+                                alg.compression, kind, nh, vals if kind == 0 else None, compress_exact=alg.compress_exact,
+                                heuristic=vals if kind == 2 else None)
 
 
 def _replay_gale(observer, prob, alg, info):

@@ -423,6 +423,7 @@ int dre_adi_default_options(dre_adi_options* o) {
     o->compression = 1; o->shift_kind = 1; o->n_history = 2; o->nshifts = 0; o->shifts_re = nullptr; o->shifts_im = nullptr;
     o->compress_tolfac = 4.0;
     o->compress_exact = 0;
+    o->heuristic_kplus = 0; o->heuristic_kminus = 0;
     return DRE_OK;
 }
 static AdiOptions convert_options(const dre_adi_options* o) {
@@ -436,6 +437,10 @@ static AdiOptions convert_options(const dre_adi_options* o) {
         a.shifts.kind = ShiftSpec::CYCLIC;
         DRE_REQUIRE(o->nshifts > 0 && o->shifts_re, "Cyclic shifts need at least one value");
         for (int i = 0; i < o->nshifts; ++i) a.shifts.values.emplace_back(o->shifts_re[i], o->shifts_im ? o->shifts_im[i] : 0.0);
+    } else if (o->shift_kind == 2) {
+        a.shifts.kind = ShiftSpec::HEURISTIC;
+        DRE_REQUIRE(o->nshifts > 0 && o->heuristic_kplus > 0 && o->heuristic_kminus > 0, "Heuristic(nshifts, k+, k-) must be positive");
+        a.shifts.h_nshifts = o->nshifts; a.shifts.h_kplus = o->heuristic_kplus; a.shifts.h_kminus = o->heuristic_kminus;
     } else {
         a.shifts.kind = ShiftSpec::PROJECTION;
         DRE_REQUIRE(o->n_history > 0 && o->n_history % 2 == 0, "History must be even");   // projection.jl:28-32

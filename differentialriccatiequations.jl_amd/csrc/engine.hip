@@ -614,14 +614,24 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
 }
 
 struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; BufP keep2; };
+std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOperator& op, int nshifts, int kplus, int kminus, int* warnings);
 
-AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
+AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
                     FactorCache* cache) {
     const Pencil& P = *op.P;
     const int n = P.n;
     FactorCache local;
     if (!cache) cache = &local;
     AdiResult res;
+    AdiOptions opt_h;                           // Cyclic(Heuristic(...)): the values are recomputed from (E, F) for this solve (adi.jl:54)
+    const AdiOptions* optp = &opt_in;
+    if (opt_in.shifts.kind == ShiftSpec::HEURISTIC) {
+        opt_h = opt_in;
+        opt_h.shifts.kind = ShiftSpec::CYCLIC;
+        opt_h.shifts.values = heuristic_shift_values(ctx, op, opt_in.shifts.h_nshifts, opt_in.shifts.h_kplus, opt_in.shifts.h_kminus, &res.warnings);
+        optp = &opt_h;
+    }
+    const AdiOptions& opt = *optp;
     const double ctf = opt.compress_tolfac;
     const bool cex = opt.compress_exact;
     ldlt_destructure(ctx, C, ctf, cex);
@@ -729,7 +739,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             Mat V1, V2;
             bool norm_done = false;
             if (is_real) {
-                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt.shifts.kind == ShiftSpec::CYCLIC);
+                // dense inverses pay off only for shift lists that persist across Lyapunov solves (user-given Cyclic values)
+                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC);
                 used_real.push_back(fe);
                 auto key = std::make_pair(mu.real(), 0.0);
                 auto sc = smw_cache.find(key);
@@ -996,6 +1007,52 @@ void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         if (herr) throw Error(ERR_SINGULAR, "heuristic shifts: SMW capacitance matrix is singular");
     }
+}
+
+// Host logic of Penzl's heuristic: stabilisation of the Ritz values (shifts/helpers.jl:115-140) and the greedy min-max
+// selection (shifts/heuristic.jl:82-101); conjugate pairs are appended adjacently.
+static std::vector<std::complex<double>> stabilize_ritz(std::vector<std::complex<double>> v, int* warnings) {
+    std::vector<std::complex<double>> stable;
+    for (auto& x : v) if (x.real() < 0.0) stable.push_back(x);
+    if (stable.size() == v.size()) return v;
+    if (stable.empty()) {                      // all unstable: flip them (helpers.jl:136-138)
+        if (warnings) *warnings |= 8;
+        for (auto& x : v) x = std::complex<double>(-x.real(), x.imag());
+        return v;
+    }
+    if (warnings) *warnings |= 4;              // some unstable: discard them (helpers.jl:133-134)
+    return stable;
+}
+static std::vector<std::complex<double>> heuristic_select(const std::vector<std::complex<double>>& R, int nshifts) {
+    DRE_REQUIRE(!R.empty(), "heuristic shifts: no Ritz values");
+    auto sfun = [](std::complex<double> t, const std::vector<std::complex<double>>& P) {
+        double out = 1.0;
+        for (auto& p : P) out *= std::abs(t - p) / std::abs(t + p);
+        return out;
+    };
+    size_t best = 0; double bestv = 0.0;
+    for (size_t i = 0; i < R.size(); ++i) {
+        double mx = 0.0;
+        for (auto& t : R) mx = std::max(mx, sfun(t, {R[i]}));
+        if (i == 0 || mx < bestv) { best = i; bestv = mx; }
+    }
+    std::vector<std::complex<double>> P;
+    auto push = [&](std::complex<double> p) { P.push_back(p); if (p.imag() != 0.0) P.push_back(std::conj(p)); };
+    push(R[best]);
+    while ((int)P.size() < nshifts) {
+        size_t arg = 0; double mv = -1.0;
+        for (size_t i = 0; i < R.size(); ++i) { const double v = sfun(R[i], P); if (v > mv) { mv = v; arg = i; } }
+        push(R[arg]);
+    }
+    return P;
+}
+std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOperator& op, int nshifts, int kplus, int kminus, int* warnings) {
+    std::vector<std::complex<double>> rp, rm;
+    heuristic_ritz(ctx, op, kplus, kminus, rp, rm);
+    rp = stabilize_ritz(rp, warnings);
+    rm = stabilize_ritz(rm, warnings);
+    for (auto& v : rm) rp.push_back(1.0 / v);
+    return heuristic_select(rp, nshifts);
 }
 
 // =============================================================================================

@@ -78,9 +78,10 @@ void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std
 
 // ---- shift strategies (/root/reference/src/Shifts.jl:79-116, src/shifts/*.jl) -----------------------------
 struct ShiftSpec {
-    enum Kind { CYCLIC = 0, PROJECTION = 1 } kind = PROJECTION;
+    enum Kind { CYCLIC = 0, PROJECTION = 1, HEURISTIC = 2 } kind = PROJECTION;
     std::vector<std::complex<double>> values;   // CYCLIC
     int n_history = 2;                          // PROJECTION
+    int h_nshifts = 0, h_kplus = 0, h_kminus = 0;   // HEURISTIC: Cyclic(Heuristic(nshifts, k+, k-)), recomputed per Lyapunov solve
 };
 
 struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30

@@ -263,7 +263,7 @@ class DeviceLDLt:
 
 
 def make_adi_options(maxiters=100, reltol=None, abstol=None, ignore_initial_guess=False, compression_interval=10,
-                     compression=True, shift_kind=1, n_history=2, shifts=None, compress_tolfac=4.0, compress_exact=False):
+                     compression=True, shift_kind=1, n_history=2, shifts=None, compress_tolfac=4.0, compress_exact=False, heuristic=None):
     o = AdiOptionsC()
     _lib.load().dre_adi_default_options(C.byref(o))
     o.maxiters = int(maxiters)
@@ -285,4 +285,6 @@ def make_adi_options(maxiters=100, reltol=None, abstol=None, ignore_initial_gues
         o.shifts_re = _dptr(re)
         o.shifts_im = _dptr(im)
         keep = (re, im)
+    elif shift_kind == 2:                     # Cyclic(Heuristic(nshifts, k+, k-)): recomputed on the device per Lyapunov solve
+        o.nshifts, o.heuristic_kplus, o.heuristic_kminus = (int(v) for v in heuristic)
     return o, keep

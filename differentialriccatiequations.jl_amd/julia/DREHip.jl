@@ -137,6 +137,11 @@ end
 module Shifts
 abstract type Strategy end
 struct Cyclic <: Strategy; inner; end
+struct Heuristic <: Strategy           # src/shifts/heuristic.jl:22-37
+    nshifts::Int
+    k₊::Int
+    k₋::Int
+end
 struct Projection <: Strategy
     n_history::Int
     Projection(u) = isodd(u) ? throw(ArgumentError("History must be even; got $u")) : new(u)
@@ -170,18 +175,25 @@ struct AdiOptionsC
     shifts_im::Ptr{Float64}
     compress_tolfac::Float64
     compress_exact::Int32
+    heuristic_kplus::Int32
+    heuristic_kminus::Int32
 end
 
 function options(alg::ADI)
-    if alg.shifts isa Shifts.Cyclic
+    if alg.shifts isa Shifts.Cyclic && alg.shifts.inner isa Shifts.Heuristic
+        h = alg.shifts.inner          # Cyclic(Heuristic(nshifts, k₊, k₋)): recomputed on the device at the start of every Lyapunov solve
+        o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
+                        alg.compression_interval, alg.compression, 2, 2, h.nshifts, C_NULL, C_NULL, 4.0, alg.compress_exact, h.k₊, h.k₋)
+        return o, nothing
+    elseif alg.shifts isa Shifts.Cyclic
         vals = ComplexF64.(collect(alg.shifts.inner))
         re, im = real.(vals), imag.(vals)
         o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact)
+                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact, 0, 0)
         return o, (re, im)
     end
     o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact)
+                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0)
     o, nothing
 end
 

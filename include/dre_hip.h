@@ -134,14 +134,17 @@ typedef struct dre_adi_options {
     int32_t ignore_initial_guess;  /* 0 */
     int32_t compression_interval;  /* 10 */
     int32_t compression;           /* 1 */
-    int32_t shift_kind;            /* 0 = Cyclic(values), 1 = Projection(n_history) */
+    int32_t shift_kind;            /* 0 = Cyclic(values), 1 = Projection(n_history), 2 = Cyclic(Heuristic(nshifts, kplus, kminus)) recomputed
+                                      on the device from (E, F) at the start of every Lyapunov solve (adi.jl:54, heuristic.jl:39-66) */
     int32_t n_history;             /* 2 */
-    int32_t nshifts;               /* Cyclic: number of values (conjugate pairs adjacent) */
+    int32_t nshifts;               /* Cyclic: number of values (conjugate pairs adjacent); Heuristic: number of shifts to select */
     const double* shifts_re;
     const double* shifts_im;       /* may be NULL (all real) */
     double compress_tolfac;        /* <= 0 -> 4: the engine's compressions drop what lies below tolfac*eps*||S||_F */
     int32_t compress_exact;        /* 1: eigen-decomposition + 100*eps*max|lambda| threshold at every compression (reference arithmetic);
                                       0 (default): Krylov-truncated compression, D stays tridiagonal inside the engine */
+    int32_t heuristic_kplus;       /* shift_kind 2: Arnoldi steps with E^-1 F */
+    int32_t heuristic_kminus;      /* shift_kind 2: Arnoldi steps with F^-1 E */
 } dre_adi_options;
 int dre_adi_default_options(dre_adi_options* opt);
 

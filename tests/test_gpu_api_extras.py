@@ -45,6 +45,26 @@ def test_device_arnoldi_matches_the_host_arnoldi_with_and_without_low_rank_part(
     assert np.allclose(mine, gold, rtol=1e-6)
 
 
+def test_engine_side_heuristic_selection_matches_the_host_logic(ctx, rail371):
+    """Cyclic(Heuristic(...)) is resolved inside the engine at the start of every Lyapunov solve (adi.jl:54): the shifts it consumed are
+    the host-side selection (Shifts.heuristic on the device Ritz values) for the same operator, low-rank part included."""
+    d, L, Dm = rail371
+    rng = np.random.default_rng(2)
+    K = 1e-2 * rng.standard_normal((d.B.shape[1], 371))
+    H = D.Shifts.Heuristic(10, 20, 20)
+    Cl = D.lowrank(rng.standard_normal((371, 3)))
+    P = D.Pencil(d.E, d.A, ctx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for F, lr in ((d.A, None), (D.lr_update(d.A, -1.0, d.B, K), (-1.0, d.B, K))):
+            X, info = D.solve_gale(D.GALEProblem(d.E, F, Cl), D.ADI(shifts=D.Shifts.Cyclic(H), maxiters=200), return_info=True)
+            expect = np.array(D.heuristic_shifts(H, P, lr))
+            used = info["shifts"]
+            assert info["converged"] and len(used) >= len(expect)
+            assert np.allclose(used[:len(expect)], expect, rtol=1e-8)
+            assert np.allclose(used[len(expect):2 * len(expect)], expect[:max(0, len(used) - len(expect))][:len(expect)], rtol=1e-8)   # cyclic wrap-around
+
+
 def test_cyclic_heuristic_and_wrapped_strategies(ctx, rail371):          # test/rail.jl:79-87 flavour, test/Shifts.jl:126-131
     d, L, Dm = rail371
     prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
