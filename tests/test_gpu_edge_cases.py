@@ -1,0 +1,66 @@
+"""Edge cases through the HIP path: tiny state dimensions (below the panel / tile widths), zero right-hand sides, zero time steps,
+rank-deficient and empty factors — the places where blocked kernels usually break."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dre_amd as D
+import dre_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(rng, n, m=2, q=2):
+    A = sp.csc_matrix(-2.0 * np.eye(n) + (0.3 * rng.standard_normal((n, n)) / np.sqrt(n) if n > 1 else 0.0))
+    A = (A + A.T).tocsc() * 0.5 - sp.identity(n, format="csc")
+    E = (sp.identity(n, format="csc") * 1.5 + sp.csc_matrix(np.diag(0.1 * rng.random(n)))).tocsc()
+    return E, A, rng.standard_normal((n, m)), rng.standard_normal((q, n))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 15, 17, 33, 65])
+def test_gdre_on_tiny_systems_matches_the_dense_oracle(ctx, n):
+    rng = np.random.default_rng(n)
+    E, A, B, Cm = _system(rng, n, m=min(2, n), q=min(2, n))
+    L0 = np.linalg.solve(E.toarray(), Cm.T)
+    prob = D.GDREProblem(E, A, B, Cm, D.lowrank(L0, 0.01 * np.eye(L0.shape[1])), (1.0, 0.0))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol = D.solve(prob, D.Ros1(D.ADI(maxiters=200)), dt=-0.25)
+        ref = o.solve_dense_ros1(o.GDREProblem(E, A, B, Cm, L0 @ (0.01 * np.eye(L0.shape[1])) @ L0.T, (1.0, 0.0)), dt=-0.25)
+    assert len(sol.K) == 5 and sol.K[-1].shape == (B.shape[1], n)
+    eps_tol = max(np.linalg.norm(ref.K[-1]) * n * np.finfo(float).eps * 100, 1e-13)       # test/rail.jl:56
+    assert np.linalg.norm(ref.K[-1] - sol.K[-1]) < 10 * eps_tol
+
+
+def test_zero_right_hand_side_and_zero_time_steps(ctx):
+    rng = np.random.default_rng(0)
+    n = 40
+    E, A, B, Cm = _system(rng, n)
+    Z = D.lowrank(np.zeros((n, 0)), np.zeros((0, 0)))
+    X, info = D.solve_gale(D.GALEProblem(E, A, Z), D.ADI(), return_info=True)          # C = 0  =>  X = 0, nothing to iterate
+    assert X.rank() == 0 and info["iters"] == 0 and info["converged"]
+    C0 = D.lowrank(rng.standard_normal((n, 3)), np.zeros((3, 3)))                        # factors present, inner matrix zero
+    X, info = D.solve_gale(D.GALEProblem(E, A, C0), D.ADI(), return_info=True)
+    assert info["converged"] and (X.rank() == 0 or np.linalg.norm(X.dense()) < 1e-14)
+    L0 = np.linalg.solve(E.toarray(), Cm.T)
+    prob = D.GDREProblem(E, A, B, Cm, D.lowrank(L0, 0.01 * np.eye(2)), (3.0, 3.0))      # empty time span: only the initial value
+    sol = D.solve(prob, D.Ros1(D.ADI()), dt=-1.0)
+    assert len(sol.K) == 1 and len(sol.t) == 1 and sol.X[0] is prob.X0
+    K0 = (B.T @ L0) @ (0.01 * np.eye(2)) @ (L0.T @ E)
+    assert np.allclose(sol.K[0], K0, rtol=1e-12, atol=1e-14)
+
+
+def test_compress_of_rank_deficient_and_cancelling_factors(ctx):
+    rng = np.random.default_rng(1)
+    n = 70
+    L = rng.standard_normal((n, 4))
+    X = D.lowrank(np.hstack([L, L, L[:, :2]]), np.diag([1.0, 2.0, -1.0, 0.5, 3.0, 1.0, 1.0, -0.5, 2.0, 1.0]))   # only 4 independent columns
+    ref = X.dense()
+    D.compress_(X)
+    assert X.rank() <= 4 and np.allclose(X.dense(), ref, rtol=1e-12, atol=1e-12 * np.linalg.norm(ref))
+    Y = D.lowrank(L) - D.lowrank(L)                                                   # exact cancellation: compress! gives the empty factor
+    D.compress_(Y)
+    assert Y.rank() == 0 or np.linalg.norm(Y.dense()) < 1e-13 * np.linalg.norm(L) ** 2
+    assert D.norm(Y) < 1e-13 * np.linalg.norm(L) ** 2
