@@ -64,3 +64,29 @@ def test_compress_of_rank_deficient_and_cancelling_factors(ctx):
     D.compress_(Y)
     assert Y.rank() == 0 or np.linalg.norm(Y.dense()) < 1e-13 * np.linalg.norm(L) ** 2
     assert D.norm(Y) < 1e-13 * np.linalg.norm(L) ** 2
+
+
+def test_two_contexts_on_two_host_threads_give_identical_results(rail371):
+    """The C ABI is thread-compatible: one context (private HIP stream + pool) per host thread, no shared mutable state that matters
+    (SURVEY §8b threading contract).  Two threads solving the same problem concurrently reproduce the single-thread result bit for bit."""
+    import os
+    import threading
+    from conftest import GOLDEN
+    d, L, Dm = rail371
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p)))
+    prob = lambda: D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 3900.0))
+    ref = D.solve_gdre(prob(), alg, dt=-100.0, ctx=D.Context(0))
+    out = [None, None]
+
+    def work(i):
+        c = D.Context(0)
+        out[i] = D.solve_gdre(prob(), alg, dt=-100.0, ctx=c)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for s in out:
+        assert s is not None and len(s.K) == len(ref.K)
+        for a, b in zip(s.K, ref.K):
+            assert np.array_equal(a, b)
