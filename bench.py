@@ -144,7 +144,7 @@ def main():
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
         # so a two-step probe picks the fastest of a few thread counts and the sample runs with that one.
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import warnings
             import dre_oracle as o
