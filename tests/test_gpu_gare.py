@@ -69,3 +69,24 @@ def test_gare_residual_of_zero_and_errors(ctx, rail371):
     assert abs(D.norm(r0) - D.norm(are.Q)) < 1e-12 * D.norm(are.Q)      # riccati/residual.jl:15: residual of zero is Q
     with pytest.raises(NotImplementedError):                            # newton.jl:8-17
         D.solve(D.GAREProblem(d.E, d.A, 2.0 * D.lowrank(d.B), are.Q), D.Newton())
+
+
+@pytest.mark.parametrize("n", [1357, 5177])
+def test_newton_adi_benchmark_configuration_at_full_sizes(ctx, n):     # benchmark/benchmarks.jl:14-49 ("adi" suite): G = lowrank(1000 B)
+    d = D.steel_profile(n)
+    are = D.GAREProblem(d.E, d.A, D.lowrank(1000.0 * d.B), D.lowrank(np.ascontiguousarray(d.C.T)))
+    S = D.Shifts
+    newton = D.Newton(D.ADI(maxiters=200, ignore_initial_guess=True, shifts=S.Cyclic(S.Heuristic(20, 30, 30))), maxiters=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve(are, newton, return_info=True)
+    assert info["converged"] and info["newton_steps"] <= 20
+    res = D.norm(D.residual(are, X)) / D.norm(are.Q)
+    assert res < 100 * n * np.finfo(float).eps                          # default Newton tolerance n*eps (types.jl:73-76), generous factor
+    # feedback gain consistency: K = B'XE from the downloaded factors is stabilising (closed-loop pencil has no eigenvalue in the right half plane)
+    a, L, Dd = X
+    K = (1000.0 * d.B).T @ L @ (a * Dd) @ (L.T @ d.E)
+    if n <= 1357:
+        Acl = d.A.toarray() - (1000.0 * d.B) @ K
+        lam = sla.eigvals(Acl, d.E.toarray())
+        assert lam.real.max() < 0
