@@ -51,3 +51,15 @@ sol = o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm), tspan), o.Ros2
 ref = o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm).dense(), tspan), o.Ros2(), dt=-100.0)
 np.savez(os.path.join(HERE, "ros2_371.npz"), K=np.array(sol.K), K_dense_end=ref.K[-1], iters=np.array([s["iters"] for s in st]), t=sol.t, shifts=p2)
 print("ros2", [s["iters"] for s in st], np.linalg.norm(ref.K[-1] - sol.K[-1]), np.linalg.norm(ref.K[-1]) * 371 * 2.2e-16 * 100)
+
+# gare_371.npz : Kleinman-Newton (oracle, exact inner solves, the fixed Cyclic shifts above) on the SteelProfile(371) surrogate:
+#                feedback gain K = B'XE (7 x 371), Newton residual history, and the dense ARE solution's K as a second opinion
+import scipy.linalg as sla
+st = []
+X = o.solve_newton(o.GAREProblem(d.E, d.A, o.lowrank(d.B), o.lowrank(d.C.T)),
+                   o.Newton(o.ADI(ignore_initial_guess=True, shifts=o.Cyclic(list(p)), maxiters=200), maxiters=12, reltol=1e-10, inexact=False), stats=st)
+a, Lx, Dx = X.destructure()
+K = (d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E)
+Xd = sla.solve_continuous_are(d.A.toarray(), d.B, d.C.T @ d.C, np.eye(d.B.shape[1]), e=d.E.toarray())
+np.savez(os.path.join(HERE, "gare_371.npz"), K=K, K_dense=d.B.T @ Xd @ d.E.toarray(), residuals=np.array([s["res"] for s in st]), rank=X.rank())
+print("gare", [f"{s['res']:.2e}" for s in st], X.rank(), np.linalg.norm(K - d.B.T @ Xd @ d.E.toarray()) / np.linalg.norm(K))

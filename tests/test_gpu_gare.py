@@ -90,3 +90,22 @@ def test_newton_adi_benchmark_configuration_at_full_sizes(ctx, n):     # benchma
         Acl = d.A.toarray() - (1000.0 * d.B) @ K
         lam = sla.eigvals(Acl, d.E.toarray())
         assert lam.real.max() < 0
+
+
+def test_newton_reproduces_the_golden_feedback_gain(ctx, rail371):
+    """tests/golden/gare_371.npz (oracle Newton with exact inner solves + dense ARE second opinion): the device run reaches the same
+    feedback gain K = B'XE and the same Newton residual history."""
+    d, L, Dm = rail371
+    gold = np.load(os.path.join(GOLDEN, "gare_371.npz"))
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve(_are(d), D.Newton(D.ADI(ignore_initial_guess=True, shifts=D.Shifts.Cyclic(p), maxiters=200), maxiters=12, reltol=1e-10,
+                                           inexact=False), return_info=True)
+    a, Lx, Dx = X
+    K = (d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E)
+    assert D.delta(K, gold["K"]) < 1e-8 and D.delta(K, gold["K_dense"]) < 1e-8
+    rg, ro = np.array(info["residual_norms"]), gold["residuals"]
+    assert len(rg) == len(ro)
+    big = ro > 1e3 * info["abstol"]
+    assert np.allclose(rg[big], ro[big], rtol=1e-6)

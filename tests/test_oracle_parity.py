@@ -59,3 +59,12 @@ def test_fixture_ros1_and_ros2_meet_reference_tolerance():
         g = np.load(os.path.join(GOLDEN, name))
         tol = np.linalg.norm(g["K_dense_end"]) * 371 * EPS * 100
         assert np.linalg.norm(g["K_dense_end"] - g["K"][-1]) < tol, name
+
+
+def test_gare_fixture_is_what_the_oracle_and_a_dense_are_solve_produce():
+    """tests/golden/gare_371.npz: the Newton oracle's feedback gain agrees with a dense ARE solve (scipy) of the same pencil."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gare_371.npz"))
+    assert gold["K"].shape == (7, 371) and gold["residuals"][-1] < 1e-10 * gold["residuals"][0] * 10
+    assert np.linalg.norm(gold["K"] - gold["K_dense"]) < 1e-9 * np.linalg.norm(gold["K_dense"])
+    assert np.all(np.diff(gold["residuals"]) < 0)                # monotone Newton convergence on this problem
