@@ -1,0 +1,61 @@
+"""Kernel-path boundaries: panel heights around 64 / 256 / 512 / 768 / 1024 / 1536 rows (register-file variants, LDS panel vs
+register panel vs TSQR), band-reduction orders around 64 / 540 / 1040, column counts that are not multiples of the panel width."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import dre_amd as D
+import dre_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m", [63, 64, 65, 255, 257, 511, 513, 767, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2049, 4095, 4097])
+def test_orthf_at_panel_height_boundaries(ctx, m):
+    rng = np.random.default_rng(m)
+    for ncol in (1, 15, 17, 33):
+        if ncol > m:
+            continue
+        A = rng.standard_normal((m, ncol))
+        if ncol > 3:
+            A[:, 2] = A[:, 1] * 2.0                                   # dependent column
+        Q, R = D.orthf(A)
+        k = min(m, ncol)
+        assert Q.shape == (m, k) and R.shape == (k, ncol)
+        assert np.abs(Q @ R - A).max() < 1e-12 * max(1.0, np.abs(A).max()) * np.sqrt(m)
+        assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-13 * np.sqrt(m)
+
+
+@pytest.mark.parametrize("n,c", [(60, 70), (64, 30), (65, 200), (300, 555), (530, 548), (545, 560), (1030, 1050), (1045, 1100), (1200, 130), (1600, 90), (2100, 70)])
+def test_compress_across_band_reduction_variants(ctx, n, c):
+    """wide (c >= n: S is n x n) and tall (QR first) compressions whose band reduction crosses the unblocked (<= 64), LDS (<= 540),
+    row-parallel (> 540) and register-panel / TSQR (> 1024) variants; true rank 9."""
+    rng = np.random.default_rng(n + c)
+    r = 9
+    Bs = rng.standard_normal((n, r))
+    Lf = Bs @ rng.standard_normal((r, c)) + 1e-13 * rng.standard_normal((n, c))
+    Dd = np.diag(rng.choice([-1.0, 1.0], size=c) * (0.5 + rng.random(c)))
+    X = D.lowrank(Lf, Dd)
+    ref = Lf @ Dd @ Lf.T
+    D.compress_(X)
+    assert X.rank() <= 4 * r + 16
+    assert np.linalg.norm(X.dense() - ref) < 1e-10 * np.linalg.norm(ref)
+    assert abs(D.norm(X) - np.linalg.norm(ref)) < 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("n", [63, 65, 127, 129, 257, 513, 1025])
+def test_gale_on_random_pencils_of_awkward_sizes(ctx, n):
+    rng = np.random.default_rng(n)
+    E = sp.random(n, n, density=2.0 / n, random_state=rng).tocsc(); E = (E + E.T + n * sp.identity(n)).tocsc()
+    A = sp.random(n, n, density=2.0 / n, random_state=rng).tocsc(); A = (A - n * sp.identity(n)).tocsc()        # nonsymmetric
+    Cl = D.lowrank(rng.standard_normal((n, 3)), np.diag([1.0, -0.5, 2.0]))
+    prob = D.GALEProblem(E, A, Cl)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve_gale(prob, D.ADI(maxiters=150), return_info=True)
+    assert info["converged"]
+    assert D.norm(D.residual(prob, X)) < 1e-9 * D.norm(Cl)
+    if n <= 300:
+        assert D.delta(X.dense(), o.lyap_dense(A, E, Cl.dense())) < 1e-9
