@@ -59,3 +59,21 @@ def test_gale_on_random_pencils_of_awkward_sizes(ctx, n):
     assert D.norm(D.residual(prob, X)) < 1e-9 * D.norm(Cl)
     if n <= 300:
         assert D.delta(X.dense(), o.lyap_dense(A, E, Cl.dense())) < 1e-9
+
+
+def test_complex_pairs_with_low_rank_update_on_the_multifrontal_path(ctx):
+    """adi.jl:181-225 with F = A - B K (LowRankUpdate.jl:90-107, complex capacitance) at n = 1357, beyond leaf-only elimination trees:
+    the complex sweeps and the complex SMW correction together, against the oracle's SuperLU-based restatement."""
+    d = D.steel_profile(1357)
+    rng = np.random.default_rng(8)
+    K = 1e-2 * rng.standard_normal((d.B.shape[1], 1357))
+    Cl = D.lowrank(rng.standard_normal((1357, 2)), np.diag([1.0, -0.3]))
+    shifts = [-1e-3 + 2e-4j, -1e-3 - 2e-4j, -1e-5, -3e-2 + 1e-3j, -3e-2 - 1e-3j, -1e-1, -1e-4]
+    F = D.lr_update(d.A, -1.0, d.B, K)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve_gale(D.GALEProblem(d.E, F, Cl), D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=28, reltol=1e-30), return_info=True)
+        Xo = o.adi_solve(o.GALEProblem(d.E, o.lr_update(d.A, -1.0, d.B, K), o.lowrank(Cl.Ls[0], Cl.Ds[0])),
+                         o.ADI(shifts=o.Cyclic(shifts), maxiters=28, reltol=1e-30))
+    assert info["iters"] == 28 and np.any(info["shifts"].imag != 0)
+    assert D.delta(X.dense(), Xo.dense()) < 1e-9
