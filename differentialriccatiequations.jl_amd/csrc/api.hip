@@ -78,6 +78,10 @@ int dre_ctx_create(int device, dre_ctx** out) {
         DRE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = std::getenv("DRE_DENSE_INV_MAX_N")) ctx->c.dense_inv_max_n = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_MAX_N")) ctx->c.compress_direct_max_n = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_RATIO")) ctx->c.compress_direct_ratio = std::atof(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_N")) ctx->c.compress_factor_min_n = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_COLS")) ctx->c.compress_factor_min_cols = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
     if (rc != DRE_OK) { g_noctx_error = ctx->c.last_error; delete ctx; return rc; }
@@ -104,6 +108,10 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
     return guarded(ctx, [&] {
         const std::string key = name ? name : "";
         if (key == "dense_inverse_max_n") ctx->c.dense_inv_max_n = (int)value;
+        else if (key == "compress_direct_max_n") ctx->c.compress_direct_max_n = (int)value;
+        else if (key == "compress_direct_ratio") ctx->c.compress_direct_ratio = value;
+        else if (key == "compress_factor_min_n") ctx->c.compress_factor_min_n = (int)value;
+        else if (key == "compress_factor_min_cols") ctx->c.compress_factor_min_cols = (int)value;
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
     });
 }

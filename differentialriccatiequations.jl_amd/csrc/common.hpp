@@ -112,6 +112,13 @@ struct Ctx {
     size_t pinned_bytes = 0;
     // tunables (dre_ctx_set_option): real shifts of pencils with n <= dense_inv_max_n use the cached dense inverse
     int dense_inv_max_n = 1536;
+    // compression: form S = L D L' (n x n) directly instead of going through QR(L) when the factor has at least
+    // n / compress_direct_ratio columns and n <= compress_direct_max_n (always for n <= 512)
+    int compress_direct_max_n = 2560;
+    double compress_direct_ratio = 8.0;
+    // compression in factor form (no QR of L, no n x n matrix) for n >= compress_factor_min_n and at least compress_factor_min_cols columns
+    int compress_factor_min_n = 2561;
+    int compress_factor_min_cols = 96;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }

@@ -2155,6 +2155,216 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     return out;
 }
 
+// =============================================================================================
+// Band reduction of S = L Dt L' WITHOUT forming S (n x n) or a QR of L (n x c): the reflectors that reduce S to band form are
+// applied to the factor,  L <- Q_k' L,  so a panel step touches n x c instead of n x n entries and the number of panel steps is
+// rank / 16 instead of c / 16 (QR of L) + rank / 16 (band reduction of R Dt R').  Dt = blockdiag(alpha_b D_b).
+//   panel k:  P = L[k:, :] (Dt L[k:k+16, :]')        the next 16 columns of the current trailing matrix (n-k x 16)
+//             QR of P[16:, :] -> V, T                 (R stays in P: the sub-diagonal band block; P[0:16, :] is the diagonal block)
+//             L[k+16:, :] -= V ((V T)' L[k+16:, :])
+// Termination: the trailing matrix is never formed, so its norm is ESTIMATED with 16 fixed pseudo-random probe vectors G:
+// E ||S_rem G_rem||_F^2 / 16 = ||S_rem||_F^2  (Hutchinson-type; relative standard deviation of the norm ~ 18 %).  The probe rides on
+// the panel's own GEMMs: G' L is updated next to (V T)' L (32 instead of 16 rows), S_rem G_rem comes out next to P (32 instead of
+// 16 columns).  The test adds the exact coupling block ||R_{k-1}||^2 and doubles the estimate (bias towards one more panel).
+// =============================================================================================
+__global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* __restrict__ out, int ld) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * cols) return;
+    auto mix = [](unsigned long long z) {
+        z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+    };
+    const unsigned long long a = mix(seed + 2 * idx), b = mix(seed + 2 * idx + 1);
+    const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+    out[idx % n + (idx / n) * (size_t)ld] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+struct LrBlockDev { int off, k, ldd, diag; const double* D; double alpha; };
+// RD = RB * blockdiag(alpha_b D_b)  (32 x c, ld 32);  colblk[j] = block of column j.  One thread per output entry.
+__global__ __launch_bounds__(256) void k_rows_blockdiag(int c, const double* __restrict__ RB, double* __restrict__ RD, const LrBlockDev* __restrict__ blocks,
+                                                        const int* __restrict__ colblk, const AdiState* st) {
+    if (st && st->done) return;
+    const int i = threadIdx.x & 31, j = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (j >= c) return;
+    const LrBlockDev b = blocks[colblk[j]];
+    const int jj = j - b.off;
+    double acc = 0.0;
+    if (b.diag) acc = RB[i + (size_t)j * 32] * b.D[jj + (size_t)jj * b.ldd];
+    else {
+        const double* dcol = b.D + (size_t)jj * b.ldd;            // D symmetric: column jj
+        const double* rb = RB + i + (size_t)b.off * 32;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int l = 0;
+        for (; l + 7 < b.k; l += 8) {                              // eight independent loads of each operand in flight
+            double x[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { x[u] = rb[(size_t)(l + u) * 32]; d[u] = dcol[l + u]; }
+            a0 += x[0] * d[0]; a1 += x[1] * d[1]; a2 += x[2] * d[2]; a3 += x[3] * d[3];
+            a0 += x[4] * d[4]; a1 += x[5] * d[5]; a2 += x[6] * d[6]; a3 += x[7] * d[7];
+        }
+        for (; l < b.k; ++l) a0 += rb[(size_t)l * 32] * dcol[l];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    RD[i + (size_t)j * 32] = b.alpha * acc;
+}
+// RB[0:16, :] = L[k:k+16, :]  and (k > 0) the band blocks of the previous panel are saved:  BS[0:16, k-16:k] = diagonal block,
+// BS[16:32, k-16:k] = R (upper triangle) from PP, which the next GEMM overwrites.
+__global__ __launch_bounds__(256) void k_lr_rows(int c, int k, const double* __restrict__ Lw, int ldl, double* __restrict__ RB,
+                                                 const double* __restrict__ PP, int ldp, double* __restrict__ BS, const AdiState* st) {
+    if (st && st->done) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)16 * c) {
+        const int i = idx & 15; const size_t j = idx >> 4;
+        RB[i + j * 32] = Lw[(size_t)(k + i) + j * ldl];
+    }
+    if (k > 0 && blockIdx.x == 0) {
+        for (int t = threadIdx.x; t < 32 * 16; t += blockDim.x) {
+            const int r = t & 31, cc = t >> 5;
+            double v = PP[r + (size_t)cc * ldp];
+            if (r >= 16 && r - 16 > cc) v = 0.0;
+            BS[r + (size_t)(k - 16 + cc) * 32] = v;
+        }
+    }
+}
+// Termination test of the factor-form band reduction at panel boundary k (see above), two launches: partial sums of squares of the
+// probe columns PG (rows x 16) over LR_PARTS workgroups, then the decision.  The coupling block R_{k-1} is read from the band store.
+// st->res_norm = estimate of ||S||_F^2 (set at k = 0).
+#define LR_PARTS 64
+__global__ __launch_bounds__(256) void k_lr_probe_parts(int rows, const double* __restrict__ PG, int ldp, double* __restrict__ part, const AdiState* st) {
+    if (st->done) return;
+    __shared__ double red[17];
+    double s0 = 0.0, s1 = 0.0;
+    const size_t tot = (size_t)rows * 16, stride = (size_t)gridDim.x * blockDim.x;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; idx + stride < tot; idx += 2 * stride) {
+        const size_t i2 = idx + stride;
+        const double v = PG[idx % rows + (idx / rows) * (size_t)ldp], w = PG[i2 % rows + (i2 / rows) * (size_t)ldp];
+        s0 += v * v; s1 += w * w;
+    }
+    if (idx < tot) { const double v = PG[idx % rows + (idx / rows) * (size_t)ldp]; s0 += v * v; }
+    const double s = block_sum(s0 + s1, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_lr_decide(int k, const double* __restrict__ part, const double* __restrict__ BS, double tolfac, AdiState* st) {
+    if (st->done) return;
+    __shared__ double red[17];
+    double s = (threadIdx.x < LR_PARTS) ? part[threadIdx.x] / 16.0 : 0.0;
+    if (k > 0) {
+        const int r = threadIdx.x & 15, cc = threadIdx.x >> 4;
+        if (r <= cc) { const double v = BS[16 + r + (size_t)(k - 16 + cc) * 32]; s += v * v; }
+    }
+    s = block_sum(s, red);                     // est^2 + ||R_{k-1}||^2   (the exact remainder is est^2 + 2 ||R||^2)
+    if (threadIdx.x == 0) {
+        const double r2 = 2.0 * s;
+        if (k == 0) st->res_norm = s;
+        const double base = (k == 0) ? s : st->res_norm;
+        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        if (r2 <= tol * tol || !(s == s)) { st->done = 1; st->iters = k; }
+    }
+}
+__global__ void k_lr_extract_band(int J, const double* __restrict__ BS, double* __restrict__ D, int ldd) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)J * J) return;
+    const int i = idx % J, j = idx / J;
+    const int bi = i >> 4, bj = j >> 4, ii = i & 15, jj = j & 15;
+    double v = 0.0;
+    if (bi == bj) v = 0.5 * (BS[ii + (size_t)(bj * 16 + jj) * 32] + BS[jj + (size_t)(bj * 16 + ii) * 32]);
+    else if (bi == bj + 1) v = BS[16 + ii + (size_t)(bj * 16 + jj) * 32];          // R_bj(ii, jj), zero below the diagonal
+    else if (bj == bi + 1) v = BS[16 + jj + (size_t)(bi * 16 + ii) * 32];
+    D[i + (size_t)j * ldd] = v;
+}
+
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol) {
+    const int n = Lw.rows, c = Lw.cols, b = QR_NB;
+    DRE_REQUIRE(b == 16 && c >= 1 && c + 64 <= n, "lr_band_reduce: needs c + 64 <= n");
+    SymBand out;
+    out.q = n; out.nb = b;
+    const int maxp = ceil_div(c, b) + 1;                 // rank(S) <= c: after that many panels nothing is left
+    const int cap = maxp * b;
+    out.V = Mat(ctx, n, cap); out.VT = Mat(ctx, n, cap); out.T = Mat(ctx, b, cap);
+    fill_mat(ctx, out.V, 0.0);
+    // block table
+    std::vector<LrBlockDev> hb; std::vector<int> hcol((size_t)c);
+    for (auto& x : blocks) {
+        DRE_REQUIRE(x.off >= 0 && x.k >= 0 && x.off + x.k <= c, "lr_band_reduce: block table out of range");
+        for (int j = 0; j < x.k; ++j) hcol[(size_t)x.off + j] = (int)hb.size();
+        hb.push_back({x.off, x.k, x.ldd, x.diag, x.D, x.alpha});
+    }
+    DevArr<LrBlockDev> dblocks(ctx, hb.size());
+    DevArr<int> dcol(ctx, (size_t)c);
+    DevArr<AdiState> st(ctx, 1);
+    {
+        AdiState h;
+        std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
+        h.abstol = abs_tol;
+        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipMemcpyAsync(dblocks.p, hb.data(), hb.size() * sizeof(LrBlockDev), hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipMemcpyAsync(dcol.p, hcol.data(), hcol.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));      // the host staging vectors go out of use here
+    }
+    Mat VG(ctx, n, 32), RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Wg(ctx, 16, 16);
+    DevArr<double> parts(ctx, LR_PARTS);
+    {
+        Mat G = VG.colsview(16, 16);
+        const size_t tot = (size_t)n * 16;
+        hipLaunchKernelGGL(k_fill_gauss, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, 16, 0x5DEECE66Dull, G.p, G.ld);
+        Mat Yg = RB.view(16, 0, 16, c);
+        gemm(ctx, true, false, 1.0, G, Lw, 0.0, Yg, nullptr, "gemm_lrband");
+    }
+    fill_mat(ctx, BS, 0.0);
+    const long hkey = -((long)n * 2 + (abs_tol > 0.0 ? 1 : 0));        // negative keys: factor-form reductions
+    auto hit = ctx->band_hint.find(hkey);
+    int chunk = hit != ctx->band_hint.end() ? std::max(4, hit->second + 1) : 4;
+    int k = 0, np = 0, J = -1;
+    bool finished = false;
+    while (!finished) {
+        int issued = 0;
+        while (issued < chunk && np < maxp) {
+            const int rows = n - k, m = rows - b;
+            hipLaunchKernelGGL(k_lr_rows, dim3(ceil_div(16 * c, 256)), dim3(256), 0, ctx->stream, c, k, Lw.p, Lw.ld, RB.p, PP.p, PP.ld, BS.p, st.p);
+            {
+                TimedScope ts(ctx, "lrband_rows", 8.0 * 32.0 * c * 3.0, 2.0 * 32.0 * c * 64.0);
+                hipLaunchKernelGGL(k_rows_blockdiag, dim3(ceil_div(c, 8)), dim3(256), 0, ctx->stream, c, RB.p, RD.p, (const LrBlockDev*)dblocks.p,
+                                   (const int*)dcol.p, st.p);
+            }
+            gemm(ctx, false, true, rows, 32, c, 1.0, Lw.p + k, Lw.ld, RD.p, RD.ld, 0.0, PP.p, PP.ld, st.p, "gemm_lrband");
+            {
+                TimedScope ts(ctx, "lrband_decide", 8.0 * rows * 16.0, 2.0 * rows * 16.0);
+                hipLaunchKernelGGL(k_lr_probe_parts, dim3(LR_PARTS), dim3(256), 0, ctx->stream, rows, PP.p + (size_t)16 * PP.ld, PP.ld, parts.p, st.p);
+                hipLaunchKernelGGL(k_lr_decide, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)parts.p, BS.p, tolfac, st.p);
+            }
+            launch_qr_panel(ctx, PP.p + b, PP.ld, m, 0, b, out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld,
+                            out.T.p + (size_t)k * out.T.ld, out.T.ld, out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p);
+            Mat Vp = out.V.view(k + b, k, m, b);
+            Mat VTp = out.VT.view(k + b, k, m, b);
+            Mat VGv = VG.view(k + b, 0, m, 16);
+            copy_mat(ctx, VTp, VGv, 1.0, st.p);
+            // [Y; Yg] = [V T, G]' L_rem  (32 x c),  Wg = V' G,  Yg -= Wg' Y,  L_rem -= V Y
+            gemm(ctx, true, false, 32, c, m, 1.0, VG.p + (k + b), VG.ld, Lw.p + (k + b), Lw.ld, 0.0, RB.p, RB.ld, st.p, "gemm_lrband");
+            gemm(ctx, true, false, 16, 16, m, 1.0, Vp.p, Vp.ld, VG.p + (k + b) + (size_t)16 * VG.ld, VG.ld, 0.0, Wg.p, Wg.ld, st.p, "gemm_lrband");
+            gemm(ctx, true, false, 16, c, 16, -1.0, Wg.p, Wg.ld, RB.p, RB.ld, 1.0, RB.p + 16, RB.ld, st.p, "gemm_lrband");
+            gemm(ctx, false, false, m, c, 16, -1.0, Vp.p, Vp.ld, RB.p, RB.ld, 1.0, Lw.p + (k + b), Lw.ld, st.p, "gemm_lrband");
+            k += b; ++np; ++issued;
+        }
+        AdiState h;
+        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (h.done) { J = h.iters; finished = true; }
+        else if (np >= maxp) {
+            // every column of L consumed: save the last panel's band blocks and stop
+            hipLaunchKernelGGL(k_lr_rows, dim3(1), dim3(256), 0, ctx->stream, 0, k, Lw.p, Lw.ld, RB.p, PP.p, PP.ld, BS.p, st.p);
+            J = k; finished = true;
+        }
+        chunk = 4;
+    }
+    np = J / b;
+    ctx->band_hint[hkey] = np;
+    out.J = J; out.npanels = np;
+    out.D = Mat(ctx, J, J);
+    const size_t tot = (size_t)J * J;
+    if (tot) hipLaunchKernelGGL(k_lr_extract_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, J, BS.p, out.D.p, out.D.ld);
+    DRE_HIP(hipGetLastError());
+    return out;
+}
+
 // Block reflector of ALL band panels at once.  With V = [V_0 ... V_{np-1}] and G = V'V the aggregated factor of
 // H = Q_0 Q_1 ... Q_{np-1} = I - V Tbig V' has the block inverse  Tbig^-1 = blockdiag(T_p^-1) + blockstriu(G),  so
 // M = Tbig R (R = V(1:J, :)') follows from a block back substitution that needs only the panel factors T_p themselves:

@@ -118,5 +118,9 @@ struct SymBand {
 // abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0);
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
+// The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
+// neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).
+struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0);
 
 }  // namespace dre

@@ -130,7 +130,29 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     if (c == 0) { set_empty(); return; }
     // Q = I is admissible whenever the n x n matrix S = L D L' is affordable; for small n this skips the whole QR
     // (two thirds of all panel factorisations at n = 371) at the price of one GEMM.
-    const bool wide = c >= n || (n <= 512 && !exact);
+    const bool wide = c >= n || (!exact && (n <= 512 || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
+    if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {
+        // large n: the band reduction works on the factor itself (dense.hip, lr_band_reduce): rank/16 panel steps on n x c data
+        // instead of a QR of all c columns followed by the reduction of R D R'
+        Mat Lw(ctx, n, c);
+        std::vector<LrBlockD> tab;
+        int off = 0;
+        for (auto& b : X.blocks) {
+            const int k = b.L.cols;
+            if (k == 0) continue;
+            Mat dst = Lw.colsview(off, k);
+            copy_mat(ctx, b.L, dst);
+            tab.push_back({off, k, b.D.ld, b.diag ? 1 : 0, b.D.p, b.alpha});
+            off += k;
+        }
+        SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
+        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += n; g_cstats.tri_steps += sb.J; g_cstats.rank_out += sb.J;
+        if (sb.J == 0) { set_empty(); return; }
+        Mat Bq = sym_band_basis(ctx, sb);
+        X.blocks.clear();
+        X.blocks.push_back({Bq, sb.D, 1.0, false, true});
+        return;
+    }
     Mat Lcat, S;
     QRFact qr;
     if (wide) {
