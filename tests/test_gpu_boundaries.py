@@ -77,3 +77,67 @@ def test_complex_pairs_with_low_rank_update_on_the_multifrontal_path(ctx):
                          o.ADI(shifts=o.Cyclic(shifts), maxiters=28, reltol=1e-30))
     assert info["iters"] == 28 and np.any(info["shifts"].imag != 0)
     assert D.delta(X.dense(), Xo.dense()) < 1e-9
+
+
+def _blocks(rng, n, c, r, nblk, decay=6.0):
+    Bs = rng.standard_normal((n, r)) * (10.0 ** -np.linspace(0, decay, r))
+    per = c // nblk
+    Ls, Ds = [], []
+    for b in range(nblk):
+        Ls.append(Bs @ rng.standard_normal((r, per)) + 1e-14 * rng.standard_normal((n, per)))
+        if b % 2 == 0:
+            Ds.append(np.diag(rng.choice([-1.0, 1.0], size=per) * (0.5 + rng.random(per))))
+        else:
+            M = rng.standard_normal((per, per)); Ds.append(M + M.T)
+    return Ls, Ds
+
+
+@pytest.mark.parametrize("n,c,r,nblk", [(2600, 130, 130, 2), (3000, 500, 40, 5), (4000, 300, 7, 3), (5000, 1200, 150, 8), (2700, 2600, 60, 4), (2561, 96, 3, 1)])
+def test_factor_form_compression(ctx, n, c, r, nblk):
+    """n > 2560: the band reduction runs on the factor L itself (no QR of L, no n x n matrix) and stops on a randomized estimate of the
+    remainder; sums of diagonal-D and dense-D blocks, indefinite, numerical rank r."""
+    rng = np.random.default_rng(n + c)
+    Ls, Ds = _blocks(rng, n, c, r, nblk)
+    X = D.lowrank(Ls[0], Ds[0])
+    for L, Dd in zip(Ls[1:], Ds[1:]):
+        X = X + D.lowrank(L, Dd)
+    ref = sum(L @ Dd @ L.T for L, Dd in zip(Ls, Ds))
+    D.compress_(X)
+    assert X.rank() <= r + 32
+    assert np.linalg.norm(X.dense() - ref) < 1e-12 * np.linalg.norm(ref)
+    Q = X.Ls[0]
+    assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() < 1e-12
+
+
+def test_factor_form_compression_edge_cases(ctx):
+    rng = np.random.default_rng(1)
+    n = 3000
+    # exact cancellation: what is left of X - X is rounding noise (kept relative to itself, as the reference's eigenvalue threshold does)
+    L = rng.standard_normal((n, 100))
+    X = D.lowrank(L, np.eye(100)) + D.lowrank(L.copy(), -np.eye(100))
+    D.compress_(X)
+    assert X.rank() <= 200 and D.norm(X) < 1e-10 * np.linalg.norm(L @ L.T)
+    # all the mass in the LAST rows (the first panels of S are exactly zero: only the probe sees that something is left)
+    L = np.zeros((n, 120)); L[-200:, :] = rng.standard_normal((200, 120))
+    X = D.lowrank(L, np.diag(1.0 + rng.random(120)))
+    ref = X.dense()
+    D.compress_(X)
+    assert np.linalg.norm(X.dense() - ref) < 1e-12 * np.linalg.norm(ref)
+    # full column rank: every column is consumed
+    L = rng.standard_normal((n, 128))
+    X = D.lowrank(L, np.diag(rng.choice([-1.0, 1.0], size=128)))
+    ref = X.dense()
+    D.compress_(X)
+    assert 112 <= X.rank() <= 160 and np.linalg.norm(X.dense() - ref) < 1e-12 * np.linalg.norm(ref)
+    # zero matrix
+    X = D.lowrank(np.zeros((n, 100)), np.eye(100))
+    D.compress_(X)
+    assert X.rank() == 0
+    # absolute tolerance: drops everything below it
+    U, _ = np.linalg.qr(rng.standard_normal((n, 100)))
+    w = 10.0 ** -np.arange(100.0)
+    Xd = D.DeviceLDLt.create(ctx, None, U, np.diag(w))
+    Xd.compress(abs_tol=1e-6)
+    a, Lc, Dc = Xd.destructure()
+    err = np.linalg.norm(a * Lc @ Dc @ Lc.T - (U * w) @ U.T)
+    assert err < 1e-5 and Lc.shape[1] <= 32
