@@ -2243,19 +2243,19 @@ __global__ __launch_bounds__(256) void k_lr_probe_parts(int rows, const double* 
     const double s = block_sum(s0 + s1, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_lr_decide(int k, const double* __restrict__ part, const double* __restrict__ BS, double tolfac, AdiState* st) {
+__global__ __launch_bounds__(256) void k_lr_decide(int k, const double* __restrict__ part, const double* __restrict__ BS, double tolfac, double safety, AdiState* st) {
     if (st->done) return;
     __shared__ double red[17];
-    double s = (threadIdx.x < LR_PARTS) ? part[threadIdx.x] / 16.0 : 0.0;
+    double s = (threadIdx.x < LR_PARTS) ? safety * part[threadIdx.x] / 16.0 : 0.0;
     if (k > 0) {
         const int r = threadIdx.x & 15, cc = threadIdx.x >> 4;
-        if (r <= cc) { const double v = BS[16 + r + (size_t)(k - 16 + cc) * 32]; s += v * v; }
+        if (r <= cc) { const double v = BS[16 + r + (size_t)(k - 16 + cc) * 32]; s += 2.0 * v * v; }
     }
-    s = block_sum(s, red);                     // est^2 + ||R_{k-1}||^2   (the exact remainder is est^2 + 2 ||R||^2)
+    s = block_sum(s, red);                     // remainder^2 = safety * est^2 + 2 ||R_{k-1}||^2
     if (threadIdx.x == 0) {
-        const double r2 = 2.0 * s;
-        if (k == 0) st->res_norm = s;
-        const double base = (k == 0) ? s : st->res_norm;
+        const double r2 = s;
+        if (k == 0) st->res_norm = s / safety;
+        const double base = (k == 0) ? s / safety : st->res_norm;
         const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
         if (r2 <= tol * tol || !(s == s)) { st->done = 1; st->iters = k; }
     }
@@ -2272,12 +2272,40 @@ __global__ void k_lr_extract_band(int J, const double* __restrict__ BS, double* 
     D[i + (size_t)j * ldd] = v;
 }
 
+// Warm start of the reductions that work in the natural coordinates (S = L D L' formed directly, or the factor form): rotate the
+// coordinates so that the leading 16 columns of L — the dominant directions of a previously compressed summand — span the first 16
+// unit vectors,  L <- Q0' L  with Q0 = I - VT0 V0' from the QR of L[:, 0:16].  Without it the reduction starts from arbitrary unit
+// vectors and needs about one panel (16 columns of rank) more to reach the same remainder; the QR path gets this order for free.
+bool lead_rotation_enabled() {
+    static const bool on = !(std::getenv("DRE_LEAD_ROTATION") && std::atoi(std::getenv("DRE_LEAD_ROTATION")) == 0);
+    return on;
+}
+void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0) {
+    const int n = L.rows, c = L.cols, b = QR_NB;
+    DRE_REQUIRE(c >= b && n >= 2 * b, "lead_rotate: at least 16 columns and 32 rows");
+    V0 = Mat(ctx, n, b); VT0 = Mat(ctx, n, b);
+    Mat T0(ctx, b, b), P0(ctx, n, b), Y0(ctx, b, c);
+    fill_mat(ctx, V0, 0.0);
+    Mat L0 = L.colsview(0, b);
+    copy_mat(ctx, L0, P0);
+    launch_qr_panel(ctx, P0.p, P0.ld, n, 0, b, V0.p, V0.ld, T0.p, T0.ld, VT0.p, VT0.ld, nullptr);
+    gemm(ctx, true, false, 1.0, VT0, L, 0.0, Y0, nullptr, "gemm_lrband");
+    gemm(ctx, false, false, -1.0, V0, Y0, 1.0, L, nullptr, "gemm_lrband");
+}
+void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B) {      // B <- Q0 B
+    if (V0.empty() || B.cols == 0) return;
+    Mat W(ctx, V0.cols, B.cols);
+    gemm(ctx, true, false, 1.0, V0, B, 0.0, W, nullptr, "gemm_band");
+    gemm(ctx, false, false, -1.0, VT0, W, 1.0, B, nullptr, "gemm_band");
+}
+
 SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol) {
     const int n = Lw.rows, c = Lw.cols, b = QR_NB;
     DRE_REQUIRE(b == 16 && c >= 1 && c + 64 <= n, "lr_band_reduce: needs c + 64 <= n");
     SymBand out;
     out.q = n; out.nb = b;
     const int maxp = ceil_div(c, b) + 1;                 // rank(S) <= c: after that many panels nothing is left
+    static const double safety = std::getenv("DRE_LR_SAFETY") ? std::atof(std::getenv("DRE_LR_SAFETY")) : 2.0;
     const int cap = maxp * b;
     out.V = Mat(ctx, n, cap); out.VT = Mat(ctx, n, cap); out.T = Mat(ctx, b, cap);
     fill_mat(ctx, out.V, 0.0);
@@ -2302,6 +2330,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, d
     }
     Mat VG(ctx, n, 32), RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Wg(ctx, 16, 16);
     DevArr<double> parts(ctx, LR_PARTS);
+    if (lead_rotation_enabled() && c >= 32) lead_rotate(ctx, Lw, out.V0, out.VT0);
     {
         Mat G = VG.colsview(16, 16);
         const size_t tot = (size_t)n * 16;
@@ -2329,7 +2358,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, d
             {
                 TimedScope ts(ctx, "lrband_decide", 8.0 * rows * 16.0, 2.0 * rows * 16.0);
                 hipLaunchKernelGGL(k_lr_probe_parts, dim3(LR_PARTS), dim3(256), 0, ctx->stream, rows, PP.p + (size_t)16 * PP.ld, PP.ld, parts.p, st.p);
-                hipLaunchKernelGGL(k_lr_decide, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)parts.p, BS.p, tolfac, st.p);
+                hipLaunchKernelGGL(k_lr_decide, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)parts.p, BS.p, tolfac, safety, st.p);
             }
             launch_qr_panel(ctx, PP.p + b, PP.ld, m, 0, b, out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld,
                             out.T.p + (size_t)k * out.T.ld, out.T.ld, out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p);
@@ -2426,7 +2455,13 @@ __global__ __launch_bounds__(256) void k_blocktri_apply(int nr, int J, const dou
         for (int r = i; r < nr; r += 16) M[r + (size_t)(j0 + j) * ldm] = Msh[r * 17 + j];
 }
 
+static Mat sym_band_basis_core(Ctx* ctx, const SymBand& sb);
 Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
+    Mat B = sym_band_basis_core(ctx, sb);
+    if (!sb.V0.empty() && sb.J > 0) lead_rotate_back(ctx, sb.V0, sb.VT0, B);     // factor-form reduction with a warm start: Qb <- Q0 Qb
+    return B;
+}
+static Mat sym_band_basis_core(Ctx* ctx, const SymBand& sb) {
     Mat B(ctx, sb.q, sb.J);
     set_identity(ctx, B, 1.0);
     const int b = sb.nb;

@@ -114,12 +114,16 @@ struct SymBand {
     Mat VT;     // V_p * T_p per panel
     Mat T;      // nb x q block-reflector factors
     Mat D;      // J x J symmetric band matrix (dense storage)
+    Mat V0, VT0; // optional leading reflector block Q0 = I - VT0 V0' (factor-form reduction with a warm start): Qb <- Q0 Qb
 };
 // abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0);
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 // The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
 // neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).
+bool lead_rotation_enabled();
+void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0);                        // L <- Q0' L,  Q0 = I - VT0 V0' from QR(L[:, 0:16])
+void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B);      // B <- Q0 B
 struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };
 SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0);
 

@@ -153,12 +153,18 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         X.blocks.push_back({Bq, sb.D, 1.0, false, true});
         return;
     }
-    Mat Lcat, S;
+    Mat Lcat, S, V0, VT0;
     QRFact qr;
     if (wide) {
         // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
         Mat LD(ctx, n, c);
-        if (X.blocks.size() == 1) { Lcat = X.blocks[0].L; mul_blockdiag(ctx, Lcat, X, LD); }
+        if (!exact && lead_rotation_enabled() && c >= 32 && n > 512) {      // (n <= 512: the extra launches cost more than a panel)
+            // start the reduction from the dominant directions (dense.hip, lead_rotate): Q = Q0 instead of I
+            Lcat = hcat_blocks(ctx, X);
+            lead_rotate(ctx, Lcat, V0, VT0);
+            mul_blockdiag(ctx, Lcat, X, LD);
+        }
+        else if (X.blocks.size() == 1) { Lcat = X.blocks[0].L; mul_blockdiag(ctx, Lcat, X, LD); }
         else { Lcat = Mat(ctx, n, c); hcat_scale_blocks(ctx, X, Lcat, LD); }
         S = Mat(ctx, n, n);
         gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
@@ -221,6 +227,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     Mat Lnew;
     if (wide) {
         Lnew = B;
+        lead_rotate_back(ctx, V0, VT0, Lnew);
     } else {
         Lnew = Mat(ctx, n, r);
         fill_mat(ctx, Lnew, 0.0);
