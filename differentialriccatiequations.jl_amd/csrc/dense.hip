@@ -2164,8 +2164,9 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
 //             L[k+16:, :] -= V ((V T)' L[k+16:, :])
 // Termination: the trailing matrix is never formed, so its norm is ESTIMATED with 16 fixed pseudo-random probe vectors G:
 // E ||S_rem G_rem||_F^2 / 16 = ||S_rem||_F^2  (Hutchinson-type; relative standard deviation of the norm ~ 18 %).  The probe rides on
-// the panel's own GEMMs: G' L is updated next to (V T)' L (32 instead of 16 rows), S_rem G_rem comes out next to P (32 instead of
-// 16 columns).  The test adds the exact coupling block ||R_{k-1}||^2 and doubles the estimate (bias towards one more panel).
+// the panel's own GEMMs: G is carried as 16 extra columns of L (rotated with it, which keeps it Gaussian: the rotations depend on S
+// only), G_rem' L_rem follows from the invariant G' L by downdating the rows that became final, S_rem G_rem comes out next to P
+// (32 instead of 16 columns).  The test adds the exact coupling block ||R_{k-1}||^2 and doubles the estimate (bias towards one more panel).
 // =============================================================================================
 __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* __restrict__ out, int ld) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2205,8 +2206,9 @@ __global__ __launch_bounds__(256) void k_rows_blockdiag(int c, const double* __r
     }
     RD[i + (size_t)j * 32] = b.alpha * acc;
 }
-// RB[0:16, :] = L[k:k+16, :]  and (k > 0) the band blocks of the previous panel are saved:  BS[0:16, k-16:k] = diagonal block,
-// BS[16:32, k-16:k] = R (upper triangle) from PP, which the next GEMM overwrites.
+// RB[0:16, :] = L[k:k+16, :]; for k > 0 the probe products are downdated by the 16 rows that became final with the previous panel,
+// RB[16+p, j] -= sum_i L[k-16+i, j] G[k-16+i, p]  (G = columns c..c+15 of the extended factor), and the band blocks of the previous
+// panel are saved:  BS[0:16, k-16:k] = diagonal block, BS[16:32, k-16:k] = R (upper triangle) from PP, which the next GEMM overwrites.
 __global__ __launch_bounds__(256) void k_lr_rows(int c, int k, const double* __restrict__ Lw, int ldl, double* __restrict__ RB,
                                                  const double* __restrict__ PP, int ldp, double* __restrict__ BS, const AdiState* st) {
     if (st && st->done) return;
@@ -2214,6 +2216,14 @@ __global__ __launch_bounds__(256) void k_lr_rows(int c, int k, const double* __r
     if (idx < (size_t)16 * c) {
         const int i = idx & 15; const size_t j = idx >> 4;
         RB[i + j * 32] = Lw[(size_t)(k + i) + j * ldl];
+        if (k > 0) {
+            const double* lj = Lw + (size_t)(k - 16) + j * ldl;                 // L[k-16:k, j]
+            const double* gp = Lw + (size_t)(k - 16) + (size_t)(c + i) * ldl;   // G[k-16:k, p],  p = i
+            double a = 0.0;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) a += lj[t] * gp[t];
+            RB[16 + i + j * 32] -= a;
+        }
     }
     if (k > 0 && blockIdx.x == 0) {
         for (int t = threadIdx.x; t < 32 * 16; t += blockDim.x) {
@@ -2299,8 +2309,10 @@ void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B) {      //
     gemm(ctx, false, false, -1.0, VT0, W, 1.0, B, nullptr, "gemm_band");
 }
 
-SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol) {
-    const int n = Lw.rows, c = Lw.cols, b = QR_NB;
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol) {
+    // Lx = [L | 16 spare columns]: the probe vectors live next to the factor and are transformed with it
+    const int n = Lx.rows, c = Lx.cols - 16, b = QR_NB;
+    Mat Lw = Lx.colsview(0, c);
     DRE_REQUIRE(b == 16 && c >= 1 && c + 64 <= n, "lr_band_reduce: needs c + 64 <= n");
     SymBand out;
     out.q = n; out.nb = b;
@@ -2328,11 +2340,11 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, d
         DRE_HIP(hipMemcpyAsync(dcol.p, hcol.data(), hcol.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));      // the host staging vectors go out of use here
     }
-    Mat VG(ctx, n, 32), RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Wg(ctx, 16, 16);
+    Mat RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Yx(ctx, 16, c + 16);
     DevArr<double> parts(ctx, LR_PARTS);
     if (lead_rotation_enabled() && c >= 32) lead_rotate(ctx, Lw, out.V0, out.VT0);
     {
-        Mat G = VG.colsview(16, 16);
+        Mat G = Lx.colsview(c, 16);
         const size_t tot = (size_t)n * 16;
         hipLaunchKernelGGL(k_fill_gauss, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, 16, 0x5DEECE66Dull, G.p, G.ld);
         Mat Yg = RB.view(16, 0, 16, c);
@@ -2364,13 +2376,10 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, d
                             out.T.p + (size_t)k * out.T.ld, out.T.ld, out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p);
             Mat Vp = out.V.view(k + b, k, m, b);
             Mat VTp = out.VT.view(k + b, k, m, b);
-            Mat VGv = VG.view(k + b, 0, m, 16);
-            copy_mat(ctx, VTp, VGv, 1.0, st.p);
-            // [Y; Yg] = [V T, G]' L_rem  (32 x c),  Wg = V' G,  Yg -= Wg' Y,  L_rem -= V Y
-            gemm(ctx, true, false, 32, c, m, 1.0, VG.p + (k + b), VG.ld, Lw.p + (k + b), Lw.ld, 0.0, RB.p, RB.ld, st.p, "gemm_lrband");
-            gemm(ctx, true, false, 16, 16, m, 1.0, Vp.p, Vp.ld, VG.p + (k + b) + (size_t)16 * VG.ld, VG.ld, 0.0, Wg.p, Wg.ld, st.p, "gemm_lrband");
-            gemm(ctx, true, false, 16, c, 16, -1.0, Wg.p, Wg.ld, RB.p, RB.ld, 1.0, RB.p + 16, RB.ld, st.p, "gemm_lrband");
-            gemm(ctx, false, false, m, c, 16, -1.0, Vp.p, Vp.ld, RB.p, RB.ld, 1.0, Lw.p + (k + b), Lw.ld, st.p, "gemm_lrband");
+            // Y = (V T)' [L_rem, G_rem]  (16 x (c + 16)),  [L_rem, G_rem] -= V Y:  the probe vectors are rotated with the factor, their
+            // products G_rem' L_rem follow by downdating the invariant G' L (k_lr_rows)
+            gemm(ctx, true, false, 16, c + 16, m, 1.0, VTp.p, VTp.ld, Lx.p + (k + b), Lx.ld, 0.0, Yx.p, Yx.ld, st.p, "gemm_lrband");
+            gemm(ctx, false, false, m, c + 16, 16, -1.0, Vp.p, Vp.ld, Yx.p, Yx.ld, 1.0, Lx.p + (k + b), Lx.ld, st.p, "gemm_lrband");
             k += b; ++np; ++issued;
         }
         AdiState h;

@@ -125,6 +125,6 @@ bool lead_rotation_enabled();
 void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0);                        // L <- Q0' L,  Q0 = I - VT0 V0' from QR(L[:, 0:16])
 void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B);      // B <- Q0 B
 struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };
-SymBand lr_band_reduce(Ctx* ctx, Mat& Lw, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0);
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0);   // Lx = [L | 16 spare columns]
 
 }  // namespace dre

@@ -134,7 +134,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {
         // large n: the band reduction works on the factor itself (dense.hip, lr_band_reduce): rank/16 panel steps on n x c data
         // instead of a QR of all c columns followed by the reduction of R D R'
-        Mat Lw(ctx, n, c);
+        Mat Lw(ctx, n, c + 16);                  // 16 spare columns: the probe vectors of the termination estimate
         std::vector<LrBlockD> tab;
         int off = 0;
         for (auto& b : X.blocks) {
