@@ -2065,9 +2065,9 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     out.VT = Mat(ctx, q, q);
     out.T = Mat(ctx, b, q);
     fill_mat(ctx, out.V, 0.0);
-    // all panels factored by the LDS panel kernel: the termination norm of the next panel is assembled from the update
+    // all panels factored by a single-workgroup panel kernel: the termination norm of the next panel is assembled from the update
     // GEMM's per-tile sums of squares plus the coupling term written by the panel kernel — no separate norm launch
-    const bool fused_rem = q - b <= QR_LDS_ROWS;
+    const bool fused_rem = q - b <= 1536;            // single-workgroup panel kernels (LDS and register variants), not the TSQR panels
     DevArr<double> part(ctx, (size_t)std::max(BAND_REM_BLOCKS, 1 + gemm_num_tiles(q, q)));
     int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
