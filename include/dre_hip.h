@@ -56,7 +56,13 @@ int dre_ctx_sync(dre_ctx* ctx);
 int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
 /* Tunables of the engine (no counterpart in the reference; they select between device code paths that compute the same result):
  *   "dense_inverse_max_n"  real ADI shifts on pencils with n <= value apply a cached dense inverse of A' + mu E' by MFMA GEMM
- *                          instead of the multifrontal triangular sweeps (default 1536, or env DRE_DENSE_INV_MAX_N; 0 disables). */
+ *                          instead of the multifrontal triangular sweeps (default 1536, or env DRE_DENSE_INV_MAX_N; 0 disables).
+ *   compress! (LDLt.jl:204-225) without a QR of the factor — the band reduction runs in the natural coordinates:
+ *   "compress_direct_max_n"     n <= value and columns >= n / compress_direct_ratio: S = L D L' (n x n) is formed directly
+ *                               (default 2560; n <= 512 always);  "compress_direct_ratio" (default 8)
+ *   "compress_factor_min_n"     n >= value: band reduction in factor form, reflectors applied to L, randomized termination estimate
+ *                               (default 2561; a huge value disables);  "compress_factor_min_cols" (default 96) fewer columns: QR path
+ *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS) */
 int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value);
 /* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
  * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */

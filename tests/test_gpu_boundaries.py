@@ -1,5 +1,6 @@
 """Kernel-path boundaries: panel heights around 64 / 256 / 512 / 768 / 1024 / 1536 rows (register-file variants, LDS panel vs
 register panel vs TSQR), band-reduction orders around 64 / 540 / 1040, column counts that are not multiples of the panel width."""
+import os
 import warnings
 
 import numpy as np
@@ -8,6 +9,7 @@ import scipy.sparse as sp
 
 import dre_amd as D
 import dre_oracle as o
+from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
@@ -141,3 +143,31 @@ def test_factor_form_compression_edge_cases(ctx):
     a, Lc, Dc = Xd.destructure()
     err = np.linalg.norm(a * Lc @ Dc @ Lc.T - (U * w) @ U.T)
     assert err < 1e-5 and Lc.shape[1] <= 32
+
+
+@pytest.mark.parametrize("n", [1357, 5177])
+def test_qr_free_compressions_reproduce_the_qr_path(ctx, n):
+    """LDLt.jl:204-225 three ways: QR(L) + band reduction of R D R' (the literal order of operations), S = L D L' formed directly
+    (n = 1357) and the factor-form reduction (n = 5177) — same ADI iteration counts, K(t) and X(t) to 1e-10."""
+    d = D.steel_profile(n); L, Dm = D.initial_value(d)
+    p = np.load(os.path.join(GOLDEN, f"heuristic_shifts_{n}.npy"))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4300.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(list(p)), maxiters=200))
+    out = {}
+    try:
+        for name, (fmin, dmax) in (("qr", (1 << 30, 512)), ("qr_free", (2561, 2560))):
+            ctx.set_option("compress_factor_min_n", fmin); ctx.set_option("compress_direct_max_n", dmax)
+            sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True, save_state=True)
+            out[name] = (sol, [g["iters"] for g in st["gales"]])
+    finally:
+        ctx.set_option("compress_factor_min_n", 2561); ctx.set_option("compress_direct_max_n", 2560)
+    (s0, it0), (s1, it1) = out["qr"], out["qr_free"]
+    assert it0 == it1
+    for K0, K1 in zip(s0.K, s1.K):
+        assert D.delta(K0, K1) < 1e-10
+    a0, L0, D0 = s0.X[-1]; a1, L1, D1 = s1.X[-1]
+    assert abs(L0.shape[1] - L1.shape[1]) <= 32
+    # || X0 - X1 ||_F through the factors (no n x n matrices)
+    Lc = np.hstack([L0, L1]); Dc = np.block([[a0 * D0, np.zeros((D0.shape[0], D1.shape[1]))], [np.zeros((D1.shape[0], D0.shape[1])), -a1 * D1]])
+    _, R = np.linalg.qr(Lc)
+    assert np.linalg.norm(R @ Dc @ R.T) < 1e-10 * np.linalg.norm(D0)
