@@ -157,15 +157,18 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     QRFact qr;
     if (wide) {
         // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
-        Mat LD(ctx, n, c);
-        if (!exact && lead_rotation_enabled() && c >= 32 && n > 512) {      // (n <= 512: the extra launches cost more than a panel)
-            // start the reduction from the dominant directions (dense.hip, lead_rotate): Q = Q0 instead of I
-            Lcat = hcat_blocks(ctx, X);
-            lead_rotate(ctx, Lcat, V0, VT0);
-            mul_blockdiag(ctx, Lcat, X, LD);
+        Mat LD;
+        static const int rot_min_n = std::getenv("DRE_LEAD_ROTATION_MIN_N") ? std::atoi(std::getenv("DRE_LEAD_ROTATION_MIN_N")) : 65;
+        if (!exact && lead_rotation_enabled() && c >= 32 && n >= rot_min_n) {
+            // start the reduction from the dominant directions (dense.hip, lead_rotate): Q = Q0 instead of I.  L and L D sit side
+            // by side so that one batched launch fills both and one block reflector rotates both
+            Mat both(ctx, n, 2 * c);
+            Lcat = both.colsview(0, c); LD = both.colsview(c, c);
+            hcat_scale_blocks(ctx, X, Lcat, LD);
+            lead_rotate(ctx, both, V0, VT0);
         }
-        else if (X.blocks.size() == 1) { Lcat = X.blocks[0].L; mul_blockdiag(ctx, Lcat, X, LD); }
-        else { Lcat = Mat(ctx, n, c); hcat_scale_blocks(ctx, X, Lcat, LD); }
+        else if (X.blocks.size() == 1) { LD = Mat(ctx, n, c); Lcat = X.blocks[0].L; mul_blockdiag(ctx, Lcat, X, LD); }
+        else { LD = Mat(ctx, n, c); Lcat = Mat(ctx, n, c); hcat_scale_blocks(ctx, X, Lcat, LD); }
         S = Mat(ctx, n, n);
         gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
     } else {
