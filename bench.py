@@ -129,7 +129,8 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))
                 sym = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm",
                        "gemm_gram": "k_gemm", "gemm_dinv": "k_gemm", "dense_step": "k_dense_step", "band_w": "k_band_w", "mf_solve_real": "k_mf_",
-                       "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm"}.get(name)
+                       "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
+                       "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_"}.get(name)
                 hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
                 if hits and n == 371:
                     tot_l = sum(h["launches"] for h in hits)
