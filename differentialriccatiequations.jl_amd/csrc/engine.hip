@@ -1,3 +1,4 @@
+#include <chrono>
 // Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
 #include "engine.hpp"
 #include <functional>
@@ -539,7 +540,10 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         DRE_HIP(hipMemcpy2DAsync(hR.data(), kq * sizeof(double), qr.R.p, qr.R.ld * sizeof(double), kq * sizeof(double), w, hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         std::vector<double> Us, sv;
+        static const bool trace = std::getenv("DRE_TRACE_PROJ") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
         host_svd_left(kq, w, hR, Us, sv);      // R = Us diag(sv) W'
+        auto t1 = std::chrono::steady_clock::now();
         std::vector<int> keep;
         for (int i = 0; i < (int)sv.size(); ++i) if (std::fabs(sv[i]) > P.n * EPS) keep.push_back(i);
         const int r = (int)keep.size();
@@ -561,7 +565,13 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         DRE_HIP(hipMemcpyAsync(hFt.data(), Ft.p, hFt.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < r; ++i) for (int j = 0; j < r; ++j) { hE[i + (size_t)j * r] = hEt[j + (size_t)i * r]; hF[i + (size_t)j * r] = hFt[j + (size_t)i * r]; }
+        auto t2 = std::chrono::steady_clock::now();
         std::vector<std::complex<double>> lam = host_gen_eigvals(r, hF, hE);
+        if (trace) {
+            auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[projection] w=%d kq=%d r=%d  svd %.1f ms  device %.1f ms  eig %.1f ms\n", w, kq, r, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+        }
         // stabilize_ritz_values! + safe_sort!  (helpers.jl:122-140)
         int nun = 0;
         for (auto& l : lam) if (!(l.real() < 0)) ++nun;
