@@ -82,6 +82,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_RATIO")) ctx->c.compress_direct_ratio = std::atof(e);
         if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_N")) ctx->c.compress_factor_min_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_COLS")) ctx->c.compress_factor_min_cols = std::atoi(e);
+        if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
     if (rc != DRE_OK) { g_noctx_error = ctx->c.last_error; delete ctx; return rc; }
@@ -112,6 +113,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "compress_direct_ratio") ctx->c.compress_direct_ratio = value;
         else if (key == "compress_factor_min_n") ctx->c.compress_factor_min_n = (int)value;
         else if (key == "compress_factor_min_cols") ctx->c.compress_factor_min_cols = (int)value;
+        else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
     });
 }

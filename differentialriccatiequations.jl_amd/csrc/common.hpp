@@ -119,6 +119,9 @@ struct Ctx {
     // compression in factor form (no QR of L, no n x n matrix) for n >= compress_factor_min_n and at least compress_factor_min_cols columns
     int compress_factor_min_n = 2561;
     int compress_factor_min_cols = 96;
+    // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense
+    // inverse of their Schur complement (reused real factors only; 0 disables)
+    int top_inverse_max_rows = 1536;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }

@@ -639,6 +639,7 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     cache->nfactor++;
     if constexpr (sizeof(T) == sizeof(double)) {
         const int n = op.P->n;
+        fe->f.allow_topinv = cache->enabled;     // a factor that keeps being reused gets the dense top-level inverse (sparse.hip)
         if (want_dense && n <= ctx->dense_inv_max_n) {      // only for shifts that will be reused (Cyclic): the inverse costs n solves
             // explicit inverse through n unit right-hand sides; kept only if the operator is well conditioned enough
             // that inverse-times-vector is as accurate as the triangular solves for the ADI recurrences

@@ -381,6 +381,7 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
     TimedScope ts(ctx, sizeof(T) == 8 ? "mf_factor_real" : "mf_factor_complex", (double)sizeof(T) * 2.0 * S.fronts_size, 0);
     DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(T), ctx->stream));
     if (!out.err.p) out.err = DevArr<int>(ctx, 1);
+    out.topinv = Mat(); out.uses = 0;          // a new factorisation invalidates the dense top inverse
     DevArr<int>& err = out.err;
     DRE_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p);
@@ -682,34 +683,167 @@ __global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_beg
     }
 }
 
-static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st) {
+// ---- top levels as one dense operator (TopPlan, sparse.hpp) --------------------------------------------------------
+static void top_plan_build(Ctx* ctx, const Pencil& P, int max_rows) {
+    TopPlan& tp = P.top;
+    tp.built = true; tp.T = 0; tp.ntop = 0;
+    const Symbolic& S = P.sym;
+    int T = 0, rows = 0;
+    while (T < S.nlevels - 2) {
+        int add = 0;
+        for (int q = S.lvl_ptr[T]; q < S.lvl_ptr[T + 1]; ++q) add += S.size[S.lvl_nodes[q]];
+        if (rows + add > max_rows) break;
+        rows += add; ++T;
+    }
+    if (T < 2 || rows < 32) return;
+    std::vector<int> topidx; topidx.reserve(rows);
+    std::vector<int> pos((size_t)S.n, -1);
+    for (int l = 0; l < T; ++l)
+        for (int q = S.lvl_ptr[l]; q < S.lvl_ptr[l + 1]; ++q) {
+            const int t = S.lvl_nodes[q];
+            for (int i = 0; i < S.size[t]; ++i) { pos[(size_t)S.first[t] + i] = (int)topidx.size(); topidx.push_back(S.first[t] + i); }
+        }
+    // update rows of the level-T nodes (children of the top) by destination
+    std::vector<std::vector<int64_t>> src((size_t)rows);
+    for (int q = S.lvl_ptr[T]; q < S.lvl_ptr[T + 1]; ++q) {
+        const int c = S.lvl_nodes[q];
+        for (int i = S.bptr[c]; i < S.bptr[c + 1]; ++i) {
+            const int pp = pos[(size_t)S.bidx[i]];
+            if (pp < 0) return;                       // border variable outside the top levels: unexpected tree shape, keep the sweeps
+            src[(size_t)pp].push_back(S.upd_off[c] + (i - S.bptr[c]));
+        }
+    }
+    std::vector<int> gptr((size_t)rows + 1, 0);
+    std::vector<int64_t> gsrc;
+    for (int pp = 0; pp < rows; ++pp) { gsrc.insert(gsrc.end(), src[pp].begin(), src[pp].end()); gptr[(size_t)pp + 1] = (int)gsrc.size(); }
+    tp.topidx = DevArr<int>(ctx, topidx.size()); tp.topidx.upload(ctx, topidx);
+    tp.gptr = DevArr<int>(ctx, gptr.size()); tp.gptr.upload(ctx, gptr);
+    tp.gsrc = DevArr<int64_t>(ctx, std::max<size_t>(gsrc.size(), 1)); tp.gsrc.upload(ctx, gsrc);
+    tp.T = T; tp.ntop = rows;
+}
+// g[p, c] = W[topidx[p], c] + sum of the update rows that the level-T nodes send to top variable p
+__global__ void k_top_gather(int ntop, int nrhs, const int* __restrict__ topidx, const int* __restrict__ gptr, const int64_t* __restrict__ gsrc,
+                             const double* __restrict__ W, int ldw, const double* __restrict__ upd, int64_t ldu, double* __restrict__ g, int ldg,
+                             const AdiState* st) {
+    if (st && st->done) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ntop * nrhs) return;
+    const int p = idx % ntop; const size_t c = idx / ntop;
+    double v = W[topidx[p] + c * ldw];
+    for (int j = gptr[p]; j < gptr[p + 1]; ++j) v += upd[gsrc[j] + c * (size_t)ldu];
+    g[p + c * ldg] = v;
+}
+__global__ void k_top_scatter(int ntop, int nrhs, const int* __restrict__ topidx, const double* __restrict__ x, int ldx, double* __restrict__ W, int ldw,
+                              const AdiState* st) {
+    if (st && st->done) return;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ntop * nrhs) return;
+    const int p = idx % ntop; const size_t c = idx / ntop;
+    W[topidx[p] + c * ldw] = x[p + c * ldx];
+}
+__global__ void k_top_unit_rows(int nrhs, int c0, const int* __restrict__ topidx, double* __restrict__ W, int ldw) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nrhs) W[topidx[c0 + j] + (size_t)j * ldw] = 1.0;
+}
+__global__ void k_top_collect(int ntop, int nrhs, int c0, const int* __restrict__ topidx, const double* __restrict__ W, int ldw, double* __restrict__ Ti, int ldt) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ntop * nrhs) return;
+    const int p = idx % ntop; const size_t c = idx / ntop;
+    Ti[p + (c0 + c) * ldt] = W[topidx[p] + c * ldw];
+}
+
+static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st);
+// inv(S) = (M^-1)[top, top]: unit right-hand sides on the top variables, sweeps over the top levels only (everything below stays zero)
+static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc);
+
+static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, double* upd, int64_t ldu,
+                            const AdiState* st, bool forward, int l_from, int l_to) {
+    // forward: levels l_from down to l_to (l_from >= l_to);  backward: levels l_from up to l_to
     const Symbolic& S = P.sym;
     MfArgs a = mf_args(P);
-    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
-    DevArr<double> upd(ctx, (size_t)ldu * nrhs);
     const int ncb = ceil_div(nrhs, MFM_KC);
-    const double bytes = 2.0 * 8.0 * (double)S.factor_nnz + 4.0 * 8.0 * (double)P.n * nrhs;
-    const double flops = 2.0 * 2.0 * (double)S.factor_nnz * nrhs;
-    TimedScope ts(ctx, "mf_solve_real", bytes, flops);
     static bool attr_set = false;
     if (!attr_set) {
         DRE_HIP(hipFuncSetAttribute((const void*)k_mf_forward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         DRE_HIP(hipFuncSetAttribute((const void*)k_mf_backward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
     }
-    for (int l = S.nlevels - 1; l >= 0; --l) {
-        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
-        const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
-        const size_t shm = ((size_t)((std::max(fm + 16, spm) + 4) | 1) + (size_t)((spm + 4) | 1)) * MFM_KC * sizeof(double);
-        const int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
-        hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd.p, ldu, st);
+    if (forward) {
+        for (int l = l_from; l >= l_to; --l) {
+            const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+            const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
+            const size_t shm = ((size_t)((std::max(fm + 16, spm) + 4) | 1) + (size_t)((spm + 4) | 1)) * MFM_KC * sizeof(double);
+            const int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
+            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st);
+        }
+    } else {
+        for (int l = l_from; l <= l_to; ++l) {
+            const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
+            const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
+            const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
+            const int nthreads = sm_ > 64 ? 512 : 256;
+            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+        }
     }
-    for (int l = 0; l < S.nlevels; ++l) {
-        const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
-        const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
-        const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
-        const int nthreads = sm_ > 64 ? 512 : 256;
-        hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+}
+
+static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc) {
+    const TopPlan& tp = P.top;
+    const Symbolic& S = P.sym;
+    const int ntop = tp.ntop, T = tp.T, n = P.n;
+    TimedScope ts(ctx, "mf_top_inverse", 8.0 * (double)ntop * ntop, 0.0);
+    Mat Ti(ctx, ntop, ntop);
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    const int chunk = 512;
+    for (int c0 = 0; c0 < ntop; c0 += chunk) {
+        const int ch = std::min(chunk, ntop - c0);
+        Mat Wk(ctx, n, ch);
+        DevArr<double> upd(ctx, (size_t)ldu * ch);
+        DRE_HIP(hipMemsetAsync(Wk.p, 0, (size_t)n * ch * sizeof(double), ctx->stream));
+        DRE_HIP(hipMemsetAsync(upd.p, 0, (size_t)ldu * ch * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(k_top_unit_rows, dim3(ceil_div(ch, 256)), dim3(256), 0, ctx->stream, ch, c0, (const int*)tp.topidx.p, Wk.p, Wk.ld);
+        mf_sweep_levels(ctx, P, Fc, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, true, T - 1, 0);
+        mf_sweep_levels(ctx, P, Fc, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, false, 0, T - 1);
+        const size_t tot = (size_t)ntop * ch;
+        hipLaunchKernelGGL(k_top_collect, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, ch, c0, (const int*)tp.topidx.p,
+                           (const double*)Wk.p, Wk.ld, Ti.p, Ti.ld);
+    }
+    DRE_HIP(hipGetLastError());
+    Fc.topinv = Ti;
+}
+
+static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st) {
+    const Symbolic& S = P.sym;
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    if (Fc.allow_topinv && ctx->top_inverse_max_rows > 0 && nrhs >= 8 && Fc.topinv.empty() && ++Fc.uses == 3) {
+        if (!P.top.built) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
+        if (P.top.T >= 2) mf_build_topinv(ctx, P, Fc);
+    }
+    DevArr<double> upd(ctx, (size_t)ldu * nrhs);
+    const double bytes = 2.0 * 8.0 * (double)S.factor_nnz + 4.0 * 8.0 * (double)P.n * nrhs;
+    const double flops = 2.0 * 2.0 * (double)S.factor_nnz * nrhs;
+    if (Fc.topinv.empty()) {
+        TimedScope ts(ctx, "mf_solve_real", bytes, flops);
+        mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, 0);
+        mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, 0, S.nlevels - 1);
+    } else {
+        const TopPlan& tp = P.top;
+        const int ntop = tp.ntop, T = tp.T;
+        Mat g(ctx, ntop, nrhs), x(ctx, ntop, nrhs);
+        const size_t tot = (size_t)ntop * nrhs;
+        {
+            TimedScope ts(ctx, "mf_solve_real", bytes, flops);
+            mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, T);
+            hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
+                               (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st);
+        }
+        gemm(ctx, false, false, 1.0, Fc.topinv, g, 0.0, x, st, "gemm_mf_top");
+        {
+            TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
+            hipLaunchKernelGGL(k_top_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
+                               (const double*)x.p, x.ld, W, ldw, st);
+            mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, T, S.nlevels - 1);
+        }
     }
     DRE_HIP(hipGetLastError());
 }

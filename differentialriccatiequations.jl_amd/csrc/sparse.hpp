@@ -41,6 +41,18 @@ struct SymbolicDev {
     DevArr<int64_t> front_off, inv_off, upd_off, asm_dest;
 };
 
+// The top levels of the elimination tree as ONE dense operator (sparse.hip, mf_solve_mfma): with the pivot variables of the levels
+// 0..T-1 collected in `topidx`, the forward and backward sweeps over those levels equal  x_top = inv(S) g,  S = Schur complement of
+// the lower levels, g = right-hand side + the update rows of the level-T nodes.  inv(S) = (M^-1)[top, top] is computed once per
+// factorisation that is reused (Cyclic shifts) and replaces 2 T latency-bound level launches by one GEMM.
+struct TopPlan {
+    bool built = false;
+    int T = 0, ntop = 0;
+    DevArr<int> topidx;         // ntop: solver-ordering index of top variable p
+    DevArr<int> gptr;           // ntop + 1
+    DevArr<int64_t> gsrc;       // row offsets into the update slab contributing to top variable p
+};
+
 // E' and A' (CSR == the caller's CSC of E and A) on one union pattern, permuted to the solver ordering.
 struct Pencil {
     int n = 0, nnz = 0;
@@ -53,6 +65,7 @@ struct Pencil {
     std::vector<int> lvl_maxsep;    // per level: largest number of pivot columns
     bool use_mfma_sweeps = true;    // real triangular sweeps on the matrix cores (env DRE_MF_SCALAR=1 selects the scalar kernels)
     bool has_device = false;
+    mutable TopPlan top;            // built on first use
 };
 
 // Build from CSC arrays (1-based or 0-based) of E and A as Julia's SparseMatrixCSC stores them.
@@ -75,6 +88,11 @@ struct Factor {
     DevArr<T> fronts;   // all frontal matrices (L\U of the eliminated block, L21, U12, Schur complement)
     DevArr<T> inv;      // inverted diagonal blocks: strict lower = inv(L11), upper = inv(U11)
     DevArr<int> err;    // device flag: zero / NaN pivot met (checked lazily by mf_check)
+    // dense inverse of the top levels' Schur complement (real MFMA sweeps only): built at the third multi-column solve of a factor
+    // the engine marked as reusable
+    bool allow_topinv = false;
+    mutable int uses = 0;
+    mutable Mat topinv;
 };
 
 // Numeric multifrontal LU (no pivoting) of  M = cF * F' + cE * E'  where valF/valE live on the pencil's pattern.

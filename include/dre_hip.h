@@ -62,7 +62,11 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               (default 2560; n <= 512 always);  "compress_direct_ratio" (default 8)
  *   "compress_factor_min_n"     n >= value: band reduction in factor form, reflectors applied to L, randomized termination estimate
  *                               (default 2561; a huge value disables);  "compress_factor_min_cols" (default 96) fewer columns: QR path
- *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS) */
+ *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS)
+ *   "top_inverse_max_rows"      multifrontal solves with a real factor that keeps being reused (third multi-column solve on): the top
+ *                               levels of the elimination tree with at most this many pivot variables are applied as ONE dense inverse
+ *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
+ *                               env DRE_TOP_INVERSE_MAX_ROWS) */
 int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value);
 /* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
  * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */

@@ -171,3 +171,25 @@ def test_qr_free_compressions_reproduce_the_qr_path(ctx, n):
     Lc = np.hstack([L0, L1]); Dc = np.block([[a0 * D0, np.zeros((D0.shape[0], D1.shape[1]))], [np.zeros((D1.shape[0], D0.shape[1])), -a1 * D1]])
     _, R = np.linalg.qr(Lc)
     assert np.linalg.norm(R @ Dc @ R.T) < 1e-10 * np.linalg.norm(D0)
+
+
+def test_dense_top_level_inverse_reproduces_the_sweeps(ctx):
+    """Reused real factors apply the top levels of the elimination tree as one dense inverse of their Schur complement (sparse.hip,
+    TopPlan): same ADI iteration counts and K(t) as the level-by-level sweeps."""
+    n = 5177
+    d = D.steel_profile(n); L, Dm = D.initial_value(d)
+    p = np.load(os.path.join(GOLDEN, f"heuristic_shifts_{n}.npy"))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4200.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(list(p)), maxiters=200))
+    out = {}
+    try:
+        for name, rows in (("sweeps", 0), ("top_inverse", 1536)):
+            ctx.set_option("top_inverse_max_rows", rows)
+            sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True)
+            out[name] = (sol, [g["iters"] for g in st["gales"]], [g["res_norm"] for g in st["gales"]])
+    finally:
+        ctx.set_option("top_inverse_max_rows", 1536)
+    (s0, it0, r0), (s1, it1, r1) = out["sweeps"], out["top_inverse"]
+    assert it0 == it1 and all(g < 1e-9 for g in r1)
+    for K0, K1 in zip(s0.K, s1.K):
+        assert D.delta(K0, K1) < 1e-10
