@@ -944,7 +944,14 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             // Small n: the compression works on the n x n matrix L D L' whatever the number of columns, and the increments
             // never depend on X, so the intermediate compressions of adi.jl:72-76 are deferred to the final one
             // (adi.jl:78-80) as long as the uncompressed factor stays small.
-            const bool defer = !cex && n <= 512 && Xw->rank() <= 16 * n;
+            // The same holds for the direct form up to compress_direct_max_n (one GEMM over all columns) and for the factor form
+            // (panel steps ~ rank, GEMM traffic ~ columns: one late compression costs the GEMMs of two early ones and half the
+            // panels) while the factor still fits the factor-form limit c + 64 <= n after the next chunk.
+            static const bool defer_on = !(std::getenv("DRE_DEFER_COMPRESS") && std::atoi(std::getenv("DRE_DEFER_COMPRESS")) == 0);
+            const long rk = Xw->rank(), next = (long)opt.compression_interval * 2 * k;
+            const bool defer = !cex && (n <= 512 ? rk <= 16L * n
+                                       : defer_on && ((n <= ctx->compress_direct_max_n && rk <= 16L * n) ||
+                                                      (n >= ctx->compress_factor_min_n && rk + next + 64 <= n)));
             if (!defer) {
                 ldlt_compress(ctx, *Xw, ctf, cex);
                 last_compression = 0;
