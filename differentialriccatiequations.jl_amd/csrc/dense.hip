@@ -307,6 +307,30 @@ void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale, const AdiState* 
     TimedScope ts(ctx, "copy", 16.0 * tot, 0);
     hipLaunchKernelGGL(k_copy, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src.rows, src.cols, src.p, src.ld, dst.p, dst.ld, scale, st);
 }
+// Several column blocks copied by ONE launch (horizontal concatenation of the summands of an LDL' object): the descriptors travel
+// as kernel arguments, no upload.
+struct CopyBatchArgs { CopyDesc d[32]; int n; };
+__global__ __launch_bounds__(256) void k_copy_batched(CopyBatchArgs a) {
+    const CopyDesc d = a.d[blockIdx.y];
+    const size_t tot = (size_t)d.rows * d.cols;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx % d.rows, c = idx / d.rows;
+        d.dst[r + c * d.ldd] = d.src[r + c * d.lds];
+    }
+}
+void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs) {
+    for (size_t b0 = 0; b0 < descs.size(); b0 += 32) {
+        CopyBatchArgs a;
+        a.n = (int)std::min<size_t>(32, descs.size() - b0);
+        size_t mx = 0; double by = 0.0;
+        for (int i = 0; i < a.n; ++i) { a.d[i] = descs[b0 + i]; const size_t t = (size_t)a.d[i].rows * a.d[i].cols; mx = std::max(mx, t); by += 16.0 * t; }
+        if (mx == 0) continue;
+        TimedScope ts(ctx, "copy", by, 0);
+        const unsigned gx = (unsigned)std::min<size_t>((mx + 255) / 256, 2048);
+        hipLaunchKernelGGL(k_copy_batched, dim3(gx, (unsigned)a.n), dim3(256), 0, ctx->stream, a);
+    }
+    DRE_HIP(hipGetLastError());
+}
 __global__ void k_fill(int rows, int cols, double* __restrict__ dst, int ldd, double v, double dv) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)rows * cols) return;

@@ -45,6 +45,8 @@ void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char*
 BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                    int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma");
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src
+struct CopyDesc { const double* src; double* dst; int rows, cols, lds, ldd; };
+void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                      // all blocks in one launch per 32
 void fill_mat(Ctx* ctx, Mat& dst, double v);
 void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
 void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst);      // dst = src'

@@ -63,12 +63,14 @@ static Mat hcat_blocks(Ctx* ctx, const LDLt& X) {
     const int c = X.rank();
     Mat L(ctx, X.n, c);
     int off = 0;
+    std::vector<CopyDesc> cd;
     for (auto& b : X.blocks) {
         if (b.L.cols == 0) continue;
         Mat dst = L.colsview(off, b.L.cols);
-        copy_mat(ctx, b.L, dst);
+        cd.push_back({b.L.p, dst.p, X.n, b.L.cols, b.L.ld, dst.ld});
         off += b.L.cols;
     }
+    copy_batched(ctx, cd);
     return L;
 }
 
@@ -137,15 +139,17 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         // instead of a QR of all c columns followed by the reduction of R D R'
         Mat Lw(ctx, n, c + 16);                  // 16 spare columns: the probe vectors of the termination estimate
         std::vector<LrBlockD> tab;
+        std::vector<CopyDesc> cd;
         int off = 0;
         for (auto& b : X.blocks) {
             const int k = b.L.cols;
             if (k == 0) continue;
             Mat dst = Lw.colsview(off, k);
-            copy_mat(ctx, b.L, dst);
+            cd.push_back({b.L.p, dst.p, n, k, b.L.ld, dst.ld});
             tab.push_back({off, k, b.D.ld, b.diag ? 1 : 0, b.D.p, b.alpha});
             off += k;
         }
+        copy_batched(ctx, cd);
         SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
         g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += n; g_cstats.tri_steps += sb.J; g_cstats.rank_out += sb.J;
         if (sb.J == 0) { set_empty(); return; }
