@@ -26,8 +26,8 @@ import numpy as np
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=371, help="SteelProfile size (371 = the configuration the metric is quoted on)")
     ap.add_argument("--nsteps", type=int, default=45, help="Rosenbrock time steps per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
