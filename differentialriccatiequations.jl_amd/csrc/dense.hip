@@ -520,6 +520,57 @@ __global__ __launch_bounds__(1024) void k_trace_sq(int k, const double* __restri
         }
     }
 }
+// The same for large k in two launches: 32 x 32 tile pairs (bi <= bj) through LDS, so that both M_ij and M_ji are read coalesced,
+// one partial sum per pair; then the fixed-order sum and the decision.
+__global__ __launch_bounds__(256) void k_trace_sq_tiles(int k, const double* __restrict__ M, int ldm, double* __restrict__ part, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double A[32][33], B[32][33];
+    __shared__ double red[17];
+    // tile pair index -> (bi, bj), bi <= bj
+    const int nt = (k + 31) / 32;
+    int bi = 0, rem = blockIdx.x;
+    while (rem >= nt - bi) { rem -= nt - bi; ++bi; }
+    const int bj = bi + rem;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int c = ty; c < 32; c += 8) {
+        const int ra = bi * 32 + tx, ca = bj * 32 + c;           // A = M[bi-block rows, bj-block cols]
+        A[c][tx] = (ra < k && ca < k) ? M[ra + (size_t)ca * ldm] : 0.0;
+        const int rb = bj * 32 + tx, cb = bi * 32 + c;           // B = M[bj-block rows, bi-block cols]
+        B[c][tx] = (rb < k && cb < k) ? M[rb + (size_t)cb * ldm] : 0.0;
+    }
+    __syncthreads();
+    double s = 0.0;
+    for (int c = ty; c < 32; c += 8) s += A[c][tx] * B[tx][c];   // M[i, j] * M[j, i]
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = (bi == bj) ? s : 2.0 * s;
+}
+__global__ __launch_bounds__(64) void k_trace_finish(int nparts, const double* __restrict__ part, double alpha, AdiState* st, int iters_after, double* out) {
+    if (st && st->done) return;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        if (out) out[0] = nrm;
+        if (st) {
+            st->res_norm = nrm;
+            st->iters = iters_after;
+            if (iters_after < 512) st->norms[iters_after] = nrm;
+            if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+        }
+    }
+}
+static void trace_sq(Ctx* ctx, const Mat& TG, double alpha, AdiState* st, int iters_after, double* out) {
+    const int k = TG.rows;
+    if (k <= 128) {
+        hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, k, TG.p, TG.ld, alpha, st, iters_after, out);
+        return;
+    }
+    const int nt = (k + 31) / 32, np = nt * (nt + 1) / 2;
+    DevArr<double> part(ctx, (size_t)np);
+    hipLaunchKernelGGL(k_trace_sq_tiles, dim3(np), dim3(256), 0, ctx->stream, k, (const double*)TG.p, TG.ld, part.p, (const AdiState*)st);
+    hipLaunchKernelGGL(k_trace_finish, dim3(1), dim3(64), 0, ctx->stream, np, (const double*)part.p, alpha, st, iters_after, out);
+}
 void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     if (tdiag) {
         TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
@@ -528,7 +579,7 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
         Mat TG(ctx, G.rows, G.cols);
         gemm(ctx, false, false, 1.0, T, G, 0.0, TG, st, "gemm_norm");
         TimedScope ts(ctx, "ldlt_norm", 16.0 * G.rows * G.cols, 4.0 * G.rows * G.cols);
-        hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, st, iters_after, (double*)nullptr);
+        trace_sq(ctx, TG, alpha, st, iters_after, nullptr);
     }
 }
 // Workgroup-wide: G = sum of `splits` k x k slabs (fixed order), M = T G (or diag(T) G), nrm = |alpha| sqrt(sum_ij M_ij M_ji),
@@ -792,7 +843,7 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
     DevArr<double> out(ctx, 1);
     Mat TG(ctx, G.rows, G.cols);
     gemm(ctx, false, false, 1.0, D, G, 0.0, TG, nullptr, "gemm_norm");
-    hipLaunchKernelGGL(k_trace_sq, dim3(1), dim3(1024), 0, ctx->stream, G.rows, TG.p, TG.ld, alpha, (AdiState*)nullptr, 0, out.p);
+    trace_sq(ctx, TG, alpha, nullptr, 0, out.p);
     return read_scalar(ctx, out.p);
 }
 
