@@ -133,7 +133,8 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     if (c == 0) { set_empty(); return; }
     // Q = I is admissible whenever the n x n matrix S = L D L' is affordable; for small n this skips the whole QR
     // (two thirds of all panel factorisations at n = 371) at the price of one GEMM.
-    const bool wide = c >= n || (!exact && (n <= 512 || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
+    // (a handful of columns: the QR path keeps the rank <= c, the direct form can only stop at panel boundaries of the n x n problem)
+    const bool wide = c >= n || (!exact && ((n <= 512 && c > 64) || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
     if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {
         // large n: the band reduction works on the factor itself (dense.hip, lr_band_reduce): rank/16 panel steps on n x c data
         // instead of a QR of all c columns followed by the reduction of R D R'
@@ -153,6 +154,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
         g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += n; g_cstats.tri_steps += sb.J; g_cstats.rank_out += sb.J;
         if (sb.J == 0) { set_empty(); return; }
+        if (sb.J >= c) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
         Mat Bq = sym_band_basis(ctx, sb);
         X.blocks.clear();
         X.blocks.push_back({Bq, sb.D, 1.0, false, true});
@@ -243,6 +245,14 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         copy_mat(ctx, B, top);
         qr_apply_q(ctx, qr, Lnew, false);
     }
+    if (!exact && r >= c) {
+        // nothing gained (numerical rank = number of columns, or a remainder that stays above the tolerance because S itself
+        // carries cancellation): keep the summands as they are, concatenated
+        ldlt_concatenate(ctx, X);
+        return;
+    }
+    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d -> r=%d  (%s, order %d)\n", n, c, r, wide ? "direct" : "qr", S.rows);
     X.blocks.clear();
     X.blocks.push_back({Lnew, Dnew, 1.0, exact, true});
 }
@@ -272,6 +282,11 @@ double ldlt_norm_accurate(Ctx* ctx, const LDLt& X) {
     LDLt Y = X;
     ldlt_compress(ctx, Y, 4.0, false);
     if (Y.rank() == 0) return 0.0;
+    if (!(Y.blocks.size() == 1 && Y.blocks[0].ortho)) {     // the compression kept the summands (nothing to gain): orthogonalise exactly
+        Y = X;
+        ldlt_compress(ctx, Y, 4.0, true);
+        if (Y.rank() == 0) return 0.0;
+    }
     auto& b = Y.blocks[0];
     return ldlt_norm_host(ctx, b.L, b.D, b.alpha);
 }

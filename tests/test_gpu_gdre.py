@@ -67,6 +67,10 @@ def test_ros2_matches_dense_oracle_and_golden(ctx, rail371):    # test/rail.jl:6
     for i in range(len(sol.K)):
         assert D.delta(sol.K[i], g["K"][i]) < 1e-7
     assert len(st["gales"]) == 6 and all(x["converged"] for x in st["gales"])
+    # the oracle's ADI iteration counts per time step (both stages): the stage-1 right-hand side [C', A'L, E'L] has full numerical
+    # rank, a compression that cannot gain anything must hand the summands back unchanged instead of adding noise directions
+    its = [x["iters"] for x in st["gales"]]
+    assert [its[2 * i] + its[2 * i + 1] for i in range(3)] == list(g["iters"])
 
 
 def test_ros1_default_adi_projection_shifts(ctx, rail371):      # Ros1() with the default ADI(): Projection(2) shifts
