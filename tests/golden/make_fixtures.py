@@ -63,3 +63,15 @@ K = (d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E)
 Xd = sla.solve_continuous_are(d.A.toarray(), d.B, d.C.T @ d.C, np.eye(d.B.shape[1]), e=d.E.toarray())
 np.savez(os.path.join(HERE, "gare_371.npz"), K=K, K_dense=d.B.T @ Xd @ d.E.toarray(), residuals=np.array([s["res"] for s in st]), rank=X.rank())
 print("gare", [f"{s['res']:.2e}" for s in st], X.rank(), np.linalg.norm(K - d.B.T @ Xd @ d.E.toarray()) / np.linalg.norm(K))
+
+# ros1_1357.npz : the oracle's low-rank Ros1 on the SteelProfile(1357) surrogate (a BASELINE.json size beyond the dense oracle's comfort
+#                 zone), 4 time steps with the committed heuristic shift list: K(t) and the ADI iteration count of every Lyapunov solve.
+#                 (skipped unless DRE_FIXTURE_1357=1: 45 s of CPU)
+if os.environ.get("DRE_FIXTURE_1357") == "1":
+    d2 = D.steel_profile(1357)
+    L2, Dm2 = D.initial_value(d2)
+    p1357 = np.load(os.path.join(HERE, "heuristic_shifts_1357.npy"))
+    st = []
+    sol = o.solve(o.GDREProblem(d2.E, d2.A, d2.B, d2.C, o.lowrank(L2, Dm2), (4500.0, 4100.0)), o.Ros1(o.ADI(shifts=o.Cyclic(list(p1357)), maxiters=200)), dt=-100.0, stats=st)
+    np.savez(os.path.join(HERE, "ros1_1357.npz"), K=np.array(sol.K), iters=np.array([s["iters"] for s in st]), t=sol.t)
+    print("ros1_1357", [s["iters"] for s in st])

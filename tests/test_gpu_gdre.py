@@ -136,3 +136,16 @@ def test_full_size_properties(ctx, n):
     assert res <= 50 * n * EPS * D.norm(rhs)
     sol2 = D.solve_gdre(prob, alg, dt=-100.0)
     assert np.array_equal(sol2.K[-1], sol.K[-1])
+
+
+def test_ros1_at_n1357_matches_the_oracle_fixture(ctx):
+    """BASELINE size 1357 (direct-form compressions, deferred intermediate compressions, dense inverse): the oracle's K(t) and its ADI
+    iteration count of every Lyapunov solve (tests/golden/ros1_1357.npz, made by tests/golden/make_fixtures.py)."""
+    g = np.load(os.path.join(GOLDEN, "ros1_1357.npz"))
+    d = D.steel_profile(1357)
+    L, Dm = D.initial_value(d)
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4100.0))
+    sol, st = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(1357)), maxiters=200)), dt=-100.0, return_stats=True)
+    assert [x["iters"] for x in st["gales"]] == list(g["iters"])
+    for K, Kg in zip(sol.K, g["K"]):
+        assert D.delta(K, Kg) < 1e-10
