@@ -1233,7 +1233,9 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 Mat d33 = S.view(q + r, q + r, r, r); gemm(ctx, true, false, -1.0, fb.BtLD, fb.BtLD, 0.0, d33);
             }
             LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);
-            ldlt_compress(ctx, *R1, ctf, cex);
+            // lowrank_ros2.jl:58 compresses here; [C', A'L, E'L] has full numerical rank q + 2r generically, so the engine's
+            // compression would run to the end and hand G back (ldlt_compress): it is only attempted in the literal (exact) mode
+            if (cex) ldlt_compress(ctx, *R1, ctf, cex);
             AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
             LDLtP K1 = a1.X;
             // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)
