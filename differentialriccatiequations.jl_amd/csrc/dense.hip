@@ -1246,6 +1246,9 @@ struct TsqrPlan { int P; int base; int rem; };     // chunk c has base + (c < re
 __device__ __host__ inline int chunk_start(const TsqrPlan& p, int c) { return c * p.base + (c < p.rem ? c : p.rem); }
 __device__ __host__ inline int chunk_rows(const TsqrPlan& p, int c) { return p.base + (c < p.rem ? 1 : 0); }
 
+// BIG: chunks of 1024 < rows <= 1536 (panels taller than 64 x 1023 rows): no LDS copy, the register-resident core works in place on the
+// chunk's slice of Vloc (global memory), like the medium single-workgroup panels.
+template <bool BIG>
 __global__ __launch_bounds__(1024) void k_tsqr_local(const double* __restrict__ A, int lda, int jb, TsqrPlan plan, double* __restrict__ Vloc, int ldvl,
                                                      double* __restrict__ Tloc, double* __restrict__ Rstack, int ldrs, const AdiState* st) {
     if (st && st->done) return;
@@ -1253,16 +1256,33 @@ __global__ __launch_bounds__(1024) void k_tsqr_local(const double* __restrict__ 
     __shared__ PanelShared sh;
     const int c = blockIdx.x, r0 = chunk_start(plan, c), rows = chunk_rows(plan, c);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const int ldp = rows | 1;
-    for (int j = wave; j < jb; j += nw)
-        for (int r = lane; r < rows; r += 64) psm[r + (size_t)j * ldp] = A[(r0 + r) + (size_t)j * lda];
-    hh_panel_core_lds(psm, ldp, rows, jb, sh);
-    for (int j = wave; j < jb; j += nw)
-        for (int r = lane; r < rows; r += 64) {
-            const double x = psm[r + (size_t)j * ldp];
-            Vloc[(r0 + r) + (size_t)j * ldvl] = (r > j) ? x : (r == j ? 1.0 : 0.0);
-            if (r < jb) Rstack[(c * jb + r) + (size_t)j * ldrs] = (r <= j) ? x : 0.0;
+    if (BIG) {
+        double* Pn = Vloc + r0;
+        for (int j = wave; j < jb; j += nw)
+            for (int r = lane; r < rows; r += 64) Pn[r + (size_t)j * ldvl] = A[(r0 + r) + (size_t)j * lda];
+        __syncthreads();
+        hh_panel_core_reg<24>(Pn, ldvl, rows, jb, sh, psm, 2048);
+        for (int i = tid; i < jb * jb; i += blockDim.x) {
+            const int r = i % jb, j = i / jb;
+            Rstack[(c * jb + r) + (size_t)j * ldrs] = (r <= j) ? Pn[r + (size_t)j * ldvl] : 0.0;
         }
+        __syncthreads();
+        for (int i = tid; i < jb * jb; i += blockDim.x) {
+            const int r = i % jb, j = i / jb;
+            if (r <= j) Pn[r + (size_t)j * ldvl] = (r == j) ? 1.0 : 0.0;
+        }
+    } else {
+        const int ldp = rows | 1;
+        for (int j = wave; j < jb; j += nw)
+            for (int r = lane; r < rows; r += 64) psm[r + (size_t)j * ldp] = A[(r0 + r) + (size_t)j * lda];
+        hh_panel_core_lds(psm, ldp, rows, jb, sh);
+        for (int j = wave; j < jb; j += nw)
+            for (int r = lane; r < rows; r += 64) {
+                const double x = psm[r + (size_t)j * ldp];
+                Vloc[(r0 + r) + (size_t)j * ldvl] = (r > j) ? x : (r == j ? 1.0 : 0.0);
+                if (r < jb) Rstack[(c * jb + r) + (size_t)j * ldrs] = (r <= j) ? x : 0.0;
+            }
+    }
     for (int i = tid; i < jb * jb; i += blockDim.x) Tloc[(size_t)c * QR_NB * QR_NB + i % jb + (i / jb) * QR_NB] = sh.Tsh[i % jb][i / jb];
 }
 
@@ -1490,19 +1510,21 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     plan.P = std::max(2, rows / TSQR_CHUNK);
     while (plan.P * jb > QR_LDS_ROWS) --plan.P;
     plan.base = rows / plan.P; plan.rem = rows % plan.P;
-    DRE_REQUIRE(plan.base >= jb && plan.base + 1 <= QR_LDS_ROWS, "TSQR panel: chunk size out of range");
+    const bool big = plan.base + 1 > QR_LDS_ROWS - 1;
+    DRE_REQUIRE(plan.base >= jb && plan.base + 1 <= 1536, "TSQR panel: chunk size out of range");
     const int rowsR = plan.P * jb;
     Mat Vloc(ctx, rows, jb), Rstack(ctx, rowsR, jb), Qt(ctx, rowsR, jb);
     DevArr<double> Tloc(ctx, (size_t)plan.P * QR_NB * QR_NB), Rfin(ctx, QR_NB * QR_NB), hr(ctx, 4 * QR_NB * QR_NB);
     TimedScope ts(ctx, "qr_panel_tsqr", 8.0 * rows * jb * 8.0, 2.0 * rows * jb * jb * 3.0);
     static bool attr_set = false;
     if (!attr_set) {
-        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
         DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_top, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
         attr_set = true;
     }
     const size_t shm1 = (size_t)((plan.base + 1) | 1) * jb * sizeof(double);
-    hipLaunchKernelGGL(k_tsqr_local, dim3(plan.P), dim3(1024), shm1, ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
+    if (big) hipLaunchKernelGGL((k_tsqr_local<true>), dim3(plan.P), dim3(1024), (size_t)2 * 2048 * sizeof(double), ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
+    else hipLaunchKernelGGL((k_tsqr_local<false>), dim3(plan.P), dim3(1024), shm1, ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
     const size_t shm2 = (size_t)(rowsR | 1) * jb * sizeof(double);
     hipLaunchKernelGGL(k_tsqr_top, dim3(1), dim3(1024), shm2, ctx->stream, Rstack.p, Rstack.ld, rowsR, jb, Rfin.p, Qt.p, st,
                        (const double*)Vloc.p, Vloc.ld, (const double*)Tloc.p, hr.p);
@@ -1530,7 +1552,7 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
         // V T as a (multi-workgroup) GEMM: inside the single-workgroup kernel it would re-read the panel 8.5 times from L2
         if (VT) gemm(ctx, false, false, rows, jb, jb, 1.0, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt, 0.0,
                      VT + (size_t)j0 * ldvt + j0, ldvt, st, "gemm_qr");
-    } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2) {
+    } else if (rows >= 2 * TSQR_CHUNK && jb <= rows / 2 && rows <= 64 * 1535) {      // one-level tree: at most 64 chunks of <= 1535 rows
         // tall panel: TSQR + Householder reconstruction on many CUs (the termination test, if any, runs on its own)
         if (part) hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, kpanel, nparts, part, tolfac, st);
         launch_tsqr_panel(ctx, A + (size_t)j0 * lda + j0, lda, rows, jb, V + (size_t)j0 * ldv + j0, ldv, T + (size_t)j0 * ldt, ldt,

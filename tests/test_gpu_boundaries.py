@@ -14,7 +14,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("m", [63, 64, 65, 255, 257, 511, 513, 767, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2049, 4095, 4097])
+@pytest.mark.parametrize("m", [63, 64, 65, 255, 257, 511, 513, 767, 769, 1023, 1024, 1025, 1535, 1536, 1537, 2047, 2049, 4095, 4097, 65472, 65473, 79841, 98240])
 def test_orthf_at_panel_height_boundaries(ctx, m):
     rng = np.random.default_rng(m)
     for ncol in (1, 15, 17, 33):

@@ -149,3 +149,22 @@ def test_ros1_at_n1357_matches_the_oracle_fixture(ctx):
     assert [x["iters"] for x in st["gales"]] == list(g["iters"])
     for K, Kg in zip(sol.K, g["K"]):
         assert D.delta(K, Kg) < 1e-10
+
+
+def test_largest_steel_profile_size(ctx):
+    """SteelProfile(79841) surrogate (largest member of the family): panels taller than 64 x 1023 rows (TSQR with register-resident
+    chunks), 14 elimination-tree levels, Penzl shifts computed on the device; two Rosenbrock steps converge and K = B'XE."""
+    n = 79841
+    d = D.steel_profile(n)
+    L, Dm = D.initial_value(d)
+    P = D.Pencil(d.E, d.A, ctx)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p = sorted(v.real for v in D.heuristic_shifts(D.Shifts.Heuristic(10, 20, 20), P))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4300.0))
+    sol, st = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p), maxiters=200)), dt=-100.0, return_stats=True)
+    assert all(g["converged"] for g in st["gales"])
+    a, Lx, Dx = sol.X[-1]
+    K = (d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E)
+    assert D.delta(K, sol.K[-1]) < 1e-10
+    assert np.abs(Lx.T @ Lx - np.eye(Lx.shape[1])).max() < 1e-10
