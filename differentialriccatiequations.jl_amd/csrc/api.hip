@@ -93,6 +93,14 @@ int dre_ctx_destroy(dre_ctx* ctx) {
     if (!ctx) return DRE_OK;
     (void)hipSetDevice(ctx->c.device);
     (void)hipStreamSynchronize(ctx->c.stream);
+    if (ctx->c.side) {
+        Ctx& sc = *ctx->c.side;
+        (void)hipStreamSynchronize(sc.stream);
+        sc.timer.reset(); sc.pool.trim();
+        (void)hipEventDestroy(ctx->c.side_e1); (void)hipEventDestroy(ctx->c.side_e2);
+        (void)hipStreamDestroy(sc.stream);
+        ctx->c.side.reset();
+    }
     ctx->c.timer.reset();
     ctx->c.pool.trim();
     (void)hipStreamDestroy(ctx->c.stream);

@@ -124,6 +124,10 @@ struct Ctx {
     int top_inverse_max_rows = 1536;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;
+    // second context (own stream, pool, hints) for work that runs beside the main stream (engine.hip: side-stream compression of X);
+    // created on first use, lives as long as this context
+    std::unique_ptr<Ctx> side;
+    hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

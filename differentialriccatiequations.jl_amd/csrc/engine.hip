@@ -1,4 +1,6 @@
 #include <chrono>
+#include <thread>
+#include <exception>
 // Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
 #include "engine.hpp"
 #include <functional>
@@ -618,10 +620,62 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
 // =============================================================================================
 // GALE residual (/root/reference/src/lyapunov/residual.jl:3-31)
 // =============================================================================================
+// P = F / s + s E,  M = F / s - s E  with  s^4 = ||F||_F^2 / ||E||_F^2  read from device memory (nrm2[0], nrm2[1])
+__global__ void k_balance_pm(size_t tot, const double* __restrict__ F, const double* __restrict__ E, const double* __restrict__ nrm2,
+                             double* __restrict__ Pm, double* __restrict__ Mm) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    const double a2 = nrm2[0], b2 = nrm2[1];
+    const double s = (a2 > 0.0 && b2 > 0.0) ? sqrt(sqrt(a2 / b2)) : 1.0;
+    const double f = F[i] / s, e = E[i] * s;
+    Pm[i] = f + e; Mm[i] = f - e;
+}
+// ||X||_F of a block list through the n x n matrix (small n only; no compression, X untouched); synchronises
+static double ldlt_norm_dense_small(Ctx* ctx, const LDLt& X) {
+    const int n = X.n, c = X.rank();
+    if (c == 0) return 0.0;
+    Mat Lcat(ctx, n, c), LD(ctx, n, c), S(ctx, n, n);
+    hcat_scale_blocks(ctx, X, Lcat, LD);
+    gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
+    return frob_norm_host(ctx, S);
+}
+// Block lists on both sides (small n, Krylov mode): the summands of C and of the warm start X are used as they are, nothing is
+// compressed on the way in.  F'XE + E'XF = (P D P' - M D M') / 2 with P = F'L / s + s E'L, M = F'L / s - s E'L (s balances the
+// two terms, so the rounding error stays at eps ||F'L|| ||E'L|| ||D|| like in the [E'L, F'L] form), i.e. per block of X two
+// blocks that share its D.
+static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& C, const LDLt& X, double tolfac, double abs_tol) {
+    const Pencil& P = *op.P;
+    const int n = P.n, c = X.rank();
+    Mat Lall = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    Mat EtL(ctx, n, c), FtL(ctx, n, c), Pm(ctx, n, c), Mm(ctx, n, c);
+    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Lall, EtL, 1.0, 0.0);
+    apply_Ft(ctx, op, Lall, FtL);
+    DevArr<double> nrm2(ctx, 2);
+    frob2_device(ctx, FtL, nrm2.p);
+    frob2_device(ctx, EtL, nrm2.p + 1);
+    const size_t tot = (size_t)n * c;
+    hipLaunchKernelGGL(k_balance_pm, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, (const double*)FtL.p, (const double*)EtL.p,
+                       (const double*)nrm2.p, Pm.p, Mm.p);
+    auto res = std::make_shared<LDLt>();
+    res->n = n;
+    res->blocks = C.blocks;
+    int off = 0;
+    for (auto& b : X.blocks) {
+        const int k = b.L.cols;
+        if (k == 0) continue;
+        res->blocks.push_back({Pm.colsview(off, k), b.D, 0.5 * b.alpha, b.diag, false});
+        res->blocks.push_back({Mm.colsview(off, k), b.D, -0.5 * b.alpha, b.diag, false});
+        off += k;
+    }
+    ldlt_compress(ctx, *res, tolfac, false, abs_tol);
+    return res;
+}
+
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol) {
     auto Cp = std::make_shared<LDLt>(C);
     if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
     const Pencil& P = *op.P;
+    if (!exact && P.n <= 512 && (C.blocks.size() > 1 || X->blocks.size() > 1)) return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol);
     ldlt_destructure(ctx, C, tolfac, exact);
     ldlt_destructure(ctx, *X, tolfac, exact);
     const LBlock& cb = C.blocks[0];
@@ -696,8 +750,10 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     const AdiOptions& opt = *optp;
     const double ctf = opt.compress_tolfac;
     const bool cex = opt.compress_exact;
-    ldlt_destructure(ctx, C, ctf, cex);
-    const double normC = ldlt_norm(ctx, C);
+    const bool keep_blocks = !cex && n <= 512 && C.blocks.size() > 1 && initial_guess && !opt.ignore_initial_guess && !initial_guess->iszero();
+    double normC;
+    if (keep_blocks) normC = ldlt_norm_dense_small(ctx, C);       // the summands go into the residual as they are (gale_residual_blocks)
+    else { ldlt_destructure(ctx, C, ctf, cex); normC = ldlt_norm(ctx, C); }
     const double reltol = opt.reltol >= 0 ? opt.reltol : n * EPS;
     const double abstol = opt.abstol >= 0 ? opt.abstol : reltol * normC;
     LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
@@ -982,7 +1038,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
         for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
     }
-    if (opt.compression && last_compression > 0) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
+    if (opt.compression && last_compression > 0 && (opt.final_compress || cex)) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
     all_shifts.resize(res.iters);
     res.shifts = all_shifts;
     res.X = Xw;
@@ -1149,6 +1205,25 @@ static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X, double ctf,
     return f;
 }
 
+// The same for a block list X = sum_b alpha_b L_b D_b L_b' that is NOT compressed first (small n, Ros1 between two compressions of X):
+// L = [L_1 ... L_p] concatenated, BtLD = (B'L) blockdiag(alpha_b D_b), K' = (E'L) BtLD'.
+static Feedback feedback_blocks(Ctx* ctx, const GdreProblem& prob, const LDLt& X) {
+    const Pencil& P = *prob.P;
+    Feedback f;
+    const int c = X.rank(), m = prob.B.cols;
+    f.L = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    f.alpha = 1.0; f.diag = false;
+    Mat BtL(ctx, m, c);
+    gemm(ctx, true, false, 1.0, prob.B, f.L, 0.0, BtL);
+    f.BtLD = Mat(ctx, m, c);
+    mul_blockdiag(ctx, BtL, X, f.BtLD);
+    f.EtL = Mat(ctx, P.n, c);
+    spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, f.L, f.EtL, 1.0, 0.0);
+    f.Kt = Mat(ctx, P.n, m);
+    gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
+    return f;
+}
+
 static uint64_t tag_of(int order, double tau) {
     uint64_t bits;
     std::memcpy(&bits, &tau, sizeof(bits));
@@ -1171,6 +1246,32 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     Feedback fb = feedback(ctx, prob, *X, ctf, cex);
     out.Kt.push_back(fb.Kt);
     FactorCache cache;
+    // Ros1 at small n: X stays "warm start + increments" between two compressions (every xevery-th step and at the end); right-hand side,
+    // feedback and warm-start residual work on the block list (the direct-form compression does not care about the number of columns)
+    static const int xevery_env = std::getenv("DRE_X_COMPRESS_EVERY") ? std::atoi(std::getenv("DRE_X_COMPRESS_EVERY")) : 1;
+    static const bool xside_env = std::getenv("DRE_X_SIDE_STREAM") && std::atoi(std::getenv("DRE_X_SIDE_STREAM")) != 0;
+    const int xevery = std::max(1, xevery_env);
+    const bool xblocks = order == 1 && (xevery > 1 || xside_env) && !cex && !save_state && n <= 512 && !adi.ignore_initial_guess;
+    // Side stream: the compression of X_{i-1} is not on the critical path of step i (right-hand side, feedback and residual take the
+    // block list), so it runs on a second stream, driven by a second host thread with its own context (stream, pool, hints), while the
+    // main stream does the residual compression and the ADI iteration of step i; its result replaces the uncompressed summands at the
+    // end of step i:  X_i = compress(X_{i-1}) + increments_i.  A single latency-bound solve leaves most of the chip idle.
+    const bool xside = xblocks && xside_env;
+    if (xside && !ctx->side) {
+        auto sc = std::make_unique<Ctx>();
+        sc->device = ctx->device; sc->num_cus = ctx->num_cus;
+        DRE_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
+        sc->timer = std::make_unique<KernelTimer>();
+        ctx->side = std::move(sc);
+    }
+    Ctx* const side = ctx->side.get();
+    if (xside) {
+        side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
+        side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
+        side->compress_factor_min_cols = ctx->compress_factor_min_cols;
+    }
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
 
@@ -1192,6 +1293,70 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         op.Vt = fb.Kt;
         op.alpha = order == 1 ? -1.0 : 1.0 / (-gamma * tau);
         const int r = fb.L.cols;
+        if (order == 1 && xblocks) {
+            // X is a block list (compressed every `xevery` steps only):  rhs = C'C + K'K + sum_b (E'L_b) (alpha_b D_b / tau) (E'L_b)'
+            // as a block list of its own; nothing is compressed before the warm-start residual (gale_residual_blocks)
+            auto rhs = std::make_shared<LDLt>();
+            rhs->n = n;
+            Mat Iq(ctx, q, q), Im(ctx, m, m);
+            set_identity(ctx, Iq, 1.0); set_identity(ctx, Im, 1.0);
+            rhs->blocks.push_back({prob.Ct, Iq, 1.0, true, false});
+            rhs->blocks.push_back({fb.Kt, Im, 1.0, true, false});
+            int off = 0;
+            for (auto& b : X->blocks) {
+                const int k = b.L.cols;
+                if (k == 0) continue;
+                rhs->blocks.push_back({fb.EtL.colsview(off, k), b.D, b.alpha / tau, b.diag, false});
+                off += k;
+            }
+            AdiOptions a2 = adi;
+            const bool last = (i == nsteps);
+            a2.final_compress = xside ? false : (last || (i % xevery == 0));
+            // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
+            std::thread worker;
+            LDLtP Xc;
+            std::exception_ptr werr;
+            const size_t nb_prev = X->blocks.size();
+            if (xside && nb_prev > 1) {
+                DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
+                Xc = std::make_shared<LDLt>(*X);               // shallow: shares the summands, which stay alive in X until the join
+                worker = std::thread([&, Xc]() {
+                    try {
+                        DRE_HIP(hipSetDevice(side->device));
+                        DRE_HIP(hipStreamWaitEvent(side->stream, ctx->side_e1, 0));
+                        ldlt_compress(side, *Xc, ctf, false);
+                        DRE_HIP(hipEventRecord(ctx->side_e2, side->stream));
+                    } catch (...) { werr = std::current_exception(); }
+                });
+            }
+            AdiResult ar;
+            try { ar = adi_solve(ctx, op, *rhs, X, a2, &cache); }
+            catch (...) { if (worker.joinable()) worker.join(); throw; }
+            if (worker.joinable()) {
+                worker.join();
+                if (werr) std::rethrow_exception(werr);
+                DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
+                // X_i = compress(X_{i-1}) + increments_i  (unless the ADI loop had to compress in between: then its X stands)
+                bool intact = ar.X->blocks.size() >= nb_prev;
+                for (size_t bi = 0; intact && bi < nb_prev; ++bi) intact = ar.X->blocks[bi].L.p == X->blocks[bi].L.p;
+                if (intact) {
+                    auto Xn = std::make_shared<LDLt>();
+                    Xn->n = n;
+                    Xn->blocks = Xc->blocks;
+                    for (size_t bi = nb_prev; bi < ar.X->blocks.size(); ++bi) Xn->blocks.push_back(ar.X->blocks[bi]);
+                    ar.X = Xn;
+                }
+            }
+            if (xside && last) ldlt_compress(ctx, *ar.X, ctf, false);
+            X = ar.X;
+            out.adi_iters += ar.iters;
+            ar.X.reset(); ar.residual.reset();
+            out.gale.push_back(std::move(ar));
+            if (save_state) out.X.push_back(X);
+            fb = feedback_blocks(ctx, prob, *X);
+            out.Kt.push_back(fb.Kt);
+            continue;
+        }
         if (order == 1) {
             // G = [C', E'L];  S = blkdiag(I_q, BtLD' BtLD + D/tau);  R = compress!(lowrank(G, S))   (lowrank_ros1.jl:42-44)
             Mat G(ctx, n, q + r);

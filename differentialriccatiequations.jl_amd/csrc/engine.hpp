@@ -95,6 +95,7 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     double compress_tolfac = 4.0;    // Krylov-truncated compression inside the engine: remainder <= tolfac*eps*||X||_F
     double residual_abs_frac = 0.05; // the warm-start residual is truncated at this fraction of abstol (Krylov mode only)
     bool compress_exact = false;     // true: eigen-based truncation at every compression (reference arithmetic)
+    bool final_compress = true;      // internal (Ros1 driver): false keeps the solution as warm start + increments (block list)
 };
 struct AdiResult {
     LDLtP X;

@@ -1,0 +1,4 @@
+set -o pipefail
+run() { echo "== $*"; env "$@" timeout -k 10 600 python -m pytest tests -x -q -m gpu 2>&1 | tail -3; }
+run DRE_X_SIDE_STREAM=1
+run DRE_X_COMPRESS_EVERY=3
