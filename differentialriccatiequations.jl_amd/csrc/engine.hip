@@ -1248,9 +1248,8 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     FactorCache cache;
     // Ros1 at small n: X stays "warm start + increments" between two compressions (every xevery-th step and at the end); right-hand side,
     // feedback and warm-start residual work on the block list (the direct-form compression does not care about the number of columns)
-    static const int xevery_env = std::getenv("DRE_X_COMPRESS_EVERY") ? std::atoi(std::getenv("DRE_X_COMPRESS_EVERY")) : 1;
-    static const bool xside_env = std::getenv("DRE_X_SIDE_STREAM") && std::atoi(std::getenv("DRE_X_SIDE_STREAM")) != 0;
-    const int xevery = std::max(1, xevery_env);
+    const bool xside_env = ctx->x_side_stream != 0;
+    const int xevery = std::max(1, ctx->x_compress_every);
     const bool xblocks = order == 1 && (xevery > 1 || xside_env) && !cex && !save_state && n <= 512 && !adi.ignore_initial_guess;
     // Side stream: the compression of X_{i-1} is not on the critical path of step i (right-hand side, feedback and residual take the
     // block list), so it runs on a second stream, driven by a second host thread with its own context (stream, pool, hints), while the

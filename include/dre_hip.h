@@ -66,7 +66,11 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *   "top_inverse_max_rows"      multifrontal solves with a real factor that keeps being reused (third multi-column solve on): the top
  *                               levels of the elimination tree with at most this many pivot variables are applied as ONE dense inverse
  *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
- *                               env DRE_TOP_INVERSE_MAX_ROWS) */
+ *                               env DRE_TOP_INVERSE_MAX_ROWS)
+ *   "x_side_stream"             Ros1, n <= 512, no save_state: X is carried as "compressed warm start + ADI increments" and its
+ *                               compression (adi.jl:78-80) runs on a second stream beside the next time step (default 1; env
+ *                               DRE_X_SIDE_STREAM);  "x_compress_every" = s (default 1) with x_side_stream = 0: single stream,
+ *                               X compressed every s-th step only */
 int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value);
 /* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
  * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */

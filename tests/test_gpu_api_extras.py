@@ -154,3 +154,31 @@ def test_dense_inverse_path_matches_the_multifrontal_path(ctx, rail371):
     assert D.delta(a0 * L0 @ D0 @ L0.T, a1 * L1 @ D1 @ L1.T) < 1e-10
     with pytest.raises(D.DREError):
         ctx.set_option("no_such_option", 1)
+
+
+def test_side_stream_and_sparse_x_compressions_reproduce_the_plain_time_loop(ctx, rail371):
+    """Ros1 at small n carries X as "compressed warm start + ADI increments": right-hand side, feedback and warm-start residual work on the
+    block list, the compression of X runs on a second stream beside the next step (default) or only every third step.  Same ADI iteration
+    counts and K(t) as the plain loop that compresses X at the end of every Lyapunov solve (adi.jl:78-80)."""
+    d, L, Dm = rail371
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 3500.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p)))
+    out = {}
+    try:
+        for name, (side, every) in (("plain", (0, 1)), ("side_stream", (1, 1)), ("every_third", (0, 3))):
+            ctx.set_option("x_side_stream", side); ctx.set_option("x_compress_every", every)
+            sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True)
+            out[name] = (sol, [g["iters"] for g in st["gales"]])
+    finally:
+        ctx.set_option("x_side_stream", 1); ctx.set_option("x_compress_every", 1)
+    s0, it0 = out["plain"]
+    gold = np.load(os.path.join(GOLDEN, "ros1_371.npz"))
+    assert it0[:5] == list(gold["iters"])
+    for name in ("side_stream", "every_third"):
+        s1, it1 = out[name]
+        assert it1 == it0
+        for K0, K1 in zip(s0.K, s1.K):
+            assert D.delta(K0, K1) < 1e-10
+        a0, L0, D0 = s0.X[-1]; a1, L1, D1 = s1.X[-1]
+        assert D.delta(a0 * L0 @ D0 @ L0.T, a1 * L1 @ D1 @ L1.T) < 1e-10
