@@ -438,13 +438,40 @@ static double read_scalar(Ctx* ctx, const double* dev) {
     DRE_HIP(hipStreamSynchronize(ctx->stream));
     return h;
 }
+// large operands: partial sums over 64 workgroups, then a fixed-order sum (deterministic)
+__global__ __launch_bounds__(256) void k_frob2_parts(int rows, int cols, const double* __restrict__ A, int ld, double* __restrict__ part) {
+    __shared__ double red[17];
+    double s0 = 0.0, s1 = 0.0;
+    const size_t tot = (size_t)rows * cols, stride = (size_t)gridDim.x * blockDim.x;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; idx + stride < tot; idx += 2 * stride) {
+        const size_t i2 = idx + stride;
+        const double v = A[idx % rows + (idx / rows) * (size_t)ld], w = A[i2 % rows + (i2 / rows) * (size_t)ld];
+        s0 += v * v; s1 += w * w;
+    }
+    if (idx < tot) { const double v = A[idx % rows + (idx / rows) * (size_t)ld]; s0 += v * v; }
+    const double s = block_sum(s0 + s1, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void k_frob2_finish(int nparts, const double* __restrict__ part, double* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s;
+}
 void frob2_device(Ctx* ctx, const Mat& A, double* out_dev) {
-    hipLaunchKernelGGL(k_frob2, dim3(1), dim3(1024), 0, ctx->stream, A.rows, A.cols, A.p, A.ld, out_dev);
+    if ((size_t)A.rows * A.cols <= 65536) {
+        hipLaunchKernelGGL(k_frob2, dim3(1), dim3(1024), 0, ctx->stream, A.rows, A.cols, A.p, A.ld, out_dev);
+        return;
+    }
+    DevArr<double> part(ctx, 64);
+    hipLaunchKernelGGL(k_frob2_parts, dim3(64), dim3(256), 0, ctx->stream, A.rows, A.cols, (const double*)A.p, A.ld, part.p);
+    hipLaunchKernelGGL(k_frob2_finish, dim3(1), dim3(64), 0, ctx->stream, 64, (const double*)part.p, out_dev);
 }
 double frob_norm_host(Ctx* ctx, const Mat& A) {
     if (A.empty()) return 0.0;
     DevArr<double> out(ctx, 1);
-    hipLaunchKernelGGL(k_frob2, dim3(1), dim3(1024), 0, ctx->stream, A.rows, A.cols, A.p, A.ld, out.p);
+    frob2_device(ctx, A, out.p);
     return std::sqrt(read_scalar(ctx, out.p));
 }
 __global__ __launch_bounds__(256) void k_offdiag_max(int n, const double* __restrict__ D, int ld, double* out) {
