@@ -191,7 +191,36 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmBatchDesc* __res
     if (n0 >= d.N) return;
     gemm_tile<false, false>(d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb, 0.0, d.C, d.ldc, m0, n0, 0, d.K, nullptr);
 }
+// up to 48 products: the descriptors travel as kernel arguments (no upload, no staging copy on the host)
+struct GemmBatchArgs { GemmBatchDesc d[48]; };
+__global__ __launch_bounds__(256) void k_gemm_batched_args(GemmBatchArgs a) {
+    const GemmBatchDesc d = a.d[blockIdx.z];
+    const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
+    if (m0 >= d.M) return;
+    if (d.copy_dst && blockIdx.y == 0) {
+        for (int id = threadIdx.x; id < GB_M * d.K; id += blockDim.x) {
+            const int r = m0 + id % GB_M, c = id / GB_M;
+            if (r < d.M) d.copy_dst[r + (size_t)c * d.ldcopy] = d.A[r + (size_t)c * d.lda];
+        }
+    }
+    if (n0 >= d.N) return;
+    gemm_tile<false, false>(d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb, 0.0, d.C, d.ldc, m0, n0, 0, d.K, nullptr);
+}
 void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag) {
+    if (!descs.empty() && descs.size() <= 48) {
+        int maxM = 0, maxN = 0; double fl = 0.0, by = 0.0;
+        GemmBatchArgs a;
+        for (size_t i = 0; i < descs.size(); ++i) {
+            const auto& d = descs[i];
+            a.d[i] = d;
+            maxM = std::max(maxM, d.M); maxN = std::max(maxN, d.N);
+            fl += 2.0 * d.M * d.N * (double)d.K; by += 8.0 * ((double)d.M * d.K * (d.copy_dst ? 2.0 : 1.0) + (double)d.K * d.N + (double)d.M * d.N);
+        }
+        TimedScope ts(ctx, tag, by, fl);
+        hipLaunchKernelGGL(k_gemm_batched_args, dim3(ceil_div(maxM, GB_M), std::max(1, ceil_div(maxN, GB_N)), (unsigned)descs.size()), dim3(256), 0, ctx->stream, a);
+        DRE_HIP(hipGetLastError());
+        return;
+    }
     if (descs.empty()) return;
     int maxM = 0, maxN = 0; double fl = 0.0, by = 0.0;
     for (auto& d : descs) {
