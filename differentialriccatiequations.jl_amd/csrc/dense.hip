@@ -737,9 +737,17 @@ template <bool HAS_LR>
 __global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int splits, const double* __restrict__ Wpart,
                                                      const double* __restrict__ WKS, int ldwk, double* __restrict__ V, int ldv,
                                                      double* __restrict__ R, int ldr, double two_mu, double* __restrict__ Gpart,
-                                                     const AdiState* st) {
+                                                     AdiState* st, int nblk_main, const double* __restrict__ Gprev, int nblk_prev,
+                                                     const double* __restrict__ Tn, int ldtn, int tdiag, double alpha_n, int iters_prev) {
     if (st->done) return;
     extern __shared__ double dsm[];
+    if ((int)blockIdx.x >= nblk_main) {
+        // rider: the residual norm and convergence decision of the PREVIOUS iteration (its Gram slabs are complete since the last launch)
+        // run beside this iteration's step instead of in a launch of their own; a positive decision stops the loop one launch later
+        __shared__ double nred[17];
+        gram_norm_body<false>(k, nblk_prev, Gprev, Tn, ldtn, tdiag, alpha_n, st, iters_prev, dsm, nred);
+        return;
+    }
     const int M = 2 * n + m;
     const size_t slab = (size_t)M * k;
     const int kp16 = (k + 15) & ~15, ldk = kp16 + 1;
@@ -767,7 +775,7 @@ __global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int sp
             small[id] = sv;
         }
     }
-    for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
+    for (int i0 = blockIdx.x * 64; i0 < n; i0 += nblk_main * 64) {
         if (HAS_LR) {
             for (int id = tid; id < 64 * m; id += nt) {
                 const int il = id & 63, j = id >> 6, i = i0 + il;
@@ -849,28 +857,54 @@ __global__ __launch_bounds__(1024) void k_dense_step(int n, int m, int k, int sp
     }
 }
 
-void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
-                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
-    DRE_REQUIRE(k <= 96 && m <= 32, "dense_adi_step: k <= 96 and m <= 32 expected");
-    const int nblk = ceil_div(n, 64), kp16 = (k + 15) & ~15, kp32 = (k + 31) & ~31;
-    DevArr<double> gpart(ctx, (size_t)nblk * k * k);
-    const size_t step_lds = ((size_t)64 * (kp16 + 1) + (size_t)m * k + 2 * (size_t)64 * m) * sizeof(double);
-    {
-        TimedScope ts(ctx, "dense_step", 8.0 * (2.0 * n * k * splits + 3.0 * n * k + 2.0 * n * m + (double)nblk * k * k), 4.0 * n * k * m + 2.0 * n * (double)k * k);
-        if (m > 0)
-            hipLaunchKernelGGL((k_dense_step<true>), dim3(nblk), dim3(1024), step_lds, ctx->stream, n, m, k, splits, Wpart, WKS, ldwk, V.p, V.ld, R.p, R.ld,
-                               two_mu, gpart.p, (const AdiState*)st);
-        else
-            hipLaunchKernelGGL((k_dense_step<false>), dim3(nblk), dim3(1024), step_lds, ctx->stream, n, 0, k, splits, Wpart, (const double*)nullptr, 0, V.p, V.ld,
-                               R.p, R.ld, two_mu, gpart.p, (const AdiState*)st);
-    }
-    // the Gram slabs of the workgroups are summed (fixed order) by the norm kernel; a hand-over inside one launch would
-    // need agent-scope fences, which cost more than a launch on a multi-XCD part
+static void launch_gram_norm(Ctx* ctx, int k, int nblk, const double* gpart, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
+    const int kp32 = (k + 31) & ~31;
     TimedScope ts(ctx, "ldlt_norm", 8.0 * nblk * k * k, 4.0 * (double)k * k * k);
     const size_t shm = 2 * (size_t)kp32 * kp32 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
-    hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, nblk, (const double*)gpart.p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
+    hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, nblk, gpart, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
+}
+void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend) {
+    if (!pend || !pend->valid) return;
+    launch_gram_norm(ctx, k, pend->nblk, (const double*)pend->gpart->p, T, tdiag, alpha, st, pend->iters_after);
+    pend->valid = false;
+    DRE_HIP(hipGetLastError());
+}
+// pend != nullptr: the norm of THIS iteration is not launched; it rides on the step kernel of the next iteration (or dense_norm_flush),
+// and the pending norm of the previous iteration rides on this step.
+void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, DenseNormPending* pend) {
+    DRE_REQUIRE(k <= 96 && m <= 32, "dense_adi_step: k <= 96 and m <= 32 expected");
+    const int nblk = ceil_div(n, 64), kp16 = (k + 15) & ~15, kp32 = (k + 31) & ~31;
+    auto gpart = std::make_shared<Buf>(ctx, (size_t)nblk * k * k * sizeof(double));
+    const bool ride = pend && pend->valid;
+    const size_t step_lds = ((size_t)64 * (kp16 + 1) + (size_t)m * k + 2 * (size_t)64 * m) * sizeof(double);
+    const size_t lds = ride ? std::max(step_lds, 2 * (size_t)kp32 * kp32 * sizeof(double)) : step_lds;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DRE_HIP(hipFuncSetAttribute((const void*)k_dense_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        DRE_HIP(hipFuncSetAttribute((const void*)k_dense_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    {
+        TimedScope ts(ctx, "dense_step", 8.0 * (2.0 * n * k * splits + 3.0 * n * k + 2.0 * n * m + (double)nblk * k * k), 4.0 * n * k * m + 2.0 * n * (double)k * k);
+        const double* gprev = ride ? (const double*)pend->gpart->p : nullptr;
+        const int nprev = ride ? pend->nblk : 0, iprev = ride ? pend->iters_after : 0;
+        if (m > 0)
+            hipLaunchKernelGGL((k_dense_step<true>), dim3(nblk + (ride ? 1 : 0)), dim3(1024), lds, ctx->stream, n, m, k, splits, Wpart, WKS, ldwk, V.p, V.ld, R.p, R.ld,
+                               two_mu, (double*)gpart->p, st, nblk, gprev, nprev, (const double*)T.p, T.ld, tdiag ? 1 : 0, alpha, iprev);
+        else
+            hipLaunchKernelGGL((k_dense_step<false>), dim3(nblk + (ride ? 1 : 0)), dim3(1024), lds, ctx->stream, n, 0, k, splits, Wpart, (const double*)nullptr, 0, V.p, V.ld,
+                               R.p, R.ld, two_mu, (double*)gpart->p, st, nblk, gprev, nprev, (const double*)T.p, T.ld, tdiag ? 1 : 0, alpha, iprev);
+    }
+    if (pend) {
+        pend->gpart = gpart; pend->nblk = nblk; pend->iters_after = iters_after; pend->valid = true;
+    } else {
+        // the Gram slabs of the workgroups are summed (fixed order) by the norm kernel; a hand-over inside one launch would
+        // need agent-scope fences, which cost more than a launch on a multi-XCD part
+        launch_gram_norm(ctx, k, nblk, (const double*)gpart->p, T, tdiag, alpha, st, iters_after);
+    }
     DRE_HIP(hipGetLastError());
 }
 

@@ -65,8 +65,13 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 // the split-K Gram GEMM and one workgroup that reduces the partial slabs, forms T G in LDS and decides (k <= 88).
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 // fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
+// The norm kernel of iteration i can ride on the step kernel of iteration i + 1 (one more workgroup) instead of being a launch of
+// its own: `pend` carries the Gram slabs of the iteration whose norm is still due.  dense_norm_flush launches it on its own (before
+// a host synchronisation or a step of another kind).
+struct DenseNormPending { BufP gpart; int nblk = 0; int iters_after = 0; bool valid = false; };
 void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
-                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
+                    double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, DenseNormPending* pend = nullptr);
+void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend);
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

@@ -843,6 +843,9 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     bool finished = false;
     std::vector<std::shared_ptr<FactorEntry<double>>> used_real;
     std::vector<std::shared_ptr<FactorEntry<cplx>>> used_cplx;
+    // dense-inverse steps: the norm kernel of iteration i rides on the step kernel of iteration i + 1 (dense.hpp, DenseNormPending)
+    DenseNormPending npend;
+    static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
 
     while (!finished) {
         std::vector<StepRec> recs;
@@ -855,7 +858,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             const bool is_real = (mu.imag() == 0.0);
             const AdiState* dst = st.p;
             Mat V1, V2;
-            bool norm_done = false;
+            bool norm_done = false, rode = false;
             if (is_real) {
                 // dense inverses pay off only for shift lists that persist across Lyapunov solves (user-given Cyclic values)
                 auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC);
@@ -893,8 +896,9 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         int zs = 1;
                         BufP wpart = gemm_partials(ctx, false, false, lds_, k, n, fe->stack.p, fe->stack.ld, R.p, R.ld, &zs, dst, "gemm_dinv");
                         dense_adi_step(ctx, n, mm, k, zs, (const double*)wpart->p, op.has_lr ? (const double*)sc->second.WU : nullptr,
-                                       op.has_lr ? sc->second.ldwu : 0, V1, R, 2.0 * mu.real(), Tm, tdiag, alpha_res, st.p, iters_host + 1);
-                        norm_done = true;
+                                       op.has_lr ? sc->second.ldwu : 0, V1, R, 2.0 * mu.real(), Tm, tdiag, alpha_res, st.p, iters_host + 1,
+                                       lazy_norm ? &npend : nullptr);
+                        norm_done = true; rode = true;
                     } else {
                         Mat Wst(ctx, lds_, k);
                         gemm(ctx, false, false, 1.0, fe->stack, R, 0.0, Wst, dst, "gemm_dinv");
@@ -989,6 +993,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                 oracle->update(R, {V1, V2});
             }
             // residual norm through the Gram matrix, convergence decision on the device
+            if (!rode) dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);     // a step of another kind: norms stay in order
             if (!norm_done) residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
             ++since_sync; chunk_shifts += is_real ? 1 : 2;
@@ -996,6 +1001,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             if (!opt.compression && since_sync >= 10) break;
         }
         // synchronise once per chunk and find out how far the device really got
+        dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
         AdiState h;
         DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
