@@ -643,12 +643,15 @@ static double ldlt_norm_dense_small(Ctx* ctx, const LDLt& X) {
 // compressed on the way in.  F'XE + E'XF = (P D P' - M D M') / 2 with P = F'L / s + s E'L, M = F'L / s - s E'L (s balances the
 // two terms, so the rounding error stays at eps ||F'L|| ||E'L|| ||D|| like in the [E'L, F'L] form), i.e. per block of X two
 // blocks that share its D.
-static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& C, const LDLt& X, double tolfac, double abs_tol) {
+static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& C, const LDLt& X, double tolfac, double abs_tol,
+                                  const Mat* warm_L = nullptr, const Mat* warm_EtL = nullptr) {
     const Pencil& P = *op.P;
     const int n = P.n, c = X.rank();
-    Mat Lall = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
-    Mat EtL(ctx, n, c), FtL(ctx, n, c), Pm(ctx, n, c), Mm(ctx, n, c);
-    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Lall, EtL, 1.0, 0.0);
+    const bool have = warm_L && warm_EtL && warm_L->cols == c && warm_EtL->cols == c && warm_L->rows == n && c > 0;
+    Mat Lall = have ? *warm_L : ((X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X));
+    Mat EtL = have ? *warm_EtL : Mat(ctx, n, c);
+    Mat FtL(ctx, n, c), Pm(ctx, n, c), Mm(ctx, n, c);
+    if (!have) spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Lall, EtL, 1.0, 0.0);
     apply_Ft(ctx, op, Lall, FtL);
     DevArr<double> nrm2(ctx, 2);
     frob2_device(ctx, FtL, nrm2.p);
@@ -671,11 +674,18 @@ static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& 
     return res;
 }
 
+static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol,
+                                const Mat* warm_L, const Mat* warm_EtL);
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol) {
+    return gale_residual_impl(ctx, op, C, X, tolfac, exact, abs_tol, nullptr, nullptr);
+}
+static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol,
+                                const Mat* warm_L, const Mat* warm_EtL) {
     auto Cp = std::make_shared<LDLt>(C);
     if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
     const Pencil& P = *op.P;
-    if (!exact && P.n <= 512 && (C.blocks.size() > 1 || X->blocks.size() > 1)) return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol);
+    if (!exact && P.n <= 512 && (C.blocks.size() > 1 || X->blocks.size() > 1))
+        return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol, warm_L, warm_EtL);
     ldlt_destructure(ctx, C, tolfac, exact);
     ldlt_destructure(ctx, *X, tolfac, exact);
     const LBlock& cb = C.blocks[0];
@@ -758,7 +768,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     const double abstol = opt.abstol >= 0 ? opt.abstol : reltol * normC;
     LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
     // Krylov mode: components of the warm-start residual far below the convergence tolerance are dropped
-    LDLtP resid = gale_residual(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol);
+    LDLtP resid = gale_residual_impl(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol,
+                                     opt.warm_L.empty() ? nullptr : &opt.warm_L, opt.warm_EtL.empty() ? nullptr : &opt.warm_EtL);
     ldlt_destructure(ctx, *resid, ctf, cex);
     LBlock rb = resid->blocks[0];
     Mat R = rb.L, Tm = rb.D;
@@ -847,6 +858,10 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     DenseNormPending npend;
     static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
 
+    // chunk length: compression_interval, or — where the intermediate compressions are deferred anyway — the iteration count of the
+    // previous solve (+2), so that a whole Lyapunov solve is enqueued before the first host synchronisation
+    const int chunk_limit = (!cex && n <= 512 && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
+                                                                          : opt.compression_interval;
     while (!finished) {
         std::vector<StepRec> recs;
         const size_t blocks_before = Xw->blocks.size();
@@ -997,7 +1012,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             if (!norm_done) residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
             ++since_sync; chunk_shifts += is_real ? 1 : 2;
-            if (opt.compression && chunk_shifts >= opt.compression_interval) break;
+            if (opt.compression && chunk_shifts >= chunk_limit) break;
             if (!opt.compression && since_sync >= 10) break;
         }
         // synchronise once per chunk and find out how far the device really got
@@ -1045,6 +1060,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
     }
     if (opt.compression && last_compression > 0 && (opt.final_compress || cex)) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
+    cache->iters_hint = res.iters;
     all_shifts.resize(res.iters);
     res.shifts = all_shifts;
     res.X = Xw;
@@ -1317,6 +1333,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             AdiOptions a2 = adi;
             const bool last = (i == nsteps);
             a2.final_compress = xside ? false : (last || (i % xevery == 0));
+            a2.warm_L = fb.L; a2.warm_EtL = fb.EtL;            // the feedback already concatenated X and applied E'
             // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
             std::thread worker;
             LDLtP Xc;

@@ -61,6 +61,7 @@ struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
     long nfactor = 0;
     bool enabled = true;
+    int iters_hint = 0;        // ADI iterations of the previous Lyapunov solve served by this cache (speculation depth of the next one)
     void clear() { real.clear(); cplx_.clear(); }
 };
 struct GaleOperator {
@@ -96,6 +97,7 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     double residual_abs_frac = 0.05; // the warm-start residual is truncated at this fraction of abstol (Krylov mode only)
     bool compress_exact = false;     // true: eigen-based truncation at every compression (reference arithmetic)
     bool final_compress = true;      // internal (Ros1 driver): false keeps the solution as warm start + increments (block list)
+    Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
 };
 struct AdiResult {
     LDLtP X;
