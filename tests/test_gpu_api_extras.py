@@ -182,3 +182,34 @@ def test_side_stream_and_sparse_x_compressions_reproduce_the_plain_time_loop(ctx
             assert D.delta(K0, K1) < 1e-10
         a0, L0, D0 = s0.X[-1]; a1, L1, D1 = s1.X[-1]
         assert D.delta(a0 * L0 @ D0 @ L0.T, a1 * L1 @ D1 @ L1.T) < 1e-10
+
+
+@pytest.mark.parametrize("symE,symA", [(True, True), (False, False)])
+def test_block_list_time_loop_on_random_nonsymmetric_pencils(ctx, symE, symA):
+    """The block-list right-hand side / feedback / residual of the two-stream Ros1 loop make no symmetry assumption: random pencils
+    (tiny_random.jl flavour), all three modes against each other and against the dense Ros1 oracle."""
+    rng = np.random.default_rng(7 + symE)
+    n, m, q = 90, 2, 3
+    sprand = lambda: sp.random(n, n, density=2 / n, random_state=rng, format="csc")
+    E = sprand(); E = ((E + E.T) if symE else E) + n * sp.identity(n)
+    A = sprand(); A = ((A + A.T) if symA else A) - n * sp.identity(n)
+    E, A = E.tocsc(), A.tocsc()
+    B = 0.1 * rng.standard_normal((n, m)); Cm = rng.standard_normal((q, n))
+    L0 = rng.standard_normal((n, 2)); D0 = np.diag([0.5, 0.2])
+    tspan, dt = (1.0, 0.0), -0.125
+    prob = D.GDREProblem(E, A, B, Cm, D.lowrank(L0, D0), tspan)
+    alg = D.Ros1()                                          # default ADI: self-generated Projection(2) shifts, real and complex
+    out = {}
+    try:
+        for name, (side, every) in (("plain", (0, 1)), ("side_stream", (1, 1)), ("every_third", (0, 3))):
+            ctx.set_option("x_side_stream", side); ctx.set_option("x_compress_every", every)
+            sol, st = D.solve_gdre(prob, alg, dt=dt, return_stats=True)
+            assert all(g["converged"] for g in st["gales"]), name
+            out[name] = (sol, [g["iters"] for g in st["gales"]])
+    finally:
+        ctx.set_option("x_side_stream", 1); ctx.set_option("x_compress_every", 1)
+    ref = o.solve(o.GDREProblem(E, A, B, Cm, o.lowrank(L0, D0).dense(), tspan), o.Ros1(), dt=dt)
+    for name, (sol, its) in out.items():           # (self-generated shifts depend on the residual's factor: counts may differ by one)
+        assert all(abs(a - b) <= 2 for a, b in zip(its, out["plain"][1]))
+        for K, Kr in zip(sol.K, ref.K):
+            assert np.linalg.norm(K - Kr) < 1e-9 * max(np.linalg.norm(Kr), 1e-300), name
