@@ -122,7 +122,7 @@ struct Ctx {
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense
     // inverse of their Schur complement (reused real factors only; 0 disables)
     int top_inverse_max_rows = 1536;
-    // Ros1, n <= 512, no save_state: X is carried as "compressed warm start + ADI increments"; its compression runs on a second stream
+    // Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments"; its compression runs on a second stream
     // beside the next time step (x_side_stream) or only every x_compress_every-th step (engine.hip, gdre_solve)
     int x_side_stream = 1;
     int x_compress_every = 1;

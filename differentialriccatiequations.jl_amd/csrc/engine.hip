@@ -620,6 +620,11 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
 // =============================================================================================
 // GALE residual (/root/reference/src/lyapunov/residual.jl:3-31)
 // =============================================================================================
+// largest n for which the Ros1 driver carries X as a block list (right-hand side, feedback and residual on the summands)
+static int xblocks_max_n() {
+    static const int v = std::getenv("DRE_XBLOCKS_MAX_N") ? std::atoi(std::getenv("DRE_XBLOCKS_MAX_N")) : 1536;
+    return v;
+}
 // P = F / s + s E,  M = F / s - s E  with  s^4 = ||F||_F^2 / ||E||_F^2  read from device memory (nrm2[0], nrm2[1])
 __global__ void k_balance_pm(size_t tot, const double* __restrict__ F, const double* __restrict__ E, const double* __restrict__ nrm2,
                              double* __restrict__ Pm, double* __restrict__ Mm) {
@@ -684,7 +689,7 @@ static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const
     auto Cp = std::make_shared<LDLt>(C);
     if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
     const Pencil& P = *op.P;
-    if (!exact && P.n <= 512 && (C.blocks.size() > 1 || X->blocks.size() > 1))
+    if (!exact && P.n <= xblocks_max_n() && (C.blocks.size() > 1 || X->blocks.size() > 1))
         return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol, warm_L, warm_EtL);
     ldlt_destructure(ctx, C, tolfac, exact);
     ldlt_destructure(ctx, *X, tolfac, exact);
@@ -760,7 +765,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     const AdiOptions& opt = *optp;
     const double ctf = opt.compress_tolfac;
     const bool cex = opt.compress_exact;
-    const bool keep_blocks = !cex && n <= 512 && C.blocks.size() > 1 && initial_guess && !opt.ignore_initial_guess && !initial_guess->iszero();
+    const bool keep_blocks = !cex && n <= xblocks_max_n() && C.blocks.size() > 1 && initial_guess && !opt.ignore_initial_guess && !initial_guess->iszero();
     double normC;
     if (keep_blocks) normC = ldlt_norm_dense_small(ctx, C);       // the summands go into the residual as they are (gale_residual_blocks)
     else { ldlt_destructure(ctx, C, ctf, cex); normC = ldlt_norm(ctx, C); }
@@ -860,7 +865,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
 
     // chunk length: compression_interval, or — where the intermediate compressions are deferred anyway — the iteration count of the
     // previous solve (+2), so that a whole Lyapunov solve is enqueued before the first host synchronisation
-    const int chunk_limit = (!cex && n <= 512 && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
+    const int chunk_limit = (!cex && n <= xblocks_max_n() && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
                                                                           : opt.compression_interval;
     while (!finished) {
         std::vector<StepRec> recs;
@@ -1272,7 +1277,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     // feedback and warm-start residual work on the block list (the direct-form compression does not care about the number of columns)
     const bool xside_env = ctx->x_side_stream != 0;
     const int xevery = std::max(1, ctx->x_compress_every);
-    const bool xblocks = order == 1 && (xevery > 1 || xside_env) && !cex && !save_state && n <= 512 && !adi.ignore_initial_guess;
+    const bool xblocks = order == 1 && (xevery > 1 || xside_env) && !cex && !save_state && n <= xblocks_max_n() && !adi.ignore_initial_guess;
     // Side stream: the compression of X_{i-1} is not on the critical path of step i (right-hand side, feedback and residual take the
     // block list), so it runs on a second stream, driven by a second host thread with its own context (stream, pool, hints), while the
     // main stream does the residual compression and the ADI iteration of step i; its result replaces the uncompressed summands at the

@@ -67,7 +67,7 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               levels of the elimination tree with at most this many pivot variables are applied as ONE dense inverse
  *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
  *                               env DRE_TOP_INVERSE_MAX_ROWS)
- *   "x_side_stream"             Ros1, n <= 512, no save_state: X is carried as "compressed warm start + ADI increments" and its
+ *   "x_side_stream"             Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments" and its
  *                               compression (adi.jl:78-80) runs on a second stream beside the next time step (default 1; env
  *                               DRE_X_SIDE_STREAM);  "x_compress_every" = s (default 1) with x_side_stream = 0: single stream,
  *                               X compressed every s-th step only */
