@@ -918,6 +918,14 @@ void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double
     }
     int splits = 1;
     BufP part = gemm_partials(ctx, true, false, k, k, R.rows, R.p, R.ld, R.p, R.ld, &splits, st, "gemm_gram");
+    if (splits > 12) {
+        // tall R: dozens of k x k slabs would be summed by the single norm workgroup (6 MB at n = 5177); reduce them on many CUs first
+        auto one = std::make_shared<Buf>(ctx, (size_t)k * k * sizeof(double));
+        const size_t tot = (size_t)k * k;
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, k, k, splits, 1.0, (const double*)part->p, 0.0,
+                           (double*)one->p, k, (const AdiState*)st);
+        part = one; splits = 1;
+    }
     TimedScope ts(ctx, "ldlt_norm", 8.0 * splits * k * k, 4.0 * (double)k * k * k);
     const int kp = (k + 31) & ~31;
     const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
