@@ -648,8 +648,12 @@ static double ldlt_norm_dense_small(Ctx* ctx, const LDLt& X) {
 // compressed on the way in.  F'XE + E'XF = (P D P' - M D M') / 2 with P = F'L / s + s E'L, M = F'L / s - s E'L (s balances the
 // two terms, so the rounding error stays at eps ||F'L|| ||E'L|| ||D|| like in the [E'L, F'L] form), i.e. per block of X two
 // blocks that share its D.
+__global__ void k_axpy_inplace(size_t tot, double a, const double* __restrict__ x, double* __restrict__ y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tot) y[i] += a * x[i];
+}
 static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& C, const LDLt& X, double tolfac, double abs_tol,
-                                  const Mat* warm_L = nullptr, const Mat* warm_EtL = nullptr) {
+                                  const Mat* warm_L = nullptr, const Mat* warm_EtL = nullptr, int lead_blocks = -1, double e_coeff = 0.0) {
     const Pencil& P = *op.P;
     const int n = P.n, c = X.rank();
     const bool have = warm_L && warm_EtL && warm_L->cols == c && warm_EtL->cols == c && warm_L->rows == n && c > 0;
@@ -658,6 +662,11 @@ static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& 
     Mat FtL(ctx, n, c), Pm(ctx, n, c), Mm(ctx, n, c);
     if (!have) spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Lall, EtL, 1.0, 0.0);
     apply_Ft(ctx, op, Lall, FtL);
+    const bool fold = lead_blocks >= 0 && lead_blocks <= (int)C.blocks.size() && e_coeff != 0.0;
+    if (fold) {      // C = lead blocks + e_coeff E'XE:  the last term joins F  (one third fewer columns in the compression below)
+        const size_t tot0 = (size_t)n * c;
+        hipLaunchKernelGGL(k_axpy_inplace, dim3((unsigned)((tot0 + 255) / 256)), dim3(256), 0, ctx->stream, tot0, 0.5 * e_coeff, (const double*)EtL.p, FtL.p);
+    }
     DevArr<double> nrm2(ctx, 2);
     frob2_device(ctx, FtL, nrm2.p);
     frob2_device(ctx, EtL, nrm2.p + 1);
@@ -666,7 +675,8 @@ static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& 
                        (const double*)nrm2.p, Pm.p, Mm.p);
     auto res = std::make_shared<LDLt>();
     res->n = n;
-    res->blocks = C.blocks;
+    if (fold) res->blocks.assign(C.blocks.begin(), C.blocks.begin() + lead_blocks);
+    else res->blocks = C.blocks;
     int off = 0;
     for (auto& b : X.blocks) {
         const int k = b.L.cols;
@@ -680,17 +690,17 @@ static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& 
 }
 
 static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol,
-                                const Mat* warm_L, const Mat* warm_EtL);
+                                const Mat* warm_L, const Mat* warm_EtL, int lead_blocks = -1, double e_coeff = 0.0);
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol) {
     return gale_residual_impl(ctx, op, C, X, tolfac, exact, abs_tol, nullptr, nullptr);
 }
 static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol,
-                                const Mat* warm_L, const Mat* warm_EtL) {
+                                const Mat* warm_L, const Mat* warm_EtL, int lead_blocks, double e_coeff) {
     auto Cp = std::make_shared<LDLt>(C);
     if (!X || X->iszero()) return ldlt_deepcopy(ctx, Cp);
     const Pencil& P = *op.P;
     if (!exact && P.n <= xblocks_max_n() && (C.blocks.size() > 1 || X->blocks.size() > 1))
-        return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol, warm_L, warm_EtL);
+        return gale_residual_blocks(ctx, op, C, *X, tolfac, abs_tol, warm_L, warm_EtL, lead_blocks, e_coeff);
     ldlt_destructure(ctx, C, tolfac, exact);
     ldlt_destructure(ctx, *X, tolfac, exact);
     const LBlock& cb = C.blocks[0];
@@ -774,7 +784,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
     // Krylov mode: components of the warm-start residual far below the convergence tolerance are dropped
     LDLtP resid = gale_residual_impl(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol,
-                                     opt.warm_L.empty() ? nullptr : &opt.warm_L, opt.warm_EtL.empty() ? nullptr : &opt.warm_EtL);
+                                     opt.warm_L.empty() ? nullptr : &opt.warm_L, opt.warm_EtL.empty() ? nullptr : &opt.warm_EtL,
+                                     opt.rhs_lead_blocks, opt.rhs_e_coeff);
     ldlt_destructure(ctx, *resid, ctf, cex);
     LBlock rb = resid->blocks[0];
     Mat R = rb.L, Tm = rb.D;
@@ -1339,6 +1350,8 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             const bool last = (i == nsteps);
             a2.final_compress = xside ? false : (last || (i % xevery == 0));
             a2.warm_L = fb.L; a2.warm_EtL = fb.EtL;            // the feedback already concatenated X and applied E'
+            static const bool fold_e = !(std::getenv("DRE_FOLD_E") && std::atoi(std::getenv("DRE_FOLD_E")) == 0);
+            if (fold_e) { a2.rhs_lead_blocks = 2; a2.rhs_e_coeff = 1.0 / tau; }     // rhs = [C'C, K'K] + E'XE / tau
             // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
             std::thread worker;
             LDLtP Xc;

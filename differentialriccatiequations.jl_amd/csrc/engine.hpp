@@ -98,6 +98,8 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     bool compress_exact = false;     // true: eigen-based truncation at every compression (reference arithmetic)
     bool final_compress = true;      // internal (Ros1 driver): false keeps the solution as warm start + increments (block list)
     Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
+    int rhs_lead_blocks = -1;        // internal (Ros1 driver): the right-hand side is  C = (first rhs_lead_blocks blocks) + rhs_e_coeff * E'XE
+    double rhs_e_coeff = 0.0;        //   with X the warm start, so the residual folds the last term into F: (F + coeff/2 E)' X E + E' X (F + coeff/2 E)
 };
 struct AdiResult {
     LDLtP X;
