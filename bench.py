@@ -126,16 +126,17 @@ def main():
                 ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
                 roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))
+                pmc_file = {371: "pmc_traffic_r01.json", 5177: "pmc_traffic_r01_n5177.json", 20209: "pmc_traffic_r01_n20209.json"}.get(n, "pmc_traffic_r01.json")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 sym = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm",
                        "gemm_gram": "k_gemm", "gemm_dinv": "k_gemm", "dense_step": "k_dense_step", "band_w": "k_band_w", "mf_solve_real": "k_mf_",
                        "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
                        "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_"}.get(name)
                 hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
-                if hits and n == 371:
+                if hits and n in (371, 5177, 20209):
                     tot_l = sum(h["launches"] for h in hits)
                     roof["traffic"] = sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
-                    roof["traffic_source"] = "profiles/pmc_traffic_r01.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated)"
+                    roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated)"
             except Exception:
                 pass
             roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
