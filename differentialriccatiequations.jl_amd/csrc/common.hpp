@@ -132,6 +132,8 @@ struct Ctx {
     // created on first use, lives as long as this context
     std::unique_ptr<Ctx> side;
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
+    bool attr_adi_fast = false;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

@@ -908,6 +908,219 @@ void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpa
     DRE_HIP(hipGetLastError());
 }
 
+// =============================================================================================
+// Fast ADI chain (dense-inverse regime, real Cyclic shifts whose stacked inverses persist across the Lyapunov solves of a run).
+// Once per Lyapunov solve and shift the rank-m Sherman-Morrison-Woodbury correction (smw.jl:20-43) is folded into the
+// stacked inverse,
+//     Seff = [inv; E' inv] - ([inv; E' inv] Vt Sinv) (U' inv)                      (2n x n),
+// so that an ADI iteration (adi.jl:149-179) is ONE launch of pure matrix-core work without split-K slabs or a separate
+// apply pass:   V = Seff_top R,   R_next = R - 2 mu Seff_bot R.
+// Seff is stored in the lane order of the MFMA A operand ("packed": strip of 16 rows x K-step of 4 columns = 64 consecutive
+// doubles), so every A fragment is one fully coalesced 512-byte load.  One workgroup owns a 16-row strip of V or of R_next,
+// one wave per 16-column tile, K = n in registers (no LDS staging: the B fragments come straight from L2).
+// The residual norm (LDLt.jl:77-89 in Gram form) is pipelined over the following two launches: the strip workgroups leave
+// per-strip Gram slabs of R_next, rider workgroups of the next launch sum them (fixed order), and one rider of the launch
+// after that forms tr((T G)^2) and takes the convergence decision of adi.jl:115-123.  A positive decision therefore arrives
+// two launches late; the speculative iterations are discarded by the host exactly like every other speculatively enqueued one.
+// =============================================================================================
+struct EffStackBatch { const double* stack[16]; const double* WKS[16]; double* out[16]; };
+__global__ __launch_bounds__(256) void k_eff_stack(int n, int m, int nstrip, int kst, int lds_, int ldwk, EffStackBatch bt) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kst * 64) return;
+    const int t = idx >> 6, lane = idx & 63;
+    const int b = blockIdx.y, half = b / nstrip, s = b - half * nstrip;
+    const int row = s * 16 + (lane & 15), col = 4 * t + (lane >> 4);
+    const double* __restrict__ stack = bt.stack[blockIdx.z];
+    const double* __restrict__ WKS = bt.WKS[blockIdx.z];
+    double v = 0.0;
+    if (row < n && col < n) {
+        const size_t r = (size_t)half * n + row;
+        v = stack[r + (size_t)col * lds_];
+        if (WKS) {
+            const double* ui = stack + 2 * (size_t)n + (size_t)col * lds_;     // (U' inv)(:, col)
+            double a0 = 0.0, a1 = 0.0;
+            int l = 0;
+            for (; l + 1 < m; l += 2) { a0 += WKS[r + (size_t)l * ldwk] * ui[l]; a1 += WKS[r + (size_t)(l + 1) * ldwk] * ui[l + 1]; }
+            if (l < m) a0 += WKS[r + (size_t)l * ldwk] * ui[l];
+            v -= a0 + a1;
+        }
+    }
+    bt.out[blockIdx.z][((size_t)b * kst + t) * 64 + lane] = v;
+}
+void adi_fast_build(Ctx* ctx, int n, int m, const std::vector<const double*>& stacks, int lds_, const std::vector<const double*>& wks, int ldwk,
+                    const std::vector<double*>& outs) {
+    const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+    for (size_t b0 = 0; b0 < stacks.size(); b0 += 16) {
+        EffStackBatch bt;
+        const int nb = (int)std::min<size_t>(16, stacks.size() - b0);
+        for (int i = 0; i < 16; ++i) { const int j = i < nb ? i : 0; bt.stack[i] = stacks[b0 + j]; bt.WKS[i] = wks[b0 + j]; bt.out[i] = outs[b0 + j]; }
+        TimedScope ts(ctx, "adi_eff_stack", 8.0 * nb * (2.0 * n * n + (double)m * n + 2.0 * n * m + 2.0 * nstrip * 16.0 * kst * 4.0), 4.0 * nb * n * n * (double)m);
+        hipLaunchKernelGGL(k_eff_stack, dim3(ceil_div(kst * 64, 256), 2 * nstrip, nb), dim3(256), 0, ctx->stream, n, m, nstrip, kst, lds_, ldwk, bt);
+    }
+    DRE_HIP(hipGetLastError());
+}
+
+// tr((T G)^2) with G and T read straight from global memory (k x k, leading dimensions k and ldt), no LDS: one workgroup,
+// 32 x 32 block pairs bi <= bj spread over the waves (same arithmetic as gram_norm_body); then the decision of adi.jl:115-123.
+__device__ __forceinline__ void gram_norm_global(int k, const double* __restrict__ G, const double* __restrict__ T, int ldt, int tdiag,
+                                                 double alpha, AdiState* st, int iters_after, double* red) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int kp = (k + 31) & ~31;
+    double s = 0.0;
+    if (tdiag) {
+        for (int idx = tid; idx < k * k; idx += blockDim.x) {
+            const int r = idx % k, c = idx / k;
+            const double g = G[idx];
+            s += T[r + (size_t)r * ldt] * T[c + (size_t)c * ldt] * g * g;
+        }
+    } else {
+        const int nbk = kp / 32, lr = lane & 15, lk = lane >> 4;
+        int p = 0;
+        for (int bi = 0; bi < nbk; ++bi)
+            for (int bj = bi; bj < nbk; ++bj, ++p) {
+                if (p % nw != wave) continue;
+                v4d m[2][2], nn[2][2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) { m[x][y] = (v4d){0.0, 0.0, 0.0, 0.0}; nn[x][y] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+                const int ri0 = bi * 32 + lr, ri1 = ri0 + 16, rj0 = bj * 32 + lr, rj1 = rj0 + 16;
+                for (int kk = 0; kk < kp / 4; ++kk) {
+                    const int c = kk * 4 + lk;                    // inner index
+                    const bool cok = c < k;
+                    // M = T G: A operand T[row, c], B operand G[c, col] = G[col, c] (G symmetric);  N = G T': A operand G[row, c], B operand T[col, c]
+                    const double ta0 = (cok && ri0 < k) ? T[ri0 + (size_t)c * ldt] : 0.0, ta1 = (cok && ri1 < k) ? T[ri1 + (size_t)c * ldt] : 0.0;
+                    const double gb0 = (cok && rj0 < k) ? G[rj0 + (size_t)c * k] : 0.0,  gb1 = (cok && rj1 < k) ? G[rj1 + (size_t)c * k] : 0.0;
+                    const double ga0 = (cok && ri0 < k) ? G[ri0 + (size_t)c * k] : 0.0,  ga1 = (cok && ri1 < k) ? G[ri1 + (size_t)c * k] : 0.0;
+                    const double tb0 = (cok && rj0 < k) ? T[rj0 + (size_t)c * ldt] : 0.0, tb1 = (cok && rj1 < k) ? T[rj1 + (size_t)c * ldt] : 0.0;
+                    m[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, gb0, m[0][0], 0, 0, 0);
+                    m[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, gb1, m[0][1], 0, 0, 0);
+                    m[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, gb0, m[1][0], 0, 0, 0);
+                    m[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, gb1, m[1][1], 0, 0, 0);
+                    nn[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga0, tb0, nn[0][0], 0, 0, 0);
+                    nn[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga0, tb1, nn[0][1], 0, 0, 0);
+                    nn[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga1, tb0, nn[1][0], 0, 0, 0);
+                    nn[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ga1, tb1, nn[1][1], 0, 0, 0);
+                }
+                double sum = 0.0;
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum += m[x][y][r] * nn[x][y][r];
+                s += (bi == bj) ? sum : 2.0 * sum;
+            }
+    }
+    s = block_sum(s, red);
+    if (tid == 0) {
+        const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        st->res_norm = nrm;
+        st->iters = iters_after;
+        if (iters_after < 512) st->norms[iters_after] = nrm;
+        if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+    }
+}
+
+// 16 x 16 output tile  C = A_strip B  over the K-steps [t0, t1) of this wave:  A packed (64 consecutive doubles per K-step),
+// B = X[4 t + lk, col] column-major; all loads of a batch of 24 K-steps are issued before its first MFMA.
+#define ADI_FAST_KB 24
+__device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, const double* __restrict__ bp, bool colok, int lk, int n, int t0, int t1) {
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += ADI_FAST_KB) {
+        double av[ADI_FAST_KB], bv[ADI_FAST_KB];
+#pragma unroll
+        for (int u = 0; u < ADI_FAST_KB; ++u) {
+            const int t = tb + u;
+            av[u] = (t < t1) ? ap[(size_t)t * 64] : 0.0;
+            bv[u] = (t < t1 && colok && 4 * t + lk < n) ? bp[4 * t] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < ADI_FAST_KB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+    return acc;
+}
+// Workgroups of one launch (256 threads = 4 waves that split K):
+//   [0, 2 nstrip ct)            tile (half, strip, column tile) of V = Seff_top R (half 0) or R_next = R - 2 mu Seff_bot R (half 1)
+//   [.., + ct ct)               Gram tile (ta, tb) of the INPUT residual R (= output of the previous launch) -> G_prev
+//   last                        norm + decision from G_prev2 (the Gram matrix the previous launch produced)
+__global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
+    if (a.st->done) return;
+    __shared__ double part[4][4][64];
+    __shared__ double nred[17];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
+    const int k = a.k, ct = (k + 15) >> 4, n = a.n;
+    int b = blockIdx.x;
+    const int nsw = a.do_strips ? 2 * a.nstrip * ct : 0;
+    if (b < nsw) {
+        const int tc = b % ct, hs = b / ct, half = hs / a.nstrip, s = hs - half * a.nstrip;
+        const int col = tc * 16 + (lane & 15);
+        const bool colok = col < k;
+        // old residual entry of the element this thread finishes in the epilogue (requested early)
+        const int erow = s * 16 + (lane >> 4) + 4 * wave;
+        const double rold = (half == 1 && colok && erow < n) ? a.Rcur[erow + (size_t)col * a.ldr] : 0.0;
+        const int per = (a.kst + 3) >> 2, t0 = wave * per, t1 = min(a.kst, t0 + per);
+        const v4d acc = adi_fast_tile(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur + (size_t)(colok ? col : 0) * a.ldr + lk, colok, lk, n, t0, t1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+        __syncthreads();
+        // thread (wave = r, lane) finishes element (row lk + 4 r, column lane & 15) of the tile: fixed-order sum over the K quarters
+        const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+        if (colok && erow < n) {
+            if (half == 0) a.V[erow + (size_t)col * a.ldv] = v;
+            else a.Rnext[erow + (size_t)col * a.ldr_next] = rold - a.two_mu * v;
+        }
+        return;
+    }
+    b -= nsw;
+    if (b < ct * ct) {
+        if (!a.G_prev) return;
+        // Gram tile (ta, tb) of the input residual:  G[ta-cols, tb-cols] = R(:, ta)' R(:, tb)
+        const int ta = b % ct, tb = b / ct;
+        if (ta > tb) return;                                      // the mirrored tile is written by (tb, ta)'s partner below
+        const int ca = ta * 16 + (lane & 15), cb = tb * 16 + (lane & 15);
+        const bool aok = ca < k, bok = cb < k;
+        const double* __restrict__ pa = a.Rcur + (size_t)(aok ? ca : 0) * a.ldr + lk;
+        const double* __restrict__ pb = a.Rcur + (size_t)(bok ? cb : 0) * a.ldr + lk;
+        const int per = (a.kst + 3) >> 2, t0 = wave * per, t1 = min(a.kst, t0 + per);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int tb0 = t0; tb0 < t1; tb0 += ADI_FAST_KB) {
+            double av[ADI_FAST_KB], bv[ADI_FAST_KB];
+#pragma unroll
+            for (int u = 0; u < ADI_FAST_KB; ++u) {
+                const int t = tb0 + u;
+                const bool ok = t < t1 && 4 * t + lk < n;
+                av[u] = (ok && aok) ? pa[4 * t] : 0.0;
+                bv[u] = (ok && bok) ? pb[4 * t] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < ADI_FAST_KB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+        __syncthreads();
+        const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+        const int gr = ta * 16 + (lane >> 4) + 4 * wave, gc = tb * 16 + (lane & 15);
+        if (gr < k && gc < k) {
+            a.G_prev[gr + (size_t)gc * k] = v;
+            if (ta != tb) a.G_prev[gc + (size_t)gr * k] = v;
+        }
+        return;
+    }
+    if (!a.G_prev2) return;
+    gram_norm_global(k, a.G_prev2, a.T, a.ldt, a.tdiag, a.alpha, a.st, a.it_prev2, nred);
+}
+void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
+    DRE_REQUIRE(a.k >= 1 && a.k <= ADI_FAST_MAX_K, "adi_fast_iter: residual too wide");
+    const int ct = (a.k + 15) >> 4;
+    const int nsw = a.do_strips ? 2 * a.nstrip * ct : 0;
+    const double fl = (a.do_strips ? 4.0 * a.n * (double)a.n * a.k : 0.0) + (a.G_prev ? 2.0 * a.n * (double)a.k * a.k : 0.0);
+    const double by = a.do_strips ? 8.0 * (2.0 * a.nstrip * 16.0 * a.kst * 4.0 + 4.0 * a.n * a.k) : 8.0 * (double)a.n * a.k;
+    TimedScope ts(ctx, a.do_strips ? "adi_fast_iter" : "adi_fast_flush", by, fl);
+    hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + 1), dim3(256), 0, ctx->stream, a);
+    DRE_HIP(hipGetLastError());
+}
+
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
     if (k > 96) {

@@ -72,6 +72,30 @@ struct DenseNormPending { BufP gpart; int nblk = 0; int iters_after = 0; bool va
 void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpart, const double* WKS, int ldwk, Mat& V, Mat& R,
                     double two_mu, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after, DenseNormPending* pend = nullptr);
 void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend);
+// Fast ADI chain (dense.hip): SMW-folded stacked inverse in MFMA-operand order, one launch per ADI iteration, residual norm
+// pipelined over the next two launches.
+#define ADI_FAST_MAX_K 128
+inline int adi_fast_nstrip(int n) { return (n + 15) / 16; }
+inline int adi_fast_kst(int n) { return (n + 3) / 4; }
+inline size_t adi_fast_pack_doubles(int n) { return (size_t)2 * adi_fast_nstrip(n) * adi_fast_kst(n) * 64; }
+// out_j = packed [inv; E'inv]_j - WKS_j (U'inv)_j for every shift j (stack_j is (2n + m) x n with leading dimension lds_; WKS_j is 2n x m or null)
+void adi_fast_build(Ctx* ctx, int n, int m, const std::vector<const double*>& stacks, int lds_, const std::vector<const double*>& wks, int ldwk,
+                    const std::vector<double*>& outs);
+struct AdiFastArgs {
+    int n, k, nstrip, kst;
+    const double* Apack;        // packed effective stack of this iteration's shift
+    const double* Rcur; int ldr;
+    double* Rnext; int ldr_next;
+    double* V; int ldv;
+    double two_mu;
+    double* G_prev;             // receives Rcur' Rcur (Gram matrix of the residual the previous launch produced), or null
+    const double* G_prev2;      // Gram matrix the previous launch produced (norm + decision now), or null
+    const double* T; int ldt; int tdiag; double alpha;
+    AdiState* st;
+    int it_prev2;               // shifts consumed after the iteration G_prev2 belongs to
+    int do_strips;              // 0: flush launch (riders only)
+};
+void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

@@ -750,7 +750,7 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
             if (cond_est == cond_est && cond_est < 1e7) { fe->dinv = W; fe->dense = true; }
         }
     }
-    if (cache->enabled) store[key] = fe;
+    if (cache->enabled) { store[key] = fe; cache->fresh.push_back(key); }
     return fe;
 }
 
@@ -870,6 +870,13 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     bool finished = false;
     std::vector<std::shared_ptr<FactorEntry<double>>> used_real;
     std::vector<std::shared_ptr<FactorEntry<cplx>>> used_cplx;
+    // every factorisation is checked once per chunk, after the chunk's synchronisation (the breakdown flag is written by the
+    // factorisation kernels only); the handles are dropped then, so single-use factors are freed chunk by chunk
+    auto check_used = [&]() {
+        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        used_real.clear(); used_cplx.clear();
+    };
     // dense-inverse steps: the norm kernel of iteration i rides on the step kernel of iteration i + 1 (dense.hpp, DenseNormPending)
     DenseNormPending npend;
     static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
@@ -878,6 +885,111 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     // previous solve (+2), so that a whole Lyapunov solve is enqueued before the first host synchronisation
     const int chunk_limit = (!cex && n <= xblocks_max_n() && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
                                                                           : opt.compression_interval;
+    // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
+    // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
+    static const bool fast_env = !(std::getenv("DRE_ADI_FAST") && std::atoi(std::getenv("DRE_ADI_FAST")) == 0);
+    bool fast = fast_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= 96 && n <= ctx->dense_inv_max_n && cache->enabled;
+    std::vector<std::shared_ptr<FactorEntry<double>>> fast_fe;      // per position of the cycle
+    std::vector<double*> fast_pack;
+    std::vector<Mat> fast_keep;
+    if (fast) {
+        const int mm = op.has_lr ? m : 0;
+        std::map<double, double*> by_mu;
+        std::vector<const double*> stacks, wks; std::vector<double*> outs;
+        for (auto& mu : opt.shifts.values) {
+            if (mu.imag() != 0.0) { fast = false; break; }
+            auto it = cache->real.find(std::make_tuple(op.tag, mu.real(), 0.0));
+            if (it == cache->real.end() || !it->second->dense || it->second->stack.empty() || it->second->stack_m != mm ||
+                (mm && it->second->stack_U != (const void*)op.U.p)) { fast = false; break; }
+            auto sc = smw_cache.find({mu.real(), 0.0});
+            if (mm && sc == smw_cache.end()) { fast = false; break; }
+            fast_fe.push_back(it->second);
+            auto bm = by_mu.find(mu.real());
+            if (bm == by_mu.end()) {
+                Mat pk(ctx, (int)adi_fast_pack_doubles(n) / 64, 64);
+                fast_keep.push_back(pk);
+                stacks.push_back(it->second->stack.p);
+                wks.push_back(mm ? (const double*)sc->second.WU : nullptr);
+                outs.push_back(pk.p);
+                bm = by_mu.emplace(mu.real(), pk.p).first;
+            }
+            fast_pack.push_back(bm->second);
+        }
+        if (fast) adi_fast_build(ctx, n, mm, stacks, 2 * n + mm, wks, 2 * n, outs);
+    }
+    if (fast) {
+        const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+        Mat Gm(ctx, k * k, 2);
+        size_t cyc = 0;                       // position in the cycle
+        while (!finished) {
+            const int base_it = iters_host;
+            // one more iteration than the previous solve needed; the two flush launches deliver the decisions of the last two
+            const int fast_chunk = cache->iters_hint > 0 ? std::max(opt.compression_interval, cache->iters_hint + 1) : chunk_limit;
+            const int nit = std::min(std::max(1, fast_chunk), opt.maxiters - iters_host);
+            if (nit <= 0) break;
+            Mat Rring(ctx, n, k * nit), Vall(ctx, n, k * nit);
+            const size_t blocks_before = Xw->blocks.size();
+            const size_t cyc_before = cyc;
+            AdiFastArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
+            a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p;
+            for (int j = 1; j <= nit; ++j) {
+                const std::complex<double> mu = opt.shifts.values[cyc % opt.shifts.values.size()];
+                all_shifts.push_back(mu);
+                used_real.push_back(fast_fe[cyc % fast_fe.size()]);
+                a.Apack = fast_pack[cyc % fast_pack.size()];
+                if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
+                a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
+                Mat Vj = Vall.colsview((j - 1) * k, k);
+                a.V = Vj.p; a.ldv = Vj.ld;
+                a.two_mu = 2.0 * mu.real();
+                const int g = base_it + j;                                  // shifts consumed after this iteration
+                // this launch also forms the Gram matrix of its INPUT residual (iteration g - 1) and decides on iteration g - 2
+                a.G_prev = j >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.G_prev2 = j >= 3 ? Gm.p + (size_t)((g - 2) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 2; a.do_strips = 1;
+                adi_fast_iter(ctx, a);
+                Xw->blocks.push_back({Vj, Tm, -2.0 * mu.real() * alpha_res, tdiag});
+                ++cyc; ++iters_host;
+            }
+            {   // drain the norm pipeline: Gram matrix of the last residual, decisions for the last two iterations of the chunk
+                const int g = base_it + nit;
+                a.do_strips = 0; a.Apack = nullptr; a.Rnext = nullptr; a.V = nullptr;
+                a.Rcur = Rring.p + (size_t)(nit - 1) * k * Rring.ld; a.ldr = Rring.ld;
+                a.G_prev = Gm.p + (size_t)(g & 1) * k * k;
+                a.G_prev2 = nit >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 1;
+                adi_fast_iter(ctx, a);
+                a.G_prev = nullptr;
+                a.G_prev2 = Gm.p + (size_t)(g & 1) * k * k;
+                a.it_prev2 = g;
+                adi_fast_iter(ctx, a);
+            }
+            AdiState h;
+            DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);          // accepted iterations of this chunk
+            for (int j = 1; j <= acc_it; ++j) { res.norms.push_back(h.norms[base_it + j]); res.norm_iters.push_back(base_it + j); }
+            Xw->blocks.resize(blocks_before + acc_it);
+            check_used();
+            if (acc_it > 0) R = Rring.colsview((acc_it - 1) * k, k);
+            iters_host = base_it + acc_it;
+            all_shifts.resize(iters_host);
+            cyc = cyc_before + acc_it;
+            last_compression += acc_it;
+            res.iters = h.iters;
+            res.res_norm = h.res_norm;
+            if (h.done || acc_it < nit) finished = true;
+            else if (opt.compression && last_compression >= opt.compression_interval) {
+                const long rk = Xw->rank();
+                const bool defer = !cex && (n <= 512 ? rk <= 16L * n : (n <= ctx->compress_direct_max_n && rk <= 16L * n));
+                if (!defer) { ldlt_compress(ctx, *Xw, ctf, cex); last_compression = 0; }
+            }
+        }
+        resid->blocks[0].L = R;                 // the residual factor after the last accepted iteration
+        finished = true;
+    }
     while (!finished) {
         std::vector<StepRec> recs;
         const size_t blocks_before = Xw->blocks.size();
@@ -1046,6 +1158,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             }
         }
         Xw->blocks.resize(nblocks);
+        check_used();
         last_compression = lc;
         res.iters = h.iters;
         res.res_norm = h.res_norm;
@@ -1070,11 +1183,13 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             }
         }
     }
-    {
-        // every factorisation is checked once (the flag is written by the factorisation kernels only)
-        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
-        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+    check_used();
+    if (opt_in.shifts.kind != ShiftSpec::CYCLIC) {
+        // self-generated shifts (Projection, per-solve Heuristic) never come back: their factors must not outlive the solve,
+        // or device memory grows with the total number of ADI iterations of a time loop
+        for (auto& key : cache->fresh) { cache->real.erase(key); cache->cplx_.erase(key); }
     }
+    cache->fresh.clear();
     if (opt.compression && last_compression > 0 && (opt.final_compress || cex)) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
     cache->iters_hint = res.iters;
     all_shifts.resize(res.iters);
@@ -1407,7 +1522,9 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
             if (r > 0) {
                 Mat d = S.view(q, q, r, r);
-                copy_mat(ctx, fb.D, d, 1.0 / tau);
+                // E'XE / tau with X = alpha L D L': the reference writes D/tau here (lowrank_ros1.jl:43), which is only right for alpha = 1
+                // (SURVEY Appendix B.3); the engine keeps alpha so that every code path solves the same equation as the dense solver
+                copy_mat(ctx, fb.D, d, fb.alpha / tau);
                 gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
             }
             LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
@@ -1433,8 +1550,8 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             set_identity(ctx, S, 0.0);
             { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
             if (r > 0) {
-                Mat d23 = S.view(q, q + r, r, r); copy_mat(ctx, fb.D, d23);
-                Mat d32 = S.view(q + r, q, r, r); copy_mat(ctx, fb.D, d32);
+                Mat d23 = S.view(q, q + r, r, r); copy_mat(ctx, fb.D, d23, fb.alpha);       // A'XE + E'XA with X = alpha L D L'
+                Mat d32 = S.view(q + r, q, r, r); copy_mat(ctx, fb.D, d32, fb.alpha);
                 Mat d33 = S.view(q + r, q + r, r, r); gemm(ctx, true, false, -1.0, fb.BtLD, fb.BtLD, 0.0, d33);
             }
             LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);

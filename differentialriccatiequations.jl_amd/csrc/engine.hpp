@@ -61,6 +61,7 @@ struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;
     long nfactor = 0;
     bool enabled = true;
+    std::vector<std::tuple<uint64_t, double, double>> fresh;   // keys created by the running Lyapunov solve (evicted unless the shift list persists)
     int iters_hint = 0;        // ADI iterations of the previous Lyapunov solve served by this cache (speculation depth of the next one)
     void clear() { real.clear(); cplx_.clear(); }
 };

@@ -117,7 +117,7 @@ def _build_mask(n: int) -> np.ndarray:
     return _trim_to(m, n)
 
 
-def _assemble(mask: np.ndarray):
+def _assemble(mask: np.ndarray, convection: float = 0.0):
     H, W = mask.shape
     h = _WIDTH / W
     inc = np.zeros((H + 1, W + 1), dtype=np.int32)
@@ -181,6 +181,15 @@ def _assemble(mask: np.ndarray):
 
     E = (_RHO_C * M).tocsc()
     A = (-_LAMBDA * K - _GAMMA * Mg).tocsc()
+    if convection != 0.0:
+        # non-symmetric variant: Galerkin convection matrix N_ij = int phi_i (v . grad phi_j) of a constant
+        # upward velocity field on the same 7-point pattern; A - rho c |v| N has complex eigenvalue pairs, so Projection shifts
+        # and perform_double_step! (adi.jl:181-225) are exercised with self-generated complex shifts
+        vx, vy = 0.3 * convection, convection
+        g = (vx * b + vy * c) / 6.0                      # nt x 3: (area/3) * v . grad phi_j
+        Nloc = np.repeat(g[:, None, :], 3, axis=1)       # row i of every element matrix is the same
+        N = sp.coo_matrix((Nloc.ravel(), (rows, cols)), shape=(n, n)).tocsc()
+        A = (A - _RHO_C * N).tocsc()
     Bm *= _GAMMA
     E.sort_indices()
     A.sort_indices()
@@ -198,13 +207,15 @@ def _assemble(mask: np.ndarray):
     return E, A, Bm, Cm, coords
 
 
-_CACHE: dict[int, SteelProfileData] = {}
+_CACHE: dict = {}
 
 
-def steel_profile(n: int) -> SteelProfileData:
-    """Return the (cached) surrogate for `SteelProfile(n)`; n is the exact state dimension."""
-    if n in _CACHE:
-        return _CACHE[n]
+def steel_profile(n: int, convection: float = 0.0) -> SteelProfileData:
+    """Return the (cached) surrogate for `SteelProfile(n)`; n is the exact state dimension.
+    convection != 0 (velocity in m/s) gives the non-symmetric convection-diffusion variant of the surrogate."""
+    key = (n, float(convection))
+    if key in _CACHE:
+        return _CACHE[key]
     d = os.environ.get("DRE_RAIL_DIR")
     if d and os.path.exists(os.path.join(d, f"rail_{n}.npz")):
         z = np.load(os.path.join(d, f"rail_{n}.npz"))
@@ -216,10 +227,10 @@ def steel_profile(n: int) -> SteelProfileData:
         if n < 40:
             raise ValueError("surrogate needs n >= 40")
         mask = _build_mask(n)
-        E, A, B, C, coords = _assemble(mask)
+        E, A, B, C, coords = _assemble(mask, convection)
         assert E.shape[0] == n, (E.shape, n)
-        out = SteelProfileData(n, E, A, B, C, coords)
-    _CACHE[n] = out
+        out = SteelProfileData(n, E, A, B, C, coords, source="surrogate" if convection == 0.0 else f"surrogate+convection({convection})")
+    _CACHE[key] = out
     return out
 
 
