@@ -124,6 +124,9 @@ struct Ctx {
     int top_inverse_max_rows = 1536;
     // Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments"; its compression runs on a second stream
     // beside the next time step (x_side_stream) or only every x_compress_every-th step (engine.hip, gdre_solve)
+    // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps
+    // (engine.hip, ros1_dense_step); 0 disables
+    int dense_x_max_n = 512;
     int x_side_stream = 1;
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)

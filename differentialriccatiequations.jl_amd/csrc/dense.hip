@@ -1026,17 +1026,25 @@ __device__ __forceinline__ void gram_norm_global(int k, const double* __restrict
 // B = X[4 t + lk, col] column-major; all loads of a batch of 24 K-steps are issued before its first MFMA.
 #define ADI_FAST_KB 24
 __device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, const double* __restrict__ bp, bool colok, int lk, int n, int t0, int t1) {
+    // branch-free: every load address is clamped into range (the packed A strip is padded, rows of B are clamped to n - 1) and
+    // out-of-range operands are zeroed by a select, so the 48 loads of a batch issue back to back without exec-mask branches
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (t1 <= t0) return acc;
     for (int tb = t0; tb < t1; tb += ADI_FAST_KB) {
         double av[ADI_FAST_KB], bv[ADI_FAST_KB];
 #pragma unroll
         for (int u = 0; u < ADI_FAST_KB; ++u) {
-            const int t = tb + u;
-            av[u] = (t < t1) ? ap[(size_t)t * 64] : 0.0;
-            bv[u] = (t < t1 && colok && 4 * t + lk < n) ? bp[4 * t] : 0.0;
+            const int t = min(tb + u, t1 - 1);
+            const int row = 4 * t + lk;
+            av[u] = ap[(size_t)t * 64];
+            bv[u] = bp[min(row, n - 1) - lk];
         }
 #pragma unroll
-        for (int u = 0; u < ADI_FAST_KB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        for (int u = 0; u < ADI_FAST_KB; ++u) {
+            const int row = 4 * (tb + u) + lk;
+            const bool ok = (tb + u < t1) && colok && row < n;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
     }
     return acc;
 }
@@ -1059,7 +1067,8 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
         // old residual entry of the element this thread finishes in the epilogue (requested early)
         const int erow = s * 16 + (lane >> 4) + 4 * wave;
         const double rold = (half == 1 && colok && erow < n) ? a.Rcur[erow + (size_t)col * a.ldr] : 0.0;
-        const int per = (a.kst + 3) >> 2, t0 = wave * per, t1 = min(a.kst, t0 + per);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
         const v4d acc = adi_fast_tile(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur + (size_t)(colok ? col : 0) * a.ldr + lk, colok, lk, n, t0, t1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
@@ -1082,19 +1091,23 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
         const bool aok = ca < k, bok = cb < k;
         const double* __restrict__ pa = a.Rcur + (size_t)(aok ? ca : 0) * a.ldr + lk;
         const double* __restrict__ pb = a.Rcur + (size_t)(bok ? cb : 0) * a.ldr + lk;
-        const int per = (a.kst + 3) >> 2, t0 = wave * per, t1 = min(a.kst, t0 + per);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
         for (int tb0 = t0; tb0 < t1; tb0 += ADI_FAST_KB) {
             double av[ADI_FAST_KB], bv[ADI_FAST_KB];
 #pragma unroll
             for (int u = 0; u < ADI_FAST_KB; ++u) {
-                const int t = tb0 + u;
-                const bool ok = t < t1 && 4 * t + lk < n;
-                av[u] = (ok && aok) ? pa[4 * t] : 0.0;
-                bv[u] = (ok && bok) ? pb[4 * t] : 0.0;
+                const int t = min(tb0 + u, t1 - 1);
+                const int off = min(4 * t + lk, n - 1) - lk;
+                av[u] = pa[off];
+                bv[u] = pb[off];
             }
 #pragma unroll
-            for (int u = 0; u < ADI_FAST_KB; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < ADI_FAST_KB; ++u) {
+                const bool ok = (tb0 + u < t1) && 4 * (tb0 + u) + lk < n;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && aok) ? av[u] : 0.0, (ok && bok) ? bv[u] : 0.0, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
@@ -1107,8 +1120,57 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
         }
         return;
     }
+    b -= ct * ct;
     if (!a.G_prev2) return;
-    gram_norm_global(k, a.G_prev2, a.T, a.ldt, a.tdiag, a.alpha, a.st, a.it_prev2, nred);
+    // norm of the residual whose Gram matrix the previous launch left: tr((T G)^2) = sum_ij M_ij N_ij with M = T G, N = G T' (= M');
+    // workgroup b owns tile row b of M and N (one 16 x 16 tile per wave and pass), all operand loads are 128-byte column segments
+    // issued before the first MFMA.  The ct partial sums meet through a ticket: the workgroup whose atomic add comes last sums
+    // them in a fixed order and takes the decision of adi.jl:115-123.
+    const int I = b;
+    double sloc = 0.0;
+    const double* __restrict__ G = a.G_prev2; const double* __restrict__ T = a.T;
+    const int lr = lane & 15;
+    for (int J = wave; J < ct; J += 4) {
+        v4d mm = (v4d){0.0, 0.0, 0.0, 0.0}, nn = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int ri = I * 16 + lr, rj = J * 16 + lr;
+        const bool iok = ri < k, jok = rj < k;
+        const int ric = iok ? ri : 0, rjc = jok ? rj : 0;
+        for (int kk0 = 0; kk0 < ct * 4; kk0 += 16) {
+            double ta[16], gb[16], ga[16], tb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = min((kk0 + u) * 4 + lk, k - 1);
+                ta[u] = T[ric + (size_t)c * a.ldt]; gb[u] = G[rjc + (size_t)c * k];
+                ga[u] = G[ric + (size_t)c * k];     tb[u] = T[rjc + (size_t)c * a.ldt];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool cok = (kk0 + u) < ct * 4 && (kk0 + u) * 4 + lk < k;
+                mm = __builtin_amdgcn_mfma_f64_16x16x4f64((cok && iok) ? ta[u] : 0.0, (cok && jok) ? gb[u] : 0.0, mm, 0, 0, 0);
+                nn = __builtin_amdgcn_mfma_f64_16x16x4f64((cok && iok) ? ga[u] : 0.0, (cok && jok) ? tb[u] : 0.0, nn, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sloc += mm[r] * nn[r];
+    }
+    sloc = block_sum(sloc, nred);
+    if (tid == 0) {
+        __hip_atomic_store(a.nws + I, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + 8);
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)(ct - 1)) {
+            double tot = 0.0;
+            for (int i = 0; i < ct; ++i) tot += __hip_atomic_load(a.nws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+            const double nrm = fabs(a.alpha) * sqrt(fmax(tot, 0.0));
+            AdiState* st = a.st;
+            st->res_norm = nrm;
+            st->iters = a.it_prev2;
+            if (a.it_prev2 < 512) st->norms[a.it_prev2] = nrm;
+            if (nrm <= st->abstol || a.it_prev2 >= st->maxiters) st->done = 1;
+        }
+    }
 }
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     DRE_REQUIRE(a.k >= 1 && a.k <= ADI_FAST_MAX_K, "adi_fast_iter: residual too wide");
@@ -1117,7 +1179,7 @@ void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     const double fl = (a.do_strips ? 4.0 * a.n * (double)a.n * a.k : 0.0) + (a.G_prev ? 2.0 * a.n * (double)a.k * a.k : 0.0);
     const double by = a.do_strips ? 8.0 * (2.0 * a.nstrip * 16.0 * a.kst * 4.0 + 4.0 * a.n * a.k) : 8.0 * (double)a.n * a.k;
     TimedScope ts(ctx, a.do_strips ? "adi_fast_iter" : "adi_fast_flush", by, fl);
-    hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + 1), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct), dim3(256), 0, ctx->stream, a);
     DRE_HIP(hipGetLastError());
 }
 
@@ -2463,7 +2525,8 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
     D[oi + (size_t)oj * ldd] = v;
 }
 
-SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
+__global__ void k_set_abstol(AdiState* st, const double* __restrict__ tol) { st->abstol = tol[0]; }
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
     SymBand out;
     const int q = S.rows, b = QR_NB;
@@ -2484,6 +2547,8 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
         std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
         h.abstol = abs_tol;
         DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
+        // absolute tolerance that only exists in device memory (no host round trip for it)
+        if (abs_tol_dev) hipLaunchKernelGGL(k_set_abstol, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol_dev);
     }
     // Panels are enqueued speculatively: every kernel returns at once after the device-side decision `done`, and the
     // host looks at the flag only every few panels.
@@ -2491,7 +2556,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol) {
     bool finished = false;
     // speculation depth: the previous reduction of the same kind (same order, same tolerance mode) needed `hint` panels; the
     // panel after the last one is the one whose prologue detects termination
-    const long hkey = (long)q * 2 + (abs_tol > 0.0 ? 1 : 0);
+    const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0);
     auto hit = ctx->band_hint.find(hkey);
     int chunk = hit != ctx->band_hint.end() ? std::max(4, hit->second + 1) : 4;
     while (!finished) {

@@ -92,6 +92,7 @@ struct AdiFastArgs {
     const double* G_prev2;      // Gram matrix the previous launch produced (norm + decision now), or null
     const double* T; int ldt; int tdiag; double alpha;
     AdiState* st;
+    double* nws;                // 8 partial sums + a ticket word (zero-initialised once per solve): meeting point of the norm workgroups
     int it_prev2;               // shifts consumed after the iteration G_prev2 belongs to
     int do_strips;              // 0: flush launch (riders only)
 };
@@ -148,7 +149,7 @@ struct SymBand {
     Mat V0, VT0; // optional leading reflector block Q0 = I - VT0 V0' (factor-form reduction with a warm start): Qb <- Q0 Qb
 };
 // abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
-SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0);
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr);   // abs_tol_dev: the tolerance lives in device memory
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 // The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
 // neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).

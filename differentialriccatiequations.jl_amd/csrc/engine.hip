@@ -411,6 +411,27 @@ __global__ __launch_bounds__(256) void k_fold_sinv_batched(int nrows, int m, int
     b.WKS[r + (size_t)j * nrows] = a0 + a1;
 }
 
+// the same with the batch table passed by value (no upload): up to 16 shifts per launch
+struct SmwBatchArgs { SmwBatch b[16]; };
+__global__ __launch_bounds__(64) void k_sinv_batched_args(int n, int m, int ldwk, double alpha, SmwBatchArgs bt, int* err) {
+    const SmwBatch b = bt.b[blockIdx.x];
+    sinv_body<double>(m, b.WK + 2 * (size_t)n, ldwk, alpha, b.Sinv, err);
+}
+__global__ __launch_bounds__(256) void k_fold_sinv_batched_args(int nrows, int m, int ldwk, SmwBatchArgs bt) {
+    const SmwBatch b = bt.b[blockIdx.y];
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)nrows * m) return;
+    const int r = id % nrows, j = id / nrows;
+    double a0 = 0.0, a1 = 0.0;
+    int l = 0;
+    for (; l + 1 < m; l += 2) {
+        a0 += b.WK[r + (size_t)l * ldwk] * b.Sinv[l + (size_t)j * m];
+        a1 += b.WK[r + (size_t)(l + 1) * ldwk] * b.Sinv[l + 1 + (size_t)j * m];
+    }
+    if (l < m) a0 += b.WK[r + (size_t)l * ldwk] * b.Sinv[l + (size_t)j * m];
+    b.WKS[r + (size_t)j * nrows] = a0 + a1;
+}
+
 // WKS = WK(0:nrows, :) * Sinv  — folds the capacitance inverse into the low-rank solve products once per shift, so that the
 // per-step apply kernel needs no inner m x m solve.  One thread per output entry.
 __global__ __launch_bounds__(256) void k_fold_sinv(int nrows, int m, const double* __restrict__ WK, int ldwk, const double* __restrict__ Sinv,
@@ -920,6 +941,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     if (fast) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         Mat Gm(ctx, k * k, 2);
+        DevArr<double> nws(ctx, 16);
+        DRE_HIP(hipMemsetAsync(nws.p, 0, 16 * sizeof(double), ctx->stream));
         size_t cyc = 0;                       // position in the cycle
         while (!finished) {
             const int base_it = iters_host;
@@ -933,7 +956,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
-            a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p;
+            a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p; a.nws = nws.p;
             for (int j = 1; j <= nit; ++j) {
                 const std::complex<double> mu = opt.shifts.values[cyc % opt.shifts.values.size()];
                 all_shifts.push_back(mu);
@@ -1377,10 +1400,303 @@ static Feedback feedback_blocks(Ctx* ctx, const GdreProblem& prob, const LDLt& X
     return f;
 }
 
+// =============================================================================================
+// Ros1 with X carried as a dense symmetric n x n matrix between the time steps (small n).
+// At these sizes every compression already forms the n x n matrix L D L' (the factors have more columns than rows: warm start
+// + ~17 ADI increments of ~64 columns each), so the factored form buys nothing between two steps: the compression of X after
+// every Lyapunov solve (adi.jl:78-80) — a strictly sequential chain of ~9 Householder panels per step that bounded the whole time
+// loop — disappears, and the warm-start residual of the step's Lyapunov equation (lyapunov/residual.jl:3-31 applied to
+// lowrank_ros1.jl:39-47) collapses to the Riccati residual
+//     Res = C'C + K'K + E'XE/tau + F'XE + E'XF = C'C - K'K + A'XE + (A'XE)'          (F = A - E/(2 tau) - B K,  K = B'XE),
+// three SpMMs and one fused assembly kernel.  The ADI iteration itself is unchanged (low-rank residual factor, low-rank increments,
+// adi.jl:97-179); X_i = X_{i-1} + sum_j (-2 mu_j) V_j T V_j' is one GEMM.  The LDL' form of X is produced once at the end (and by
+// the generic path whenever save_state asks for every X(t)).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dense_residual(int n, int q, int m, const double* __restrict__ Ct, int ldc, const double* __restrict__ Kt, int ldk,
+                                                        const double* __restrict__ M, int ldm, const double* __restrict__ EY, int ldey, double inv_tau,
+                                                        double* __restrict__ Res, int ldres, double* __restrict__ part) {
+    __shared__ double red[17];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+    double s = 0.0;
+    if (i < n && j < n) {
+        double cc = 0.0, kk = 0.0;
+        for (int l = 0; l < q; ++l) cc += Ct[i + (size_t)l * ldc] * Ct[j + (size_t)l * ldc];
+        for (int l = 0; l < m; ++l) kk += Kt[i + (size_t)l * ldk] * Kt[j + (size_t)l * ldk];
+        const double mm = M[i + (size_t)j * ldm] + M[j + (size_t)i * ldm];
+        const double ey = 0.5 * (EY[i + (size_t)j * ldey] + EY[j + (size_t)i * ldey]);
+        Res[i + (size_t)j * ldres] = (cc - kk) + mm;
+        const double rhs = (cc + kk) + inv_tau * ey;              // right-hand side of the step's Lyapunov equation (lowrank_ros1.jl:42-43)
+        s = rhs * rhs;
+    }
+    // block_sum (dense.hip) is not visible here: fixed-order reduction through LDS
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    s = wave_sum_t<double>(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x + (size_t)gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F
+__global__ __launch_bounds__(64) void k_dense_tols(int nparts, const double* __restrict__ part, double reltol, double abstol_given, double frac, double* __restrict__ tols) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
+    s = wave_sum_t<double>(s);
+    if (threadIdx.x == 0) {
+        const double nc = sqrt(s), at = abstol_given >= 0.0 ? abstol_given : reltol * nc;
+        tols[0] = at; tols[1] = frac * at; tols[2] = nc;
+    }
+}
+// control block of the Lyapunov solve: residual = R D R' with orthonormal R, so its norm is ||D||_F
+__global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int id = threadIdx.x; id < J * J; id += 256) { const double x = D[id % J + (size_t)(id / J) * ldd]; s += x * x; }
+    s = wave_sum_t<double>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        st->iters = 0; st->maxiters = maxiters; st->smw_singular = 0;
+        st->abstol = tols[0]; st->res_norm = nrm; st->norms[0] = nrm;
+        st->done = (nrm <= tols[0]) ? 1 : 0;
+    }
+}
+
+// SMW products of every shift of a real Cyclic list for the low-rank factor (U, Vt) of `op`, and the SMW-folded packed stacks of the
+// fast chain (dense.hip).  Factors, dense inverses and stacked inverses come from the cache (built on first use).  false: some shift
+// cannot take the dense-inverse path (complex, or its inverse was rejected by the condition estimate).
+struct CycleOps {
+    std::vector<double*> pack;          // per position of the cycle
+    std::vector<std::shared_ptr<FactorEntry<double>>> fe;
+    std::vector<Mat> keep;
+    std::vector<BufP> keepb;
+    DevArr<int> serr;
+};
+static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& fe) {
+    const Pencil& P = *op.P;
+    const int n = P.n, mm = op.has_lr ? op.U.cols : 0;
+    if (!fe.stack.empty() && fe.stack_m == mm && (!mm || fe.stack_U == (const void*)op.U.p)) return;
+    Mat stk(ctx, 2 * n + mm, n);
+    { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, fe.dinv, top); }
+    { Mat mid = stk.view(n, 0, n, n); spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, fe.dinv, mid, 1.0, 0.0, nullptr); }
+    if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe.dinv, 0.0, bot, nullptr, "gemm_dinv"); }
+    fe.stack = stk; fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
+}
+static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache, CycleOps& co) {
+    const Pencil& P = *op.P;
+    const int n = P.n, m = op.has_lr ? op.U.cols : 0;
+    if (m > 32) return false;
+    std::map<double, double*> by_mu;
+    std::vector<GemmBatchDesc> descs;
+    std::vector<SmwBatch> hb;
+    std::vector<const double*> stacks, wks; std::vector<double*> outs;
+    for (auto& mu : values) {
+        if (mu.imag() != 0.0) return false;
+        auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, true);
+        if (!fe->dense) return false;
+        ensure_stack(ctx, op, *fe);
+        co.fe.push_back(fe);
+        auto bm = by_mu.find(mu.real());
+        if (bm == by_mu.end()) {
+            Mat pk(ctx, (int)(adi_fast_pack_doubles(n) / 64), 64);
+            co.keep.push_back(pk);
+            const double* wksp = nullptr;
+            if (m) {
+                Mat WK(ctx, 2 * n + m, m), WKS(ctx, 2 * n, m);
+                auto sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                co.keep.push_back(WK); co.keep.push_back(WKS); co.keepb.push_back(sinv);
+                descs.push_back({fe->stack.p, op.Vt.p, WK.p, nullptr, 1.0, 2 * n + m, m, n, fe->stack.ld, op.Vt.ld, WK.ld, 0});
+                hb.push_back({WK.p, (double*)sinv->p, WKS.p});
+                wksp = WKS.p;
+            }
+            stacks.push_back(fe->stack.p); wks.push_back(wksp); outs.push_back(pk.p);
+            bm = by_mu.emplace(mu.real(), pk.p).first;
+        }
+        co.pack.push_back(bm->second);
+    }
+    if (m) {
+        co.serr = DevArr<int>(ctx, 1);
+        DRE_HIP(hipMemsetAsync(co.serr.p, 0, sizeof(int), ctx->stream));
+        gemm_batched(ctx, descs, "gemm_dinv");
+        for (size_t b0 = 0; b0 < hb.size(); b0 += 16) {
+            SmwBatchArgs ba;
+            const unsigned nb = (unsigned)std::min<size_t>(16, hb.size() - b0);
+            for (unsigned i = 0; i < 16; ++i) ba.b[i] = hb[b0 + (i < nb ? i : 0)];
+            TimedScope ts(ctx, "smw_batched", 8.0 * nb * (2.0 * n * m * 2.0 + 3.0 * m * m), 4.0 * nb * n * (double)m * m);
+            hipLaunchKernelGGL(k_sinv_batched_args, dim3(nb), dim3(64), 0, ctx->stream, n, m, 2 * n + m, op.alpha, ba, co.serr.p);
+            hipLaunchKernelGGL(k_fold_sinv_batched_args, dim3(ceil_div(2 * n * m, 256), nb), dim3(256), 0, ctx->stream, 2 * n, m, 2 * n + m, ba);
+        }
+    }
+    adi_fast_build(ctx, n, m, stacks, 2 * n + m, wks, 2 * n, outs);
+    return true;
+}
+
+struct DenseXState {
+    Mat X;        // n x n, symmetric
+    Mat P1;       // E' X
+    Mat Kt;       // K' = E' X B  (n x m)
+    int hint = 0; // ADI iterations of the previous step
+};
+// One Ros1 step on the dense state.  Returns false (state untouched) when the fast chain cannot take the step.
+static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperator& op_base, double tau, const AdiOptions& adi, FactorCache* cache,
+                            DenseXState& sx, AdiResult& ar) {
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    GaleOperator op = op_base;
+    op.Vt = sx.Kt;
+    CycleOps co;
+    if (!cycle_ops_prepare(ctx, op, adi.shifts.values, cache, co)) return false;
+    // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side
+    Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
+    transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
+    spmm(ctx, n, P.ptr.p, P.idx.p, P.valAt.p, Y, Mx, 1.0, 0.0);                 // A' X E
+    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Y, EY, 1.0, 0.0);                 // E' X E
+    const int nt = ceil_div(n, 16);
+    DevArr<double> part(ctx, (size_t)nt * nt), tols(ctx, 4);
+    hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
+                       (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
+    const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
+    hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
+    // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
+    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1);
+    const int k = sb.J;
+    DevArr<AdiState> st(ctx, 1);
+    AdiState h;
+    std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 3);
+    ar = AdiResult();
+    ar.rhs_cols = k;
+    if (k > ADI_FAST_MAX_K) return false;
+    std::vector<Mat> keepV;
+    Mat Vall, Wall;
+    int acc_total = 0;
+    std::vector<double> coef;
+    if (k > 0) {
+        Mat R = sym_band_basis(ctx, sb);
+        Mat Tm = sb.D;
+        hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p);
+        const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+        Mat Gm(ctx, k * k, 2);
+        DevArr<double> nws(ctx, 16);
+        DRE_HIP(hipMemsetAsync(nws.p, 0, 16 * sizeof(double), ctx->stream));
+        // the whole solve is enqueued at once (one more iteration than the previous step needed); further chunks only if that was not enough
+        int iters_host = 0;
+        size_t cyc = 0;
+        bool finished = false;
+        const int cap = std::max(1, adi.maxiters);
+        Vall = Mat(ctx, n, k * std::min(cap, std::max(adi.compression_interval, sx.hint + 1) + 64));
+        int vcols_used = 0;
+        while (!finished) {
+            const int base_it = iters_host;
+            int nit = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters - iters_host);
+            nit = std::min(nit, (Vall.cols - vcols_used) / k);
+            if (nit <= 0) break;
+            Mat Rring(ctx, n, k * nit);
+            keepV.push_back(Rring);
+            AdiFastArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
+            a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
+            for (int j = 1; j <= nit; ++j) {
+                const std::complex<double> mu = adi.shifts.values[cyc % adi.shifts.values.size()];
+                a.Apack = co.pack[cyc % co.pack.size()];
+                if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
+                a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
+                Mat Vj = Vall.colsview(vcols_used + (j - 1) * k, k);
+                a.V = Vj.p; a.ldv = Vj.ld;
+                a.two_mu = 2.0 * mu.real();
+                const int g = base_it + j;
+                a.G_prev = j >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.G_prev2 = j >= 3 ? Gm.p + (size_t)((g - 2) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 2; a.do_strips = 1;
+                adi_fast_iter(ctx, a);
+                ar.shifts.push_back(mu);
+                coef.push_back(-2.0 * mu.real());
+                ++cyc; ++iters_host;
+            }
+            {
+                const int g = base_it + nit;
+                a.do_strips = 0; a.Apack = nullptr; a.Rnext = nullptr; a.V = nullptr;
+                a.Rcur = Rring.p + (size_t)(nit - 1) * k * Rring.ld; a.ldr = Rring.ld;
+                a.G_prev = Gm.p + (size_t)(g & 1) * k * k;
+                a.G_prev2 = nit >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 1;
+                adi_fast_iter(ctx, a);
+                a.G_prev = nullptr;
+                a.G_prev2 = Gm.p + (size_t)(g & 1) * k * k;
+                a.it_prev2 = g;
+                adi_fast_iter(ctx, a);
+            }
+            DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
+            for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[base_it + j]); ar.norm_iters.push_back(base_it + j); }
+            iters_host = base_it + acc_it;
+            vcols_used += acc_it * k;
+            cyc = cyc - nit + acc_it;
+            ar.shifts.resize(iters_host); coef.resize(iters_host);
+            if (acc_it > 0) R = Rring.colsview((acc_it - 1) * k, k);
+            if (h.done || acc_it < nit || iters_host >= adi.maxiters) finished = true;
+        }
+        acc_total = iters_host;
+        for (auto& f : co.fe) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        if (m) {
+            int herr = 0;
+            DRE_HIP(hipMemcpyAsync(&herr, co.serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+        }
+        // X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated, one GEMM)
+        if (acc_total > 0) {
+            Wall = Mat(ctx, n, k * acc_total);
+            std::vector<GemmBatchDesc> descs;
+            for (int j = 0; j < acc_total; ++j) {
+                Mat Vj = Vall.colsview(j * k, k), Wj = Wall.colsview(j * k, k);
+                descs.push_back({Vj.p, Tm.p, Wj.p, nullptr, coef[j], n, k, k, Vj.ld, Tm.ld, Wj.ld, 0});
+            }
+            gemm_batched(ctx, descs, "gemm_xupdate");
+            Mat Vacc = Vall.colsview(0, k * acc_total);
+            gemm(ctx, false, true, 1.0, Wall, Vacc, 1.0, sx.X, nullptr, "gemm_xupdate");
+            symmetrize(ctx, sx.X);
+        }
+    } else {
+        // zero residual: read the tolerances back for the record
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    {
+        double ht[4];
+        DRE_HIP(hipMemcpyAsync(ht, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        ar.abstol = ht[0];
+    }
+    ar.iters = acc_total;
+    ar.initial_norm = k > 0 ? h.norms[0] : 0.0;
+    ar.res_norm = k > 0 ? (acc_total > 0 ? h.res_norm : h.norms[0]) : 0.0;
+    ar.norms.insert(ar.norms.begin(), ar.initial_norm); ar.norm_iters.insert(ar.norm_iters.begin(), 0);
+    ar.converged = ar.res_norm <= ar.abstol;
+    if (!ar.converged) ar.warnings |= 1;
+    sx.hint = acc_total;
+    cache->iters_hint = acc_total;
+    // feedback of the new X:  P1 = E' X,  K' = P1 B      (lowrank_ros1.jl:53-56)
+    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+    Mat Kt(ctx, n, m);
+    gemm(ctx, false, false, 1.0, sx.P1, prob.B, 0.0, Kt);
+    sx.Kt = Kt;
+    return true;
+}
+
 static uint64_t tag_of(int order, double tau) {
     uint64_t bits;
     std::memcpy(&bits, &tau, sizeof(bits));
     return bits * 1315423911ull + (uint64_t)order * 0x9E3779B97F4A7C15ull + 1;
+}
+
+// LDL' form of a dense symmetric X: compress!(lowrank(I, X))  (LDLt.jl:204-225; S = I X I' is X itself)
+static LDLtP dense_to_ldlt(Ctx* ctx, int n, const Mat& Xd, double ctf) {
+    Mat I(ctx, n, n), D(ctx, n, n);
+    set_identity(ctx, I, 1.0);
+    copy_mat(ctx, Xd, D);
+    LDLtP X = ldlt_make(ctx, n, I, D, 1.0, false);
+    ldlt_compress(ctx, *X, ctf, false);
+    return X;
 }
 
 GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {
@@ -1426,6 +1742,12 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     }
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
+    // Ros1, small n, real Cyclic shifts, no save_state: from the second step on X is carried as a dense symmetric matrix (ros1_dense_step)
+    bool densex = order == 1 && !cex && !save_state && !adi.ignore_initial_guess && adi.compression && adi.shifts.kind == ShiftSpec::CYCLIC &&
+                  n <= ctx->dense_x_max_n && n <= ctx->dense_inv_max_n && m <= 32 && !adi.shifts.values.empty();
+    for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
+    DenseXState sx;
+    bool sx_init = false, x_is_dense = false;
 
     for (int i = 1; i <= nsteps; ++i) {
         const double tau = out.t[i - 1] - out.t[i];
@@ -1445,6 +1767,35 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         op.Vt = fb.Kt;
         op.alpha = order == 1 ? -1.0 : 1.0 / (-gamma * tau);
         const int r = fb.L.cols;
+        if (densex && i >= 2) {
+            if (!sx_init) {
+                // X_1 (block list: warm start + increments of the first solve) as a dense matrix
+                const int c = X->rank();
+                sx.X = Mat(ctx, n, n);
+                if (c > 0) {
+                    Mat Lcat(ctx, n, c), LD(ctx, n, c);
+                    hcat_scale_blocks(ctx, *X, Lcat, LD);
+                    gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, sx.X, nullptr, "gemm_xupdate");
+                    symmetrize(ctx, sx.X);
+                } else fill_mat(ctx, sx.X, 0.0);
+                sx.P1 = Mat(ctx, n, n);
+                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+                sx.Kt = fb.Kt;
+                sx.hint = cache.iters_hint;
+                sx_init = true;
+            }
+            AdiResult ar;
+            if (ros1_dense_step(ctx, prob, op, tau, adi, &cache, sx, ar)) {
+                out.adi_iters += ar.iters;
+                out.gale.push_back(std::move(ar));
+                out.Kt.push_back(sx.Kt);
+                x_is_dense = true;
+                continue;
+            }
+            // the fast chain refused (residual too wide, ill-conditioned shifted operator): back to the factored form for good
+            densex = false;
+            if (x_is_dense) { X = dense_to_ldlt(ctx, n, sx.X, ctf); x_is_dense = false; fb = feedback(ctx, prob, *X, ctf, false); op.Vt = fb.Kt; }
+        }
         if (order == 1 && xblocks) {
             // X is a block list (compressed every `xevery` steps only):  rhs = C'C + K'K + sum_b (E'L_b) (alpha_b D_b / tau) (E'L_b)'
             // as a block list of its own; nothing is compressed before the warm-start residual (gale_residual_blocks)
@@ -1587,6 +1938,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         fb = feedback(ctx, prob, *X, ctf, cex);
         out.Kt.push_back(fb.Kt);
     }
+    if (x_is_dense) X = dense_to_ldlt(ctx, n, sx.X, ctf);
     if (!save_state) out.X.push_back(X);
     out.nfactor = cache.nfactor;
     return out;
