@@ -2510,6 +2510,140 @@ __global__ __launch_bounds__(256) void k_band_w_rows(int m, int splits, const do
         P2[r + (size_t)c * ldp] = v[c];      P2[r + (size_t)(b + c) * ldp] = acc;
     }
 }
+// Panels of at most 540 rows: the two-sided update in two lean launches instead of three (split-K GEMM + single-workgroup W kernel + update GEMM).
+// k_band_z:   Z = S22 (V T)   — one workgroup per 16 rows, the four waves split K, all operand loads of a batch issued before its first MFMA
+// k_band_upd: every 64 x 64 tile workgroup recomputes the 16 x 16 matrix N = T' (V' Z) (two 45 KB operands from L2), forms the rows of
+//             W = Z - V N / 2 it needs, updates its tile  S22 -= W V' + V W'  on the matrix cores and leaves the tile's sum of squares for
+//             the termination test of the next panel.
+__global__ __launch_bounds__(256) void k_band_z(int m, const double* __restrict__ S22, int lds_, const double* __restrict__ VT, int ldvt,
+                                                double* __restrict__ Z, int ldz, const AdiState* st) {
+    if (st->done) return;
+    __shared__ double part[4][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int r0 = blockIdx.x * 16, row = r0 + lr, rowc = min(row, m - 1);
+    const int kst = (m + 3) >> 2, per = (kst + 3) >> 2, t0 = wv * per, t1 = min(kst, t0 + per);
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], bv[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int t = min(tb + u, t1 - 1), cc = min(4 * t + lk, m - 1);
+            av[u] = S22[rowc + (size_t)cc * lds_];
+            bv[u] = VT[cc + (size_t)lr * ldvt];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool ok = (tb + u < t1) && 4 * (tb + u) + lk < m;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && row < m) ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    const int orow = r0 + lk + 4 * wave;
+    if (orow < m) Z[orow + (size_t)lr * ldz] = v;
+}
+__global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S22, int lds_, const double* __restrict__ V, int ldv,
+                                                  const double* __restrict__ Z, int ldz, const double* __restrict__ T, int ldt,
+                                                  double* __restrict__ tile_sumsq, const AdiState* st) {
+    if (st->done) return;
+    __shared__ double part[4][4][64];
+    __shared__ double Msh[16][17], Nsh[16][17];
+    __shared__ double Ar[64][33], Bc[64][33];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    {   // M = V' Z  (16 x 16, K = m)
+        const int kst = (m + 3) >> 2, per = (kst + 3) >> 2, t0 = wv * per, t1 = min(kst, t0 + per);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int tb = t0; tb < t1; tb += 24) {
+            double av[24], bv[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) {
+                const int t = min(tb + u, t1 - 1), cc = min(4 * t + lk, m - 1);
+                av[u] = V[cc + (size_t)lr * ldv];
+                bv[u] = Z[cc + (size_t)lr * ldz];
+            }
+#pragma unroll
+            for (int u = 0; u < 24; ++u) {
+                const bool ok = (tb + u < t1) && 4 * (tb + u) + lk < m;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+        __syncthreads();
+        Msh[lk + 4 * wave][lr] = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    }
+    __syncthreads();
+    {   // N = T' M  (T upper triangular)
+        const int i = tid & 15, j = tid >> 4;
+        double a0 = 0.0;
+        for (int l = 0; l <= i; ++l) a0 += T[l + (size_t)i * ldt] * Msh[l][j];
+        Nsh[i][j] = a0;
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    {   // rows of [W V] for the tile's row block and of [V W] for its column block
+        const int rr = tid & 63, cq = tid >> 6;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int r = (side == 0 ? i0 : j0) + rr;
+            double vrow[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) vrow[l] = r < m ? V[r + (size_t)l * ldv] : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = cq * 4 + cc;
+                double a0 = r < m ? Z[r + (size_t)c * ldz] : 0.0, a1 = 0.0;
+#pragma unroll
+                for (int l = 0; l < 16; l += 2) { a0 -= 0.5 * vrow[l] * Nsh[l][c]; a1 -= 0.5 * vrow[l + 1] * Nsh[l + 1][c]; }
+                const double w = a0 + a1;
+                if (side == 0) { Ar[rr][c] = w; Ar[rr][16 + c] = vrow[c]; }
+                else { Bc[rr][c] = vrow[c]; Bc[rr][16 + c] = w; }
+            }
+        }
+    }
+    __syncthreads();
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    v4d acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int qk = 0; qk < 8; ++qk) {
+        const double a0 = Ar[wm + lr][4 * qk + lk], a1 = Ar[wm + 16 + lr][4 * qk + lk];
+        const double b0 = Bc[wn + lr][4 * qk + lk], b1 = Bc[wn + 16 + lr][4 * qk + lk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    double ssq = 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm + x * 16 + lk + 4 * r, col = j0 + wn + y * 16 + lr;
+                if (row < m && col < m) {
+                    double* c = S22 + row + (size_t)col * lds_;
+                    const double v = *c - acc[x][y][r];
+                    *c = v;
+                    ssq += v * v;
+                }
+            }
+    if (tile_sumsq) {
+        ssq = wave_sum(ssq);
+        if (lane == 0) red[wave] = ssq;
+        __syncthreads();
+        if (tid == 0) tile_sumsq[blockIdx.x + (size_t)gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
 // D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
 __global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2526,6 +2660,10 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
 }
 
 __global__ void k_set_abstol(AdiState* st, const double* __restrict__ tol) { st->abstol = tol[0]; }
+static bool band_fused_enabled() {
+    static const bool v = !(std::getenv("DRE_BAND_FUSED") && std::atoi(std::getenv("DRE_BAND_FUSED")) == 0);
+    return v;
+}
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
     SymBand out;
@@ -2593,6 +2731,21 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 TimedScope ts(ctx, "band_w", 8.0 * m * b * 6.0, 2.0 * m * b * b);
                 hipLaunchKernelGGL(k_band_w_rows, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, m, ms, Z.p, Z.ld, (const double*)mpart->p,
                                    Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
+            } else if (band_fused_enabled()) {
+                Mat Z(ctx, m, b);
+                {
+                    TimedScope ts(ctx, "band_z", 8.0 * ((double)m * m + 2.0 * m * b), 2.0 * m * (double)m * b);
+                    hipLaunchKernelGGL(k_band_z, dim3(ceil_div(m, 16)), dim3(256), 0, ctx->stream, m, (const double*)S22.p, S22.ld, (const double*)VTp.p, VTp.ld, Z.p, Z.ld,
+                                       (const AdiState*)st.p);
+                }
+                {
+                    TimedScope ts(ctx, "band_upd", 8.0 * (2.0 * m * m + 2.0 * m * b), 4.0 * m * (double)m * b);
+                    hipLaunchKernelGGL(k_band_upd, dim3(ceil_div(m, 64), ceil_div(m, 64)), dim3(256), 0, ctx->stream, m, S22.p, S22.ld, (const double*)Vp.p, Vp.ld,
+                                       (const double*)Z.p, Z.ld, (const double*)Tp.p, Tp.ld, fused_rem ? part.p + 1 : (double*)nullptr, (const AdiState*)st.p);
+                }
+                if (fused_rem) nparts = 1 + gemm_num_tiles(m, m);
+                k += b; ++np; ++issued;
+                continue;
             } else {
             int zs = 1;
             BufP zpart = gemm_partials(ctx, false, false, m, b, m, S22.p, S22.ld, VTp.p, VTp.ld, &zs, st.p, "gemm_band");

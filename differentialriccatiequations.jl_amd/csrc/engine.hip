@@ -1535,6 +1535,13 @@ struct DenseXState {
     Mat P1;       // E' X
     Mat Kt;       // K' = E' X B  (n x m)
     int hint = 0; // ADI iterations of the previous step
+    // pinned host landing zone: control block, tolerances and the SMW breakdown flag come back with ONE synchronisation per chunk
+    struct Landing { AdiState st; double tols[4]; int serr; };
+    Landing* land = nullptr;
+    DenseXState() { if (hipHostMalloc((void**)&land, sizeof(Landing), hipHostMallocDefault) != hipSuccess) land = nullptr; }
+    ~DenseXState() { if (land) (void)hipHostFree(land); }
+    DenseXState(const DenseXState&) = delete;
+    DenseXState& operator=(const DenseXState&) = delete;
 };
 // One Ros1 step on the dense state.  Returns false (state untouched) when the fast chain cannot take the step.
 static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperator& op_base, double tau, const AdiOptions& adi, FactorCache* cache,
@@ -1543,8 +1550,17 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
     GaleOperator op = op_base;
     op.Vt = sx.Kt;
+    DRE_REQUIRE(sx.land != nullptr, "pinned host memory unavailable");
+    // SMW products and the folded stacks depend on K only: they are built on the side stream while the main stream assembles and
+    // compresses the residual; the ADI chain waits for them through an event
+    Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
+    if (wctx != ctx) {
+        DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
+        DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+    }
     CycleOps co;
-    if (!cycle_ops_prepare(ctx, op, adi.shifts.values, cache, co)) return false;
+    if (!cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co)) return false;
+    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side
     Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
     transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
@@ -1573,6 +1589,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         Mat R = sym_band_basis(ctx, sb);
         Mat Tm = sb.D;
         hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p);
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         Mat Gm(ctx, k * k, 2);
         DevArr<double> nws(ctx, 16);
@@ -1625,8 +1642,12 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 a.it_prev2 = g;
                 adi_fast_iter(ctx, a);
             }
-            DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipMemcpyAsync(&sx.land->st, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipMemcpyAsync(sx.land->tols, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (m) DRE_HIP(hipMemcpyAsync(&sx.land->serr, co.serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            else sx.land->serr = 0;
             DRE_HIP(hipStreamSynchronize(ctx->stream));
+            h = sx.land->st;
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
             for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[base_it + j]); ar.norm_iters.push_back(base_it + j); }
             iters_host = base_it + acc_it;
@@ -1638,12 +1659,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         }
         acc_total = iters_host;
         for (auto& f : co.fe) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
-        if (m) {
-            int herr = 0;
-            DRE_HIP(hipMemcpyAsync(&herr, co.serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            DRE_HIP(hipStreamSynchronize(ctx->stream));
-            if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
-        }
+        if (sx.land->serr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
         // X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated, one GEMM)
         if (acc_total > 0) {
             Wall = Mat(ctx, n, k * acc_total);
@@ -1659,14 +1675,11 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         }
     } else {
         // zero residual: read the tolerances back for the record
+        DRE_HIP(hipMemcpyAsync(sx.land->tols, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
     }
-    {
-        double ht[4];
-        DRE_HIP(hipMemcpyAsync(ht, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
-        ar.abstol = ht[0];
-    }
+    ar.abstol = sx.land->tols[0];
     ar.iters = acc_total;
     ar.initial_norm = k > 0 ? h.norms[0] : 0.0;
     ar.res_norm = k > 0 ? (acc_total > 0 ? h.res_norm : h.norms[0]) : 0.0;
@@ -1725,7 +1738,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     // main stream does the residual compression and the ADI iteration of step i; its result replaces the uncompressed summands at the
     // end of step i:  X_i = compress(X_{i-1}) + increments_i.  A single latency-bound solve leaves most of the chip idle.
     const bool xside = xblocks && xside_env;
-    if (xside && !ctx->side) {
+    if (xside_env && !ctx->side) {
         auto sc = std::make_unique<Ctx>();
         sc->device = ctx->device; sc->num_cus = ctx->num_cus;
         DRE_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
@@ -1735,7 +1748,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         ctx->side = std::move(sc);
     }
     Ctx* const side = ctx->side.get();
-    if (xside) {
+    if (side) {
         side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
         side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
         side->compress_factor_min_cols = ctx->compress_factor_min_cols;
