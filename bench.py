@@ -23,6 +23,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
+# kernel-class tag of the library's timers -> symbol prefix in the rocprofv3 outputs (profiles/pmc_traffic_r02_n<n>.json)
+KERNEL_SYMBOL = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm",
+                 "gemm_gram": "k_gemm", "gemm_dinv": "k_gemm", "dense_step": "k_dense_step", "band_w": "k_band_w", "mf_solve_real": "k_mf_",
+                 "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
+                 "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_", "adi_fast_iter": "k_adi_fast",
+                 "adi_fast_flush": "k_adi_fast", "band_z": "k_band_z", "band_upd": "k_band_upd", "adi_eff_stack": "k_eff_stack",
+                 "gemm_xupdate": "k_gemm"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -35,12 +44,32 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (fresh child processes under
+    torch.distributed.run, BEFORE anything in this process touches the GPU) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without torchrun)")
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -71,6 +100,8 @@ def main():
     nt = args.nsteps + 1
     Kdev = torch.empty((nt, n, m), dtype=torch.float64, device="cuda")       # nt blocks of m x n column-major
 
+    width = {"kw": 0.0}
+
     def one_solve(gather=True):
         r = C.c_void_p()
         ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, tf, dt, 1, 0, C.byref(opt), C.byref(r)))
@@ -79,10 +110,13 @@ def main():
         ctx.chk(lib.dre_gdre_result_K_device(ctx.ptr, r, C.c_void_p(Kdev.data_ptr())))
         ngale = ii[4]
         nconv = 0
+        kw = 0.0                      # sum over Lyapunov solves of iterations x residual width (for the whole-solve byte count)
         for j in range(ngale):
             gi = (C.c_int64 * 4)(); gd = (C.c_double * 2)()
             lib.dre_gdre_result_gale(r, j, gi, gd)
             nconv += int(gi[1])
+            kw += float(gi[0]) * float(gi[3])
+        width["kw"] = kw
         lib.dre_gdre_result_free(r)
         if world > 1 and gather:
             gather_trajectories(Kdev, world)     # RCCL over xGMI: the K(t) feedback trajectories of all replicas
@@ -116,6 +150,7 @@ def main():
         ctx.prof_enable(False)
         roof = None
         if stats:
+            # dominant kernel class over BOTH streams of the context (dre_prof_* merges the side context)
             name, s = max(stats.items(), key=lambda kv: kv[1]["ms"])
             total_ms = sum(v["ms"] for v in stats.values())
             avg_s = s["ms"] * 1e-3 / max(s["launches"], 1)
@@ -125,23 +160,33 @@ def main():
             else:
                 ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
                 roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
+            roof["algorithmic_bytes_per_launch"] = s["bytes"] / max(s["launches"], 1)
+            roof["algorithmic_flops_per_launch"] = s["flops"] / max(s["launches"], 1)
             try:
-                pmc_file = {371: "pmc_traffic_r01.json", 5177: "pmc_traffic_r01_n5177.json", 20209: "pmc_traffic_r01_n20209.json"}.get(n, "pmc_traffic_r01.json")
+                pmc_file = f"pmc_traffic_r02_n{n}.json"
                 pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-                sym = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm",
-                       "gemm_gram": "k_gemm", "gemm_dinv": "k_gemm", "dense_step": "k_dense_step", "band_w": "k_band_w", "mf_solve_real": "k_mf_",
-                       "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
-                       "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_"}.get(name)
+                sym = KERNEL_SYMBOL.get(name)
                 hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
-                if hits and n in (371, 5177, 20209):
+                if hits:
                     tot_l = sum(h["launches"] for h in hits)
-                    roof["traffic"] = sum(h["hbm_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
-                    roof["traffic_source"] = f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated)"
+                    roof["traffic"] = sum(h["fabric_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
+                    roof["traffic_source"] = (f"profiles/{pmc_file}: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE in separate passes; these are L2-fabric "
+                                              "bytes, Infinity-Cache hits included (the working set of this size is MALL resident), not pure HBM bytes")
             except Exception:
                 pass
             roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
-                        measured_on="one extra profiled solve after the timed region (HIP events on the library stream)")
+                        measured_on="one extra profiled solve after the timed region (HIP events on the library's streams, main + side context merged)")
             roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+            # whole solve against the HBM roofline: SURVEY.md §8(d) B_iter per ADI iteration, summed with the measured residual widths
+            pinfo = pencil.info()
+            z, nnzF = float(pinfo["nnz"]), float(pinfo["factor_nnz"])
+            its_solve = total_iters / (args.steps * world)
+            kavg = width["kw"] / max(its_solve, 1.0)
+            b_iter = 24.0 * z + 8.0 * n + 48.0 * n * kavg + 24.0 * n * m + 24.0 * nnzF + 32.0 * n * (kavg + m)
+            wall = elapsed / args.steps
+            ws = b_iter * its_solve / wall / 1e9
+            roof["whole_solve"] = dict(bytes_per_iteration=b_iter, avg_residual_width=kavg, achieved=ws, unit="GB/s", peak=8000.0, frac=ws / 8000.0,
+                                       note="SURVEY.md §8(d) B_iter (algorithmic bytes of one real-shift ADI iteration) x ADI iterations / measured wall-clock of one solve")
         # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample.
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
         # so a two-step probe picks the fastest of a few thread counts and the sample runs with that one.

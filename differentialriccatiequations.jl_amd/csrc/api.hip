@@ -10,7 +10,7 @@
 
 using namespace dre;
 
-struct dre_ctx { Ctx c; };
+struct dre_ctx { Ctx c; std::map<std::string, KernelStat> merged; };
 struct dre_dense { Mat m; };
 struct dre_pencil {
     std::unique_ptr<Pencil> p;
@@ -131,18 +131,39 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
     });
 }
+// Both contexts of a library context are timed (the side context carries the work that runs beside the main stream): enable/reset act on
+// both, count/get see the per-class sums.
+static void prof_collect_merge(dre_ctx* ctx) {
+    ctx->c.timer->collect(&ctx->c);
+    ctx->merged = ctx->c.timer->stats;
+    if (ctx->c.side && ctx->c.side->timer) {
+        ctx->c.side->timer->collect(ctx->c.side.get());
+        for (auto& kv : ctx->c.side->timer->stats) {
+            auto& d = ctx->merged[kv.first];
+            d.ms += kv.second.ms; d.launches += kv.second.launches; d.bytes += kv.second.bytes; d.flops += kv.second.flops;
+        }
+    }
+}
 int dre_prof_enable(dre_ctx* ctx, int on) {
-    return guarded(ctx, [&] { ctx->c.timer->collect(&ctx->c); ctx->c.timer->enabled = on != 0; });
+    return guarded(ctx, [&] {
+        ctx->c.timer->collect(&ctx->c); ctx->c.timer->enabled = on != 0;
+        ctx->c.prof_side = on != 0;
+        if (ctx->c.side && ctx->c.side->timer) { ctx->c.side->timer->collect(ctx->c.side.get()); ctx->c.side->timer->enabled = on != 0; }
+    });
 }
 int dre_prof_reset(dre_ctx* ctx) {
-    return guarded(ctx, [&] { ctx->c.timer->collect(&ctx->c); ctx->c.timer->stats.clear(); });
+    return guarded(ctx, [&] {
+        ctx->c.timer->collect(&ctx->c); ctx->c.timer->stats.clear();
+        if (ctx->c.side && ctx->c.side->timer) { ctx->c.side->timer->collect(ctx->c.side.get()); ctx->c.side->timer->stats.clear(); }
+        ctx->merged.clear();
+    });
 }
 int dre_prof_count(dre_ctx* ctx, int* n) {
-    return guarded(ctx, [&] { ctx->c.timer->collect(&ctx->c); *n = (int)ctx->c.timer->stats.size(); });
+    return guarded(ctx, [&] { prof_collect_merge(ctx); *n = (int)ctx->merged.size(); });
 }
 int dre_prof_get(dre_ctx* ctx, int i, char* name, int name_len, double* ms, int64_t* launches, double* bytes, double* flops) {
     return guarded(ctx, [&] {
-        auto& st = ctx->c.timer->stats;
+        auto& st = ctx->merged;
         DRE_REQUIRE(i >= 0 && i < (int)st.size(), "dre_prof_get: index out of range");
         auto it = st.begin();
         std::advance(it, i);

@@ -137,6 +137,7 @@ struct Ctx {
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
     bool attr_adi_fast = false;
+    bool prof_side = false;     // timing was switched on before the side context existed: it is created with its timer enabled
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

@@ -95,8 +95,10 @@ struct AdiFastArgs {
     double* nws;                // 8 partial sums + a ticket word (zero-initialised once per solve): meeting point of the norm workgroups
     int it_prev2;               // shifts consumed after the iteration G_prev2 belongs to
     int do_strips;              // 0: flush launch (riders only)
+    int chain_timed;            // 1: the caller brackets the whole chain with one TimedScope (adi_fast_chain_cost)
 };
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
+void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops);     // algorithmic bytes / flops of one launch
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 
 // --- blocked Householder QR (compact WY) ----------------------------------------------------

@@ -1612,6 +1612,10 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
+            a.chain_timed = 1; a.do_strips = 1; a.G_prev = Gm.p;
+            double by1 = 0.0, fl1 = 0.0;
+            adi_fast_cost(a, &by1, &fl1);
+            auto chain_ts = std::make_unique<TimedScope>(ctx, "adi_fast_iter", by1 * nit, fl1 * nit, nit + 2);   // the two flush launches ride along (riders only)
             for (int j = 1; j <= nit; ++j) {
                 const std::complex<double> mu = adi.shifts.values[cyc % adi.shifts.values.size()];
                 a.Apack = co.pack[cyc % co.pack.size()];
@@ -1642,6 +1646,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 a.it_prev2 = g;
                 adi_fast_iter(ctx, a);
             }
+            chain_ts.reset();
             DRE_HIP(hipMemcpyAsync(&sx.land->st, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
             DRE_HIP(hipMemcpyAsync(sx.land->tols, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             if (m) DRE_HIP(hipMemcpyAsync(&sx.land->serr, co.serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1745,6 +1750,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
         DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
         sc->timer = std::make_unique<KernelTimer>();
+        sc->timer->enabled = ctx->prof_side;
         ctx->side = std::move(sc);
     }
     Ctx* const side = ctx->side.get();

@@ -13,7 +13,7 @@ struct KernelStat {
 };
 
 struct KernelTimer {
-    struct Pending { std::string name; hipEvent_t a, b; double bytes, flops; };
+    struct Pending { std::string name; hipEvent_t a, b; double bytes, flops; long count; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
     std::map<std::string, KernelStat> stats;
@@ -30,7 +30,7 @@ struct KernelTimer {
             float ms = 0.f;
             DRE_HIP(hipEventElapsedTime(&ms, p.a, p.b));
             auto& s = stats[p.name];
-            s.ms += ms; s.launches += 1; s.bytes += p.bytes; s.flops += p.flops;
+            s.ms += ms; s.launches += p.count; s.bytes += p.bytes; s.flops += p.flops;
             free_events.push_back(p.a); free_events.push_back(p.b);
         }
         pending.clear();
@@ -43,9 +43,11 @@ struct KernelTimer {
 
 // RAII scope: records an event pair around whatever is launched inside when timing is enabled.
 struct TimedScope {
-    Ctx* ctx; bool on; hipEvent_t a{}, b{}; const char* name; double bytes, flops;
-    TimedScope(Ctx* c, const char* nm, double by = 0, double fl = 0)
-        : ctx(c), on(c->timer && c->timer->enabled), name(nm), bytes(by), flops(fl) {
+    // count > 1: the scope brackets a back-to-back chain of `count` launches of one class (one event pair for the whole chain: the
+    // per-launch average then includes the launch boundaries and is not inflated by two event packets per short kernel)
+    Ctx* ctx; bool on; hipEvent_t a{}, b{}; const char* name; double bytes, flops; long count;
+    TimedScope(Ctx* c, const char* nm, double by = 0, double fl = 0, long cnt = 1)
+        : ctx(c), on(c->timer && c->timer->enabled), name(nm), bytes(by), flops(fl), count(cnt) {
         if (on) {
             a = ctx->timer->get_event(); b = ctx->timer->get_event();
             (void)hipEventRecord(a, ctx->stream);
@@ -54,7 +56,7 @@ struct TimedScope {
     ~TimedScope() {
         if (on) {
             (void)hipEventRecord(b, ctx->stream);
-            ctx->timer->pending.push_back({name, a, b, bytes, flops});
+            ctx->timer->pending.push_back({name, a, b, bytes, flops, count});
             if (ctx->timer->pending.size() > 4096) {
                 try { ctx->timer->collect(ctx); } catch (...) {}
             }

@@ -28,39 +28,34 @@ def test_rail_jl_parity_configuration_default_adi(ctx, rail371, order):
     On the SteelProfile surrogate the oracle's own low-rank path does NOT meet that criterion with default settings: from the second step
     on the warm-started residual is ~110 columns wide, one Projection batch (up to 2k Ritz values, consumed most-negative first) outlasts
     maxiters and the Lyapunov solves stop unconverged (the reference would warn "ADI did not converge" as well).
-    What is asserted: the HIP path behaves like the oracle — the first (converging) step reproduces the oracle's K to the cuda.jl tolerance,
-    the same Lyapunov solves hit maxiters (same warning bit), and the distance to the dense solution is of the oracle's size."""
+    What is asserted: in the literal mode (eigen-based truncation at every compression = the reference's arithmetic, so the residual widths
+    and with them the self-generated shifts are the oracle's) the HIP path reproduces the oracle's ADI iteration count of every time step,
+    the same Lyapunov solves end with the "did not converge" warning bit, the converging first step reproduces the oracle's K to the
+    cuda.jl tolerance, and the distance to the dense solution is of the oracle's size.  The engine's default (Krylov-truncated) compression
+    is held to the dense-distance criterion only (its residual widths differ, hence every shift of an unconverged solve differs)."""
     d, L, Dm = rail371
     g = np.load(os.path.join(GOLDEN, "rail_default_371.npz"))
     name = f"ros{order}"
     prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
-    alg = D.Ros1() if order == 1 else D.Ros2()
-    # Ros2: the engine's default (Krylov-truncated) compression leaves the full-rank stage-1 right-hand side uncompressed, which changes
-    # the width of the residual and with it every self-generated shift of an unconverged solve; the literal mode (eigen-based truncation
-    # at every compression, lowrank_ros2.jl:58) is the one comparable with the oracle
-    if order == 2:
-        alg = D.Ros2(D.ADI(compress_exact=True))
-    sol, st = _quiet(D.solve_gdre, prob, alg, dt=-20.0, return_stats=True)
     Kd = g[f"{name}_K_dense_end"]
     tol = np.linalg.norm(Kd) * 371 * EPS * 100
-    err_hip = np.linalg.norm(Kd - sol.K[-1])
     err_orc = float(g[f"{name}_err_vs_dense"])
-    assert err_hip < max(tol, 10.0 * err_orc), (err_hip, err_orc, tol)
+    ref_its = [int(x) for x in g[f"{name}_iters"]]
+    Alg = D.Ros1 if order == 1 else D.Ros2
+    sol, st = _quiet(D.solve_gdre, prob, Alg(D.ADI(compress_exact=True)), dt=-20.0, return_stats=True)
+    assert np.linalg.norm(Kd - sol.K[-1]) < max(tol, 10.0 * err_orc)
     its = [x["iters"] for x in st["gales"]]
+    assert len(its) == 5 * order
     per_step = [sum(its[i * order:(i + 1) * order]) for i in range(5)]
-    ref_its = list(g[f"{name}_iters"])
+    # (Projection shifts are Ritz values of a projected pencil: the counts can move by a shift or two with the host LAPACK build)
+    assert all(abs(a - b) <= 2 for a, b in zip(per_step, ref_its)), (per_step, ref_its)
+    assert st["gales"][0]["converged"] and D.delta(sol.K[1], g[f"{name}_K_lr"][1]) < 1e-7
+    for j in range(1, 5):
+        unconverged = any(bool(x["warnings"] & 1) for x in st["gales"][j * order:(j + 1) * order])
+        assert unconverged == (ref_its[j] >= 100 * order - 10)          # adi.jl:125-126
     if order == 1:
-        # step 1 converges in both (same self-generated shifts up to roundoff in the Ritz values), the later ones stop at maxiters
-        # (Projection shifts are Ritz values of a projected pencil: the count moves with the last bits of the host LAPACK/BLAS build)
-        assert st["gales"][0]["converged"] and abs(per_step[0] - ref_its[0]) <= max(4, ref_its[0] // 4)
-        assert D.delta(sol.K[1], g["ros1_K_lr"][1]) < 1e-7
-        for j in range(1, 5):
-            assert (per_step[j] >= 100) == (ref_its[j] >= 100)
-            assert bool(st["gales"][j]["warnings"] & 1) == (ref_its[j] >= 100)
-    else:
-        assert len(its) == 10
-        for j in range(5):
-            assert abs(per_step[j] - ref_its[j]) <= max(12, ref_its[j] // 4), (per_step, ref_its)
+        sol, st = _quiet(D.solve_gdre, prob, D.Ros1(), dt=-20.0, return_stats=True)
+        assert st["gales"][0]["converged"] and np.linalg.norm(Kd - sol.K[-1]) < max(tol, 10.0 * err_orc)
 
 
 def test_rail_jl_parity_with_converging_shifts(ctx, rail371):
