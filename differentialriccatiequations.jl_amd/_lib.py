@@ -91,6 +91,13 @@ PROTOTYPES = {
     "dre_ldlt_destructure": (C.c_int, [_vp, _vp, _pd, _pd, C.c_int, _pd, C.c_int]),
     "dre_adi_default_options": (C.c_int, [C.POINTER(AdiOptionsC)]),
     "dre_gale_solve": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
+    "dre_adi_init": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
+    "dre_adi_step": (C.c_int, [_vp, _vp]),
+    "dre_adi_solve": (C.c_int, [_vp, _vp]),
+    "dre_adi_isdone": (C.c_int, [_vp, _pint]),
+    "dre_adi_state": (C.c_int, [_vp, _pi64, _pd, _pd]),
+    "dre_adi_finish": (C.c_int, [_vp, _vp, _pvp]),
+    "dre_adi_free": (C.c_int, [_vp]),
     "dre_heuristic_ritz": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, C.c_int, C.c_int, _pd, _pd, _pd, _pd]),
     "dre_gale_residual": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _pvp]),
     "dre_adi_result_info": (C.c_int, [_vp, _pi64, _pd]),

@@ -552,6 +552,107 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
     return (X, info) if return_info else X
 
 
+class ADISolver:
+    """The reference's `ADICache` protocol (src/lyapunov/adi.jl:5-21,91-141) on the device: `init(prob, alg)` -> solver, `step_(solver)` (one
+    shift or one conjugate pair), `isdone(solver)`, `solve_(solver)`; iterating the solver steps it (`Base.iterate`, adi.jl:91-95).
+    `X` materialises the current result (final compression included once the solve is done, adi.jl:78-80)."""
+
+    def __init__(self, prob, alg, initial_guess=None, observer=None, ctx=None):
+        self.ctx = ctx or dev.default_context()
+        self.prob, self.alg, self.observer = prob, alg, observer
+        A0, lr = _split_operator(prob.E, prob.A)
+        self.pencil = _pencil_for(prob.E, A0, self.ctx)
+        opt, self._keep = _adi_options(alg, self.pencil, lr)
+        self._Cd = prob.C._to_device(self.ctx, self.pencil)
+        self._X0d = initial_guess._to_device(self.ctx, self.pencil) if initial_guess is not None else None
+        self._U = self._Vt = None
+        alpha = 1.0
+        if lr is not None:
+            alpha, Uh, Vh = lr
+            self._U, self._Vt = self.ctx.upload(Uh), self.ctx.upload(np.asarray(Vh).T)
+        self._ptr = C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_adi_init(self.ctx.ptr, self.pencil.ptr, 1.0, 0.0, float(alpha), self._U.ptr if self._U else None,
+                                               self._Vt.ptr if self._Vt else None, self._Cd.ptr, self._X0d.ptr if self._X0d else None,
+                                               C.byref(opt), C.byref(self._ptr)))
+        self._result = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ptr", None):
+                self.ctx.lib.dre_adi_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+    def isdone(self) -> bool:
+        d = C.c_int()
+        self.ctx.lib.dre_adi_isdone(self._ptr, C.byref(d))
+        return bool(d.value)
+
+    def state(self):
+        it, rn, at = C.c_int64(), C.c_double(), C.c_double()
+        self.ctx.lib.dre_adi_state(self._ptr, C.byref(it), C.byref(rn), C.byref(at))
+        return dict(iters=it.value, res_norm=rn.value, abstol=at.value)
+
+    def step(self):
+        self.ctx.chk(self.ctx.lib.dre_adi_step(self.ctx.ptr, self._ptr))
+        return self
+
+    def solve(self):
+        self.ctx.chk(self.ctx.lib.dre_adi_solve(self.ctx.ptr, self._ptr))
+        return self.X
+
+    def __iter__(self):
+        while not self.isdone():
+            yield self.step()
+
+    def _finish(self):
+        if self._result is None:
+            r = C.c_void_p()
+            self.ctx.chk(self.ctx.lib.dre_adi_finish(self.ctx.ptr, self._ptr, C.byref(r)))
+            try:
+                info = _adi_result_info(self.ctx, r)
+                xp = C.c_void_p()
+                self.ctx.lib.dre_adi_result_take_x(r, C.byref(xp))
+                X = LDLt([], [], [], _handle=dev.DeviceLDLt(self.ctx, xp, self.pencil))
+            finally:
+                self.ctx.lib.dre_adi_result_free(r)
+            self._result = (X, info)
+            _replay_gale(self.observer, self.prob, self.alg, info)
+            _call(self.observer, "observe_gale_done", info["iters"], X, None, info["res_norm"])
+        return self._result
+
+    @property
+    def X(self) -> LDLt:
+        if not self.isdone():
+            raise RuntimeError("the iterate is device resident while the solve is running: finish it first (solve_ / step_ until isdone)")
+        return self._finish()[0]
+
+    @property
+    def info(self):
+        return self._finish()[1]
+
+
+def init(prob, alg, initial_guess=None, observer=None, ctx=None) -> ADISolver:
+    """CommonSolve.init(::GALEProblem{<:LDLᵀ}, ::ADI; initial_guess, observer)  (adi.jl:29-69)"""
+    return ADISolver(prob, alg, initial_guess, observer, ctx)
+
+
+def step_(solver: ADISolver) -> ADISolver:
+    """step!(cache)  (adi.jl:97-128)"""
+    return solver.step()
+
+
+def isdone(solver: ADISolver) -> bool:
+    """isdone(cache)  (adi.jl:130-141)"""
+    return solver.isdone()
+
+
+def solve_(solver: ADISolver) -> LDLt:
+    """solve!(cache)  (adi.jl:71-89)"""
+    return solver.solve()
+
+
 def residual(prob, X: LDLt, ctx=None) -> LDLt:
     """residual(::GALEProblem{<:LDLᵀ}, ::LDLᵀ)  (lyapunov/residual.jl:3-31);  residual(::GAREProblem, ::LDLᵀ)  (riccati/residual.jl:5-52)"""
     if isinstance(prob, GAREProblem):

@@ -2,6 +2,7 @@
 #include "../../include/dre_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 
 #include "engine.hpp"
@@ -294,7 +295,7 @@ int dre_spmm(dre_ctx* ctx, const dre_pencil* p, int which, double alpha, const d
         DRE_REQUIRE(P.has_device, "pencil was created host-only");
         Mat Xs = to_solver_order(&ctx->c, p, X->m);
         Mat Ys = to_solver_order(&ctx->c, p, Y->m);
-        spmm(&ctx->c, P.n, P.ptr.p, P.idx.p, which == 0 ? P.valEt.p : P.valAt.p, Xs, Ys, alpha, beta);
+        spmm(&ctx->c, P, which == 0 ? P.valEt.p : P.valAt.p, Xs, Ys, alpha, beta);
         Mat Yu = to_user_order(&ctx->c, p, Ys);
         copy_mat(&ctx->c, Yu, Y->m);
     });
@@ -493,7 +494,7 @@ static AdiOptions convert_options(const dre_adi_options* o) {
     }
     return a;
 }
-static uint64_t g_tag_counter = 1ull << 40;
+static std::atomic<uint64_t> g_tag_counter{1ull << 40};     // operator identities for the factor caches (unique across threads)
 static GaleOperator make_operator(Ctx* c, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt) {
     const Pencil& P = *p->p;
     DRE_REQUIRE(P.has_device, "pencil was created host-only");
@@ -523,6 +524,47 @@ int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, doub
         *out = r;
     });
 }
+// ---- stepwise protocol: init / step! / isdone / solve! on the solver object (src/lyapunov/adi.jl:29-141) -------------------------
+struct dre_adi_solver {
+    std::shared_ptr<AdiRun> run;
+    const dre_pencil* pen = nullptr;
+};
+int dre_adi_init(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                 dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_solver** out) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        DRE_REQUIRE(C->pen == p && (!X0 || X0->pen == p), "LDLt operands must be created with the same pencil");
+        GaleOperator op = make_operator(c, p, cA, cE, lr_alpha, U, Vt);
+        AdiOptions ao = convert_options(opt);
+        auto* s = new dre_adi_solver();
+        s->pen = p;
+        try { s->run = adi_begin(c, op, *C->x, X0 ? X0->x : nullptr, ao, nullptr); } catch (...) { delete s; throw; }
+        *out = s;
+    });
+}
+int dre_adi_step(dre_ctx* ctx, dre_adi_solver* s) { return guarded(ctx, [&] { adi_advance(*s->run, 1); }); }
+int dre_adi_solve(dre_ctx* ctx, dre_adi_solver* s) {
+    return guarded(ctx, [&] { while (!adi_isdone(*s->run)) adi_advance(*s->run, 1 << 30); });
+}
+int dre_adi_isdone(const dre_adi_solver* s, int* done) { *done = adi_isdone(*s->run) ? 1 : 0; return DRE_OK; }
+int dre_adi_state(const dre_adi_solver* s, int64_t* iters, double* res_norm, double* abstol) {
+    int it = 0; double rn = 0, at = 0;
+    adi_peek(*s->run, &it, &rn, &at);
+    if (iters) *iters = it;
+    if (res_norm) *res_norm = rn;
+    if (abstol) *abstol = at;
+    return DRE_OK;
+}
+int dre_adi_finish(dre_ctx* ctx, dre_adi_solver* s, dre_adi_result** out) {
+    return guarded(ctx, [&] {
+        auto* r = new dre_adi_result();
+        r->pen = s->pen;
+        try { r->r = adi_finish(*s->run); } catch (...) { delete r; throw; }
+        *out = r;
+    });
+}
+int dre_adi_free(dre_adi_solver* s) { delete s; return DRE_OK; }
+
 int dre_heuristic_ritz(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
                        int kplus, int kminus, double* plus_re, double* plus_im, double* minus_re, double* minus_im) {
     return guarded(ctx, [&] {

@@ -137,6 +137,11 @@ struct Ctx {
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
     bool attr_adi_fast = false;
+    // kernels whose dynamic-LDS limit was raised for this context's device (hipFuncSetAttribute is per device, so the record is per
+    // context, not per process)
+    std::unordered_map<const void*, int> lds_attr_done;
+    // compression bookkeeping of this context (diagnostics only)
+    struct CompressCounters { long calls = 0, cols_in = 0, order = 0, tri_steps = 0, rank_out = 0; } cstats;
     bool prof_side = false;     // timing was switched on before the side context existed: it is created with its timer enabled
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
@@ -184,5 +189,13 @@ struct Mat {
 };
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// raise the dynamic shared memory limit of a kernel once per context (device)
+inline void lds_attr(Ctx* ctx, const void* func, int bytes) {
+    auto it = ctx->lds_attr_done.find(func);
+    if (it != ctx->lds_attr_done.end() && it->second >= bytes) return;
+    DRE_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->lds_attr_done[func] = bytes;
+}
 
 }  // namespace dre

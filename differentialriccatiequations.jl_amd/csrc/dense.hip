@@ -861,8 +861,7 @@ static void launch_gram_norm(Ctx* ctx, int k, int nblk, const double* gpart, con
     const int kp32 = (k + 31) & ~31;
     TimedScope ts(ctx, "ldlt_norm", 8.0 * nblk * k * k, 4.0 * (double)k * k * k);
     const size_t shm = 2 * (size_t)kp32 * kp32 * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    lds_attr(ctx, (const void*)k_gram_norm, 150 * 1024);
     hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, nblk, gpart, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
 }
 void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend) {
@@ -881,12 +880,7 @@ void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpa
     const bool ride = pend && pend->valid;
     const size_t step_lds = ((size_t)64 * (kp16 + 1) + (size_t)m * k + 2 * (size_t)64 * m) * sizeof(double);
     const size_t lds = ride ? std::max(step_lds, 2 * (size_t)kp32 * kp32 * sizeof(double)) : step_lds;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DRE_HIP(hipFuncSetAttribute((const void*)k_dense_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        DRE_HIP(hipFuncSetAttribute((const void*)k_dense_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    lds_attr(ctx, (const void*)k_dense_step<true>, 150 * 1024); lds_attr(ctx, (const void*)k_dense_step<false>, 150 * 1024);
     {
         TimedScope ts(ctx, "dense_step", 8.0 * (2.0 * n * k * splits + 3.0 * n * k + 2.0 * n * m + (double)nblk * k * k), 4.0 * n * k * m + 2.0 * n * (double)k * k);
         const double* gprev = ride ? (const double*)pend->gpart->p : nullptr;
@@ -1041,9 +1035,10 @@ __device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, cons
         }
 #pragma unroll
         for (int u = 0; u < ADI_FAST_KB; ++u) {
+            // lane & 15 is the ROW of the A fragment but the COLUMN of the B fragment: the column mask applies to B only
             const int row = 4 * (tb + u) + lk;
-            const bool ok = (tb + u < t1) && colok && row < n;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
+            const bool kok = (tb + u < t1) && row < n;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? av[u] : 0.0, (kok && colok) ? bv[u] : 0.0, acc, 0, 0, 0);
         }
     }
     return acc;
@@ -1213,8 +1208,7 @@ void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double
     TimedScope ts(ctx, "ldlt_norm", 8.0 * splits * k * k, 4.0 * (double)k * k * k);
     const int kp = (k + 31) & ~31;
     const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_gram_norm, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    lds_attr(ctx, (const void*)k_gram_norm, 150 * 1024);
     hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, splits, (const double*)part->p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
 }
 
@@ -1898,12 +1892,7 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     Mat Vloc(ctx, rows, jb), Rstack(ctx, rowsR, jb), Qt(ctx, rowsR, jb);
     DevArr<double> Tloc(ctx, (size_t)plan.P * QR_NB * QR_NB), Rfin(ctx, QR_NB * QR_NB), hr(ctx, 4 * QR_NB * QR_NB);
     TimedScope ts(ctx, "qr_panel_tsqr", 8.0 * rows * jb * 8.0, 2.0 * rows * jb * jb * 3.0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_local<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
-        DRE_HIP(hipFuncSetAttribute((const void*)k_tsqr_top, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024));
-        attr_set = true;
-    }
+    lds_attr(ctx, (const void*)k_tsqr_local<false>, 132 * 1024); lds_attr(ctx, (const void*)k_tsqr_top, 132 * 1024);
     const size_t shm1 = (size_t)((plan.base + 1) | 1) * jb * sizeof(double);
     if (big) hipLaunchKernelGGL((k_tsqr_local<true>), dim3(plan.P), dim3(1024), (size_t)2 * 2048 * sizeof(double), ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
     else hipLaunchKernelGGL((k_tsqr_local<false>), dim3(plan.P), dim3(1024), shm1, ctx->stream, A, lda, jb, plan, Vloc.p, Vloc.ld, Tloc.p, Rstack.p, Rstack.ld, st);
@@ -1922,8 +1911,7 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
     if (rows <= QR_LDS_ROWS) {
         TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_qr_panel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); attr_set = true; }
+        lds_attr(ctx, (const void*)k_qr_panel<true>, 132 * 1024);
         hipLaunchKernelGGL((k_qr_panel<true>), dim3(1), dim3(1024), shm, ctx->stream, A, lda, m, j0, jb, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
     } else if (rows <= 1536) {
         {
@@ -2296,8 +2284,7 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol) {
         TimedScope ts(ctx, "sym_tridiag", 0, 0);
         size_t shm = 2 * (size_t)q * sizeof(double);
         if (shm > 60 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)); attr_set = true; }
+            lds_attr(ctx, (const void*)k_tridiag, 140 * 1024);
         }
         hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, abs_tol, info.p);
     }
@@ -2319,8 +2306,7 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol) {
         TimedScope ts(ctx, "sym_tql", 16.0 * j * j, 6.0 * 1.7 * (double)j * j * j);
         if (j <= 128) {
             size_t shm = (6 * (size_t)j + (size_t)j * j) * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_tql<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+            lds_attr(ctx, (const void*)k_tql<true>, 150 * 1024);
             hipLaunchKernelGGL((k_tql<true>), dim3(1), dim3(256), shm, ctx->stream, j, dw.p, ew.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
         } else {
             set_identity(ctx, out.Z, 1.0);
@@ -2762,8 +2748,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 TimedScope ts(ctx, "band_w", 8.0 * m * b * (zs + 5.0), 2.0 * m * b * b * 2.0);
                 if (m <= 540) {
                     const size_t shm = 2 * (size_t)(m | 1) * b * sizeof(double);
-                    static bool attr_set = false;
-                    if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_band_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+                    lds_attr(ctx, (const void*)k_band_w<true>, 150 * 1024);
                     hipLaunchKernelGGL((k_band_w<true>), dim3(1), dim3(1024), shm, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
                 } else {
                     hipLaunchKernelGGL((k_band_w<false>), dim3(1), dim3(1024), 0, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
@@ -3122,8 +3107,7 @@ static Mat sym_band_basis_core(Ctx* ctx, const SymBand& sb) {
         {
             TimedScope ts(ctx, "blocktri", 8.0 * (nr * (double)nr / 2 + 2.0 * nr * sb.J), (double)nr * nr * sb.J);
             const size_t shm = ((size_t)2 * nr + 48) * 17 * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set) { DRE_HIP(hipFuncSetAttribute((const void*)k_blocktri_apply, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr_set = true; }
+            lds_attr(ctx, (const void*)k_blocktri_apply, 80 * 1024);
             hipLaunchKernelGGL(k_blocktri_apply, dim3((sb.J + 15) / 16), dim3(256), shm, ctx->stream, nr, sb.J, G.p, G.ld, sb.T.p, sb.T.ld, sb.V.p, sb.V.ld, M.p, M.ld);
         }
         gemm(ctx, false, false, -1.0, Vall, M, 1.0, B, nullptr, "gemm_band");

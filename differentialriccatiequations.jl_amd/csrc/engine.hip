@@ -123,8 +123,6 @@ static void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD) {
     gemm_batched(ctx, descs, "gemm_compress");
 }
 
-static CompressStats g_cstats;
-CompressStats& compress_stats() { return g_cstats; }
 
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol) {
     const int n = X.n, c = X.rank();
@@ -154,7 +152,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         }
         copy_batched(ctx, cd);
         SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
-        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += n; g_cstats.tri_steps += sb.J; g_cstats.rank_out += sb.J;
+        ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += n; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
         if (sb.J == 0) { set_empty(); return; }
         if (sb.J >= c) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
         Mat Bq = sym_band_basis(ctx, sb);
@@ -195,7 +193,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     int r = 0;
     if (exact) {
         SymEig e = sym_eig(ctx, S, tolfac, true);
-        g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
+        ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += e.j;
         if (e.j == 0) { set_empty(); return; }
         double wmax = 0.0;
         for (double w : e.w) wmax = std::max(wmax, std::fabs(w));
@@ -205,7 +203,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
             if (std::fabs(e.w[i]) >= thr && wmax > 0.0) ids.push_back(i);
         std::sort(ids.begin(), ids.end(), [&](int a, int b) { return e.w[a] < e.w[b]; });
         r = (int)ids.size();
-        g_cstats.rank_out += r;
+        ctx->cstats.rank_out += r;
         if (r == 0) { set_empty(); return; }
         B = sym_eig_backtransform(ctx, e, ids);
         std::vector<double> hd((size_t)r * r, 0.0);
@@ -218,9 +216,9 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
             // small problems: unblocked reduction with per-column termination gives the exact truncation rank
             // (the blocked variant can only stop at multiples of the panel width)
             SymEig e = sym_eig(ctx, S, tolfac, false, abs_tol);
-            g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += e.j;
+            ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += e.j;
             r = e.j;
-            g_cstats.rank_out += r;
+            ctx->cstats.rank_out += r;
             if (r == 0) { set_empty(); return; }
             std::vector<int> ids(r);
             for (int i = 0; i < r; ++i) ids[i] = i;
@@ -228,9 +226,9 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
             Dnew = sym_tridiag_dense(ctx, e);
         } else {
             SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
-            g_cstats.calls++; g_cstats.cols_in += c; g_cstats.order += S.rows; g_cstats.tri_steps += sb.J;
+            ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += sb.J;
             r = sb.J;
-            g_cstats.rank_out += r;
+            ctx->cstats.rank_out += r;
             if (r == 0) { set_empty(); return; }
             B = sym_band_basis(ctx, sb);
             Dnew = sb.D;
@@ -540,7 +538,7 @@ struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
 static void apply_Ft(Ctx* ctx, const GaleOperator& op, const Mat& L, Mat& out) {
     // out = F' L = Fs' L + inv(alpha) Vt (U' L)      (LowRankUpdate.jl:51-54,82-85)
     const Pencil& P = *op.P;
-    spmm(ctx, P.n, P.ptr.p, P.idx.p, op.valFt.p, L, out, 1.0, 0.0);
+    spmm(ctx, P, op.valFt.p, L, out, 1.0, 0.0);
     if (op.has_lr && L.cols > 0) {
         Mat tmp(ctx, op.U.cols, L.cols);
         gemm(ctx, true, false, 1.0, op.U, L, 0.0, tmp);
@@ -598,7 +596,7 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         qr_apply_q(ctx, qr, Q, false);
         // restrictions: Q'EQ = (Q'E'Q)',  Q'FQ = (Q'F'Q)'
         Mat EQ(ctx, P.n, r), FQ(ctx, P.n, r), Et(ctx, r, r), Ft(ctx, r, r);
-        spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, Q, EQ, 1.0, 0.0);
+        spmm(ctx, P, P.valEt.p, Q, EQ, 1.0, 0.0);
         apply_Ft(ctx, *op, Q, FQ);
         gemm(ctx, true, false, 1.0, Q, EQ, 0.0, Et);
         gemm(ctx, true, false, 1.0, Q, FQ, 0.0, Ft);
@@ -681,7 +679,7 @@ static LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& 
     Mat Lall = have ? *warm_L : ((X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X));
     Mat EtL = have ? *warm_EtL : Mat(ctx, n, c);
     Mat FtL(ctx, n, c), Pm(ctx, n, c), Mm(ctx, n, c);
-    if (!have) spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Lall, EtL, 1.0, 0.0);
+    if (!have) spmm(ctx, P, P.valEt.p, Lall, EtL, 1.0, 0.0);
     apply_Ft(ctx, op, Lall, FtL);
     const bool fold = lead_blocks >= 0 && lead_blocks <= (int)C.blocks.size() && e_coeff != 0.0;
     if (fold) {      // C = lead blocks + e_coeff E'XE:  the last term joins F  (one third fewer columns in the compression below)
@@ -729,7 +727,7 @@ static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const
     const int nG = cb.L.cols, n0 = xb.L.cols, dim = nG + 2 * n0;
     Mat R(ctx, P.n, dim);
     { Mat d = R.colsview(0, nG); copy_mat(ctx, cb.L, d); }
-    { Mat d = R.colsview(nG, n0); spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, xb.L, d, 1.0, 0.0); }
+    { Mat d = R.colsview(nG, n0); spmm(ctx, P, P.valEt.p, xb.L, d, 1.0, 0.0); }
     { Mat d = R.colsview(nG + n0, n0); apply_Ft(ctx, op, xb.L, d); }
     Mat T(ctx, dim, dim);
     fill_mat(ctx, T, 0.0);
@@ -778,13 +776,61 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
 struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; BufP keep2; };
 std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOperator& op, int nshifts, int kplus, int kminus, int* warnings);
 
-AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
-                    FactorCache* cache) {
+// The solver object of one Lyapunov solve (the reference's ADICache, adi.jl:5-21): adi_begin = init (adi.jl:29-69), adi_advance = step!
+// / solve! (adi.jl:71-128; one call enqueues up to `budget` shifts speculatively and synchronises once), adi_finish = the tail of solve!
+// (final compression adi.jl:78-80, result).  adi_solve runs the three in sequence.
+struct StepRec { int iters_after; size_t nblocks; int nshifts; };
+struct AdiRun {
+    Ctx* ctx = nullptr;
+    GaleOperator op;
+    AdiOptions opt_in, opt;
+    FactorCache local;
+    FactorCache* cache = nullptr;
+    AdiResult res;
+    LDLtP X, resid;
+    Mat R, Tm;
+    double alpha_res = 1.0, abstol = 0.0, ctf = 4.0;
+    bool cex = false, tdiag = false;
+    int n = 0, k = 0, m = 0;
+    std::unique_ptr<ShiftOracle> oracle;
+    DevArr<AdiState> st;
+    AdiState h0;
+    std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
+    std::shared_ptr<LDLt> Xw;
+    int iters_host = 0, last_compression = 0, chunk_limit = 10;
+    std::vector<std::complex<double>> all_shifts;
+    bool finished = false, finalized = false;
+    std::vector<std::shared_ptr<FactorEntry<double>>> used_real;
+    std::vector<std::shared_ptr<FactorEntry<cplx>>> used_cplx;
+    DenseNormPending npend;
+    // fast chain
+    bool fast = false, fast_ready = false;
+    std::vector<std::shared_ptr<FactorEntry<double>>> fast_fe;
+    std::vector<double*> fast_pack;
+    std::vector<Mat> fast_keep;
+    Mat Gm;
+    DevArr<double> nws;
+    size_t cyc = 0;
+    // every factorisation is checked once per chunk, after the chunk's synchronisation (the breakdown flag is written by the
+    // factorisation kernels only); the handles are dropped then, so single-use factors are freed chunk by chunk
+    void check_used() {
+        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        used_real.clear(); used_cplx.clear();
+    }
+};
+
+std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
+                                  FactorCache* cache) {
+    auto runp = std::make_shared<AdiRun>();
+    AdiRun& run = *runp;
+    run.ctx = ctx; run.op = op_in; run.opt_in = opt_in;
+    const GaleOperator& op = run.op;
     const Pencil& P = *op.P;
     const int n = P.n;
-    FactorCache local;
-    if (!cache) cache = &local;
-    AdiResult res;
+    if (!cache) cache = &run.local;
+    run.cache = cache;
+    AdiResult& res = run.res;
     AdiOptions opt_h;                           // Cyclic(Heuristic(...)): the values are recomputed from (E, F) for this solve (adi.jl:54)
     const AdiOptions* optp = &opt_in;
     if (opt_in.shifts.kind == ShiftSpec::HEURISTIC) {
@@ -793,7 +839,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         opt_h.shifts.values = heuristic_shift_values(ctx, op, opt_in.shifts.h_nshifts, opt_in.shifts.h_kplus, opt_in.shifts.h_kminus, &res.warnings);
         optp = &opt_h;
     }
-    const AdiOptions& opt = *optp;
+    run.opt = *optp;
+    const AdiOptions& opt = run.opt;
     const double ctf = opt.compress_tolfac;
     const bool cex = opt.compress_exact;
     const bool keep_blocks = !cex && n <= xblocks_max_n() && C.blocks.size() > 1 && initial_guess && !opt.ignore_initial_guess && !initial_guess->iszero();
@@ -809,7 +856,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                                      opt.rhs_lead_blocks, opt.rhs_e_coeff);
     ldlt_destructure(ctx, *resid, ctf, cex);
     LBlock rb = resid->blocks[0];
-    Mat R = rb.L, Tm = rb.D;
+    Mat& R = run.R; Mat& Tm = run.Tm;
+    R = rb.L; Tm = rb.D;
     const double alpha_res = rb.alpha;
     const int k = R.cols;
     const bool tdiag = rb.diag;      // a numerically diagonal T that is not flagged takes the general (dense-T) kernels: same result
@@ -819,10 +867,13 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     res.residual = resid;
     res.X = X;
     res.res_norm = norm0;
-    DRE_REQUIRE(opt.maxiters < 500, "ADI: maxiters must be below 500");
-    if (norm0 <= abstol || k == 0) { res.converged = true; return res; }
+    DRE_REQUIRE(opt.maxiters < 500, "ADI: maxiters must be below 500 (dre_hip.h, DRE_ADI_MAX_ITERS)");
+    run.X = X; run.resid = resid; run.alpha_res = alpha_res; run.abstol = abstol; run.ctf = ctf; run.cex = cex; run.tdiag = tdiag;
+    run.n = n; run.k = k; run.m = op.has_lr ? op.U.cols : 0;
+    run.Xw = std::make_shared<LDLt>(*X);        // the iterate: never mutate the caller's initial guess (adi.jl:174 builds a new list)
+    if (norm0 <= abstol || k == 0) { res.converged = true; run.finished = true; return runp; }
 
-    std::unique_ptr<ShiftOracle> oracle;
+    std::unique_ptr<ShiftOracle>& oracle = run.oracle;
     if (opt.shifts.kind == ShiftSpec::CYCLIC) {
         DRE_REQUIRE(!opt.shifts.values.empty(), "Cyclic shifts: empty list");
         auto o = std::make_unique<CyclicOracle>();
@@ -836,15 +887,16 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     oracle->update(R, {});
 
     // device-resident control block
-    DevArr<AdiState> st(ctx, 1);
+    run.st = DevArr<AdiState>(ctx, 1);
+    DevArr<AdiState>& st = run.st;
     if (auto* po = dynamic_cast<ProjectionOracle*>(oracle.get())) po->st_dev = st.p;
-    AdiState h0;                     // stays alive until the function returns (source of an asynchronous upload)
+    AdiState& h0 = run.h0;           // stays alive with the solver object (source of an asynchronous upload)
     std::memset(&h0, 0, sizeof(h0));
     h0.maxiters = opt.maxiters; h0.abstol = abstol; h0.res_norm = norm0; h0.norms[0] = norm0;
     DRE_HIP(hipMemcpyAsync(st.p, &h0, sizeof(int) * 4 + sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
     const int m = op.has_lr ? op.U.cols : 0;
-    DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported");
-    std::map<std::pair<double, double>, SmwCacheEntry> smw_cache;
+    DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported (dre_hip.h, DRE_SMW_MAX_RANK)");
+    auto& smw_cache = run.smw_cache;
     int* const serr = &st.p->smw_singular;     // lives in the control block: comes back with every chunk synchronisation
     if (op.has_lr && opt.shifts.kind == ShiftSpec::CYCLIC) {
         // Dense-inverse path: the SMW products of ALL shifts of the cycle whose stacked inverses already exist (i.e. from the
@@ -883,36 +935,17 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         }
     }
 
-    // the iterate: never mutate the caller's initial guess (adi.jl:174 `cache.X += increment` builds a new list)
-    auto Xw = std::make_shared<LDLt>(*X);
-    struct StepRec { int iters_after; size_t nblocks; int nshifts; };
-    int iters_host = 0, last_compression = 0;
-    std::vector<std::complex<double>> all_shifts;
-    bool finished = false;
-    std::vector<std::shared_ptr<FactorEntry<double>>> used_real;
-    std::vector<std::shared_ptr<FactorEntry<cplx>>> used_cplx;
-    // every factorisation is checked once per chunk, after the chunk's synchronisation (the breakdown flag is written by the
-    // factorisation kernels only); the handles are dropped then, so single-use factors are freed chunk by chunk
-    auto check_used = [&]() {
-        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
-        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
-        used_real.clear(); used_cplx.clear();
-    };
-    // dense-inverse steps: the norm kernel of iteration i rides on the step kernel of iteration i + 1 (dense.hpp, DenseNormPending)
-    DenseNormPending npend;
-    static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
-
     // chunk length: compression_interval, or — where the intermediate compressions are deferred anyway — the iteration count of the
     // previous solve (+2), so that a whole Lyapunov solve is enqueued before the first host synchronisation
-    const int chunk_limit = (!cex && n <= xblocks_max_n() && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
+    run.chunk_limit = (!cex && n <= xblocks_max_n() && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
                                                                           : opt.compression_interval;
     // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
     // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
     static const bool fast_env = !(std::getenv("DRE_ADI_FAST") && std::atoi(std::getenv("DRE_ADI_FAST")) == 0);
-    bool fast = fast_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= 96 && n <= ctx->dense_inv_max_n && cache->enabled;
-    std::vector<std::shared_ptr<FactorEntry<double>>> fast_fe;      // per position of the cycle
-    std::vector<double*> fast_pack;
-    std::vector<Mat> fast_keep;
+    bool fast = fast_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= ADI_FAST_MAX_K && n <= ctx->dense_inv_max_n && cache->enabled;
+    auto& fast_fe = run.fast_fe;            // per position of the cycle
+    auto& fast_pack = run.fast_pack;
+    auto& fast_keep = run.fast_keep;
     if (fast) {
         const int mm = op.has_lr ? m : 0;
         std::map<double, double*> by_mu;
@@ -938,18 +971,57 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
         }
         if (fast) adi_fast_build(ctx, n, mm, stacks, 2 * n + mm, wks, 2 * n, outs);
     }
-    if (fast) {
+    run.fast = fast;
+    return runp;
+}
+
+// One chunk: up to `budget` shifts are enqueued speculatively (at least one; a conjugate pair counts two and is never split), then one
+// synchronisation tells how far the device got.  budget = 1 is the reference's step! (adi.jl:97-128).
+void adi_advance(AdiRun& run, int budget) {
+    if (run.finished) return;
+    Ctx* ctx = run.ctx;
+    const GaleOperator& op = run.op;
+    const Pencil& P = *op.P;
+    const int n = run.n, k = run.k, m = run.m;
+    FactorCache* cache = run.cache;
+    AdiResult& res = run.res;
+    const AdiOptions& opt = run.opt;
+    const AdiOptions& opt_in = run.opt_in;
+    const double ctf = run.ctf, alpha_res = run.alpha_res;
+    const bool cex = run.cex, tdiag = run.tdiag;
+    Mat& R = run.R; Mat& Tm = run.Tm;
+    auto& oracle = run.oracle;
+    auto& st = run.st;
+    auto& smw_cache = run.smw_cache;
+    int* const serr = &st.p->smw_singular;     // lives in the control block: comes back with every chunk synchronisation
+    auto& Xw = run.Xw;
+    int& iters_host = run.iters_host; int& last_compression = run.last_compression;
+    auto& all_shifts = run.all_shifts;
+    bool& finished = run.finished;
+    auto& used_real = run.used_real; auto& used_cplx = run.used_cplx;
+    auto& npend = run.npend;
+    auto& resid = run.resid;
+    const int chunk_limit = std::max(1, std::min(run.chunk_limit, budget));
+    auto check_used = [&]() { run.check_used(); };
+    static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
+    (void)P; (void)opt_in; (void)serr; (void)lazy_norm;
+    if (run.fast) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
-        Mat Gm(ctx, k * k, 2);
-        DevArr<double> nws(ctx, 16);
-        DRE_HIP(hipMemsetAsync(nws.p, 0, 16 * sizeof(double), ctx->stream));
-        size_t cyc = 0;                       // position in the cycle
-        while (!finished) {
+        if (!run.fast_ready) {
+            run.Gm = Mat(ctx, k * k, 2);
+            run.nws = DevArr<double>(ctx, 16);
+            DRE_HIP(hipMemsetAsync(run.nws.p, 0, 16 * sizeof(double), ctx->stream));
+            run.fast_ready = true;
+        }
+        Mat& Gm = run.Gm; auto& nws = run.nws;
+        size_t& cyc = run.cyc;                // position in the cycle
+        auto& fast_fe = run.fast_fe; auto& fast_pack = run.fast_pack;
+        {
             const int base_it = iters_host;
             // one more iteration than the previous solve needed; the two flush launches deliver the decisions of the last two
-            const int fast_chunk = cache->iters_hint > 0 ? std::max(opt.compression_interval, cache->iters_hint + 1) : chunk_limit;
-            const int nit = std::min(std::max(1, fast_chunk), opt.maxiters - iters_host);
-            if (nit <= 0) break;
+            const int fast_chunk = cache->iters_hint > 0 ? std::max(opt.compression_interval, cache->iters_hint + 1) : run.chunk_limit;
+            const int nit = std::min(std::min(std::max(1, fast_chunk), std::max(1, budget)), opt.maxiters - iters_host);
+            if (nit <= 0) { finished = true; resid->blocks[0].L = R; return; }
             Mat Rring(ctx, n, k * nit), Vall(ctx, n, k * nit);
             const size_t blocks_before = Xw->blocks.size();
             const size_t cyc_before = cyc;
@@ -1011,9 +1083,9 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             }
         }
         resid->blocks[0].L = R;                 // the residual factor after the last accepted iteration
-        finished = true;
+        return;
     }
-    while (!finished) {
+    {
         std::vector<StepRec> recs;
         const size_t blocks_before = Xw->blocks.size();
         const int lc_before = last_compression;
@@ -1039,7 +1111,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                     if (fe->stack.empty() || fe->stack_U != (const void*)op.U.p || fe->stack_m != mm) {
                         Mat stk(ctx, 2 * n + mm, n);
                         { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, fe->dinv, top); }
-                        { Mat mid = stk.view(n, 0, n, n); spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, fe->dinv, mid, 1.0, 0.0, nullptr); }
+                        { Mat mid = stk.view(n, 0, n, n); spmm(ctx, P, P.valEt.p, fe->dinv, mid, 1.0, 0.0, nullptr); }
                         if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe->dinv, 0.0, bot, nullptr, "gemm_dinv"); }
                         fe->stack = stk; fe->stack_U = (const void*)op.U.p; fe->stack_m = mm;
                     }
@@ -1103,7 +1175,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                         V1 = W;
                     }
                     // R <- R - 2 mu E' V   (adi.jl:171)
-                    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);
+                    spmm(ctx, P, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);
                 }
                 Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
                 iters_host += 1; last_compression += 1;
@@ -1152,7 +1224,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
                                        V1.p, V1.ld, V2.p, V2.ld, delta, dst);
                 }
                 // R <- R - 2 sqrt2 Re(mu) E' V1   (adi.jl:217)
-                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, V1, R, -2.0 * 1.4142135623730951 * mu.real(), 1.0, dst);
+                spmm(ctx, P, P.valEt.p, V1, R, -2.0 * 1.4142135623730951 * mu.real(), 1.0, dst);
                 Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
                 Xw->blocks.push_back({V2, Tm, -2.0 * mu.real() * alpha_res, tdiag});
                 iters_host += 2; last_compression += 2;
@@ -1164,7 +1236,7 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
             ++since_sync; chunk_shifts += is_real ? 1 : 2;
             if (opt.compression && chunk_shifts >= chunk_limit) break;
-            if (!opt.compression && since_sync >= 10) break;
+            if (!opt.compression && since_sync >= std::min(10, chunk_limit)) break;
         }
         // synchronise once per chunk and find out how far the device really got
         dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
@@ -1206,6 +1278,22 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
             }
         }
     }
+}
+
+AdiResult adi_finish(AdiRun& run) {
+    Ctx* ctx = run.ctx;
+    FactorCache* cache = run.cache;
+    AdiResult& res = run.res;
+    const AdiOptions& opt = run.opt;
+    const AdiOptions& opt_in = run.opt_in;
+    const double ctf = run.ctf, abstol = run.abstol;
+    const bool cex = run.cex;
+    auto& Xw = run.Xw;
+    int& last_compression = run.last_compression;
+    auto& all_shifts = run.all_shifts;
+    if (run.finalized || run.res.rhs_cols == 0 || (run.iters_host == 0 && run.res.converged)) { run.finalized = true; return res; }
+    run.finalized = true;
+    auto check_used = [&]() { run.check_used(); };
     check_used();
     if (opt_in.shifts.kind != ShiftSpec::CYCLIC) {
         // self-generated shifts (Projection, per-solve Heuristic) never come back: their factors must not outlive the solve,
@@ -1222,6 +1310,16 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     if (!res.converged) res.warnings |= 1;
     return res;
 }
+
+AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
+                    FactorCache* cache) {
+    auto run = adi_begin(ctx, op, C, initial_guess, opt_in, cache);
+    while (!run->finished) adi_advance(*run, 1 << 30);
+    return adi_finish(*run);
+}
+bool adi_isdone(const AdiRun& run) { return run.finished; }
+void adi_peek(const AdiRun& run, int* iters, double* res_norm, double* abstol) { *iters = run.res.iters; *res_norm = run.res.res_norm; *abstol = run.abstol; }
+
 
 // =============================================================================================
 // Penzl's heuristic: Ritz values of E^-1 F and F^-1 E by two Arnoldi runs from ones(n), everything on the device
@@ -1285,7 +1383,7 @@ void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std
     }
     // w = E'^-1 (F' x)
     rplus = arnoldi_ritz(ctx, n, kplus, [&](const Mat& x, Mat& w) {
-        spmm(ctx, n, P.ptr.p, P.idx.p, op.valFt.p, x, w, 1.0, 0.0, nullptr);
+        spmm(ctx, P, op.valFt.p, x, w, 1.0, 0.0, nullptr);
         if (m) {
             gemm(ctx, true, false, 1.0, op.U, x, 0.0, t1, nullptr, "gemm_arnoldi");
             gemm(ctx, false, false, 1.0 / op.alpha, op.Vt, t1, 1.0, w, nullptr, "gemm_arnoldi");
@@ -1294,7 +1392,7 @@ void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std
     });
     // w = F'^-1 (E' x)
     rminus = arnoldi_ritz(ctx, n, kminus, [&](const Mat& x, Mat& w) {
-        spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, x, w, 1.0, 0.0, nullptr);
+        spmm(ctx, P, P.valEt.p, x, w, 1.0, 0.0, nullptr);
         mf_solve<double>(ctx, P, fF, w.p, w.ld, 1, nullptr);
         if (m) {
             gemm(ctx, true, false, 1.0, op.U, w, 0.0, t1, nullptr, "gemm_arnoldi");
@@ -1374,7 +1472,7 @@ static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X, double ctf,
     f.BtLD = Mat(ctx, m, r);
     gemm(ctx, false, false, b.alpha, BtL, b.D, 0.0, f.BtLD);
     f.EtL = Mat(ctx, P.n, r);
-    spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, b.L, f.EtL, 1.0, 0.0);
+    spmm(ctx, P, P.valEt.p, b.L, f.EtL, 1.0, 0.0);
     f.Kt = Mat(ctx, P.n, m);
     if (r > 0) gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
     else fill_mat(ctx, f.Kt, 0.0);
@@ -1394,7 +1492,7 @@ static Feedback feedback_blocks(Ctx* ctx, const GdreProblem& prob, const LDLt& X
     f.BtLD = Mat(ctx, m, c);
     mul_blockdiag(ctx, BtL, X, f.BtLD);
     f.EtL = Mat(ctx, P.n, c);
-    spmm(ctx, P.n, P.ptr.p, P.idx.p, P.valEt.p, f.L, f.EtL, 1.0, 0.0);
+    spmm(ctx, P, P.valEt.p, f.L, f.EtL, 1.0, 0.0);
     f.Kt = Mat(ctx, P.n, m);
     gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
     return f;
@@ -1477,7 +1575,7 @@ static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& 
     if (!fe.stack.empty() && fe.stack_m == mm && (!mm || fe.stack_U == (const void*)op.U.p)) return;
     Mat stk(ctx, 2 * n + mm, n);
     { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, fe.dinv, top); }
-    { Mat mid = stk.view(n, 0, n, n); spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, fe.dinv, mid, 1.0, 0.0, nullptr); }
+    { Mat mid = stk.view(n, 0, n, n); spmm(ctx, P, P.valEt.p, fe.dinv, mid, 1.0, 0.0, nullptr); }
     if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe.dinv, 0.0, bot, nullptr, "gemm_dinv"); }
     fe.stack = stk; fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
 }
@@ -1564,8 +1662,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side
     Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
     transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
-    spmm(ctx, n, P.ptr.p, P.idx.p, P.valAt.p, Y, Mx, 1.0, 0.0);                 // A' X E
-    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, Y, EY, 1.0, 0.0);                 // E' X E
+    spmm(ctx, P, P.valAt.p, Y, Mx, 1.0, 0.0);                 // A' X E
+    spmm(ctx, P, P.valEt.p, Y, EY, 1.0, 0.0);                 // E' X E
     const int nt = ceil_div(n, 16);
     DevArr<double> part(ctx, (size_t)nt * nt), tols(ctx, 4);
     hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
@@ -1694,7 +1792,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     sx.hint = acc_total;
     cache->iters_hint = acc_total;
     // feedback of the new X:  P1 = E' X,  K' = P1 B      (lowrank_ros1.jl:53-56)
-    spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+    spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
     Mat Kt(ctx, n, m);
     gemm(ctx, false, false, 1.0, sx.P1, prob.B, 0.0, Kt);
     sx.Kt = Kt;
@@ -1798,7 +1896,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                     symmetrize(ctx, sx.X);
                 } else fill_mat(ctx, sx.X, 0.0);
                 sx.P1 = Mat(ctx, n, n);
-                spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+                spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
                 sx.Kt = fb.Kt;
                 sx.hint = cache.iters_hint;
                 sx_init = true;
@@ -1913,7 +2011,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             Mat G(ctx, n, nG);
             { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
             if (r > 0) {
-                Mat d = G.colsview(q, r); spmm(ctx, n, P.ptr.p, P.idx.p, P.valAt.p, fb.L, d, 1.0, 0.0);
+                Mat d = G.colsview(q, r); spmm(ctx, P, P.valAt.p, fb.L, d, 1.0, 0.0);
                 Mat d2 = G.colsview(q + r, r); copy_mat(ctx, fb.EtL, d2);
             }
             Mat S(ctx, nG, nG);
@@ -1938,7 +2036,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             gemm(ctx, true, false, 1.0, prob.B, kb.L, 0.0, BtT1);
             gemm(ctx, false, false, kb.alpha, BtT1, kb.D, 0.0, BtT1D1);
             Mat G2(ctx, n, r1);
-            spmm(ctx, n, P.ptr.p, P.idx.p, P.valEt.p, kb.L, G2, 1.0, 0.0);
+            spmm(ctx, P, P.valEt.p, kb.L, G2, 1.0, 0.0);
             Mat S2(ctx, r1, r1);
             copy_mat(ctx, kb.D, S2, 2.0 - 1.0 / gamma);
             if (r1 > 0) gemm(ctx, true, false, tau * tau, BtT1D1, BtT1D1, 1.0, S2);

@@ -45,8 +45,6 @@ double ldlt_norm(Ctx* ctx, LDLt& X);                             // LDLt.jl:77-8
 double ldlt_norm_accurate(Ctx* ctx, const LDLt& X);   // QR/compression based like LDLt.jl:77-89 (robust to cancellation); X unchanged
 void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true);   // LDLt.jl:54-60: compress iff more than one block
 
-struct CompressStats { long calls = 0; long cols_in = 0; long order = 0; long tri_steps = 0; long rank_out = 0; };
-CompressStats& compress_stats();
 
 // ---- GALE operator  F = Fs + inv(alpha) U V  with sparse Fs on the pencil's pattern ----------------------
 // (/root/reference/src/LowRankUpdate.jl:18-26, src/lyapunov/types.jl:10-16)
@@ -116,6 +114,16 @@ struct AdiResult {
 };
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
                     FactorCache* cache);
+// The same solve as a resumable object (the reference's ADICache protocol init / step! / isdone / solve!, adi.jl:29-141): adi_begin = init,
+// adi_advance(run, budget) enqueues up to `budget` shifts (a conjugate pair counts two and is never split) and synchronises once,
+// adi_finish = final compression (adi.jl:78-80) + result.  adi_solve = begin, advance until done, finish — the stepwise and the
+// one-shot form run the same kernels in the same order, so their results are identical bit for bit (test/tiny_random.jl:48-57).
+struct AdiRun;
+std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt, FactorCache* cache);
+void adi_advance(AdiRun& run, int budget);
+bool adi_isdone(const AdiRun& run);
+void adi_peek(const AdiRun& run, int* iters, double* res_norm, double* abstol);
+AdiResult adi_finish(AdiRun& run);
 // residual of A'XE + E'XA + C for an LDL' iterate (/root/reference/src/lyapunov/residual.jl:3-31)
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 

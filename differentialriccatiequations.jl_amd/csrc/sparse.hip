@@ -114,13 +114,53 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ ptr
             *y = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
         }
 }
+// LDS-staged variant: the CSR segment (column indices + values) of the workgroup's 256 consecutive rows is one contiguous range of
+// the arrays; it is loaded cooperatively (fully coalesced) into LDS once and every thread then walks its own row in LDS.  The gathered
+// rows of the dense panel X stay L2 gathers (the nested-dissection ordering keeps the neighbours of a row close).
+#define SPMM_LDS_NNZ 3584
+__global__ __launch_bounds__(256) void k_spmm_lds(int n, const int* __restrict__ ptr, const int* __restrict__ idx,
+                                                  const double* __restrict__ val, const double* __restrict__ X, int ldx,
+                                                  double* __restrict__ Y, int ldy, int ncols, double alpha, double beta,
+                                                  const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double vs[SPMM_LDS_NNZ];
+    __shared__ int is[SPMM_LDS_NNZ];
+    const int r0 = blockIdx.x * 256, r1 = min(n, r0 + 256);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    const bool staged = (p1 - p0) <= SPMM_LDS_NNZ;
+    if (staged)
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) { vs[p - p0] = val[p]; is[p - p0] = idx[p]; }
+    __syncthreads();
+    const int i = r0 + threadIdx.x;
+    if (i >= n) return;
+    const int c0 = blockIdx.y * SPMM_CB;
+    const int c1 = min(ncols, c0 + SPMM_CB);
+    const int pb = ptr[i], pe = ptr[i + 1];
+    double acc[SPMM_CB];
+#pragma unroll
+    for (int c = 0; c < SPMM_CB; ++c) acc[c] = 0.0;
+    for (int p = pb; p < pe; ++p) {
+        const double v = staged ? vs[p - p0] : val[p];
+        const double* x = X + (staged ? is[p - p0] : idx[p]) + (size_t)c0 * ldx;
+#pragma unroll
+        for (int c = 0; c < SPMM_CB; ++c)
+            if (c0 + c < c1) acc[c] += v * x[(size_t)c * ldx];
+    }
+#pragma unroll
+    for (int c = 0; c < SPMM_CB; ++c)
+        if (c0 + c < c1) {
+            double* y = Y + i + (size_t)(c0 + c) * ldy;
+            *y = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
+        }
+}
 void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
-          double beta, const AdiState* st) {
+          double beta, const AdiState* st, int nnz) {
     DRE_REQUIRE(X.rows == n && Y.rows == n && X.cols == Y.cols, "spmm: shape mismatch");
     if (X.cols == 0) return;
-    // algorithmic bytes: CSR (12 B/nnz + 4 B/row) + X read + Y read/write
-    TimedScope ts(ctx, "spmm_csr", 12.0 * 7.0 * n + 4.0 * n + 8.0 * n * X.cols * (beta == 0.0 ? 2.0 : 3.0), 2.0 * 7.0 * n * X.cols);
-    hipLaunchKernelGGL(k_spmm, dim3(ceil_div(n, 256), ceil_div(X.cols, SPMM_CB)), dim3(256), 0, ctx->stream, n, ptr, idx, val,
+    // algorithmic bytes: CSR (12 B/nnz + 4 B/row) + X read + Y read/write; nnz < 0: unknown to the caller, 7-point estimate
+    const double z = nnz >= 0 ? (double)nnz : 7.0 * n;
+    TimedScope ts(ctx, "spmm_csr", 12.0 * z + 4.0 * n + 8.0 * n * X.cols * (beta == 0.0 ? 2.0 : 3.0), 2.0 * z * X.cols);
+    hipLaunchKernelGGL(k_spmm_lds, dim3(ceil_div(n, 256), ceil_div(X.cols, SPMM_CB)), dim3(256), 0, ctx->stream, n, ptr, idx, val,
                        X.p, X.ld, Y.p, Y.ld, X.cols, alpha, beta, st);
     DRE_HIP(hipGetLastError());
 }
@@ -395,12 +435,7 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
         if (panel_b <= lim) {
             const int inv_lds = inv_b <= lim ? 1 : 0;
             const size_t shm = std::max(panel_b, inv_lds ? inv_b : (size_t)0);
-            static bool attr_set = false;
-            if (!attr_set) {
-                DRE_HIP(hipFuncSetAttribute((const void*)k_front_factor_blocked<double>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                DRE_HIP(hipFuncSetAttribute((const void*)k_front_factor_blocked<cplx>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                attr_set = true;
-            }
+            lds_attr(ctx, (const void*)k_front_factor_blocked<double>, 150 * 1024); lds_attr(ctx, (const void*)k_front_factor_blocked<cplx>, 150 * 1024);
             hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds);
         } else {
             hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p);
@@ -762,12 +797,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc,
     const Symbolic& S = P.sym;
     MfArgs a = mf_args(P);
     const int ncb = ceil_div(nrhs, MFM_KC);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DRE_HIP(hipFuncSetAttribute((const void*)k_mf_forward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        DRE_HIP(hipFuncSetAttribute((const void*)k_mf_backward_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
-    }
+    lds_attr(ctx, (const void*)k_mf_forward_mfma, 150 * 1024); lds_attr(ctx, (const void*)k_mf_backward_mfma, 150 * 1024);
     if (forward) {
         for (int l = l_from; l >= l_to; --l) {
             const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];

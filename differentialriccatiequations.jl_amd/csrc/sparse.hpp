@@ -77,7 +77,12 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
 
 // Y = alpha * M * X + beta * Y with M given by CSR (ptr, idx, val) of order n; X, Y are n x ncols.
 void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
-          double beta, const AdiState* st = nullptr);
+          double beta, const AdiState* st = nullptr, int nnz = -1);
+// the same on the pencil's pattern (val = one of its value arrays): the CSR segment of each 256-row workgroup is staged through LDS
+// with coalesced loads, and the byte count of the timers uses the real number of nonzeros
+inline void spmm(Ctx* ctx, const Pencil& P, const double* val, const Mat& X, Mat& Y, double alpha, double beta, const AdiState* st = nullptr) {
+    spmm(ctx, P.n, P.ptr.p, P.idx.p, val, X, Y, alpha, beta, st, P.nnz);
+}
 // out = a*x + b*y on value arrays of the shared pattern (shifted-operator assembly K4, values only)
 void vals_axpby(Ctx* ctx, int nnz, double a, const double* x, double b, const double* y, double* out);
 // row permutation helpers: dst(i,:) = src(map[i],:)

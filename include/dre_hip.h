@@ -34,6 +34,10 @@ extern "C" {
 #define DRE_ERR_INTERNAL (-5)
 #define DRE_ERR_NODEVICE (-6)
 
+/* hard limits of the engine */
+#define DRE_ADI_MAX_ITERS 499         /* dre_adi_options.maxiters must stay below 500 (size of the device-resident norm history) */
+#define DRE_SMW_MAX_RANK 32           /* columns of the low-rank factors U, V of F = cA*A + cE*E + inv(alpha)*U*V */
+
 /* warning bits reported by ADI (AdiResult.warnings) */
 #define DRE_WARN_NOT_CONVERGED 1      /* src/lyapunov/adi.jl:125-126 */
 #define DRE_WARN_RITZ_DISCARDED 4     /* src/shifts/helpers.jl:133 */
@@ -166,6 +170,24 @@ int dre_adi_default_options(dre_adi_options* opt);
  * (LowRankUpdate, src/LowRankUpdate.jl:18-39).  U is n x m, Vt = V' is n x m; both NULL for a plain sparse F. */
 int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
                    const dre_dense* Vt, dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_result** out);
+/* The same solve as the reference's stepwise protocol on the solver object (ADICache, src/lyapunov/adi.jl:5-21):
+ *   dre_adi_init   = CommonSolve.init(::GALEProblem, ::ADI; initial_guess)   adi.jl:29-69   (residual, tolerances, shift oracle)
+ *   dre_adi_step   = step!(cache)          adi.jl:97-128  — ONE shift, or one conjugate pair (counts two, adi.jl:181-225), then the
+ *                                                           residual norm and the convergence test (adi.jl:115-123)
+ *   dre_adi_isdone = isdone(cache)         adi.jl:130-141
+ *   dre_adi_solve  = solve!(cache)         adi.jl:71-76   — steps until done (whole chunks are enqueued speculatively)
+ *   dre_adi_finish = the tail of solve!    adi.jl:78-89   — final compression, observe_gale_done! payload; call once
+ * Stepping to the end and solving in one go run the same kernels in the same order: the results are identical bit for bit
+ * (test/tiny_random.jl:48-57).  dre_gale_solve = init + solve + finish. */
+typedef struct dre_adi_solver dre_adi_solver;
+int dre_adi_init(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                 dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_solver** out);
+int dre_adi_step(dre_ctx* ctx, dre_adi_solver* s);
+int dre_adi_solve(dre_ctx* ctx, dre_adi_solver* s);
+int dre_adi_isdone(const dre_adi_solver* s, int* done);
+int dre_adi_state(const dre_adi_solver* s, int64_t* iters, double* res_norm, double* abstol);     /* shifts consumed, last residual norm, abstol */
+int dre_adi_finish(dre_ctx* ctx, dre_adi_solver* s, dre_adi_result** out);
+int dre_adi_free(dre_adi_solver* s);
 /* Penzl's heuristic, device part (src/shifts/heuristic.jl:39-66,103-130): Ritz values of E^-1 F (kplus Arnoldi steps) and of F^-1 E
  * (kminus steps), both from ones(n), for F = cA*A + cE*E + inv(lr_alpha)*U*V (products and solves see the low-rank part, the solves
  * through Sherman-Morrison-Woodbury like heuristic.jl:51-60).  Outputs: kplus + kminus complex numbers, raw (unsorted, unstabilised);

@@ -81,6 +81,45 @@ def test_adi_vs_dense_lyapunov(ctx, symE, symA):       # test/tiny_random.jl:25-
     assert D.delta(X.dense(), Xo.dense()) < 1e-10
 
 
+@pytest.mark.parametrize("symE,symA", [(True, True), (False, False)])
+def test_adi_stepwise_protocol_equals_one_shot_bit_for_bit(ctx, symE, symA):     # test/tiny_random.jl:48-57
+    """init / step! / isdone / iterate on the device-resident solver object: every step advances by one shift or one conjugate pair,
+    and stepping to the end gives exactly the bits of the one-shot solve (same kernels in the same order, dre_hip.h)."""
+    rng = np.random.default_rng(10 * symE + symA)
+    n, g = 50, 4
+    E, A = _rand_pencil(rng, n, symE, symA)
+    Cl = (-2) * D.lowrank(rng.random((n, g)), -np.eye(g))
+    prob = D.GALEProblem(E, A, Cl)
+    X, info = D.solve_gale(prob, D.ADI(), return_info=True)
+    solver = D.init(prob, D.ADI())
+    prev = 0
+    for s in solver:                                    # Base.iterate(::ADICache) (adi.jl:91-95)
+        it = s.state()["iters"]
+        assert prev + 1 <= it <= prev + 2
+        prev = it
+    assert D.isdone(solver) and prev == info["iters"]
+    a1, L1, D1 = solver.X
+    a0, L0, D0 = X
+    assert a1 == a0 and np.array_equal(L1, L0) and np.array_equal(D1, D0)
+    assert np.array_equal(solver.info["shifts"], info["shifts"]) and np.array_equal(solver.info["norms"], info["norms"])
+    # solve!(init(...)) is the one-shot solve
+    s2 = D.init(prob, D.ADI())
+    a2, L2, D2 = D.solve_(s2)
+    assert np.array_equal(L2, L0) and np.array_equal(D2, D0)
+    # Cyclic real shifts with a low-rank-updated operator (the Rosenbrock situation): stepwise == one-shot as well
+    U = rng.random((n, 2)); V = rng.random((2, n))
+    F = D.lr_update(A, -1.0 * n, U, V)
+    pr2 = D.GALEProblem(E, F, Cl)
+    alg = D.ADI(shifts=D.Shifts.Cyclic([-0.5, -1.0, -2.0]), maxiters=80)
+    X3, i3 = D.solve_gale(pr2, alg, return_info=True)
+    s3 = D.init(pr2, alg)
+    while not D.isdone(s3):
+        D.step_(s3)
+    _, L3, D3 = s3.X
+    _, L3o, D3o = X3
+    assert i3["converged"] and np.array_equal(L3, L3o) and np.array_equal(D3, D3o)
+
+
 def test_adi_with_explicit_conjugate_pair_shifts(ctx):  # helpers.jl:91-93 + adi.jl:181-225 (perform_double_step!)
     rng = np.random.default_rng(5)
     n = 60
