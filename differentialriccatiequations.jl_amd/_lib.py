@@ -36,7 +36,13 @@ class AdiOptionsC(C.Structure):
         ("compress_exact", C.c_int32),
         ("heuristic_kplus", C.c_int32),
         ("heuristic_kminus", C.c_int32),
+        ("inner_solve", C.c_void_p),
+        ("inner_user", C.c_void_p),
     ]
+
+
+# dre_block_solver_fn (include/dre_hip.h): int (*)(void* user, int n, int nrhs, double cA, double cE_re, double cE_im, const double* B, double* X_re, double* X_im)
+BLOCK_SOLVER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 _vp = C.c_void_p
@@ -76,6 +82,7 @@ PROTOTYPES = {
     "dre_sym_eig": (C.c_int, [_vp, _vp, C.c_double, _pvp, _pvp]),
     "dre_shift_factor": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _pvp]),
     "dre_shift_solve": (C.c_int, [_vp, _vp, _vp, _pvp, _pvp]),
+    "dre_shift_solve_smw": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _pvp, _pvp]),
     "dre_factor_free": (C.c_int, [_vp, _vp]),
     "dre_ldlt_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _pvp]),
     "dre_ldlt_zero": (C.c_int, [_vp, _vp, C.c_int, _pvp]),

@@ -407,6 +407,92 @@ class GALEProblem:
     C: LDLt
 
 
+# ------------------------------------------------------------------------------------------------
+# Block linear solvers                       src/blocklinear/types.jl:10-62, backslash.jl, sherman-morrison-woodbury.jl
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class BlockLinearProblem:
+    """A X = B with a block right-hand side (blocklinear/types.jl:10-13)."""
+    A: Any
+    B: np.ndarray
+
+
+class BlockLinearSolver:
+    """Plug-in point of the reference (blocklinear/types.jl:15-30): subclass and implement `solve(prob) -> X` (the fallback protocol of
+    types.jl:46-60).  Inside ADI the engine hands over the SPARSE shifted system  (cA A' + (cE_re + i cE_im) E') X = B  as a SciPy
+    matrix + a host array — the role of ALG in `ShermanMorrisonWoodbury(ALG, alg)`; the rank-m correction stays on the device.
+    A subclass that wants to stay on the device overrides `solve_device(n, nrhs, cA, cE_re, cE_im, B_ptr, Xre_ptr, Xim_ptr) -> int`
+    (raw device pointers, exactly `dre_block_solver_fn` of include/dre_hip.h)."""
+
+    def solve(self, prob: BlockLinearProblem):
+        raise NotImplementedError
+
+    solve_device = None
+
+
+class Backslash(BlockLinearSolver):
+    """`Backslash()` (blocklinear/backslash.jl): the library's own sparse direct solver (multifrontal LU on the device)."""
+
+    def solve(self, prob: BlockLinearProblem):
+        import scipy.sparse.linalg as spla
+        return spla.splu(sp.csc_matrix(prob.A)).solve(np.asarray(prob.B))
+
+
+@dataclass
+class ShermanMorrisonWoodbury(BlockLinearSolver):
+    """`ShermanMorrisonWoodbury(alg_sparse, alg_dense)` (blocklinear/types.jl:35-39): `alg_sparse` solves with the sparse part,
+    the small dense capacitance system is always solved on the device."""
+    alg_sparse: Any = field(default_factory=Backslash)
+    alg_dense: Any = field(default_factory=Backslash)
+
+
+_hip_rt = None
+
+
+def _hip_memcpy(dst, src, nbytes, kind):
+    global _hip_rt
+    if _hip_rt is None:
+        _hip_rt = C.CDLL("libamdhip64.so")
+        _hip_rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        _hip_rt.hipMemcpy.restype = C.c_int
+    rc = _hip_rt.hipMemcpy(dst, src, nbytes, kind)
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed with {rc}")
+
+
+def _inner_solver_callback(inner_alg, E, A0):
+    """ctypes trampoline for a user BlockLinearSolver (dre_block_solver_fn).  Returns (function pointer, keep-alive) or (None, None)."""
+    from ._lib import BLOCK_SOLVER_FN
+    if inner_alg is None or type(inner_alg) is Backslash:
+        return None, None
+    alg = inner_alg.alg_sparse if isinstance(inner_alg, ShermanMorrisonWoodbury) else inner_alg
+    if alg is None or type(alg) is Backslash:
+        return None, None
+    Et, At = sp.csc_matrix(E).T.tocsc(), sp.csc_matrix(A0).T.tocsc()
+    errors = []
+
+    def tramp(user, n, nrhs, cA, cE_re, cE_im, Bp, Xrp, Xip):
+        try:
+            if alg.solve_device is not None:
+                return int(alg.solve_device(n, nrhs, cA, cE_re, cE_im, Bp, Xrp, Xip))
+            B = np.empty((n, nrhs), order="F")
+            _hip_memcpy(B.ctypes.data, Bp, B.nbytes, 2)                       # device -> host
+            cE = complex(cE_re, cE_im) if cE_im != 0.0 else cE_re
+            X = np.asarray(alg.solve(BlockLinearProblem((cA * At + cE * Et).tocsc(), B)))
+            Xr = np.asfortranarray(X.real.astype(np.float64))
+            _hip_memcpy(Xrp, Xr.ctypes.data, Xr.nbytes, 1)                    # host -> device
+            if Xip:
+                Xi = np.asfortranarray(np.imag(X).astype(np.float64))
+                _hip_memcpy(Xip, Xi.ctypes.data, Xi.nbytes, 1)
+            return 0
+        except Exception as e:                                                # no exception may cross the C boundary
+            errors.append(e)
+            return 1
+
+    cb = BLOCK_SOLVER_FN(tramp)
+    return cb, (cb, errors)
+
+
 @dataclass
 class ADI:
     """ADI options (lyapunov/types.jl:20-30)."""
@@ -418,6 +504,7 @@ class ADI:
     compression_interval: int = 10
     compression: bool = True
     warn_convergence: bool = True
+    inner_alg: Any = None             # None / Backslash(): the device multifrontal LU; a BlockLinearSolver (or SMW(solver, ...)) plugs in
     # engine knob (not in the reference): True = eigen-based truncation at every compression, exactly the
     # reference's arithmetic; False = Krylov-truncated compression (same accuracy class, far cheaper on a GPU)
     compress_exact: bool = False
@@ -487,8 +574,17 @@ def _split_operator(E, A):
     return A, None
 
 
-def _adi_options(alg: ADI, pencil, lr=None):
+def _adi_options(alg: ADI, pencil, lr=None, E=None, A0=None):
     kind, nh, vals = _resolve_shifts(alg.shifts, pencil, lr)
+    cb, keep_cb = _inner_solver_callback(getattr(alg, "inner_alg", None), E, A0) if E is not None else (None, None)
+    opt, keep = _make_adi_options(alg, kind, nh, vals)
+    if cb is not None:
+        opt.inner_solve = C.cast(cb, C.c_void_p)
+        keep = (keep, keep_cb)
+    return opt, keep
+
+
+def _make_adi_options(alg, kind, nh, vals):
     return dev.make_adi_options(alg.maxiters, alg.reltol, alg.abstol, alg.ignore_initial_guess, alg.compression_interval,
                                 alg.compression, kind, nh, vals if kind == 0 else None, compress_exact=alg.compress_exact,
                                 heuristic=vals if kind == 2 else None)
@@ -527,7 +623,7 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
     ctx = ctx or dev.default_context()
     A0, lr = _split_operator(prob.E, prob.A)
     pencil = _pencil_for(prob.E, A0, ctx)
-    opt, keep = _adi_options(alg, pencil, lr)
+    opt, keep = _adi_options(alg, pencil, lr, prob.E, A0)
     Cd = prob.C._to_device(ctx, pencil)
     X0d = initial_guess._to_device(ctx, pencil) if initial_guess is not None else None
     U = Vt = None
@@ -562,7 +658,7 @@ class ADISolver:
         self.prob, self.alg, self.observer = prob, alg, observer
         A0, lr = _split_operator(prob.E, prob.A)
         self.pencil = _pencil_for(prob.E, A0, self.ctx)
-        opt, self._keep = _adi_options(alg, self.pencil, lr)
+        opt, self._keep = _adi_options(alg, self.pencil, lr, prob.E, A0)
         self._Cd = prob.C._to_device(self.ctx, self.pencil)
         self._X0d = initial_guess._to_device(self.ctx, self.pencil) if initial_guess is not None else None
         self._U = self._Vt = None
@@ -686,7 +782,7 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     inner = alg.inner_alg if alg.inner_alg is not None else ADI()
     _call(observer, "observe_gdre_start", prob, alg)
     pencil = _pencil_for(prob.E, prob.A, ctx)
-    opt, keep = _adi_options(inner, pencil)
+    opt, keep = _adi_options(inner, pencil, None, prob.E, prob.A)
     X0d = prob.X0._to_device(ctx, pencil)
     Bd, Cd = ctx.upload(prob.B), ctx.upload(prob.C)
     r = C.c_void_p()

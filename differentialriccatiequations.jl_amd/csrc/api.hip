@@ -401,6 +401,35 @@ int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_d
         }
     });
 }
+int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const dre_dense* U, const dre_dense* Vt, const dre_dense* B,
+                        dre_dense** X_re, dre_dense** X_im) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        const Pencil& P = *f->pen->p;
+        DRE_REQUIRE(U && Vt && B && X_re, "dre_shift_solve_smw: null argument");
+        Mat Us = to_solver_order(c, f->pen, U->m), Vs = to_solver_order(c, f->pen, Vt->m), Bs = to_solver_order(c, f->pen, B->m);
+        if (!f->is_cplx) {
+            Mat X = smw_solve(c, P, f->fr, alpha, Us, Vs, Bs);
+            auto* Xr = new dre_dense();
+            Xr->m = Mat(c, P.n, Bs.cols);
+            Mat Xu = to_user_order(c, f->pen, X);
+            copy_mat(c, Xu, Xr->m);
+            c->sync();
+            *X_re = Xr;
+            if (X_im) *X_im = nullptr;
+        } else {
+            DRE_REQUIRE(X_im != nullptr, "complex factor needs an imaginary output");
+            Mat re, im;
+            smw_solve(c, P, f->fc, alpha, Us, Vs, Bs, re, im);
+            auto* Xr = new dre_dense(); auto* Xi = new dre_dense();
+            Xr->m = Mat(c, P.n, Bs.cols); Xi->m = Mat(c, P.n, Bs.cols);
+            Mat ru = to_user_order(c, f->pen, re), iu = to_user_order(c, f->pen, im);
+            copy_mat(c, ru, Xr->m); copy_mat(c, iu, Xi->m);
+            c->sync();
+            *X_re = Xr; *X_im = Xi;
+        }
+    });
+}
 int dre_factor_free(dre_ctx*, dre_factor* f) { delete f; return DRE_OK; }
 
 // ---- LDLt --------------------------------------------------------------------------------------
@@ -479,6 +508,7 @@ static AdiOptions convert_options(const dre_adi_options* o) {
     a.compression_interval = o->compression_interval; a.compression = o->compression != 0;
     a.compress_tolfac = o->compress_tolfac > 0 ? o->compress_tolfac : 4.0;
     a.compress_exact = o->compress_exact != 0;
+    a.inner_solve = o->inner_solve; a.inner_user = o->inner_user;
     if (o->shift_kind == 0) {
         a.shifts.kind = ShiftSpec::CYCLIC;
         DRE_REQUIRE(o->nshifts > 0 && o->shifts_re, "Cyclic shifts need at least one value");
@@ -503,6 +533,7 @@ static GaleOperator make_operator(Ctx* c, const dre_pencil* p, double cA, double
     op.valFt = DevArr<double>(c, P.nnz);
     vals_axpby(c, P.nnz, cA, P.valAt.p, cE, P.valEt.p, op.valFt.p);
     op.tag = g_tag_counter++;
+    op.cA = cA; op.cE = cE;
     if (U && Vt) {
         DRE_REQUIRE(U->m.rows == P.n && Vt->m.rows == P.n && U->m.cols == Vt->m.cols, "low-rank factors must be n x m");
         op.has_lr = true; op.alpha = lr_alpha;

@@ -512,6 +512,25 @@ __global__ __launch_bounds__(256) void k_dense_apply(int n, int m, int k, const 
     R[i + (size_t)c * ldr] -= two_mu * ev;
 }
 
+// X(:, c) = W(:, c) - WU (Sinv small(:, c))  for a complex system, split into real and imaginary parts; one workgroup column per c
+__global__ __launch_bounds__(256) void k_smw_plain_cplx(int n, int m, const cplx* __restrict__ W, int ldw, const cplx* __restrict__ WU, int ldwu,
+                                                        const cplx* __restrict__ Sinv, const cplx* __restrict__ small, int lds_,
+                                                        double* __restrict__ Xre, double* __restrict__ Xim, int ldx) {
+    __shared__ double ybuf[64];
+    cplx* y = reinterpret_cast<cplx*>(ybuf);
+    const int c = blockIdx.y, tid = threadIdx.x;
+    if (tid < m) {
+        cplx acc = {0.0, 0.0};
+        for (int l = 0; l < m; ++l) acc += Sinv[tid + (size_t)l * m] * small[l + (size_t)c * lds_];
+        y[tid] = acc;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    cplx v = W[i + (size_t)c * ldw];
+    for (int j = 0; j < m; ++j) v -= WU[i + (size_t)j * ldwu] * y[j];
+    Xre[i + (size_t)c * ldx] = v.re; Xim[i + (size_t)c * ldx] = v.im;
+}
 __global__ void k_real_to_cplx(int rows, int cols, const double* __restrict__ src, int lds_, cplx* __restrict__ dst, int ldd,
                                const AdiState* st) {
     if (st && st->done) return;
@@ -773,6 +792,87 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     return fe;
 }
 
+__global__ void k_join_cplx(int rows, int cols, const double* __restrict__ re, const double* __restrict__ im, int lds_, cplx* __restrict__ dst, int ldd) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)rows * cols) return;
+    int r = id % rows, c = id / rows;
+    dst[r + (size_t)c * ldd] = {re[r + (size_t)c * lds_], im ? im[r + (size_t)c * lds_] : 0.0};
+}
+__global__ void k_split_cplx2(int rows, int cols, const cplx* __restrict__ src, int lds_, double* __restrict__ re, double* __restrict__ im, int ldd) {
+    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (size_t)rows * cols) return;
+    int r = id % rows, c = id / rows;
+    const cplx z = src[r + (size_t)c * lds_];
+    re[r + (size_t)c * ldd] = z.re; im[r + (size_t)c * ldd] = z.im;
+}
+// The plug-in point of the reference's BlockLinearSolver protocol: the user solves the sparse shifted system for the block right-hand
+// side W (n x ncols, solver ordering, overwritten by the solution).  The panel is handed over in the caller's row ordering after a
+// stream synchronisation; the callback must have finished its own device work when it returns.
+static void user_block_solve(Ctx* ctx, const GaleOperator& op, const AdiOptions& opt, std::complex<double> mu, Mat& W, cplx* Wc) {
+    const Pencil& P = *op.P;
+    const int n = P.n, nc = W.cols;
+    Mat Bu(ctx, n, nc), Xr(ctx, n, nc), Xi;
+    permute_rows(ctx, W, P.iperm.p, Bu);                  // Bu(old, :) = W(iperm[old], :)
+    const bool cx = mu.imag() != 0.0;
+    if (cx) Xi = Mat(ctx, n, nc);
+    ctx->sync();
+    const int rc = opt.inner_solve(opt.inner_user, n, nc, op.cA, op.cE + mu.real(), mu.imag(), Bu.p, Xr.p, cx ? Xi.p : nullptr);
+    if (rc != 0) throw Error(ERR_INTERNAL, "user block solver (inner_alg) failed with code " + std::to_string(rc));
+    if (!cx) { permute_rows(ctx, Xr, P.perm.p, W); return; }
+    Mat Xr2(ctx, n, nc), Xi2(ctx, n, nc);
+    permute_rows(ctx, Xr, P.perm.p, Xr2); permute_rows(ctx, Xi, P.perm.p, Xi2);
+    const size_t tot = (size_t)n * nc;
+    hipLaunchKernelGGL(k_join_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, nc, (const double*)Xr2.p, (const double*)Xi2.p, n, Wc, n);
+}
+
+Mat smw_solve(Ctx* ctx, const Pencil& P, const Factor<double>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B) {
+    const int n = P.n, k = B.cols, m = U.cols;
+    DRE_REQUIRE(U.rows == n && Vt.rows == n && Vt.cols == m && B.rows == n, "smw_solve: shape mismatch");
+    DRE_REQUIRE(m >= 1 && m <= 32, "SMW: between 1 and 32 low-rank columns (DRE_SMW_MAX_RANK)");
+    Mat W(ctx, n, k + m), X(ctx, n, k);
+    { Mat d = W.colsview(0, k); copy_mat(ctx, B, d); }
+    { Mat d = W.colsview(k, m); copy_mat(ctx, Vt, d); }
+    mf_solve<double>(ctx, P, F, W.p, W.ld, k + m, nullptr);
+    Mat small(ctx, m, k + m);
+    gemm(ctx, true, false, 1.0, U, W, 0.0, small, nullptr, "smw_small");
+    DevArr<double> sinv(ctx, (size_t)m * m);
+    DevArr<int> serr(ctx, 1);
+    DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, alpha, sinv.p, (const AdiState*)nullptr, serr.p);
+    hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream, n, m, k, W.p, W.ld,
+                       (const double*)(W.p + (size_t)k * W.ld), W.ld, (const double*)sinv.p, (const double*)small.p, small.ld, X.p, X.ld, (double*)nullptr, 0, 0.0,
+                       (const AdiState*)nullptr);
+    int herr = 0;
+    DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+    return X;
+}
+void smw_solve(Ctx* ctx, const Pencil& P, const Factor<cplx>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B, Mat& X_re, Mat& X_im) {
+    const int n = P.n, k = B.cols, m = U.cols;
+    DRE_REQUIRE(U.rows == n && Vt.rows == n && Vt.cols == m && B.rows == n, "smw_solve: shape mismatch");
+    DRE_REQUIRE(m >= 1 && m <= 32, "SMW: between 1 and 32 low-rank columns (DRE_SMW_MAX_RANK)");
+    const int nc = k + m;
+    DevArr<cplx> W(ctx, (size_t)n * nc), small(ctx, (size_t)m * nc), sinv(ctx, (size_t)m * m), Xc(ctx, (size_t)n * k);
+    DevArr<int> serr(ctx, 1);
+    DRE_HIP(hipMemsetAsync(serr.p, 0, sizeof(int), ctx->stream));
+    size_t tot = (size_t)n * k;
+    hipLaunchKernelGGL(k_real_to_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, B.p, B.ld, W.p, n, (const AdiState*)nullptr);
+    tot = (size_t)n * m;
+    hipLaunchKernelGGL(k_real_to_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, m, Vt.p, Vt.ld, W.p + (size_t)k * n, n, (const AdiState*)nullptr);
+    mf_solve<cplx>(ctx, P, F, W.p, n, nc, nullptr);
+    hipLaunchKernelGGL((k_smw_small<cplx>), dim3(nc), dim3(256), 0, ctx->stream, n, m, U.p, U.ld, (const cplx*)W.p, n, small.p, m, (const AdiState*)nullptr);
+    hipLaunchKernelGGL((k_sinv<cplx>), dim3(1), dim3(64), 0, ctx->stream, m, (const cplx*)(small.p + (size_t)k * m), m, alpha, sinv.p, (const AdiState*)nullptr, serr.p);
+    // X = W_B - W_Vt (Sinv small_B): the apply kernel's complex epilogue produces the real ADI pair, so the plain complex result is formed here
+    X_re = Mat(ctx, n, k); X_im = Mat(ctx, n, k);
+    hipLaunchKernelGGL(k_smw_plain_cplx, dim3(ceil_div(n, 256), k), dim3(256), 0, ctx->stream, n, m, (const cplx*)W.p, n, (const cplx*)(W.p + (size_t)k * n), n,
+                       (const cplx*)sinv.p, (const cplx*)small.p, m, X_re.p, X_im.p, X_re.ld);
+    int herr = 0;
+    DRE_HIP(hipMemcpyAsync(&herr, serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    if (herr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+}
+
 struct SmwCacheEntry { BufP keep; void* WU; int ldwu; BufP sinv; BufP keep2; };
 std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOperator& op, int nshifts, int kplus, int kminus, int* warnings);
 
@@ -942,7 +1042,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
     // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
     static const bool fast_env = !(std::getenv("DRE_ADI_FAST") && std::atoi(std::getenv("DRE_ADI_FAST")) == 0);
-    bool fast = fast_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= ADI_FAST_MAX_K && n <= ctx->dense_inv_max_n && cache->enabled;
+    bool fast = fast_env && !opt_in.inner_solve && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= ADI_FAST_MAX_K && n <= ctx->dense_inv_max_n && cache->enabled;
     auto& fast_fe = run.fast_fe;            // per position of the cycle
     auto& fast_pack = run.fast_pack;
     auto& fast_keep = run.fast_keep;
@@ -1099,13 +1199,17 @@ void adi_advance(AdiRun& run, int budget) {
             bool norm_done = false, rode = false;
             if (is_real) {
                 // dense inverses pay off only for shift lists that persist across Lyapunov solves (user-given Cyclic values)
-                auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC);
-                used_real.push_back(fe);
+                const bool user_inner = opt.inner_solve != nullptr;
+                std::shared_ptr<FactorEntry<double>> fe;
+                if (!user_inner) {
+                    fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC);
+                    used_real.push_back(fe);
+                }
                 auto key = std::make_pair(mu.real(), 0.0);
                 auto sc = smw_cache.find(key);
                 const bool have = op.has_lr && sc != smw_cache.end();
                 const int ncols = k + ((op.has_lr && !have) ? m : 0);
-                if (fe->dense) {
+                if (fe && fe->dense) {
                     // dense-inverse step: one stacked GEMM + one fused apply (V and the residual recurrence)
                     const int mm = op.has_lr ? m : 0;
                     if (fe->stack.empty() || fe->stack_U != (const void*)op.U.p || fe->stack_m != mm) {
@@ -1154,7 +1258,8 @@ void adi_advance(AdiRun& run, int budget) {
                     Mat W(ctx, n, ncols);
                     { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
                     if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
-                    mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
+                    if (user_inner) user_block_solve(ctx, op, opt, mu, W, nullptr);
+                    else mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
                     if (op.has_lr) {
                         V1 = Mat(ctx, n, k);
                         Mat small(ctx, m, ncols);
@@ -1186,8 +1291,12 @@ void adi_advance(AdiRun& run, int budget) {
                 DRE_REQUIRE(std::abs(mu2 - std::conj(mu)) <= 1e-8 * std::abs(mu), "complex shifts must come in conjugate pairs (adi.jl:190)");
                 V1 = Mat(ctx, n, k);
                 V2 = Mat(ctx, n, k);
-                auto fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu);
-                used_cplx.push_back(fe);
+                const bool user_inner = opt.inner_solve != nullptr;
+                std::shared_ptr<FactorEntry<cplx>> fe;
+                if (!user_inner) {
+                    fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu);
+                    used_cplx.push_back(fe);
+                }
                 auto key = std::make_pair(mu.real(), mu.imag());
                 auto sc = smw_cache.find(key);
                 const bool have = op.has_lr && sc != smw_cache.end();
@@ -1202,7 +1311,13 @@ void adi_advance(AdiRun& run, int budget) {
                         hipLaunchKernelGGL(k_real_to_cplx, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, m, op.Vt.p, op.Vt.ld, W + (size_t)k * n, n, dst);
                     }
                 }
-                mf_solve<cplx>(ctx, P, fe->f, W, n, ncols, dst);
+                if (user_inner) {
+                    // the real right-hand side [R, Vt] goes to the user's solver; the complex solution comes back interleaved
+                    Mat Wr(ctx, n, ncols);
+                    { Mat d = Wr.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
+                    if (op.has_lr && !have) { Mat d = Wr.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
+                    user_block_solve(ctx, op, opt, mu, Wr, W);
+                } else mf_solve<cplx>(ctx, P, fe->f, W, n, ncols, dst);
                 const double delta = mu.real() / mu.imag();
                 if (op.has_lr) {
                     auto sb = std::make_shared<Buf>(ctx, (size_t)m * ncols * sizeof(cplx));
@@ -1860,7 +1975,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
     // Ros1, small n, real Cyclic shifts, no save_state: from the second step on X is carried as a dense symmetric matrix (ros1_dense_step)
-    bool densex = order == 1 && !cex && !save_state && !adi.ignore_initial_guess && adi.compression && adi.shifts.kind == ShiftSpec::CYCLIC &&
+    bool densex = order == 1 && !cex && !save_state && !adi.inner_solve && !adi.ignore_initial_guess && adi.compression && adi.shifts.kind == ShiftSpec::CYCLIC &&
                   n <= ctx->dense_x_max_n && n <= ctx->dense_inv_max_n && m <= 32 && !adi.shifts.values.empty();
     for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
     DenseXState sx;
@@ -1879,6 +1994,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             it = valF_by_tau.emplace(op.tag, v).first;
         }
         op.valFt = it->second;
+        if (order == 1) { op.cA = 1.0; op.cE = -1.0 / (2.0 * tau); } else { op.cA = gamma * tau; op.cE = -0.5; }
         op.has_lr = true;
         op.U = prob.B;
         op.Vt = fb.Kt;

@@ -67,6 +67,7 @@ struct GaleOperator {
     const Pencil* P = nullptr;
     DevArr<double> valFt;      // values of the sparse part of F' on the pencil's pattern
     uint64_t tag = 0;          // identity of valFt for the factor cache
+    double cA = 1.0, cE = 0.0; // Fs = cA*A + cE*E (coefficients behind valFt; handed to a user-supplied block solver)
     bool has_lr = false;
     double alpha = 1.0;        // F = Fs + inv(alpha) * U * V
     Mat U;                     // n x m
@@ -84,6 +85,11 @@ struct ShiftSpec {
     int h_nshifts = 0, h_kplus = 0, h_kminus = 0;   // HEURISTIC: Cyclic(Heuristic(nshifts, k+, k-)), recomputed per Lyapunov solve
 };
 
+// User-supplied solver of the SPARSE shifted system  (cA*A' + (cE_re + i cE_im)*E') X = B  (the ALG of ShermanMorrisonWoodbury(ALG, alg),
+// src/blocklinear/types.jl:35-39; plug-in protocol types.jl:15-62, example test/cuda.jl:23-30,74).  Device pointers, caller's row
+// ordering, column-major with leading dimension n; X_im is null for a real system.  Returns 0 on success.
+typedef int (*BlockSolverFn)(void* user, int n, int nrhs, double cA, double cE_re, double cE_im, const double* B, double* X_re, double* X_im);
+
 struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     int maxiters = 100;
     double reltol = -1.0;   // < 0: "nothing" -> n*eps
@@ -95,6 +101,8 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     double compress_tolfac = 4.0;    // Krylov-truncated compression inside the engine: remainder <= tolfac*eps*||X||_F
     double residual_abs_frac = 0.05; // the warm-start residual is truncated at this fraction of abstol (Krylov mode only)
     bool compress_exact = false;     // true: eigen-based truncation at every compression (reference arithmetic)
+    BlockSolverFn inner_solve = nullptr;   // inner_alg = ShermanMorrisonWoodbury(user solver, Backslash) instead of the library's multifrontal LU
+    void* inner_user = nullptr;
     bool final_compress = true;      // internal (Ros1 driver): false keeps the solution as warm start + increments (block list)
     Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
     int rhs_lead_blocks = -1;        // internal (Ros1 driver): the right-hand side is  C = (first rhs_lead_blocks blocks) + rhs_e_coeff * E'XE
@@ -124,6 +132,10 @@ void adi_advance(AdiRun& run, int budget);
 bool adi_isdone(const AdiRun& run);
 void adi_peek(const AdiRun& run, int* iters, double* res_norm, double* abstol);
 AdiResult adi_finish(AdiRun& run);
+// X = (M + inv(alpha) Vt U')^-1 B  through Sherman-Morrison-Woodbury with a factorisation of the sparse part M
+// (src/blocklinear/sherman-morrison-woodbury.jl:10-45): W = M^-1 [B, Vt], S = alpha I + U' W_Vt, X = W_B - W_Vt S^-1 (U' W_B).  Solver ordering.
+Mat smw_solve(Ctx* ctx, const Pencil& P, const Factor<double>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B);
+void smw_solve(Ctx* ctx, const Pencil& P, const Factor<cplx>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B, Mat& X_re, Mat& X_im);
 // residual of A'XE + E'XA + C for an LDL' iterate (/root/reference/src/lyapunov/residual.jl:3-31)
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 

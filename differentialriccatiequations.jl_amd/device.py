@@ -199,6 +199,18 @@ class Factor:
         return Xr
 
 
+    def solve_smw(self, alpha, U, Vt, B):
+        """(M + inv(alpha) Vt U') \\ B through Sherman-Morrison-Woodbury (dre_shift_solve_smw; blocklinear/sherman-morrison-woodbury.jl:10-45)."""
+        ctx = self.pencil.ctx
+        Ud, Vd, Bd = ctx.upload(U), ctx.upload(Vt), ctx.upload(B)
+        xr, xi = C.c_void_p(), C.c_void_p()
+        ctx.chk(ctx.lib.dre_shift_solve_smw(ctx.ptr, self.ptr, float(alpha), Ud.ptr, Vd.ptr, Bd.ptr, C.byref(xr), C.byref(xi)))
+        Xr = DenseMatrix(ctx, xr).numpy()
+        if self.is_complex:
+            return Xr + 1j * DenseMatrix(ctx, xi).numpy()
+        return Xr
+
+
 class DeviceLDLt:
     """Handle of an LDLᵀ object living on the device (dre_ldlt_*)."""
 

@@ -122,6 +122,11 @@ int dre_sym_eig(dre_ctx* ctx, const dre_dense* S, double tolfac, dre_dense** val
 int dre_shift_factor(dre_ctx* ctx, const dre_pencil* p, double cA, double cE_re, double cE_im, dre_factor** out);
 /* X = F \ B  (src/blocklinear/backslash.jl:17-21); X_im may be NULL for a real factor */
 int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_dense** X_re, dre_dense** X_im);
+/* X = (M + inv(alpha) * Vt * U') \ B  with M the factorised sparse matrix: ShermanMorrisonWoodbury(Backslash) applied to
+ * BlockLinearProblem(LowRankUpdate(M, alpha, Vt, U'), B)  (src/blocklinear/sherman-morrison-woodbury.jl:10-45, src/LowRankUpdate.jl:61-64).
+ * U and Vt are n x m (m <= DRE_SMW_MAX_RANK); complex iff the factor is. */
+int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const dre_dense* U, const dre_dense* Vt, const dre_dense* B,
+                        dre_dense** X_re, dre_dense** X_im);
 int dre_factor_free(dre_ctx* ctx, dre_factor* f);
 
 /* ---- LDLᵀ objects (src/LDLt.jl) ------------------------------------------------------------ */
@@ -145,6 +150,16 @@ int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x);
 int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* L_host, int ldl, double* D_host, int ldd);
 
 /* ---- GALE / ADI (src/lyapunov/types.jl:10-32, adi.jl:29-225) --------------------------------- */
+/* Pluggable inner solver (src/blocklinear/types.jl:15-62; src/lyapunov/types.jl:26 `inner_alg`; example test/cuda.jl:23-30,74):
+ * a user-supplied solver of the SPARSE shifted system
+ *      (cA*A' + (cE_re + i*cE_im)*E') X = B,        B real n x nrhs, column-major, leading dimension n,
+ * i.e. the ALG of inner_alg = ShermanMorrisonWoodbury(ALG, Backslash): the engine keeps doing the rank-m Sherman-Morrison-Woodbury
+ * correction for F = Fs + inv(alpha) U V around it.  All pointers are DEVICE pointers in the caller's row ordering; X_im is NULL for a
+ * real system.  The engine synchronises its stream before the call; the callback must have completed its own device work when it
+ * returns.  Return 0 on success (anything else aborts the solve with DRE_ERR_INTERNAL).  With a user solver the engine neither caches
+ * factorisations nor takes the dense-inverse fast paths. */
+typedef int (*dre_block_solver_fn)(void* user, int n, int nrhs, double cA, double cE_re, double cE_im, const double* B, double* X_re, double* X_im);
+
 typedef struct dre_adi_options {
     int32_t maxiters;              /* 100 */
     double reltol;                 /* < 0 = nothing -> n*eps */
@@ -163,6 +178,8 @@ typedef struct dre_adi_options {
                                       0 (default): Krylov-truncated compression, D stays tridiagonal inside the engine */
     int32_t heuristic_kplus;       /* shift_kind 2: Arnoldi steps with E^-1 F */
     int32_t heuristic_kminus;      /* shift_kind 2: Arnoldi steps with F^-1 E */
+    dre_block_solver_fn inner_solve; /* NULL (default): inner_alg = Backslash() on the library's multifrontal LU (src/blocklinear/backslash.jl) */
+    void* inner_user;              /* passed back to inner_solve */
 } dre_adi_options;
 int dre_adi_default_options(dre_adi_options* opt);
 

@@ -213,3 +213,64 @@ def test_block_list_time_loop_on_random_nonsymmetric_pencils(ctx, symE, symA):
         assert all(abs(a - b) <= 2 for a, b in zip(its, out["plain"][1]))
         for K, Kr in zip(sol.K, ref.K):
             assert np.linalg.norm(K - Kr) < 1e-9 * max(np.linalg.norm(Kr), 1e-300), name
+
+
+def test_standalone_smw_solve_real_and_complex(ctx):          # blocklinear/sherman-morrison-woodbury.jl:10-45, LowRankUpdate.jl:61-64
+    """dre_shift_solve_smw: (M + inv(alpha) Vt U') X = B with the multifrontal factor of the sparse part M, against a dense solve
+    (the check of test/LowRankUpdate.jl:31-40: M*X ~ B for the explicitly formed matrix)."""
+    d = D.steel_profile(371)
+    P = D.Pencil(d.E, d.A, ctx)
+    rng = np.random.default_rng(3)
+    U, Vt, B = rng.standard_normal((371, 5)), 1e-3 * rng.standard_normal((371, 5)), rng.standard_normal((371, 9))
+    E, A = d.E.toarray(), d.A.toarray()
+    for mu in (-0.7, -0.3 + 0.2j):
+        f = P.factor(1.0, complex(mu))
+        X = f.solve_smw(-2.0, U, Vt, B)
+        M = A.T + mu * E.T + (1.0 / -2.0) * Vt @ U.T
+        assert np.iscomplexobj(X) == (mu.imag != 0)
+        assert np.linalg.norm(M @ X - B) < 1e-11 * np.linalg.norm(B)
+
+
+def test_user_block_solver_plugs_into_adi(ctx):                # blocklinear/types.jl:15-62, lyapunov/types.jl:26; example test/cuda.jl:23-30,74
+    """inner_alg = ShermanMorrisonWoodbury(My(), Backslash()) with a user-defined BlockLinearSolver: every sparse shifted system of the ADI
+    (real shifts and a complex pair) goes through the user's `solve`, the rank-m correction stays in the engine; same result as the
+    library's own inner solver."""
+    import scipy.sparse.linalg as spla
+    from test_gpu_ldlt_gale import _rand_pencil
+
+    class My(D.BlockLinearSolver):
+        def __init__(self): self.calls, self.complex_calls, self.cols = 0, 0, []
+        def solve(self, prob):
+            self.calls += 1
+            self.complex_calls += int(np.iscomplexobj(prob.A.data))
+            self.cols.append(prob.B.shape[1])
+            return spla.splu(prob.A.tocsc()).solve(prob.B.astype(prob.A.dtype))
+
+    rng = np.random.default_rng(11)
+    n = 60
+    E, A = _rand_pencil(rng, n, True, False)
+    U, V = rng.random((n, 2)), rng.random((2, n))
+    F = D.lr_update(A, -1.0 * n, U, V)
+    Cl = D.lowrank(rng.random((n, 3)), np.diag([1.0, -1.0, 2.0]))
+    prob = D.GALEProblem(E, F, Cl)
+    shifts = [-1 + 0.5j, -1 - 0.5j, -2.0, -0.8, -1.3]
+    Xref, iref = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=80), return_info=True)
+    my = My()
+    X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=80, inner_alg=D.ShermanMorrisonWoodbury(my, D.Backslash())), return_info=True)
+    assert info["converged"] and info["iters"] == iref["iters"]
+    assert my.calls >= 3 and my.complex_calls >= 1 and max(my.cols) == 3 + 2          # [R, V'] in one block on first use of a shift
+    assert D.delta(X.dense(), Xref.dense()) < 1e-10
+    # a failing user solver surfaces as an error, not as a wrong result
+    class Bad(D.BlockLinearSolver):
+        def solve(self, prob): raise RuntimeError("boom")
+    with pytest.raises(D.DREError):
+        D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=8, inner_alg=Bad(), warn_convergence=False))
+    # inside the Rosenbrock time loop as well (lowrank_ros1.jl:34: inner_alg is forwarded to every Lyapunov solve)
+    d = D.steel_profile(371)
+    L, Dm = D.initial_value(d)
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    gp = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
+    ref = D.solve_gdre(gp, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p))), dt=-100.0)
+    my2 = My()
+    sol = D.solve_gdre(gp, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p), inner_alg=my2)), dt=-100.0)
+    assert my2.calls > 10 and D.delta(sol.K[-1], ref.K[-1]) < 1e-9
