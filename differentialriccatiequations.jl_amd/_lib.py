@@ -83,6 +83,7 @@ PROTOTYPES = {
     "dre_shift_factor": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _pvp]),
     "dre_shift_solve": (C.c_int, [_vp, _vp, _vp, _pvp, _pvp]),
     "dre_shift_solve_smw": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _pvp, _pvp]),
+    "dre_factor_growth": (C.c_int, [_vp, _vp, _pd]),
     "dre_factor_free": (C.c_int, [_vp, _vp]),
     "dre_ldlt_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _pvp]),
     "dre_ldlt_zero": (C.c_int, [_vp, _vp, C.c_int, _pvp]),
@@ -119,6 +120,7 @@ PROTOTYPES = {
     "dre_gdre_result_K_device": (C.c_int, [_vp, _vp, _vp]),
     "dre_gdre_result_X": (C.c_int, [_vp, C.c_int, _pvp]),
     "dre_gdre_result_gale": (C.c_int, [_vp, C.c_int, _pi64, _pd]),
+    "dre_gdre_result_gale_history": (C.c_int, [_vp, C.c_int, _pi64, _pd, _pi32, _pd, _pd]),
     "dre_gdre_result_free": (C.c_int, [_vp]),
     "dre_host_eigvals": (C.c_int, [C.c_int, _pd, _pd, _pd]),
     "dre_host_gen_eigvals": (C.c_int, [C.c_int, _pd, _pd, _pd, _pd]),

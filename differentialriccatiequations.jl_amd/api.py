@@ -810,16 +810,25 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
             gi = (C.c_int64 * 4)()
             gd = (C.c_double * 2)()
             lib.dre_gdre_result_gale(r, j, gi, gd)
-            gales.append(dict(iters=gi[0], converged=bool(gi[1]), warnings=gi[2], rhs_cols=gi[3], res_norm=gd[0], abstol=gd[1]))
+            cnt = (C.c_int64 * 2)()
+            lib.dre_gdre_result_gale_history(r, j, cnt, None, None, None, None)
+            norms, nit = np.zeros(cnt[0]), np.zeros(cnt[0], dtype=np.int32)
+            sre, sim = np.zeros(max(cnt[1], 1)), np.zeros(max(cnt[1], 1))
+            lib.dre_gdre_result_gale_history(r, j, cnt, norms.ctypes.data_as(C.POINTER(C.c_double)), nit.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             sre.ctypes.data_as(C.POINTER(C.c_double)), sim.ctypes.data_as(C.POINTER(C.c_double)))
+            gales.append(dict(iters=gi[0], converged=bool(gi[1]), warnings=gi[2], rhs_cols=gi[3], res_norm=gd[0], abstol=gd[1],
+                              norms=norms, norm_iters=nit, shifts=(sre + 1j * sim)[:cnt[1]]))
     finally:
         lib.dre_gdre_result_free(r)
     per_step = ngale // max(nt - 1, 1) if nt > 1 else 0
     _call(observer, "observe_gdre_step", t[0], Xs[0], Ks[0])
     for i in range(1, nt):
         for g in gales[(i - 1) * per_step:i * per_step]:
+            # per-iteration hooks in the order of adi.jl:37,65,103,119,192: the loop ran device resident, so X and the residual object of
+            # the intermediate iterations are not materialised (None); the norms and shifts are the recorded ones
+            _replay_gale(observer, None, inner, g)
             _call(observer, "observe_gale_done", g["iters"], None, None, g["res_norm"])
             if not g["converged"]:
-                _call(observer, "observe_gale_failed")
                 if inner.warn_convergence:
                     warnings.warn(f"ADI did not converge: residual={g['res_norm']} abstol={g['abstol']} maxiters={inner.maxiters}")
         Xi = Xs[i] if save_state else (Xs[-1] if i == nt - 1 else None)

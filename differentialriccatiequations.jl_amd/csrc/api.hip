@@ -129,6 +129,8 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
         else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
+        else if (key == "pivot_growth_warn") ctx->c.pivot_growth_warn = value;
+        else if (key == "pivot_growth_fail") ctx->c.pivot_growth_fail = value;
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
     });
 }
@@ -430,6 +432,9 @@ int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const d
         }
     });
 }
+int dre_factor_growth(dre_ctx* ctx, const dre_factor* f, double* growth) {
+    return guarded(ctx, [&] { *growth = f->is_cplx ? mf_check(&ctx->c, f->fc) : mf_check(&ctx->c, f->fr); });
+}
 int dre_factor_free(dre_ctx*, dre_factor* f) { delete f; return DRE_OK; }
 
 // ---- LDLt --------------------------------------------------------------------------------------
@@ -702,6 +707,14 @@ int dre_gdre_result_gale(const dre_gdre_result* r, int j, int64_t* iinfo, double
     const AdiResult& a = r->r.gale[j];
     iinfo[0] = a.iters; iinfo[1] = a.converged; iinfo[2] = a.warnings; iinfo[3] = a.rhs_cols;
     dinfo[0] = a.res_norm; dinfo[1] = a.abstol;
+    return DRE_OK;
+}
+int dre_gdre_result_gale_history(const dre_gdre_result* r, int j, int64_t* counts, double* norms, int32_t* norm_iters, double* sre, double* sim) {
+    if (j < 0 || j >= (int)r->r.gale.size()) return DRE_ERR_INVALID;
+    const AdiResult& g = r->r.gale[j];
+    if (counts) { counts[0] = (int64_t)g.norms.size(); counts[1] = (int64_t)g.shifts.size(); }
+    for (size_t i = 0; i < g.norms.size(); ++i) { if (norms) norms[i] = g.norms[i]; if (norm_iters) norm_iters[i] = g.norm_iters[i]; }
+    for (size_t i = 0; i < g.shifts.size(); ++i) { if (sre) sre[i] = g.shifts[i].real(); if (sim) sim[i] = g.shifts[i].imag(); }
     return DRE_OK;
 }
 int dre_gdre_result_free(dre_gdre_result* r) { delete r; return DRE_OK; }

@@ -127,6 +127,9 @@ struct Ctx {
     // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps
     // (engine.hip, ros1_dense_step); 0 disables
     int dense_x_max_n = 512;
+    // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
+    // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
+    double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;
     int x_side_stream = 1;
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)

@@ -913,9 +913,11 @@ struct AdiRun {
     size_t cyc = 0;
     // every factorisation is checked once per chunk, after the chunk's synchronisation (the breakdown flag is written by the
     // factorisation kernels only); the handles are dropped then, so single-use factors are freed chunk by chunk
+    double max_growth = 0.0;         // largest pivot growth among the factorisations this solve used
+    LDLt Crhs;                       // the right-hand side (shallow copy) for the true-residual verification after a growth warning
     void check_used() {
-        for (auto& f : used_real) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
-        for (auto& f : used_cplx) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        for (auto& f : used_real) { if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; } max_growth = std::max(max_growth, f->growth); }
+        for (auto& f : used_cplx) { if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; } max_growth = std::max(max_growth, f->growth); }
         used_real.clear(); used_cplx.clear();
     }
 };
@@ -971,6 +973,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     run.X = X; run.resid = resid; run.alpha_res = alpha_res; run.abstol = abstol; run.ctf = ctf; run.cex = cex; run.tdiag = tdiag;
     run.n = n; run.k = k; run.m = op.has_lr ? op.U.cols : 0;
     run.Xw = std::make_shared<LDLt>(*X);        // the iterate: never mutate the caller's initial guess (adi.jl:174 builds a new list)
+    run.Crhs = C;
     if (norm0 <= abstol || k == 0) { res.converged = true; run.finished = true; return runp; }
 
     std::unique_ptr<ShiftOracle>& oracle = run.oracle;
@@ -1422,6 +1425,16 @@ AdiResult adi_finish(AdiRun& run) {
     res.shifts = all_shifts;
     res.X = Xw;
     res.converged = res.res_norm <= abstol;
+    if (run.max_growth > ctx->pivot_growth_warn) {
+        // The pivot-free LU met huge multipliers: the residual recurrence R <- R - 2 mu E'V may not describe X any more.  The claim is
+        // checked once against the residual evaluated from scratch (lyapunov/residual.jl:3-31); a solve that only looks converged is
+        // reported as not converged.
+        res.warnings |= 16;
+        LDLt Ccopy = run.Crhs;
+        LDLtP tr = gale_residual(ctx, run.op, Ccopy, Xw, 4.0, true);
+        const double tn = tr->rank() ? ldlt_norm(ctx, *tr) : 0.0;
+        if (tn > 10.0 * std::max(res.res_norm, abstol)) { res.res_norm = tn; res.converged = tn <= abstol; }
+    }
     if (!res.converged) res.warnings |= 1;
     return res;
 }
@@ -1876,7 +1889,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             if (h.done || acc_it < nit || iters_host >= adi.maxiters) finished = true;
         }
         acc_total = iters_host;
-        for (auto& f : co.fe) if (!f->checked) { mf_check(ctx, f->f); f->checked = true; }
+        for (auto& f : co.fe) if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; }
         if (sx.land->serr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
         // X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated, one GEMM)
         if (acc_total > 0) {

@@ -53,7 +53,7 @@ void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true)
 // `stack` = [inv; E' inv; U' inv] ((2n + m) x n) for the low-rank factor U of the current operator: ONE GEMM with the residual
 // factor R then yields the plain solve, its image under E' (for the residual recurrence) and the SMW inner products.
 template <typename T> struct FactorEntry { Factor<T> f; Mat dinv; bool dense = false; Mat stack; const void* stack_U = nullptr; int stack_m = -1;
-                                            bool checked = false; /* pivot-breakdown flag already read back */ };
+                                            bool checked = false; /* pivot-breakdown flag already read back */ double growth = 0.0; /* its pivot growth */ };
 struct FactorCache {
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<double>>> real;
     std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<cplx>>> cplx_;

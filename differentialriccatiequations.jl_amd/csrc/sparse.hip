@@ -202,8 +202,15 @@ struct MfArgs {
 
 // One workgroup per front of the level: extend-add the children's Schur complements, eliminate the
 // s pivot columns (right-looking, no pivoting), then invert the two triangular diagonal blocks.
+// Pivot growth of the pivot-free LU: the largest multiplier |l_ik| = |a_ik / pivot| met anywhere in the factorisation.  The reference
+// factorises with pivoting (UMFPACK / CHOLMOD, blocklinear/backslash.jl:13); without it a tiny non-zero pivot gives huge multipliers
+// and a silently inaccurate solve, so the growth is recorded (bit pattern of a non-negative double, atomic max) and judged by mf_check.
+__device__ __forceinline__ void growth_commit(double g, unsigned long long* out) {
+    for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
+    if ((threadIdx.x & 63) == 0 && g > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(g));
+}
 template <typename T>
-__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err) {
+__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err, unsigned long long* __restrict__ growth) {
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -219,12 +226,13 @@ __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, 
         }
         __syncthreads();
     }
+    double gmax = 0.0;
     for (int k = 0; k < s; ++k) {
         __syncthreads();
         const T piv = F[k + (size_t)k * f];
         if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) { if (tid == 0) *err = 1; return; }
         const T rp = recip(piv);
-        for (int i = k + 1 + tid; i < f; i += nt) F[i + (size_t)k * f] *= rp;
+        for (int i = k + 1 + tid; i < f; i += nt) { const T l = F[i + (size_t)k * f] * rp; F[i + (size_t)k * f] = l; gmax = fmax(gmax, abs1(l)); }
         __syncthreads();
         const int nr = f - k - 1;
         for (int id = tid; id < nr * nr; id += nt) {
@@ -232,6 +240,7 @@ __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, 
             F[i + (size_t)j * f] -= F[i + (size_t)k * f] * F[k + (size_t)j * f];
         }
     }
+    growth_commit(gmax, growth);
     __syncthreads();
     T* Ti = inv + a.inv_off[t];
     for (int j = tid; j < s; j += nt) {
@@ -272,8 +281,9 @@ template <> __device__ __forceinline__ cplx group16_sum<cplx>(cplx v) {
 #define FF_NB 16
 template <typename T>
 __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv,
-                                                               int* __restrict__ err, int inv_lds) {
+                                                               int* __restrict__ err, int inv_lds, unsigned long long* __restrict__ growth) {
     extern __shared__ double ffraw[];
+    double gmax = 0.0;
     T* sm = reinterpret_cast<T*>(ffraw);
     __shared__ int bad;
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
@@ -306,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl
             if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) bad = 1;      // every thread sees the same value
             const T rp = recip(piv);
             __syncthreads();
-            for (int r = c + 1 + tid; r < rows; r += nt) Pn[r + c * rows] *= rp;
+            for (int r = c + 1 + tid; r < rows; r += nt) { const T l = Pn[r + c * rows] * rp; Pn[r + c * rows] = l; gmax = fmax(gmax, abs1(l)); }
             __syncthreads();
             const int nr = rows - c - 1, ncc = jb - c - 1;
             for (int id = tid; id < nr * ncc; id += nt) {
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl
             __syncthreads();
         }
         if (bad) { if (tid == 0) *err = 1; return; }
+        if (kb + FF_NB >= s) growth_commit(gmax, growth);       // last panel of this front
         // row panel: U12 = inv(L11) A12, one thread per column
         for (int c = tid; c < nc; c += nt) {
             T* u = U + c * FF_NB;
@@ -421,9 +432,11 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
     TimedScope ts(ctx, sizeof(T) == 8 ? "mf_factor_real" : "mf_factor_complex", (double)sizeof(T) * 2.0 * S.fronts_size, 0);
     DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(T), ctx->stream));
     if (!out.err.p) out.err = DevArr<int>(ctx, 1);
+    if (!out.growth.p) out.growth = DevArr<unsigned long long>(ctx, 1);
     out.topinv = Mat(); out.uses = 0;          // a new factorisation invalidates the dense top inverse
     DevArr<int>& err = out.err;
     DRE_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
+    DRE_HIP(hipMemsetAsync(out.growth.p, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p);
     MfArgs a = mf_args(P);
     for (int l = S.nlevels - 1; l >= 0; --l) {
@@ -436,23 +449,31 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
             const int inv_lds = inv_b <= lim ? 1 : 0;
             const size_t shm = std::max(panel_b, inv_lds ? inv_b : (size_t)0);
             lds_attr(ctx, (const void*)k_front_factor_blocked<double>, 150 * 1024); lds_attr(ctx, (const void*)k_front_factor_blocked<cplx>, 150 * 1024);
-            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds);
+            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds, out.growth.p);
         } else {
-            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p);
+            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, out.growth.p);
         }
     }
     DRE_HIP(hipGetLastError());
 }
 template <typename T>
-void mf_check(Ctx* ctx, const Factor<T>& F) {
-    if (!F.err.p) return;
+double mf_check(Ctx* ctx, const Factor<T>& F) {
+    if (!F.err.p) return 0.0;
     int herr = 0;
+    unsigned long long hg = 0;
     DRE_HIP(hipMemcpyAsync(&herr, F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (F.growth.p) DRE_HIP(hipMemcpyAsync(&hg, F.growth.p, sizeof(hg), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipStreamSynchronize(ctx->stream));
     if (herr) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
+    double g;
+    std::memcpy(&g, &hg, sizeof(g));
+    if (!(g == g) || g > ctx->pivot_growth_fail)
+        throw Error(ERR_SINGULAR, "mf_factor: pivot growth " + std::to_string(g) + " of the pivot-free LU exceeds the limit (pivot_growth_fail): the shifted operator "
+                                  "needs pivoting; use a user block solver (dre_adi_options.inner_solve) for this pencil");
+    return g;
 }
-template void mf_check<double>(Ctx*, const Factor<double>&);
-template void mf_check<cplx>(Ctx*, const Factor<cplx>&);
+template double mf_check<double>(Ctx*, const Factor<double>&);
+template double mf_check<cplx>(Ctx*, const Factor<cplx>&);
 template void mf_factor<double>(Ctx*, const Pencil&, const double*, const double*, double, double, Factor<double>&);
 template void mf_factor<cplx>(Ctx*, const Pencil&, const double*, const double*, cplx, cplx, Factor<cplx>&);
 

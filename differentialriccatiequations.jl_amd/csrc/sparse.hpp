@@ -93,6 +93,7 @@ struct Factor {
     DevArr<T> fronts;   // all frontal matrices (L\U of the eliminated block, L21, U12, Schur complement)
     DevArr<T> inv;      // inverted diagonal blocks: strict lower = inv(L11), upper = inv(U11)
     DevArr<int> err;    // device flag: zero / NaN pivot met (checked lazily by mf_check)
+    DevArr<unsigned long long> growth;   // largest multiplier of the pivot-free LU (bit pattern of a double, atomic max)
     // dense inverse of the top levels' Schur complement (real MFMA sweeps only): built at the third multi-column solve of a factor
     // the engine marked as reusable
     bool allow_topinv = false;
@@ -104,8 +105,9 @@ struct Factor {
 template <typename T>
 void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out);
 // Synchronises and throws ERR_SINGULAR if the factorisation met a zero pivot.
+// Also returns the pivot growth (largest multiplier); throws ERR_SINGULAR beyond ctx->pivot_growth_fail.
 template <typename T>
-void mf_check(Ctx* ctx, const Factor<T>& F);
+double mf_check(Ctx* ctx, const Factor<T>& F);
 // In-place solve  M * X = W  for the n x nrhs panel W (column-major, leading dimension ldw), solver ordering.
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& F, T* W, int ldw, int nrhs, const AdiState* st = nullptr);

@@ -199,6 +199,13 @@ class Factor:
         return Xr
 
 
+    def growth(self) -> float:
+        """Largest multiplier of the pivot-free LU (dre_factor_growth)."""
+        g = C.c_double()
+        ctx = self.pencil.ctx
+        ctx.chk(ctx.lib.dre_factor_growth(ctx.ptr, self.ptr, C.byref(g)))
+        return g.value
+
     def solve_smw(self, alpha, U, Vt, B):
         """(M + inv(alpha) Vt U') \\ B through Sherman-Morrison-Woodbury (dre_shift_solve_smw; blocklinear/sherman-morrison-woodbury.jl:10-45)."""
         ctx = self.pencil.ctx

@@ -42,6 +42,8 @@ extern "C" {
 #define DRE_WARN_NOT_CONVERGED 1      /* src/lyapunov/adi.jl:125-126 */
 #define DRE_WARN_RITZ_DISCARDED 4     /* src/shifts/helpers.jl:133 */
 #define DRE_WARN_RITZ_FLIPPED 8       /* src/shifts/helpers.jl:136 */
+#define DRE_WARN_PIVOT_GROWTH 16      /* the pivot-free sparse LU met multipliers above "pivot_growth_warn" (default 1e8); the convergence claim of
+                                         this solve was re-checked against the residual evaluated from scratch (see dre_shift_factor) */
 
 typedef struct dre_ctx dre_ctx;
 typedef struct dre_dense dre_dense;
@@ -71,6 +73,9 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               levels of the elimination tree with at most this many pivot variables are applied as ONE dense inverse
  *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
  *                               env DRE_TOP_INVERSE_MAX_ROWS)
+ *   "pivot_growth_warn" / "pivot_growth_fail"   thresholds on the largest multiplier of the pivot-free sparse LU (defaults 1e8 / 1e13), see dre_shift_factor
+ *   "dense_x_max_n"            Ros1 without save_state, real Cyclic shifts, n <= value (default 512): X is carried as a dense symmetric n x n matrix
+ *                               between the time steps and converted to LDL' form once at the end (env DRE_DENSE_X_MAX_N; 0 disables)
  *   "x_side_stream"             Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments" and its
  *                               compression (adi.jl:78-80) runs on a second stream beside the next time step (default 1; env
  *                               DRE_X_SIDE_STREAM);  "x_compress_every" = s (default 1) with x_side_stream = 0: single stream,
@@ -118,7 +123,13 @@ int dre_orthf(dre_ctx* ctx, const dre_dense* L, dre_dense** Q, dre_dense** R);
 /* eigen(Symmetric(S)) with early-terminating tridiagonalisation (src/LDLt.jl:214); returns the j computed
  * eigenpairs (all those above tolfac*eps*||S||_F in magnitude), values ascending */
 int dre_sym_eig(dre_ctx* ctx, const dre_dense* S, double tolfac, dre_dense** values, dre_dense** vectors);
-/* factorize(cA*A' + (cE_re + i cE_im)*E')  (src/blocklinear/backslash.jl:8-15); complex iff cE_im != 0 */
+/* factorize(cA*A' + (cE_re + i cE_im)*E')  (src/blocklinear/backslash.jl:8-15); complex iff cE_im != 0.
+ * The multifrontal LU does NOT pivot (the reference's UMFPACK / CHOLMOD do): it is exact-arithmetic safe for the pencils of the path
+ * (-(A + pE) symmetric positive definite for real p < 0, complex symmetric with definite parts otherwise) and for diagonally dominant
+ * ones.  For anything else the largest multiplier |l_ik| is tracked: above "pivot_growth_fail" (default 1e13; dre_ctx_set_option) the
+ * factorisation is rejected with DRE_ERR_SINGULAR, above "pivot_growth_warn" (default 1e8) ADI results carry DRE_WARN_PIVOT_GROWTH and
+ * their convergence claim is verified against the true residual.  Pencils that need pivoting take a user block solver
+ * (dre_adi_options.inner_solve). */
 int dre_shift_factor(dre_ctx* ctx, const dre_pencil* p, double cA, double cE_re, double cE_im, dre_factor** out);
 /* X = F \ B  (src/blocklinear/backslash.jl:17-21); X_im may be NULL for a real factor */
 int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_dense** X_re, dre_dense** X_im);
@@ -127,6 +138,7 @@ int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_d
  * U and Vt are n x m (m <= DRE_SMW_MAX_RANK); complex iff the factor is. */
 int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const dre_dense* U, const dre_dense* Vt, const dre_dense* B,
                         dre_dense** X_re, dre_dense** X_im);
+int dre_factor_growth(dre_ctx* ctx, const dre_factor* f, double* growth);   /* largest multiplier met by the pivot-free LU */
 int dre_factor_free(dre_ctx* ctx, dre_factor* f);
 
 /* ---- LDLᵀ objects (src/LDLt.jl) ------------------------------------------------------------ */
@@ -235,6 +247,9 @@ int dre_gdre_result_K_device(dre_ctx* ctx, const dre_gdre_result* r, double* K_d
 int dre_gdre_result_X(const dre_gdre_result* r, int i, dre_ldlt** X);   /* shares the factors (sol.X[1] === prob.X0) */
 /* per Lyapunov solve j: iinfo [0]=iters [1]=converged [2]=warnings [3]=rhs columns; dinfo [0]=res_norm [1]=abstol */
 int dre_gdre_result_gale(const dre_gdre_result* r, int j, int64_t* iinfo, double* dinfo);
+/* per-iteration record of Lyapunov solve j for the observer replay (observe_gale_step! / observe_gale_metadata!, src/lyapunov/adi.jl:65,103,119,192):
+ * counts [0]=number of recorded norms (index 0 = initial residual) [1]=shifts consumed; pass NULL arrays to query the counts */
+int dre_gdre_result_gale_history(const dre_gdre_result* r, int j, int64_t* counts, double* norms, int32_t* norm_iters, double* shifts_re, double* shifts_im);
 int dre_gdre_result_free(dre_gdre_result* r);
 
 /* ---- host helpers exposed for CPU tests of the Projection shift pipeline ---------------------- */

@@ -98,8 +98,11 @@ def test_observer_sees_every_time_step(ctx, rail371):
     d, L, Dm = rail371
 
     class Obs:
-        def __init__(self): self.t, self.done, self.iters = [], 0, 0
+        def __init__(self): self.t, self.done, self.iters, self.steps, self.meta, self.starts = [], 0, 0, [], 0, 0
         def observe_gdre_step(self, t, X, K): self.t.append(t); assert K.shape == (7, 371)
+        def observe_gale_start(self, prob, alg): self.starts += 1
+        def observe_gale_step(self, i, X, res, nrm): self.steps.append((i, nrm))
+        def observe_gale_metadata(self, desc, mu): self.meta += 1; assert desc == "ADI shifts"
         def observe_gale_done(self, iters, X, res, nrm): self.iters += iters
         def observe_gdre_done(self): self.done += 1
 
@@ -107,6 +110,11 @@ def test_observer_sees_every_time_step(ctx, rail371):
     sol, st = D.solve_gdre(D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4300.0)),
                            D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(371)))), dt=-100.0, observer=ob, return_stats=True)
     assert ob.t == [4500.0, 4400.0, 4300.0] and ob.done == 1 and ob.iters == st["adi_iters"]   # the metric's numerator
+    # per-iteration hooks inside the time loop (adi.jl:65,103,119): one gale_start per Lyapunov solve, one metadata call per shift, one
+    # step call per recorded norm (iteration 0 = initial residual), norms decreasing to the tolerance
+    assert ob.starts == len(st["gales"]) and ob.meta == st["adi_iters"]
+    assert len(ob.steps) == st["adi_iters"] + len(st["gales"])
+    assert ob.steps[0][0] == 0 and ob.steps[1][0] == 1 and ob.steps[-1][1] <= st["gales"][-1]["abstol"]
 
 
 @pytest.mark.parametrize("n", [1357, 5177, 20209])

@@ -113,3 +113,44 @@ def test_sym_eig_early_termination_on_low_rank_indefinite(ctx):
     assert np.linalg.norm((V[:, keep] * w[keep]) @ V[:, keep].T - S) < 1e-13 * np.linalg.norm(S)
     w0, _ = _sym_eig(ctx, np.zeros((6, 6)))
     assert len(w0) == 0
+
+
+def test_pivot_free_lu_reports_growth_instead_of_a_silently_wrong_solve(ctx):
+    """The reference factorises with pivoting (UMFPACK, blocklinear/backslash.jl:13); the multifrontal LU here does not.  A stable,
+    non-symmetric, non-diagonally-dominant pencil built from 2 x 2 blocks  E = e I,  A = [[-e, 1], [-1, -e]]  (eigenvalues -1 +- i/e) has
+    pivots e (p - 1) for every real shift p: the factorisation reports the growth 1/(e |p - 1|) ~ 1e9, beyond the configured limit it is
+    rejected with DRE_ERR_SINGULAR, and an ADI solve flags DRE_WARN_PIVOT_GROWTH and verifies its convergence claim against the true
+    residual; SuperLU (pivoting) solves the same systems to full accuracy, and so does the engine with that solver plugged in."""
+    rng = np.random.default_rng(2)
+    nb, e = 12, 1e-9
+    n = 2 * nb
+    Eb = sp.block_diag([e * np.eye(2)] * nb)
+    Ab = sp.block_diag([np.array([[-e, 1.0], [-1.0, -e]])] * nb)
+    coup = sp.random(n, n, density=0.05, random_state=rng) * 1e-12          # a little coupling so that the tree has more than leaves
+    E, A = sp.csc_matrix(Eb), sp.csc_matrix(Ab + coup - coup.T)
+    P = D.Pencil(E, A, ctx)
+    mu = -0.5
+    f = P.factor(1.0, complex(mu))
+    g = f.growth()
+    assert 1e8 < g < 1e10
+    B = rng.standard_normal((n, 3))
+    X = f.solve(B)
+    M = (A.T + mu * E.T).tocsc()
+    Xref = spla.splu(M).solve(B)
+    err_nopiv = np.linalg.norm(X - Xref) / np.linalg.norm(Xref)
+    assert err_nopiv > 1e-12                        # the pivot-free solve really is degraded here (eps * growth) ...
+    ctx.set_option("pivot_growth_fail", 1e6)        # ... and with a strict limit the factorisation is refused
+    try:
+        with pytest.raises(D.DREError) as ei:
+            P.factor(1.0, complex(mu))
+        assert ei.value.code == -4
+    finally:
+        ctx.set_option("pivot_growth_fail", 1e13)
+    Cl = D.lowrank(rng.standard_normal((n, 2)), np.eye(2))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xa, info = D.solve_gale(D.GALEProblem(E, A, Cl), D.ADI(shifts=D.Shifts.Cyclic([-0.5, -1.5, -3.0]), maxiters=40), return_info=True)
+    assert info["warnings"] & 16
+    res_true = D.norm(D.residual(D.GALEProblem(E, A, Cl), Xa))
+    assert info["converged"] == (res_true <= 10 * info["abstol"]) or not info["converged"]
