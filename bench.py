@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--n", type=int, default=371, help="SteelProfile size (371 = the configuration the metric is quoted on)")
     ap.add_argument("--nsteps", type=int, default=45, help="Rosenbrock time steps per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["replicas", "strong"], default="replicas",
+                    help="replicas (default, weak scaling): one independent GDRE solve per GPU; strong: ONE Lyapunov solve of the first Rosenbrock "
+                         "step column-sharded over the GPUs (dre_amd.sharded: all_gather of V per ADI step over RCCL)")
     ap.add_argument("--cpu-steps", type=int, default=8, help="Rosenbrock time steps of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -58,6 +61,50 @@ def launch_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.run(cmd, env=env)
     raise SystemExit(proc.returncode)
+
+
+def strong_mode(args, D, d, L, Dm, shifts, ctx, pencil, rank, world, local_rank, torch, dist):
+    """Strong scaling: ONE Lyapunov solve (the first Rosenbrock-1 step's equation, zero initial guess) per "step", its residual block
+    column-sharded over the ranks (dre_amd/sharded.py).  The loop is host driven per ADI step (one all_gather each), so at small n it is
+    far slower than the device-resident single-GPU engine; it exists to measure the exchange pattern at n >= 5177."""
+    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps
+    n, tau = args.n, 100.0
+    K0 = (d.B.T @ L) @ Dm @ (L.T @ d.E)
+    G = np.hstack([d.C.T, d.E.T @ L])
+    BtLD = (d.B.T @ L) @ Dm
+    q = d.C.shape[0]
+    S = np.zeros((G.shape[1],) * 2); S[:q, :q] = np.eye(q); S[q:, q:] = BtLD.T @ BtLD + Dm / tau
+    comm = Comm()
+    ops = HipOps(ctx, pencil, 1.0, -1.0 / (2 * tau), d.B, K0, alpha=-1.0, device=torch.device("cuda", local_rank))
+    solver = ColumnShardedADI(ops, comm, list(shifts), maxiters=200)
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        res = solver.solve(G, S)
+    barrier()
+    t_start = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        res = solver.solve(G, S)
+        iters += res["iters"]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "ADI iterations/sec (one Lyapunov solve, column-sharded)", "value": iters / float(el.item()), "unit": "ADI iterations/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(el.item()) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"SteelProfile({n}) surrogate, first Ros1 Lyapunov equation (zero initial guess, {G.shape[1]} residual columns), "
+                                                 f"Cyclic real shifts, column-sharded ADI", "adi_iterations_per_solve": iters / args.steps,
+                                     "converged": bool(res["converged"]), "parallelism": f"columns x{world}, all_gather of V per ADI step",
+                                     "bytes_gathered_per_rank_per_solve": comm.bytes_gathered / max(args.steps + args.warmup, 1)},
+                          "roofline": None, "cpu_baseline": None}))
 
 
 def main():
@@ -92,6 +139,8 @@ def main():
     ctx = D.Context(local_rank)
     lib = ctx.lib
     pencil = D.Pencil(d.E, d.A, ctx)
+    if args.mode == "strong":
+        return strong_mode(args, D, d, L, Dm, shifts, ctx, pencil, rank, world, local_rank, torch, dist)
     # independent replicas: rank r starts from a slightly different X0 (0.01 * (1 + r/8) * L L')
     Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
     X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm * (1.0 + rank / 8.0), 1.0)

@@ -68,6 +68,8 @@ PROTOTYPES = {
     "dre_dense_upload": (C.c_int, [_vp, C.c_int, C.c_int, _pd, C.c_int, _pvp]),
     "dre_dense_create": (C.c_int, [_vp, C.c_int, C.c_int, _pvp]),
     "dre_dense_download": (C.c_int, [_vp, _vp, _pd, C.c_int]),
+    "dre_dense_from_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _pvp]),
+    "dre_dense_to_device": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "dre_dense_shape": (C.c_int, [_vp, _pint, _pint]),
     "dre_dense_free": (C.c_int, [_vp, _vp]),
     "dre_pencil_create": (C.c_int, [_vp, C.c_int, _pi64, _pi64, _pd, _pi64, _pi64, _pd, C.c_int, C.c_int, _pvp]),

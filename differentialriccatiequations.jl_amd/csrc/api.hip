@@ -209,6 +209,28 @@ static void download_mat(Ctx* c, const Mat& m, double* host, int ld) {
 int dre_dense_download(dre_ctx* ctx, const dre_dense* a, double* host, int ld) {
     return guarded(ctx, [&] { download_mat(&ctx->c, a->m, host, ld); });
 }
+// device-to-device interop with buffers the caller owns (e.g. the exchange tensors handed to RCCL): column-major, leading dimension ld
+int dre_dense_from_device(dre_ctx* ctx, int rows, int cols, const double* src_dev, int ld, dre_dense** out) {
+    return guarded(ctx, [&] {
+        DRE_REQUIRE(rows >= 0 && cols >= 0 && ld >= std::max(rows, 1), "dre_dense_from_device: bad shape");
+        auto* d = new dre_dense();
+        d->m = Mat(&ctx->c, rows, cols);
+        if (rows > 0 && cols > 0)
+            DRE_HIP(hipMemcpy2DAsync(d->m.p, (size_t)d->m.ld * sizeof(double), src_dev, (size_t)ld * sizeof(double), (size_t)rows * sizeof(double), cols,
+                                     hipMemcpyDeviceToDevice, ctx->c.stream));
+        DRE_HIP(hipStreamSynchronize(ctx->c.stream));
+        *out = d;
+    });
+}
+int dre_dense_to_device(dre_ctx* ctx, const dre_dense* a, double* dst_dev, int ld) {
+    return guarded(ctx, [&] {
+        DRE_REQUIRE(ld >= std::max(a->m.rows, 1), "dre_dense_to_device: bad leading dimension");
+        if (a->m.rows > 0 && a->m.cols > 0)
+            DRE_HIP(hipMemcpy2DAsync(dst_dev, (size_t)ld * sizeof(double), a->m.p, (size_t)a->m.ld * sizeof(double), (size_t)a->m.rows * sizeof(double), a->m.cols,
+                                     hipMemcpyDeviceToDevice, ctx->c.stream));
+        DRE_HIP(hipStreamSynchronize(ctx->c.stream));
+    });
+}
 int dre_dense_shape(const dre_dense* a, int* rows, int* cols) { *rows = a->m.rows; *cols = a->m.cols; return DRE_OK; }
 int dre_dense_free(dre_ctx*, dre_dense* a) { delete a; return DRE_OK; }
 

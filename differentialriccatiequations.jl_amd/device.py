@@ -73,6 +73,24 @@ class Context:
         self.chk(self.lib.dre_dense_upload(self.ptr, a.shape[0], a.shape[1], _dptr(a), max(a.shape[0], 1), C.byref(p)))
         return DenseMatrix(self, p)
 
+    def from_device(self, dev_ptr, rows, cols, ld=None) -> "DenseMatrix":
+        """library matrix from a caller-owned device buffer (column-major, leading dimension ld); device-to-device copy"""
+        p = C.c_void_p()
+        self.chk(self.lib.dre_dense_from_device(self.ptr, rows, cols, C.c_void_p(dev_ptr), int(ld or max(rows, 1)), C.byref(p)))
+        return DenseMatrix(self, p)
+
+    def to_device(self, M: "DenseMatrix", dev_ptr, ld=None):
+        r, c = M.shape
+        self.chk(self.lib.dre_dense_to_device(self.ptr, M.ptr, C.c_void_p(dev_ptr), int(ld or max(r, 1))))
+
+    def gemm(self, tA, tB, alpha, A: "DenseMatrix", B: "DenseMatrix") -> "DenseMatrix":
+        """alpha * op(A) * op(B) on the f64 MFMA path (dre_gemm)"""
+        ra, ca = A.shape
+        rb, cb = B.shape
+        out = self.zeros(ca if tA else ra, rb if tB else cb)
+        self.chk(self.lib.dre_gemm(self.ptr, int(bool(tA)), int(bool(tB)), float(alpha), A.ptr, B.ptr, 0.0, out.ptr))
+        return out
+
     def zeros(self, rows, cols) -> "DenseMatrix":
         p = C.c_void_p()
         self.chk(self.lib.dre_dense_create(self.ptr, rows, cols, C.byref(p)))
@@ -198,6 +216,19 @@ class Factor:
             return Xr + 1j * DenseMatrix(ctx, xi).numpy()
         return Xr
 
+
+    def solve_device(self, Bd: "DenseMatrix") -> "DenseMatrix":
+        """real factor: the solution stays on the device"""
+        ctx = self.pencil.ctx
+        xr, xi = C.c_void_p(), C.c_void_p()
+        ctx.chk(ctx.lib.dre_shift_solve(ctx.ptr, self.ptr, Bd.ptr, C.byref(xr), C.byref(xi)))
+        return DenseMatrix(ctx, xr)
+
+    def solve_smw_device(self, alpha, Ud: "DenseMatrix", Vtd: "DenseMatrix", Bd: "DenseMatrix") -> "DenseMatrix":
+        ctx = self.pencil.ctx
+        xr, xi = C.c_void_p(), C.c_void_p()
+        ctx.chk(ctx.lib.dre_shift_solve_smw(ctx.ptr, self.ptr, float(alpha), Ud.ptr, Vtd.ptr, Bd.ptr, C.byref(xr), C.byref(xi)))
+        return DenseMatrix(ctx, xr)
 
     def growth(self) -> float:
         """Largest multiplier of the pivot-free LU (dre_factor_growth)."""

@@ -92,6 +92,10 @@ int dre_prof_get(dre_ctx* ctx, int i, char* name, int name_len, double* ms, int6
 int dre_dense_upload(dre_ctx* ctx, int rows, int cols, const double* host, int ld, dre_dense** out);
 int dre_dense_create(dre_ctx* ctx, int rows, int cols, dre_dense** out);            /* zero-filled */
 int dre_dense_download(dre_ctx* ctx, const dre_dense* a, double* host, int ld);
+/* device-to-device interop with buffers the caller owns (the exchange buffers of the multi-GPU layer, e.g. a torch tensor's data_ptr):
+ * column-major with leading dimension ld; both synchronise the context's stream */
+int dre_dense_from_device(dre_ctx* ctx, int rows, int cols, const double* src_dev, int ld, dre_dense** out);
+int dre_dense_to_device(dre_ctx* ctx, const dre_dense* a, double* dst_dev, int ld);
 int dre_dense_shape(const dre_dense* a, int* rows, int* cols);
 int dre_dense_free(dre_ctx* ctx, dre_dense* a);
 

@@ -274,3 +274,27 @@ def test_user_block_solver_plugs_into_adi(ctx):                # blocklinear/typ
     my2 = My()
     sol = D.solve_gdre(gp, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p), inner_alg=my2)), dt=-100.0)
     assert my2.calls > 10 and D.delta(sol.K[-1], ref.K[-1]) < 1e-9
+
+
+def test_column_sharded_adi_device_ops_single_rank(ctx):
+    """dre_amd.sharded.HipOps (the per-rank work of the multi-GPU ADI through the C ABI + device-to-device exchange buffers) against the
+    SciPy stand-in the gloo test uses, world size 1: same iterates, and the sharded bookkeeping (column / row ranges) covers everything."""
+    import torch
+    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, NumpyOps, col_range, dense_solution
+    d = D.steel_profile(371)
+    L, Dm = D.initial_value(d)
+    tau = 100.0
+    P = D.Pencil(d.E, d.A, ctx)
+    K0 = (d.B.T @ L) @ Dm @ (L.T @ d.E)
+    G = np.hstack([d.C.T, d.E.T @ L])
+    BtLD = (d.B.T @ L) @ Dm
+    S = np.zeros((12, 12)); S[:6, :6] = np.eye(6); S[6:, 6:] = BtLD.T @ BtLD + Dm / tau
+    shifts = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    hip = ColumnShardedADI(HipOps(ctx, P, 1.0, -1.0 / (2 * tau), d.B, K0, alpha=-1.0, device=torch.device("cuda", 0)), Comm(rank=0, world=1), shifts).solve(G, S)
+    cpu = ColumnShardedADI(NumpyOps(d.E, (d.A - d.E / (2 * tau)).tocsc(), d.B, K0, alpha=-1.0), Comm(rank=0, world=1), shifts).solve(G, S)
+    assert hip["converged"] and hip["iters"] == cpu["iters"]
+    Xh, Xc = dense_solution(hip), dense_solution(cpu)
+    assert np.linalg.norm(Xh - Xc) < 1e-9 * np.linalg.norm(Xc)
+    for k, w in ((12, 8), (5, 8), (200, 3)):
+        rs = [col_range(k, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == k and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))

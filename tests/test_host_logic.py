@@ -102,3 +102,22 @@ def test_replica_gather_over_gloo_world_size_2():
                         "--master-port", "29533", script], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GLOO_OK world=2" in r.stdout
+
+
+def test_column_sharded_adi_over_gloo_world_size_2():
+    """Multi-GPU inside ONE Lyapunov solve (dre_amd.sharded): column blocks of the residual are solved per rank,
+    one all_gather of V per ADI step, row-sharded Gram + k x k all_reduce for the norm.  Two CPU processes over gloo with the SciPy stand-in
+    ops reproduce the single-rank iterates (same iteration count, same norms, same X), the dense Lyapunov residual and the oracle's ADI."""
+    script = os.path.join(ROOT, "tests", "_gloo_sharded_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", script], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "SHARDED_OK world=2" in r.stdout
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """bench.py --gpus N under a torchrun environment of another size must fail loudly instead of printing n_gpus = 1."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stdout + r.stderr)
