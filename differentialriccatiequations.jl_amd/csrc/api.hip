@@ -101,12 +101,14 @@ int dre_ctx_destroy(dre_ctx* ctx) {
         Ctx& sc = *ctx->c.side;
         (void)hipStreamSynchronize(sc.stream);
         sc.timer.reset(); sc.pool.trim();
+        if (sc.fetch_host) { (void)hipHostFree((void*)sc.fetch_host); sc.fetch_host = nullptr; }
         (void)hipEventDestroy(ctx->c.side_e1); (void)hipEventDestroy(ctx->c.side_e2);
         (void)hipStreamDestroy(sc.stream);
         ctx->c.side.reset();
     }
     ctx->c.timer.reset();
     ctx->c.pool.trim();
+    if (ctx->c.fetch_host) { (void)hipHostFree((void*)ctx->c.fetch_host); ctx->c.fetch_host = nullptr; }
     (void)hipStreamDestroy(ctx->c.stream);
     delete ctx;
     return DRE_OK;

@@ -126,7 +126,7 @@ struct Ctx {
     // beside the next time step (x_side_stream) or only every x_compress_every-th step (engine.hip, gdre_solve)
     // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps
     // (engine.hip, ros1_dense_step); 0 disables
-    int dense_x_max_n = 512;
+    int dense_x_max_n = 1536;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;
@@ -140,6 +140,13 @@ struct Ctx {
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
     bool attr_adi_fast = false;
+    // host-visible landing zone for small device->host reads on the critical path (ctx_fetch, dense.hip): a tiny kernel copies the words
+    // into pinned, device-mapped host memory and bumps a sequence number the host spins on — an order of magnitude cheaper than a copy
+    // command + hipStreamSynchronize per read-back
+    struct FetchZone { volatile unsigned long long seq; unsigned long long pad[7]; unsigned long long words[1024]; };
+    FetchZone* fetch_host = nullptr;   // host address
+    FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it
+    unsigned long long fetch_seq = 0;
     // kernels whose dynamic-LDS limit was raised for this context's device (hipFuncSetAttribute is per device, so the record is per
     // context, not per process)
     std::unordered_map<const void*, int> lds_attr_done;

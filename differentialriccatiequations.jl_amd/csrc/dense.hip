@@ -1,6 +1,8 @@
 // Dense f64 kernels for gfx950: MFMA GEMM, Householder QR, symmetric eigensolver, small helpers.
 #include "dense.hpp"
 #include "profiling.hpp"
+#include <atomic>
+#include <chrono>
 
 namespace dre {
 
@@ -496,6 +498,62 @@ void frob2_device(Ctx* ctx, const Mat& A, double* out_dev) {
     DevArr<double> part(ctx, 64);
     hipLaunchKernelGGL(k_frob2_parts, dim3(64), dim3(256), 0, ctx->stream, A.rows, A.cols, (const double*)A.p, A.ld, part.p);
     hipLaunchKernelGGL(k_frob2_finish, dim3(1), dim3(64), 0, ctx->stream, 64, (const double*)part.p, out_dev);
+}
+struct FetchSrc { const unsigned long long* p[3]; int n[3]; };
+__global__ __launch_bounds__(256) void k_fetch(FetchSrc s, unsigned long long* __restrict__ dst, unsigned long long* seq, unsigned long long value) {
+    int off = 0;
+    for (int a = 0; a < 3; ++a) {
+        for (int i = threadIdx.x; i < s.n[a]; i += 256) __hip_atomic_store(dst + off + i, s.p[a][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        off += s.n[a];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1, const void* d2, size_t b2, void* h2) {
+    static const bool spin_on = std::getenv("DRE_FETCH_SPIN") && std::atoi(std::getenv("DRE_FETCH_SPIN")) != 0;   // measured neutral at n = 371: off by default
+    const size_t tot = (b0 + b1 + b2) / 8;
+    DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
+    if (spin_on && !ctx->fetch_host) {
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, sizeof(Ctx::FetchZone), hipHostMallocMapped) == hipSuccess) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                ctx->fetch_host = (Ctx::FetchZone*)hp; ctx->fetch_dev = (Ctx::FetchZone*)dp;
+                ctx->fetch_host->seq = 0; ctx->fetch_seq = 0;
+            } else (void)hipHostFree(hp);
+        }
+    }
+    if (!spin_on || !ctx->fetch_host) {
+        if (b0) DRE_HIP(hipMemcpyAsync(h0, d0, b0, hipMemcpyDeviceToHost, ctx->stream));
+        if (b1) DRE_HIP(hipMemcpyAsync(h1, d1, b1, hipMemcpyDeviceToHost, ctx->stream));
+        if (b2) DRE_HIP(hipMemcpyAsync(h2, d2, b2, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        return;
+    }
+    FetchSrc s;
+    s.p[0] = (const unsigned long long*)d0; s.n[0] = (int)(b0 / 8);
+    s.p[1] = (const unsigned long long*)d1; s.n[1] = (int)(b1 / 8);
+    s.p[2] = (const unsigned long long*)d2; s.n[2] = (int)(b2 / 8);
+    const unsigned long long want = ++ctx->fetch_seq;
+    hipLaunchKernelGGL(k_fetch, dim3(1), dim3(256), 0, ctx->stream, s, (unsigned long long*)ctx->fetch_dev->words, (unsigned long long*)&ctx->fetch_dev->seq, want);
+    DRE_HIP(hipGetLastError());
+    // bounded spin on the host-visible sequence number, then the plain synchronisation as a safety net
+    const auto t0 = std::chrono::steady_clock::now();
+    bool ok = false;
+    for (long it = 0;; ++it) {
+        if (ctx->fetch_host->seq == want) { ok = true; break; }
+        if ((it & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+    }
+    if (!ok) {
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        DRE_REQUIRE(ctx->fetch_host->seq == want, "ctx_fetch: the signal kernel did not complete");
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned long long* w = (const unsigned long long*)ctx->fetch_host->words;
+    if (b0) std::memcpy(h0, w, b0);
+    if (b1) std::memcpy(h1, w + b0 / 8, b1);
+    if (b2) std::memcpy(h2, w + (b0 + b1) / 8, b2);
 }
 double frob_norm_host(Ctx* ctx, const Mat& A) {
     if (A.empty()) return 0.0;
@@ -1152,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     if (tid == 0) {
         __hip_atomic_store(a.nws + I, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + 8);
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + ADI_FAST_MAX_K / 16);
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tk == (unsigned)(ct - 1)) {
             double tot = 0.0;
@@ -2760,8 +2818,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
             k += b; ++np; ++issued;
         }
         AdiState h;
-        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        ctx_fetch(ctx, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
         if (h.done) { J = h.iters; np = J / b; finished = true; }
         else if (k >= q) { J = q; finished = true; }
         chunk = 4;

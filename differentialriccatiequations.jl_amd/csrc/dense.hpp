@@ -54,6 +54,10 @@ void add_diag(Ctx* ctx, Mat& dst, const double* diag_dev, double scale);  // dst
 void symmetrize(Ctx* ctx, Mat& S);                           // S = (S+S')/2
 void scale_cols_by_diag(Ctx* ctx, const Mat& L, const Mat& D, Mat& out, double alpha);  // out = alpha * L * diag(D_ii)
 double frob_norm_host(Ctx* ctx, const Mat& A);               // synchronising
+// Small device->host read-back ordered after everything enqueued on the context's stream so far (replaces hipMemcpyAsync + hipStreamSynchronize
+// on the critical path): up to three device ranges (multiples of 8 bytes, together at most 8 KB) land in the given host buffers.
+void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1 = nullptr, size_t b1 = 0, void* h1 = nullptr,
+               const void* d2 = nullptr, size_t b2 = 0, void* h2 = nullptr);
 void frob2_device(Ctx* ctx, const Mat& A, double* out_dev);   // ||A||_F^2 into device memory (no synchronisation)
 bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (small)
 
@@ -74,7 +78,7 @@ void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpa
 void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend);
 // Fast ADI chain (dense.hip): SMW-folded stacked inverse in MFMA-operand order, one launch per ADI iteration, residual norm
 // pipelined over the next two launches.
-#define ADI_FAST_MAX_K 128
+#define ADI_FAST_MAX_K 256
 inline int adi_fast_nstrip(int n) { return (n + 15) / 16; }
 inline int adi_fast_kst(int n) { return (n + 3) / 4; }
 inline size_t adi_fast_pack_doubles(int n) { return (size_t)2 * adi_fast_nstrip(n) * adi_fast_kst(n) * 64; }
@@ -92,7 +96,7 @@ struct AdiFastArgs {
     const double* G_prev2;      // Gram matrix the previous launch produced (norm + decision now), or null
     const double* T; int ldt; int tdiag; double alpha;
     AdiState* st;
-    double* nws;                // 8 partial sums + a ticket word (zero-initialised once per solve): meeting point of the norm workgroups
+    double* nws;                // ADI_FAST_MAX_K / 16 partial sums + a ticket word (zero-initialised once per solve): meeting point of the norm workgroups
     int it_prev2;               // shifts consumed after the iteration G_prev2 belongs to
     int do_strips;              // 0: flush launch (riders only)
     int chain_timed;            // 1: the caller brackets the whole chain with one TimedScope (adi_fast_chain_cost)

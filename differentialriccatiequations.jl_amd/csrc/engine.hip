@@ -1112,8 +1112,8 @@ void adi_advance(AdiRun& run, int budget) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         if (!run.fast_ready) {
             run.Gm = Mat(ctx, k * k, 2);
-            run.nws = DevArr<double>(ctx, 16);
-            DRE_HIP(hipMemsetAsync(run.nws.p, 0, 16 * sizeof(double), ctx->stream));
+            run.nws = DevArr<double>(ctx, ADI_FAST_MAX_K / 16 + 8);
+            DRE_HIP(hipMemsetAsync(run.nws.p, 0, (ADI_FAST_MAX_K / 16 + 8) * sizeof(double), ctx->stream));
             run.fast_ready = true;
         }
         Mat& Gm = run.Gm; auto& nws = run.nws;
@@ -1696,6 +1696,7 @@ struct CycleOps {
     std::vector<Mat> keep;
     std::vector<BufP> keepb;
     DevArr<int> serr;
+    DevArr<long long> serr8;      // the breakdown flag as an 8-byte word (read back together with the control block)
 };
 static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& fe) {
     const Pencil& P = *op.P;
@@ -1740,8 +1741,10 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
         co.pack.push_back(bm->second);
     }
     if (m) {
-        co.serr = DevArr<int>(ctx, 1);
-        DRE_HIP(hipMemsetAsync(co.serr.p, 0, sizeof(int), ctx->stream));
+        co.serr8 = DevArr<long long>(ctx, 1);
+        co.serr = DevArr<int>();
+        co.serr.buf = co.serr8.buf; co.serr.p = (int*)co.serr8.p; co.serr.n = 2;     // the kernels write the low word
+        DRE_HIP(hipMemsetAsync(co.serr8.p, 0, sizeof(long long), ctx->stream));
         gemm_batched(ctx, descs, "gemm_dinv");
         for (size_t b0 = 0; b0 < hb.size(); b0 += 16) {
             SmwBatchArgs ba;
@@ -1764,6 +1767,28 @@ struct DenseXState {
     // pinned host landing zone: control block, tolerances and the SMW breakdown flag come back with ONE synchronisation per chunk
     struct Landing { AdiState st; double tols[4]; int serr; };
     Landing* land = nullptr;
+    // optional phase timing (DRE_PHASE_TIMING=1): events at the phase boundaries of every step, summed at the end
+    bool phase_on = std::getenv("DRE_PHASE_TIMING") != nullptr;
+    std::vector<hipEvent_t> pev;
+    std::vector<int> ptag;
+    void mark(Ctx* ctx, int tag) {
+        if (!phase_on) return;
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, ctx->stream);
+        pev.push_back(e); ptag.push_back(tag);
+    }
+    void report() {
+        if (!phase_on || pev.size() < 2) return;
+        (void)hipEventSynchronize(pev.back());
+        static const char* names[] = {"start", "assembly", "band_reduce", "basis+init", "adi_chain", "sync+xupdate", "feedback"};
+        double acc[8] = {0};
+        for (size_t i = 1; i < pev.size(); ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, pev[i - 1], pev[i]); if (ptag[i] > 0 && ptag[i] < 8) acc[ptag[i]] += ms; }
+        double tot = 0; for (int i = 1; i < 7; ++i) tot += acc[i];
+        std::fprintf(stderr, "[phase timing, ms per solve] ");
+        for (int i = 1; i < 7; ++i) std::fprintf(stderr, "%s %.2f | ", names[i], acc[i]);
+        std::fprintf(stderr, "sum %.2f\n", tot);
+        for (auto e : pev) (void)hipEventDestroy(e);
+        pev.clear(); ptag.clear();
+    }
     DenseXState() { if (hipHostMalloc((void**)&land, sizeof(Landing), hipHostMallocDefault) != hipSuccess) land = nullptr; }
     ~DenseXState() { if (land) (void)hipHostFree(land); }
     DenseXState(const DenseXState&) = delete;
@@ -1787,6 +1812,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     CycleOps co;
     if (!cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co)) return false;
     if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+    sx.mark(ctx, 0);
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side
     Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
     transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
@@ -1798,8 +1824,10 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                        (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
     hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
+    sx.mark(ctx, 1);
     // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1);
+    sx.mark(ctx, 2);
     const int k = sb.J;
     DevArr<AdiState> st(ctx, 1);
     AdiState h;
@@ -1816,10 +1844,11 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         Mat Tm = sb.D;
         hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p);
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
+        sx.mark(ctx, 3);
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         Mat Gm(ctx, k * k, 2);
-        DevArr<double> nws(ctx, 16);
-        DRE_HIP(hipMemsetAsync(nws.p, 0, 16 * sizeof(double), ctx->stream));
+        DevArr<double> nws(ctx, ADI_FAST_MAX_K / 16 + 8);
+        DRE_HIP(hipMemsetAsync(nws.p, 0, (ADI_FAST_MAX_K / 16 + 8) * sizeof(double), ctx->stream));
         // the whole solve is enqueued at once (one more iteration than the previous step needed); further chunks only if that was not enough
         int iters_host = 0;
         size_t cyc = 0;
@@ -1873,11 +1902,14 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 adi_fast_iter(ctx, a);
             }
             chain_ts.reset();
-            DRE_HIP(hipMemcpyAsync(&sx.land->st, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
-            DRE_HIP(hipMemcpyAsync(sx.land->tols, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-            if (m) DRE_HIP(hipMemcpyAsync(&sx.land->serr, co.serr.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            else sx.land->serr = 0;
-            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            sx.mark(ctx, 4);
+            {
+                // control block (header + the norms of this chunk), tolerances and the SMW breakdown flag in ONE read-back
+                const size_t stb = sizeof(int) * 4 + sizeof(double) * (2 + (size_t)std::min(511, base_it + nit + 1));
+                long long serr8 = 0;
+                ctx_fetch(ctx, st.p, stb, &sx.land->st, tols.p, 4 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
+                sx.land->serr = (int)serr8;
+            }
             h = sx.land->st;
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
             for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[base_it + j]); ar.norm_iters.push_back(base_it + j); }
@@ -1919,11 +1951,13 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     if (!ar.converged) ar.warnings |= 1;
     sx.hint = acc_total;
     cache->iters_hint = acc_total;
+    sx.mark(ctx, 5);
     // feedback of the new X:  P1 = E' X,  K' = P1 B      (lowrank_ros1.jl:53-56)
     spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
     Mat Kt(ctx, n, m);
     gemm(ctx, false, false, 1.0, sx.P1, prob.B, 0.0, Kt);
     sx.Kt = Kt;
+    sx.mark(ctx, 6);
     return true;
 }
 
@@ -2184,6 +2218,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         fb = feedback(ctx, prob, *X, ctf, cex);
         out.Kt.push_back(fb.Kt);
     }
+    sx.report();
     if (x_is_dense) X = dense_to_ldlt(ctx, n, sx.X, ctf);
     if (!save_state) out.X.push_back(X);
     out.nfactor = cache.nfactor;

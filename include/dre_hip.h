@@ -74,7 +74,7 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
  *                               env DRE_TOP_INVERSE_MAX_ROWS)
  *   "pivot_growth_warn" / "pivot_growth_fail"   thresholds on the largest multiplier of the pivot-free sparse LU (defaults 1e8 / 1e13), see dre_shift_factor
- *   "dense_x_max_n"            Ros1 without save_state, real Cyclic shifts, n <= value (default 512): X is carried as a dense symmetric n x n matrix
+ *   "dense_x_max_n"            Ros1 without save_state, real Cyclic shifts, n <= value (default 1536): X is carried as a dense symmetric n x n matrix
  *                               between the time steps and converted to LDL' form once at the end (env DRE_DENSE_X_MAX_N; 0 disables)
  *   "x_side_stream"             Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments" and its
  *                               compression (adi.jl:78-80) runs on a second stream beside the next time step (default 1; env
