@@ -1179,11 +1179,13 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     // workgroup b owns tile row b of M and N (one 16 x 16 tile per wave and pass), all operand loads are 128-byte column segments
     // issued before the first MFMA.  The ct partial sums meet through a ticket: the workgroup whose atomic add comes last sums
     // them in a fixed order and takes the decision of adi.jl:115-123.
-    const int I = b;
+    // workgroup b = (tile row I, group of four tile columns): one 16 x 16 tile pair per wave
+    const int ngrp = (ct + 3) >> 2;
+    const int I = b / ngrp, J0 = (b - I * ngrp) * 4;
     double sloc = 0.0;
     const double* __restrict__ G = a.G_prev2; const double* __restrict__ T = a.T;
     const int lr = lane & 15;
-    for (int J = wave; J < ct; J += 4) {
+    for (int J = J0 + wave; J < min(ct, J0 + 4); J += 4) {
         v4d mm = (v4d){0.0, 0.0, 0.0, 0.0}, nn = (v4d){0.0, 0.0, 0.0, 0.0};
         const int ri = I * 16 + lr, rj = J * 16 + lr;
         const bool iok = ri < k, jok = rj < k;
@@ -1208,13 +1210,14 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     }
     sloc = block_sum(sloc, nred);
     if (tid == 0) {
-        __hip_atomic_store(a.nws + I, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nrb = ct * ngrp;                       // norm workgroups of this launch
+        __hip_atomic_store(a.nws + b, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + ADI_FAST_MAX_K / 16);
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + ADI_FAST_NWS - 1);
         const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tk == (unsigned)(ct - 1)) {
+        if (tk == (unsigned)(nrb - 1)) {
             double tot = 0.0;
-            for (int i = 0; i < ct; ++i) tot += __hip_atomic_load(a.nws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < nrb; ++i) tot += __hip_atomic_load(a.nws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
             const double nrm = fabs(a.alpha) * sqrt(fmax(tot, 0.0));
             AdiState* st = a.st;
@@ -1235,12 +1238,12 @@ void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     const int ct = (a.k + 15) >> 4;
     const int nsw = a.do_strips ? 2 * a.nstrip * ct : 0;
     if (a.chain_timed) {
-        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), 0, ctx->stream, a);
     } else {
         double by, fl;
         adi_fast_cost(a, &by, &fl);
         TimedScope ts(ctx, a.do_strips ? "adi_fast_iter" : "adi_fast_flush", by, fl);
-        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), 0, ctx->stream, a);
     }
     DRE_HIP(hipGetLastError());
 }

@@ -78,7 +78,8 @@ void dense_adi_step(Ctx* ctx, int n, int m, int k, int splits, const double* Wpa
 void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, DenseNormPending* pend);
 // Fast ADI chain (dense.hip): SMW-folded stacked inverse in MFMA-operand order, one launch per ADI iteration, residual norm
 // pipelined over the next two launches.
-#define ADI_FAST_MAX_K 256
+#define ADI_FAST_MAX_K 512
+#define ADI_FAST_NWS 264          // doubles of the norm meeting point: (MAX_K/16) * (MAX_K/64) partial sums + the ticket word in the last slot
 inline int adi_fast_nstrip(int n) { return (n + 15) / 16; }
 inline int adi_fast_kst(int n) { return (n + 3) / 4; }
 inline size_t adi_fast_pack_doubles(int n) { return (size_t)2 * adi_fast_nstrip(n) * adi_fast_kst(n) * 64; }

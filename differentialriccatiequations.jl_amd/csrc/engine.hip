@@ -1112,8 +1112,8 @@ void adi_advance(AdiRun& run, int budget) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         if (!run.fast_ready) {
             run.Gm = Mat(ctx, k * k, 2);
-            run.nws = DevArr<double>(ctx, ADI_FAST_MAX_K / 16 + 8);
-            DRE_HIP(hipMemsetAsync(run.nws.p, 0, (ADI_FAST_MAX_K / 16 + 8) * sizeof(double), ctx->stream));
+            run.nws = DevArr<double>(ctx, ADI_FAST_NWS);
+            DRE_HIP(hipMemsetAsync(run.nws.p, 0, (ADI_FAST_NWS) * sizeof(double), ctx->stream));
             run.fast_ready = true;
         }
         Mat& Gm = run.Gm; auto& nws = run.nws;
@@ -1847,8 +1847,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         sx.mark(ctx, 3);
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         Mat Gm(ctx, k * k, 2);
-        DevArr<double> nws(ctx, ADI_FAST_MAX_K / 16 + 8);
-        DRE_HIP(hipMemsetAsync(nws.p, 0, (ADI_FAST_MAX_K / 16 + 8) * sizeof(double), ctx->stream));
+        DevArr<double> nws(ctx, ADI_FAST_NWS);
+        DRE_HIP(hipMemsetAsync(nws.p, 0, (ADI_FAST_NWS) * sizeof(double), ctx->stream));
         // the whole solve is enqueued at once (one more iteration than the previous step needed); further chunks only if that was not enough
         int iters_host = 0;
         size_t cyc = 0;

@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < hp.size(); ++i) hp[i] = 1e-3 * sin(0.37 * i);
         for (size_t i = 0; i < hr.size(); ++i) hr[i] = cos(0.11 * i);
         for (int i = 0; i < k; ++i) ht[i + (size_t)i * k] = 1.0;
-        double *P[10], *R, *V, *G, *T, *W; AdiState* st; hipMalloc(&W, 512); hipMemset(W, 0, 512);
+        double *P[10], *R, *V, *G, *T, *W; AdiState* st; hipMalloc(&W, ADI_FAST_NWS * 8); hipMemset(W, 0, ADI_FAST_NWS * 8);
         for (int j = 0; j < 10; ++j) { hipMalloc(&P[j], hp.size() * 8); hipMemcpy(P[j], hp.data(), hp.size() * 8, hipMemcpyHostToDevice); }
         hipMalloc(&R, hr.size() * 8 * (NIT + 1)); hipMalloc(&V, hr.size() * 8 * NIT); hipMalloc(&G, (size_t)k * k * 16); hipMalloc(&T, ht.size() * 8); hipMalloc(&st, sizeof(AdiState));
         hipMemcpy(R, hr.data(), hr.size() * 8, hipMemcpyHostToDevice); hipMemcpy(T, ht.data(), ht.size() * 8, hipMemcpyHostToDevice);
