@@ -1112,9 +1112,15 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
     const int k = a.k, ct = (k + 15) >> 4, n = a.n;
     int b = blockIdx.x;
-    const int nsw = a.do_strips ? 2 * a.nstrip * ct : 0;
+    // XCD-aware order of the tile workgroups: workgroups are dealt round-robin over the 8 XCDs, so the ct column tiles that re-read the same
+    // packed strip get indices that differ by a multiple of 8 (strip-major with a stride padded to 8; the padding workgroups exit) — the
+    // re-reads then hit that XCD's L2 instead of going out to the fabric ct times
+    const int hstride = (2 * a.nstrip + 7) & ~7;
+    const int nsw = a.do_strips ? hstride * ct : 0;
     if (b < nsw) {
-        const int tc = b % ct, hs = b / ct, half = hs / a.nstrip, s = hs - half * a.nstrip;
+        const int tc = b / hstride, hs = b - tc * hstride;
+        if (hs >= 2 * a.nstrip) return;
+        const int half = hs / a.nstrip, s = hs - half * a.nstrip;
         const int col = tc * 16 + (lane & 15);
         const bool colok = col < k;
         // old residual entry of the element this thread finishes in the epilogue (requested early)
@@ -1236,7 +1242,7 @@ void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops) {
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     DRE_REQUIRE(a.k >= 1 && a.k <= ADI_FAST_MAX_K, "adi_fast_iter: residual too wide");
     const int ct = (a.k + 15) >> 4;
-    const int nsw = a.do_strips ? 2 * a.nstrip * ct : 0;
+    const int nsw = a.do_strips ? ((2 * a.nstrip + 7) & ~7) * ct : 0;
     if (a.chain_timed) {
         hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), 0, ctx->stream, a);
     } else {
