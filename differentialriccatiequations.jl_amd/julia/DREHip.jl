@@ -9,7 +9,7 @@ module DREHip
 
 using LinearAlgebra, SparseArrays
 import CommonSolve
-import CommonSolve: solve
+import CommonSolve: solve, init, solve!, step!
 
 const LIB = get(ENV, "DRE_HIP_LIB", joinpath(@__DIR__, "..", "libdre_hip.so"))
 
@@ -18,15 +18,31 @@ struct DREError <: Exception
     msg::String
 end
 
+# Julia runs finalizers in no particular order, and a device object freed after its context would touch freed memory
+# (the pool lives in the context).  Every handle therefore counts itself in (`retain!`) and out (`release!`); the native context is
+# destroyed by whoever goes last — the Context's own finalizer or the last handle's.
 mutable struct Context
     ptr::Ptr{Cvoid}
+    live::Int          # device objects that still reference this context
+    dead::Bool         # the Context object itself has been finalized
     function Context(device::Integer=0)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:dre_ctx_create, LIB), Cint, (Cint, Ref{Ptr{Cvoid}}), device, out)
         rc == 0 || throw(DREError(rc, unsafe_string(ccall((:dre_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL))))
-        ctx = new(out[])
-        finalizer(c -> ccall((:dre_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.ptr), ctx)
+        ctx = new(out[], 0, false)
+        finalizer(ctx) do c
+            c.dead = true
+            c.live == 0 && c.ptr != C_NULL && (ccall((:dre_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), c.ptr); c.ptr = C_NULL)
+        end
     end
+end
+retain!(ctx::Context) = (ctx.live += 1; ctx)
+function release!(ctx::Context)
+    ctx.live -= 1
+    if ctx.dead && ctx.live == 0 && ctx.ptr != C_NULL
+        ccall((:dre_ctx_destroy, LIB), Cint, (Ptr{Cvoid},), ctx.ptr); ctx.ptr = C_NULL
+    end
+    nothing
 end
 
 function chk(ctx::Context, rc)
@@ -51,8 +67,8 @@ function upload(ctx::Context, A::AbstractMatrix{<:Real})
     out = Ref{Ptr{Cvoid}}(C_NULL)
     chk(ctx, ccall((:dre_dense_upload, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Cint, Ref{Ptr{Cvoid}}),
                    ctx.ptr, size(M, 1), size(M, 2), M, max(size(M, 1), 1), out))
-    d = Dense(ctx, out[])
-    finalizer(x -> ccall((:dre_dense_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.ptr, x.ptr), d)
+    d = Dense(retain!(ctx), out[])
+    finalizer(x -> (ccall((:dre_dense_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.ptr, x.ptr); release!(x.ctx)), d)
 end
 
 # A Julia SparseMatrixCSC is handed over verbatim: CSC of M is CSR of M' (include/dre_hip.h conventions)
@@ -67,8 +83,8 @@ function Pencil(ctx::Context, E::SparseMatrixCSC{Float64,Int64}, A::SparseMatrix
     chk(ctx, ccall((:dre_pencil_create, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Cint, Cint, Ref{Ptr{Cvoid}}),
                    ctx.ptr, n, E.colptr, E.rowval, E.nzval, A.colptr, A.rowval, A.nzval, 1, leaf_size, out))
-    p = Pencil(ctx, out[], n)
-    finalizer(x -> ccall((:dre_pencil_free, LIB), Cint, (Ptr{Cvoid},), x.ptr), p)
+    p = Pencil(retain!(ctx), out[], n)
+    finalizer(x -> (ccall((:dre_pencil_free, LIB), Cint, (Ptr{Cvoid},), x.ptr); release!(x.ctx)), p)
 end
 Pencil(ctx, E, A; kw...) = Pencil(ctx, SparseMatrixCSC{Float64,Int64}(sparse(E)), SparseMatrixCSC{Float64,Int64}(sparse(A)); kw...)
 
@@ -158,7 +174,12 @@ Base.@kwdef struct ADI
     compression::Bool = true
     warn_convergence::Bool = true
     compress_exact::Bool = false
+    # `nothing` / Backslash(): the device multifrontal LU.  A `Ptr{Cvoid}` obtained with `@cfunction` for a function of the signature
+    # `dre_block_solver_fn` (include/dre_hip.h) plugs a user solver of the sparse shifted system in — the ALG of
+    # `ShermanMorrisonWoodbury(ALG, Backslash())` (src/blocklinear/types.jl:15-62, example test/cuda.jl:23-30,74)
+    inner_alg::Union{Nothing,Ptr{Cvoid}} = nothing
 end
+inner_ptr(alg::ADI) = something(alg.inner_alg, C_NULL)
 
 # mirrors `dre_adi_options` of include/dre_hip.h field by field
 struct AdiOptionsC
@@ -177,24 +198,153 @@ struct AdiOptionsC
     compress_exact::Int32
     heuristic_kplus::Int32
     heuristic_kminus::Int32
+    inner_solve::Ptr{Cvoid}     # dre_block_solver_fn or C_NULL (inner_alg = Backslash() on the device LU)
+    inner_user::Ptr{Cvoid}
 end
 
 function options(alg::ADI)
     if alg.shifts isa Shifts.Cyclic && alg.shifts.inner isa Shifts.Heuristic
         h = alg.shifts.inner          # Cyclic(Heuristic(nshifts, k₊, k₋)): recomputed on the device at the start of every Lyapunov solve
         o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                        alg.compression_interval, alg.compression, 2, 2, h.nshifts, C_NULL, C_NULL, 4.0, alg.compress_exact, h.k₊, h.k₋)
+                        alg.compression_interval, alg.compression, 2, 2, h.nshifts, C_NULL, C_NULL, 4.0, alg.compress_exact, h.k₊, h.k₋, inner_ptr(alg), C_NULL)
         return o, nothing
     elseif alg.shifts isa Shifts.Cyclic
         vals = ComplexF64.(collect(alg.shifts.inner))
         re, im = real.(vals), imag.(vals)
         o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact, 0, 0)
+                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL)
         return o, (re, im)
     end
     o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0)
+                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL)
     o, nothing
+end
+
+# ---- Callbacks (src/Callbacks.jl:97-187): no-op generic functions taking the observer first --------------------------------------
+module Callbacks
+observe_gale_start!(::Any, args...) = nothing
+observe_gale_step!(::Any, args...) = nothing
+observe_gale_done!(::Any, args...) = nothing
+observe_gale_failed!(::Any, args...) = nothing
+observe_gale_metadata!(::Any, args...) = nothing
+observe_gdre_start!(::Any, args...) = nothing
+observe_gdre_step!(::Any, args...) = nothing
+observe_gdre_done!(::Any, args...) = nothing
+end
+using .Callbacks
+
+# ---- GALE: A'XE + E'XA = -C  (src/lyapunov/types.jl:10-16) ------------------------------------------------------------------------
+"`A` is a sparse matrix or a `LowRankUpdate(A0, α, U, V)` = A0 + inv(α) U V (src/LowRankUpdate.jl:18-39)"
+struct LowRankUpdate
+    A; α::Float64; U::Matrix{Float64}; V::Matrix{Float64}
+end
+lr_update(A, α, U, V) = LowRankUpdate(A, Float64(α), Matrix{Float64}(U), Matrix{Float64}(V))
+struct GALEProblem
+    E; A; C::LDLᵀ
+end
+split_operator(A::LowRankUpdate) = (A.A, A.α, A.U, permutedims(A.V))
+split_operator(A) = (A, 1.0, nothing, nothing)
+
+function gale_operands(ctx, prob::GALEProblem, X0)
+    A0, α, U, Vt = split_operator(prob.A)
+    pencil = Pencil(ctx, prob.E, A0)
+    Ud = U === nothing ? nothing : upload(ctx, U)
+    Vd = Vt === nothing ? nothing : upload(ctx, Vt)
+    Ch = to_device(ctx, pencil, prob.C)
+    Xh = X0 === nothing ? C_NULL : to_device(ctx, pencil, X0)
+    (; pencil, α, Ud, Vd, Ch, Xh)
+end
+dptr(x) = x === nothing ? C_NULL : x.ptr
+
+"iteration record of a finished ADI run (dre_adi_result_info / dre_adi_result_history)"
+function adi_history(res::Ptr{Cvoid})
+    ii = zeros(Int64, 5); dd = zeros(3)
+    ccall((:dre_adi_result_info, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}), res, ii, dd)
+    norms = zeros(ii[4]); its = zeros(Int32, ii[4]); sre = zeros(max(ii[1], 1)); sim = zeros(max(ii[1], 1))
+    ccall((:dre_adi_result_history, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}), res, norms, its, sre, sim)
+    (; iters=Int(ii[1]), converged=ii[2] != 0, warnings=Int(ii[3]), res_norm=dd[1], abstol=dd[2], norms, its, shifts=complex.(sre, sim)[1:ii[1]])
+end
+"replays observe_gale_start!/step!/metadata!/failed! in the order of src/lyapunov/adi.jl:37,65,103,119,125,192 (the loop ran on the device)"
+function replay_gale(observer, prob, alg, h)
+    observer === nothing && return
+    Callbacks.observe_gale_start!(observer, prob, alg)
+    pos = 0
+    for (it, nrm) in zip(h.its, h.norms)
+        while pos < it
+            pos += 1
+            Callbacks.observe_gale_metadata!(observer, "ADI shifts", h.shifts[pos])
+        end
+        Callbacks.observe_gale_step!(observer, Int(it), nothing, nothing, nrm)
+    end
+    h.converged || Callbacks.observe_gale_failed!(observer)
+end
+
+"solve(::GALEProblem, ::ADI; initial_guess, observer)  — src/lyapunov/adi.jl:29-89"
+function CommonSolve.solve(prob::GALEProblem, alg::ADI; initial_guess=nothing, observer=nothing, ctx::Context=default_context())
+    solver = CommonSolve.init(prob, alg; initial_guess, observer, ctx)
+    CommonSolve.solve!(solver)
+end
+
+"The reference's ADICache protocol on the device (src/lyapunov/adi.jl:5-21,91-141): init / step! / isdone / solve! / iterate"
+mutable struct ADISolver
+    ctx::Context
+    ptr::Ptr{Cvoid}
+    prob::GALEProblem
+    alg::ADI
+    observer
+    keep
+end
+function CommonSolve.init(prob::GALEProblem, alg::ADI; initial_guess=nothing, observer=nothing, ctx::Context=default_context())
+    o = gale_operands(ctx, prob, initial_guess)
+    opt, keep = options(alg)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve keep chk(ctx, ccall((:dre_adi_init, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{AdiOptionsC}, Ref{Ptr{Cvoid}}),
+        ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Ch, o.Xh, Ref(opt), out))
+    s = ADISolver(retain!(ctx), out[], prob, alg, observer, (o, keep))
+    finalizer(x -> (ccall((:dre_adi_free, LIB), Cint, (Ptr{Cvoid},), x.ptr); release!(x.ctx)), s)
+end
+isdone(s::ADISolver) = (d = Ref{Cint}(0); ccall((:dre_adi_isdone, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), s.ptr, d); d[] != 0)
+CommonSolve.step!(s::ADISolver) = (chk(s.ctx, ccall((:dre_adi_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, s.ptr)); s)
+Base.iterate(s::ADISolver, _=nothing) = isdone(s) ? nothing : (CommonSolve.step!(s), nothing)
+function CommonSolve.solve!(s::ADISolver)
+    chk(s.ctx, ccall((:dre_adi_solve, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, s.ptr))
+    res = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(s.ctx, ccall((:dre_adi_finish, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), s.ctx.ptr, s.ptr, res))
+    h = adi_history(res[])
+    xh = Ref{Ptr{Cvoid}}(C_NULL)
+    ccall((:dre_adi_result_take_x, LIB), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), res[], xh)
+    X = from_device(s.ctx, xh[])
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, xh[])
+    ccall((:dre_adi_result_free, LIB), Cint, (Ptr{Cvoid},), res[])
+    replay_gale(s.observer, s.prob, s.alg, h)
+    s.observer === nothing || Callbacks.observe_gale_done!(s.observer, h.iters, X, nothing, h.res_norm)
+    h.converged || !s.alg.warn_convergence || @warn "ADI did not converge" residual = h.res_norm abstol = h.abstol maxiters = s.alg.maxiters
+    X
+end
+
+"residual(::GALEProblem, ::LDLᵀ)  — src/lyapunov/residual.jl:3-31"
+function residual(prob::GALEProblem, X::LDLᵀ; ctx::Context=default_context())
+    o = gale_operands(ctx, prob, X)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(ctx, ccall((:dre_gale_residual, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Ch, o.Xh, out))
+    R = from_device(ctx, out[])
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, out[])
+    R
+end
+
+"concatenate!(X)  — src/LDLt.jl:174-191 (host side: hcat of the factors, block-diagonal of the scaled inner matrices)"
+function concatenate!(X::LDLᵀ)
+    length(X.Ls) <= 1 && return X
+    L = reduce(hcat, X.Ls)
+    r = size(L, 2); D = zeros(r, r); off = 0
+    for (a, Di) in zip(X.alphas, X.Ds)
+        k = size(Di, 1); D[off+1:off+k, off+1:off+k] .= a .* Di; off += k
+    end
+    X.alphas, X.Ls, X.Ds = [1.0], [L], [D]
+    X
 end
 
 struct GDREProblem{XT}
@@ -239,10 +389,35 @@ function CommonSolve.solve(prob::GDREProblem{LDLᵀ}, alg::Union{Ros1,Ros2}; dt:
         push!(Xs, from_device(ctx, h[]))
         ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, h[])
     end
+    if observer !== nothing
+        # hooks in the reference's order (lowrank_ros1.jl:10,32,59,63 around adi.jl:37-126); X of intermediate steps only with save_state
+        ngale = Int(info[5]); per = nt > 1 ? ngale ÷ (nt - 1) : 0
+        Callbacks.observe_gdre_start!(observer, prob, alg)
+        Callbacks.observe_gdre_step!(observer, t[1], Xs[1], Ks[1])
+        for i in 2:nt
+            for j in (i-2)*per:(i-1)*per-1
+                cnt = zeros(Int64, 2)
+                ccall((:dre_gdre_result_gale_history, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+                      res[], j, cnt, C_NULL, C_NULL, C_NULL, C_NULL)
+                norms = zeros(cnt[1]); its = zeros(Int32, cnt[1]); sre = zeros(max(cnt[2], 1)); sim = zeros(max(cnt[2], 1))
+                ccall((:dre_gdre_result_gale_history, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+                      res[], j, cnt, norms, its, sre, sim)
+                gi = zeros(Int64, 4); gd = zeros(2)
+                ccall((:dre_gdre_result_gale, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Ptr{Float64}), res[], j, gi, gd)
+                h = (; iters=Int(gi[1]), converged=gi[2] != 0, res_norm=gd[1], abstol=gd[2], norms, its, shifts=complex.(sre, sim)[1:cnt[2]])
+                replay_gale(observer, nothing, inner, h)
+                Callbacks.observe_gale_done!(observer, h.iters, nothing, nothing, h.res_norm)
+            end
+            Xi = save_state ? Xs[i] : (i == nt ? Xs[end] : nothing)
+            Callbacks.observe_gdre_step!(observer, t[i], Xi, Ks[i])
+        end
+        Callbacks.observe_gdre_done!(observer)
+    end
     ccall((:dre_gdre_result_free, LIB), Cint, (Ptr{Cvoid},), res[])
     DRESolution(Xs, Ks, t)
 end
 
-export Context, Pencil, LDLᵀ, lowrank, compress!, ADI, Shifts, GDREProblem, DRESolution, Ros1, Ros2, solve
+export Context, Pencil, LDLᵀ, lowrank, compress!, concatenate!, residual, ADI, Shifts, Callbacks, GALEProblem, GDREProblem, DRESolution, Ros1, Ros2,
+       LowRankUpdate, lr_update, ADISolver, isdone, solve
 
 end # module
