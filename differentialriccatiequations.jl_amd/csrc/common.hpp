@@ -102,7 +102,10 @@ struct KernelTimer;  // profiling.hpp
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    DevicePool pool;
+    // The pool is shared with every buffer allocated from it: a device object that outlives its context (finalizers of a garbage-collected
+    // host language run in no particular order) still returns its block to a live pool, which frees the memory when the last owner goes.
+    std::shared_ptr<DevicePool> pool_sp = std::make_shared<DevicePool>();
+    DevicePool& pool = *pool_sp;
     std::string last_error;
     int num_cus = 256;
     // optional per-kernel-class timing with HIP events (bench.py's roofline leg)
@@ -157,11 +160,11 @@ struct Ctx {
 };
 
 struct Buf {
-    Ctx* ctx;
+    std::shared_ptr<DevicePool> pool;      // keeps the pool (not the context) alive
     void* p;
     size_t bytes;
-    Buf(Ctx* c, size_t b) : ctx(c), p(c->pool.alloc(b ? b : 8)), bytes(b) {}
-    ~Buf() { ctx->pool.release(p); }
+    Buf(Ctx* c, size_t b) : pool(c->pool_sp), p(c->pool_sp->alloc(b ? b : 8)), bytes(b) {}
+    ~Buf() { pool->release(p); }
     Buf(const Buf&) = delete;
     Buf& operator=(const Buf&) = delete;
 };

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_fetch(FetchSrc s, unsigned long long* _
     if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1, const void* d2, size_t b2, void* h2) {
-    static const bool spin_on = std::getenv("DRE_FETCH_SPIN") && std::atoi(std::getenv("DRE_FETCH_SPIN")) != 0;   // measured neutral at n = 371: off by default
+    static const bool spin_on = !(std::getenv("DRE_FETCH_SPIN") && std::atoi(std::getenv("DRE_FETCH_SPIN")) == 0);   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
     const size_t tot = (b0 + b1 + b2) / 8;
     DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
     if (spin_on && !ctx->fetch_host) {
