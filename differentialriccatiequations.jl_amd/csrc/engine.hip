@@ -2047,9 +2047,9 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         op.Vt = fb.Kt;
         op.alpha = order == 1 ? -1.0 : 1.0 / (-gamma * tau);
         const int r = fb.L.cols;
-        if (densex && i >= 2) {
+        if (densex) {
             if (!sx_init) {
-                // X_1 (block list: warm start + increments of the first solve) as a dense matrix
+                // the current X (X0, or a block list: warm start + increments) as a dense matrix
                 const int c = X->rank();
                 sx.X = Mat(ctx, n, n);
                 if (c > 0) {
@@ -2061,7 +2061,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 sx.P1 = Mat(ctx, n, n);
                 spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
                 sx.Kt = fb.Kt;
-                sx.hint = cache.iters_hint;
+                sx.hint = cache.iters_hint > 0 ? cache.iters_hint : 3 * adi.compression_interval;    // first solve: a few chunks at most
                 sx_init = true;
             }
             AdiResult ar;
