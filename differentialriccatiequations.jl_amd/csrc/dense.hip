@@ -1101,13 +1101,160 @@ __device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, cons
     }
     return acc;
 }
+// The same for NT column tiles per wave (wide residuals / larger n): one A fragment feeds NT MFMAs, so the packed strip is read once per
+// NT tiles, and the operand batches are double buffered — the loads of batch i + 1 are in flight while batch i multiplies.
+template <int NT>
+__device__ __forceinline__ void adi_fast_tiles(const double* __restrict__ ap, const double* __restrict__ R, int ldr, int col0, int k, int lk, int lr, int n,
+                                               int t0, int t1, v4d (&acc)[NT]) {
+    constexpr int KB = 24 / NT;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (t1 <= t0) return;
+    const double* bp[NT];
+    bool cok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + j * 16 + lr;
+        cok[j] = col < k;
+        bp[j] = R + (size_t)(cok[j] ? col : 0) * ldr;
+    }
+    double a0[KB], a1[KB], b0[NT][KB], b1[NT][KB];
+    auto load = [&](double (&av)[KB], double (&bv)[NT][KB], int tb) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int t = min(tb + u, t1 - 1);
+            const int row = min(4 * t + lk, n - 1);
+            av[u] = ap[(size_t)t * 64];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j][u] = bp[j][row];
+        }
+    };
+    auto mma = [&](const double (&av)[KB], const double (&bv)[NT][KB], int tb) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < n;
+            const double x = kok ? av[u] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, (kok && cok[j]) ? bv[j][u] : 0.0, acc[j], 0, 0, 0);
+        }
+    };
+    load(a0, b0, t0);
+    for (int tb = t0; tb < t1; tb += 2 * KB) {
+        load(a1, b1, tb + KB);
+        mma(a0, b0, tb);
+        load(a0, b0, tb + 2 * KB);
+        mma(a1, b1, tb + KB);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void adi_fast_strip_group(const AdiFastArgs& a, int hs, int tg, double* part /* [4][4*NT][64] */) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int k = a.k, n = a.n;
+    const int half = hs / a.nstrip, s = hs - half * a.nstrip;
+    const int col0 = tg * NT * 16;
+    const int erow = s * 16 + lk + 4 * wave;
+    double rold[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + j * 16 + lr;
+        rold[j] = (half == 1 && col < k && erow < n) ? a.Rcur[erow + (size_t)col * a.ldr] : 0.0;
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
+    v4d acc[NT];
+    adi_fast_tiles<NT>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur, a.ldr, col0, k, lk, lr, n, t0, t1, acc);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[((size_t)wave * 4 * NT + j * 4 + r) * 64 + lane] = acc[j][r];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = col0 + j * 16 + lr;
+        const size_t o = ((size_t)j * 4 + wave) * 64 + lane, ws = (size_t)4 * NT * 64;
+        const double v = ((part[o] + part[ws + o]) + part[2 * ws + o]) + part[3 * ws + o];
+        if (col < k && erow < n) {
+            if (half == 0) a.V[erow + (size_t)col * a.ldv] = v;
+            else a.Rnext[erow + (size_t)col * a.ldr_next] = rold[j] - a.two_mu * v;
+        }
+    }
+}
+// Large n (mode 1): every wave owns one 16-row strip over the FULL K range and NT column tiles; the four waves of a workgroup share the
+// B operand (64 rows x NT*16 columns of R per K-chunk), staged through LDS with coalesced loads and double buffered — without it every
+// wave re-gathers R in 32-byte pieces and the vector memory pipeline, not the matrix cores, bounds the launch (77 us at n = 1357, k = 160
+// against a matrix-core floor of 15 us).  The A fragments stay single 512-byte loads of the packed strip, register double buffered.
+#define ADI_WIDE_KC 64
+#define ADI_WIDE_LDB 68
+template <int NT>
+__device__ __forceinline__ void adi_fast_wide(const AdiFastArgs& a, int sg, int tg, double* lds /* 2 x NT*16 x ADI_WIDE_LDB */) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int k = a.k, n = a.n, kst = a.kst;
+    const int hs = sg * 4 + wave;
+    const bool active = hs < 2 * a.nstrip;
+    const int hsc = active ? hs : 0;
+    const int half = hsc / a.nstrip, s = hsc - half * a.nstrip;
+    const int col0 = tg * NT * 16, ncolw = NT * 16;
+    const double* __restrict__ ap = a.Apack + (size_t)hsc * kst * 64 + lane;
+    v4d acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int nchunk = (n + ADI_WIDE_KC - 1) / ADI_WIDE_KC;
+    constexpr int PER = NT * 16 * ADI_WIDE_KC / 256;           // doubles of the B chunk per thread
+    double breg[PER], areg[16];
+    auto load_b = [&](int ch) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + 256 * i, row = ch * ADI_WIDE_KC + (idx & (ADI_WIDE_KC - 1)), col = col0 + (idx >> 6);
+            breg[i] = a.Rcur[min(row, n - 1) + (size_t)min(col, k - 1) * a.ldr];
+            if (row >= n || col >= k) breg[i] = 0.0;
+        }
+    };
+    auto store_b = [&](int buf) {
+        double* B = lds + (size_t)buf * ncolw * ADI_WIDE_LDB;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { const int idx = tid + 256 * i; B[(idx >> 6) * ADI_WIDE_LDB + (idx & (ADI_WIDE_KC - 1))] = breg[i]; }
+    };
+    auto load_a = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int t = min(ch * 16 + u, kst - 1); areg[u] = ap[(size_t)t * 64]; }
+    };
+    load_b(0); load_a(0);
+    store_b(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const double* B = lds + (size_t)(ch & 1) * ncolw * ADI_WIDE_LDB;
+        double acur[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acur[u] = (ch * 16 + u < kst) ? areg[u] : 0.0;
+        if (ch + 1 < nchunk) { load_b(ch + 1); load_a(ch + 1); }         // in flight while this chunk multiplies
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[u], B[(j * 16 + lr) * ADI_WIDE_LDB + 4 * u + lk], acc[j], 0, 0, 0);
+        if (ch + 1 < nchunk) store_b((ch + 1) & 1);
+        __syncthreads();
+    }
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = s * 16 + lk + 4 * r, col = col0 + j * 16 + lr;
+            if (row < n && col < k) {
+                if (half == 0) a.V[row + (size_t)col * a.ldv] = acc[j][r];
+                else a.Rnext[row + (size_t)col * a.ldr_next] = a.Rcur[row + (size_t)col * a.ldr] - a.two_mu * acc[j][r];
+            }
+        }
+}
 // Workgroups of one launch (256 threads = 4 waves that split K):
 //   [0, 2 nstrip ct)            tile (half, strip, column tile) of V = Seff_top R (half 0) or R_next = R - 2 mu Seff_bot R (half 1)
 //   [.., + ct ct)               Gram tile (ta, tb) of the INPUT residual R (= output of the previous launch) -> G_prev
 //   last                        norm + decision from G_prev2 (the Gram matrix the previous launch produced)
 __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     if (a.st->done) return;
-    __shared__ double part[4][4][64];
+    __shared__ double partbuf[4 * 16 * 64];                       // K-quarter partial tiles: [4 waves][4 NT][64 lanes], NT <= 4
+    double (*part)[4][64] = reinterpret_cast<double (*)[4][64]>(partbuf);
     __shared__ double nred[17];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
     const int k = a.k, ct = (k + 15) >> 4, n = a.n;
@@ -1116,7 +1263,28 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
     // packed strip get indices that differ by a multiple of 8 (strip-major with a stride padded to 8; the padding workgroups exit) — the
     // re-reads then hit that XCD's L2 instead of going out to the fabric ct times
     const int hstride = (2 * a.nstrip + 7) & ~7;
-    const int nsw = a.do_strips ? hstride * ct : 0;
+    const int ntile = a.nt > 0 ? a.nt : 1, ngroups = (ct + ntile - 1) / ntile;
+    // grid order: norm workgroups, Gram tiles, then the strip tiles — the riders are the longer dependent chains, so they start first and
+    // run beside the strips instead of queueing behind them
+    const int nnorm = ct * ((ct + 3) >> 2), nrider = nnorm + ct * ct;
+    const int nsw = a.do_strips ? (a.mode == 1 ? ((2 * a.nstrip + 3) / 4) * ngroups : hstride * ngroups) : 0;
+    b = (b >= nrider) ? b - nrider : b + nsw;                     // strips occupy [0, nsw) of the logical index, riders follow
+    if (b < nsw && a.mode == 1) {
+        extern __shared__ double wide_lds[];
+        const int nsg = (2 * a.nstrip + 3) / 4;
+        const int tg = b / nsg, sg = b - tg * nsg;
+        if (ntile == 1) adi_fast_wide<1>(a, sg, tg, wide_lds);
+        else if (ntile == 2) adi_fast_wide<2>(a, sg, tg, wide_lds);
+        else adi_fast_wide<4>(a, sg, tg, wide_lds);
+        return;
+    }
+    if (b < nsw && ntile > 1) {
+        const int tg = b / hstride, hs = b - tg * hstride;
+        if (hs >= 2 * a.nstrip) return;
+        if (ntile == 2) adi_fast_strip_group<2>(a, hs, tg, partbuf);
+        else adi_fast_strip_group<4>(a, hs, tg, partbuf);
+        return;
+    }
     if (b < nsw) {
         const int tc = b / hstride, hs = b - tc * hstride;
         if (hs >= 2 * a.nstrip) return;
@@ -1242,14 +1410,19 @@ void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops) {
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     DRE_REQUIRE(a.k >= 1 && a.k <= ADI_FAST_MAX_K, "adi_fast_iter: residual too wide");
     const int ct = (a.k + 15) >> 4;
-    const int nsw = a.do_strips ? ((2 * a.nstrip + 7) & ~7) * ct : 0;
+    const int ntile = a.nt > 0 ? a.nt : 1;
+    DRE_REQUIRE(ntile == 1 || ntile == 2 || ntile == 4, "adi_fast_iter: nt must be 1, 2 or 4");
+    const int ngroups = (ct + ntile - 1) / ntile;
+    const int nsw = a.do_strips ? (a.mode == 1 ? ((2 * a.nstrip + 3) / 4) * ngroups : ((2 * a.nstrip + 7) & ~7) * ngroups) : 0;
+    const size_t lds = (a.do_strips && a.mode == 1) ? (size_t)2 * ntile * 16 * ADI_WIDE_LDB * sizeof(double) : 0;
+    if (lds > 48 * 1024) lds_attr(ctx, (const void*)k_adi_fast, 80 * 1024);
     if (a.chain_timed) {
-        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), lds, ctx->stream, a);
     } else {
         double by, fl;
         adi_fast_cost(a, &by, &fl);
         TimedScope ts(ctx, a.do_strips ? "adi_fast_iter" : "adi_fast_flush", by, fl);
-        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_adi_fast, dim3(nsw + ct * ct + ct * ((ct + 3) / 4)), dim3(256), lds, ctx->stream, a);
     }
     DRE_HIP(hipGetLastError());
 }

@@ -1,6 +1,7 @@
 // Dense f64 building blocks (column-major): MFMA GEMM, copies, Gram/trace norms,
 // blocked Householder QR, symmetric eigensolver with early-terminating tridiagonalisation.
 #pragma once
+#include <cstdlib>
 #include "common.hpp"
 
 namespace dre {
@@ -101,7 +102,21 @@ struct AdiFastArgs {
     int it_prev2;               // shifts consumed after the iteration G_prev2 belongs to
     int do_strips;              // 0: flush launch (riders only)
     int chain_timed;            // 1: the caller brackets the whole chain with one TimedScope (adi_fast_chain_cost)
+    int nt;                     // column tiles per tile workgroup (1, 2 or 4; 0 = 1): adi_fast_pick
+    int mode;                   // 0: K-split tile workgroups (small n: latency); 1: strip per wave over the full K, B through LDS (large n: throughput)
 };
+// column tiles per workgroup: as many as keep at least ~2 tile workgroups per CU in the launch
+inline int adi_fast_pick_nt(int n, int k) {
+    const long tiles = 2L * adi_fast_nstrip(n) * ((k + 15) / 16);
+    return tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
+}
+// kernel variant and column tiles per workgroup: the K-split tiles win while a launch is latency bound (n < 768 or residuals narrower than 128 columns); beyond that the LDS-staged
+// full-K strips with two column tiles per wave keep >= 1 wave per SIMD busy without re-gathering R
+inline void adi_fast_pick(int n, int k, int* mode, int* nt) {
+    static const int wide_min_n = std::getenv("DRE_ADI_WIDE_MIN_N") ? std::atoi(std::getenv("DRE_ADI_WIDE_MIN_N")) : 768;
+    if (n >= wide_min_n && k >= 128) { *mode = 1; *nt = 2; }       // measured at n = 1357: k = 64: 41 us (K-split) vs 53 us; k = 160: 77 vs 55 us; k = 294: 131 vs 80 us
+    else { *mode = 0; *nt = adi_fast_pick_nt(n, k); }
+}
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
 void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops);     // algorithmic bytes / flops of one launch
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising

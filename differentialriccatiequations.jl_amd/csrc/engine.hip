@@ -1130,7 +1130,7 @@ void adi_advance(AdiRun& run, int budget) {
             const size_t cyc_before = cyc;
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
-            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
+            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p; a.nws = nws.p;
             for (int j = 1; j <= nit; ++j) {
                 const std::complex<double> mu = opt.shifts.values[cyc % opt.shifts.values.size()];
@@ -1865,7 +1865,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             keepV.push_back(Rring);
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
-            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst;
+            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
             a.chain_timed = 1; a.do_strips = 1; a.G_prev = Gm.p;
             double by1 = 0.0, fl1 = 0.0;

@@ -6,7 +6,7 @@ using namespace dre;
 __global__ void k_empty(AdiFastArgs a) { if (a.st->done) return; }
 int main(int argc, char** argv) {
     Ctx ctx; hipStreamCreate(&ctx.stream);
-    for (int n : {371, 1357}) for (int k : {48, 64, 96}) {
+    for (int n : {371, 1357}) for (int k : {64, 160, 294}) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n), NIT = 200;
         std::vector<double> hp(adi_fast_pack_doubles(n)), hr((size_t)n * k), ht((size_t)k * k, 0.0);
         for (size_t i = 0; i < hp.size(); ++i) hp[i] = 1e-3 * sin(0.37 * i);
@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
                 hipEventRecord(e0, ctx.stream);
                 for (int j = 1; j <= NIT; ++j) {
                     AdiFastArgs a; memset(&a, 0, sizeof(a));
-                    a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; a.Apack = P[j % 10];
+                    a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; a.Apack = P[j % 10]; adi_fast_pick(n, k, &a.mode, &a.nt); if (getenv("NT")) a.nt = atoi(getenv("NT")); if (getenv("MODE")) a.mode = atoi(getenv("MODE"));
                     a.Rcur = R + (size_t)(j - 1) * n * k; a.ldr = n; a.Rnext = R + (size_t)j * n * k; a.ldr_next = n; a.V = V + (size_t)(j - 1) * n * k; a.ldv = n;
                     a.two_mu = 1e-3; a.T = T; a.ldt = k; a.tdiag = 0; a.alpha = 1.0; a.st = st; a.nws = W; a.it_prev2 = j - 2;
                     a.G_prev = (mode == 0 && j >= 2) ? G + (size_t)((j - 1) & 1) * k * k : nullptr;
