@@ -2144,10 +2144,212 @@ static void launch_tsqr_panel(Ctx* ctx, double* A, int lda, int rows, int jb, do
     DRE_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small panels (rows <= 512, exactly 16 columns, j0 = 0): four waves, wave w keeps columns 4w .. 4w+3 in registers (NR rows per lane and
+// column).  Same Householder arithmetic as hh_panel_core_reg, restructured for latency: the column loop is fully unrolled (every register
+// index is a compile-time constant, the pivot entry is one readlane), the owner of column j derives (tau, beta, scale) alone and
+// publishes the SCALED reflector through LDS (double buffered), so the other waves need one barrier per column and no redundant
+// sqrt/div chain; the dot products of a wave's (up to four) trailing columns and the look-ahead norm are independent DPP reduction
+// chains the scheduler interleaves.  T comes from V'V on the matrix cores after the loop, V T as well.
+// ---------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int lda, int rows, double* __restrict__ V, int ldv,
+                                                    double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, AdiState* st,
+                                                    const double* __restrict__ part, int nparts, int kpanel, double tolfac,
+                                                    double* __restrict__ part_out) {
+    if (st && st->done) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (part) {
+        const double resn = st->res_norm, atol = st->abstol;
+        double r2 = 0.0;
+        for (int i = lane; i < nparts; i += 64) r2 += part[i];
+        r2 = wave_sum(r2);
+        const double base = (kpanel == 0) ? r2 : resn;
+        const double tol = atol > 0.0 ? atol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const bool stop = r2 <= tol * tol;
+        __syncthreads();
+        if (tid == 0) {
+            if (kpanel == 0) st->res_norm = r2;
+            if (stop) { st->done = 1; st->iters = kpanel; }
+        }
+        if (stop) return;
+    }
+    extern __shared__ double q16[];
+    double* pv = q16;                                 // 2 x 512: the published reflector
+    double* Vs = q16 + 1024;                          // rows x 17: V (explicit) for V'V and V T
+    __shared__ double taus[16], Zs[4][16][17], Tsh[16][17];
+    const int c0 = wave * 4;
+    double x[4][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { const int r = lane + 64 * u; x[c][u] = r < rows ? A[r + (size_t)(c0 + c) * lda] : 0.0; }
+    double sig = 0.0;                                 // ||column[j+1:]||^2 of the column this wave owns next (valid in its owner)
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { const int r = lane + 64 * u; if (r >= 1) sig += x[0][u] * x[0][u]; }
+        sig = wave_sum(sig);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        constexpr int dummy = 0; (void)dummy;
+        const int wo = jj >> 2, co = jj & 3;
+        double* pvb = pv + (jj & 1) * 512;
+        if (wave == wo) {
+            const double alpha = lane_bcast(x[co][0], jj);
+            double tau = 0.0, beta = alpha, scale = 0.0;
+            if (sig > 0.0) {
+                const double nrm = sqrt(alpha * alpha + sig);
+                beta = alpha >= 0.0 ? -nrm : nrm;
+                tau = (beta - alpha) / beta;
+                scale = 1.0 / (alpha - beta);
+            }
+#pragma unroll
+            for (int u = 0; u < NR; ++u) {
+                const int r = lane + 64 * u;
+                double v = 0.0;
+                if (r > jj) { v = x[co][u] * scale; x[co][u] = v; }
+                else if (r == jj) { v = 1.0; x[co][u] = beta; }
+                pvb[r] = v;
+            }
+            if (lane == 0) taus[jj] = tau;
+        }
+        __syncthreads();
+        if (jj == 15) break;
+        const double tau = taus[jj];
+        double v[NR];
+#pragma unroll
+        for (int u = 0; u < NR; ++u) v[u] = pvb[lane + 64 * u];
+        double w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            w[c] = 0.0;
+            if (c0 + c > jj) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) w[c] += v[u] * x[c][u];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c0 + c > jj) w[c] = wave_sum(w[c]) * tau;
+        double nn = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c0 + c > jj) {
+#pragma unroll
+                for (int u = 0; u < NR; ++u) {
+                    x[c][u] -= w[c] * v[u];
+                    if (c0 + c == jj + 1 && lane + 64 * u > jj + 1) nn += x[c][u] * x[c][u];
+                }
+            }
+        }
+        if (c0 <= jj + 1 && jj + 1 < c0 + 4) sig = wave_sum(nn);        // the next owner's look-ahead norm
+    }
+    // V (explicit) to LDS and global, the panel (R above, reflectors below) back to A
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = lane + 64 * u, gc = c0 + c;
+            if (r < rows) {
+                const double val = x[c][u];
+                A[r + (size_t)gc * lda] = val;
+                const double vv = r > gc ? val : (r == gc ? 1.0 : 0.0);
+                V[r + (size_t)gc * ldv] = vv;
+                Vs[r * 17 + gc] = vv;
+            }
+        }
+    if (part_out && wave == 0) {
+        // coupling term of the NEXT termination test: 2 ||triu(R)||_F^2 of this panel — R sits in rows 0..15, i.e. lanes 0..15 of register 0
+        double c2 = 0.0;
+        (void)c2;
+    }
+    __syncthreads();
+    if (part_out) {
+        // every wave holds four columns of R in lanes 0..15 of x[c][0]
+        double c2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (lane <= c0 + c && lane < rows) c2 += 2.0 * x[c][0] * x[c][0];
+        c2 = wave_sum(c2);
+        if (lane == 0) Zs[wave][0][16] = c2;
+    }
+    {   // Z = V'V on the matrix cores: the waves split the rows, fixed-order sum of the four partials
+        const int lr = lane & 15, lk = lane >> 4;
+        const int kst = (rows + 3) >> 2, per = (kst + 3) >> 2, t0 = wave * per, t1 = min(kst, t0 + per);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int t = t0; t < t1; ++t) {
+            const int r = 4 * t + lk;
+            const double a = r < rows ? Vs[r * 17 + lr] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Zs[wave][lk + 4 * r][lr] = acc[r];
+    }
+    __syncthreads();
+    if (part_out && tid == 0) part_out[0] = (Zs[0][0][16] + Zs[1][0][16]) + (Zs[2][0][16] + Zs[3][0][16]);
+    if (wave == 0) {
+        // T(0:j, j) = -tau_j T(0:j, 0:j) Z(0:j, j),  T(j, j) = tau_j   (lane i owns row i)
+        const int i = lane;
+        double trow[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) trow[j] = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double tj = taus[j];
+            double accv = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l)
+                if (l < j) {
+                    const double z = ((Zs[0][l][j] + Zs[1][l][j]) + Zs[2][l][j]) + Zs[3][l][j];
+                    accv += trow[l] * z;                 // trow[l] = T(i, l), zero for l < i
+                }
+            trow[j] = (i < j) ? -tj * accv : (i == j ? tj : 0.0);
+        }
+        if (i < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { Tsh[i][j] = trow[j]; T[i + (size_t)j * ldt] = trow[j]; }
+        }
+    }
+    __syncthreads();
+    if (VT) {
+        // VT = V T: one 16-row tile per wave and pass, K = 16
+        const int lr = lane & 15, lk = lane >> 4;
+        for (int rt = wave; rt * 16 < rows; rt += 4) {
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rt * 16 + lr;
+                const double a = r < rows ? Vs[r * 17 + 4 * q + lk] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Tsh[4 * q + lk][lr], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + lk + 4 * r;
+                if (row < rows) VT[row + (size_t)lr * ldvt] = acc[r];
+            }
+        }
+    }
+}
+static bool qr_panel16_enabled() {
+    static const bool v = !(std::getenv("DRE_QR_PANEL16") && std::atoi(std::getenv("DRE_QR_PANEL16")) == 0);
+    return v;
+}
+
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
                             double tolfac = 0.0, double* part_out = nullptr) {
     const int rows = m - j0;
+    if (rows <= 512 && rows >= 16 && jb == 16 && j0 == 0 && qr_panel16_enabled()) {
+        TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
+        const size_t shm = ((size_t)1024 + (size_t)rows * 17) * sizeof(double);
+        if (rows <= 256) {
+            lds_attr(ctx, (const void*)k_qr_panel16<4>, 96 * 1024);
+            hipLaunchKernelGGL((k_qr_panel16<4>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
+        } else {
+            lds_attr(ctx, (const void*)k_qr_panel16<8>, 96 * 1024);
+            hipLaunchKernelGGL((k_qr_panel16<8>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
+        }
+        return;
+    }
     if (rows <= QR_LDS_ROWS) {
         TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = (size_t)(rows | 1) * jb * sizeof(double);
