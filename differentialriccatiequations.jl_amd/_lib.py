@@ -101,6 +101,8 @@ PROTOTYPES = {
     "dre_ldlt_destructure": (C.c_int, [_vp, _vp, _pd, _pd, C.c_int, _pd, C.c_int]),
     "dre_adi_default_options": (C.c_int, [C.POINTER(AdiOptionsC)]),
     "dre_gale_solve": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
+    "dre_ldlt_dot": (C.c_int, [_vp, _vp, _vp, _pd]),
+    "dre_gale_apply": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _pvp]),
     "dre_adi_init": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
     "dre_adi_step": (C.c_int, [_vp, _vp]),
     "dre_adi_solve": (C.c_int, [_vp, _vp]),

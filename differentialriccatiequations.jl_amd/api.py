@@ -857,8 +857,19 @@ class GMRES:
     warn_convergence: bool = True
 
 
-def dot(X1: LDLt, X2: LDLt) -> float:
-    """dot(::LDLᵀ, ::LDLᵀ) = <X1, X2>_F  (LDLt.jl:91-108); small host GEMMs on the factors."""
+def dot(X1: LDLt, X2: LDLt, ctx=None, pencil=None) -> float:
+    """dot(::LDLᵀ, ::LDLᵀ) = <X1, X2>_F  (LDLt.jl:91-108).  With a pencil (or operands that already live on one) the Gram products run on
+    the device (dre_ldlt_dot); plain host objects without a pencil fall back to small host GEMMs on the factors."""
+    if pencil is None:
+        for X in (X1, X2):
+            if X._handle is not None and X._handle.pencil is not None:
+                pencil = X._handle.pencil
+    if pencil is not None:
+        ctx = ctx or pencil.ctx
+        h1, h2 = X1._to_device(ctx, pencil), X2._to_device(ctx, pencil)
+        out = C.c_double()
+        ctx.chk(ctx.lib.dre_ldlt_dot(ctx.ptr, h1.ptr, h2.ptr, C.byref(out)))
+        return out.value
     a, A, Bm = X1
     b, Cm, Dm = X2
     M = A.T @ Cm
@@ -872,8 +883,21 @@ def _opT_mul(A, Z):
     return _spT_mul(A, Z)
 
 
-def lyapunov_apply(E, A, X: LDLt) -> LDLt:
-    """LyapunovOperator(E, A) * X = A'XE + E'XA = a [E'Z, A'Z] [0 Y; Y 0] [E'Z, A'Z]'  (gmres.jl:108-120)."""
+def lyapunov_apply(E, A, X: LDLt, ctx=None) -> LDLt:
+    """LyapunovOperator(E, A) * X = A'XE + E'XA = a [E'Z, A'Z] [0 Y; Y 0] [E'Z, A'Z]'  (gmres.jl:108-120).  On the device when a context is
+    given (dre_gale_apply: two SpMMs + the rank-m part of a LowRankUpdate), host NumPy otherwise."""
+    if ctx is not None:
+        A0, lr = _split_operator(E, A)
+        pencil = _pencil_for(E, A0, ctx)
+        Xd = X._to_device(ctx, pencil)
+        U = Vt = None
+        alpha = 1.0
+        if lr is not None:
+            alpha, Uh, Vh = lr
+            U, Vt = ctx.upload(Uh), ctx.upload(np.asarray(Vh).T)
+        out = C.c_void_p()
+        ctx.chk(ctx.lib.dre_gale_apply(ctx.ptr, pencil.ptr, 1.0, 0.0, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None, Xd.ptr, C.byref(out)))
+        return LDLt([], [], [], _handle=dev.DeviceLDLt(ctx, out, pencil))
     a, Z, Y = X
     O = np.zeros_like(Y)
     return a * lowrank(np.hstack([_spT_mul(E, Z), _opT_mul(A, Z)]), np.block([[O, Y], [Y, O]]))
@@ -920,11 +944,11 @@ def solve_gmres(prob: GALEProblem, alg: GMRES, initial_guess: LDLt | None = None
             else:
                 sub = GALEProblem(E, A, V[j])
                 Zs.append(solve_gale(sub, pre, observer=observer, ctx=ctx) if isinstance(pre, ADI) else solve_gmres(sub, pre, observer=observer, ctx=ctx))
-            W = lyapunov_apply(E, A, Zs[j])
+            W = lyapunov_apply(E, A, Zs[j], ctx)       # device: dre_gale_apply
             if alg.compression:
                 compress_(W)
             for i in range(j + 1):
-                H[i, j] = dot(V[i], W)
+                H[i, j] = dot(V[i], W, ctx)            # device: dre_ldlt_dot
                 W = W - H[i, j] * V[i]
             H[j + 1, j] = norm(W)
             V.append(W / H[j + 1, j])

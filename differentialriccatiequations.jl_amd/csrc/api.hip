@@ -647,6 +647,24 @@ int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, d
         *out = h;
     });
 }
+int dre_ldlt_dot(dre_ctx* ctx, const dre_ldlt* a, const dre_ldlt* b, double* out) {
+    return guarded(ctx, [&] {
+        DRE_REQUIRE(a->pen == b->pen, "dot: both operands must be created with the same pencil (same row ordering)");
+        *out = ldlt_dot(&ctx->c, *a->x, *b->x);
+    });
+}
+int dre_gale_apply(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                   const dre_ldlt* X, dre_ldlt** out) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        DRE_REQUIRE(X->pen == p, "LDLt operand must be created with the same pencil");
+        GaleOperator op = make_operator(c, p, cA, cE, lr_alpha, U, Vt);
+        auto* h = new dre_ldlt();
+        h->pen = p;
+        try { h->x = lyapunov_apply(c, op, X->x); } catch (...) { delete h; throw; }
+        *out = h;
+    });
+}
 int dre_adi_result_info(const dre_adi_result* r, int64_t* info, double* dinfo) {
     info[0] = r->r.iters; info[1] = r->r.converged; info[2] = r->r.warnings; info[3] = (int64_t)r->r.norms.size(); info[4] = r->r.rhs_cols;
     dinfo[0] = r->r.res_norm; dinfo[1] = r->r.abstol; dinfo[2] = r->r.initial_norm;

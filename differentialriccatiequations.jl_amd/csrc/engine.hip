@@ -759,6 +759,53 @@ static LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const
 }
 
 // =============================================================================================
+// dot and LyapunovOperator on the device (the two pieces of the low-rank GMRES that are not ADI, gmres.jl:108-120, LDLt.jl:91-108)
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dot_hadamard(int r, int c, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, double* out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (size_t id = threadIdx.x; id < (size_t)r * c; id += 256) { const int i = id % r, j = id / r; s += A[i + (size_t)j * lda] * B[i + (size_t)j * ldb]; }
+    s = wave_sum_t<double>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+double ldlt_dot(Ctx* ctx, const LDLt& X1, const LDLt& X2) {
+    DRE_REQUIRE(X1.n == X2.n, "dot: outer dimensions must match");
+    if (X1.rank() == 0 || X2.rank() == 0) return 0.0;
+    LDLt A = X1, B = X2;                      // shallow copies: concatenation builds new factors, the operands stay untouched
+    ldlt_concatenate(ctx, A); ldlt_concatenate(ctx, B);
+    const LBlock& a = A.blocks[0]; const LBlock& b = B.blocks[0];
+    const int r1 = a.L.cols, r2 = b.L.cols;
+    Mat M(ctx, r1, r2), T1(ctx, r1, r2), T2(ctx, r1, r2);
+    gemm(ctx, true, false, 1.0, a.L, b.L, 0.0, M, nullptr, "gemm_dot");          // L1' L2
+    gemm(ctx, false, false, a.alpha, a.D, M, 0.0, T1, nullptr, "gemm_dot");      // a1 D1 (L1' L2)
+    gemm(ctx, false, false, b.alpha, T1, b.D, 0.0, T2, nullptr, "gemm_dot");     // ... a2 D2     (D2 symmetric)
+    DevArr<double> out(ctx, 1);
+    hipLaunchKernelGGL(k_dot_hadamard, dim3(1), dim3(256), 0, ctx->stream, r1, r2, (const double*)T2.p, T2.ld, (const double*)M.p, M.ld, out.p);
+    double h = 0.0;
+    DRE_HIP(hipMemcpyAsync(&h, out.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    return h;
+}
+LDLtP lyapunov_apply(Ctx* ctx, const GaleOperator& op, const LDLtP& X) {
+    const Pencil& P = *op.P;
+    const int n = P.n;
+    if (!X || X->rank() == 0) return ldlt_zero(n);
+    LDLt A = *X;
+    ldlt_concatenate(ctx, A);
+    const LBlock& a = A.blocks[0];
+    const int r = a.L.cols;
+    Mat L2(ctx, n, 2 * r), D2(ctx, 2 * r, 2 * r);
+    { Mat d = L2.colsview(0, r); spmm(ctx, P, P.valEt.p, a.L, d, 1.0, 0.0); }
+    { Mat d = L2.colsview(r, r); apply_Ft(ctx, op, a.L, d); }
+    fill_mat(ctx, D2, 0.0);
+    { Mat d = D2.view(0, r, r, r); copy_mat(ctx, a.D, d, a.alpha); }
+    { Mat d = D2.view(r, 0, r, r); copy_mat(ctx, a.D, d, a.alpha); }
+    return ldlt_make(ctx, n, L2, D2, 1.0, false);
+}
+
+// =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
 // =============================================================================================
 template <typename T>

@@ -136,6 +136,10 @@ AdiResult adi_finish(AdiRun& run);
 // (src/blocklinear/sherman-morrison-woodbury.jl:10-45): W = M^-1 [B, Vt], S = alpha I + U' W_Vt, X = W_B - W_Vt S^-1 (U' W_B).  Solver ordering.
 Mat smw_solve(Ctx* ctx, const Pencil& P, const Factor<double>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B);
 void smw_solve(Ctx* ctx, const Pencil& P, const Factor<cplx>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B, Mat& X_re, Mat& X_im);
+// dot(X1, X2) = <X1, X2>_F = sum_ij a_i a_j tr(D_i (L_i' L_j) D_j (L_j' L_i))   (/root/reference/src/LDLt.jl:91-108); synchronises
+double ldlt_dot(Ctx* ctx, const LDLt& X1, const LDLt& X2);
+// LyapunovOperator(E, F) * X = F'XE + E'XF = [E'L, F'L] [0 D; D 0] [E'L, F'L]'   (/root/reference/src/lyapunov/gmres.jl:108-120)
+LDLtP lyapunov_apply(Ctx* ctx, const GaleOperator& op, const LDLtP& X);
 // residual of A'XE + E'XA + C for an LDL' iterate (/root/reference/src/lyapunov/residual.jl:3-31)
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
 

@@ -162,6 +162,8 @@ int dre_ldlt_compress_tol(dre_ctx* ctx, dre_ldlt* x, double abs_tol);
 int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out);                                     /* LDLt.jl:77-89 */
 /* bring an engine result to the reference's canonical form: one component, D = diag(eigenvalues), |lambda| >= 100 eps max|lambda| */
 int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x);
+/* dot(X1, X2) = <X1, X2>_F (LDLt.jl:91-108): Gram products and the two small congruences on the device; both operands on the same pencil */
+int dre_ldlt_dot(dre_ctx* ctx, const dre_ldlt* a, const dre_ldlt* b, double* out);
 /* alpha, L, D = X  (LDLt.jl:54-60; compresses when more than one component); pass NULL buffers to query sizes */
 int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* L_host, int ldl, double* D_host, int ldd);
 
@@ -230,6 +232,9 @@ int dre_heuristic_ritz(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, 
 /* residual(GALEProblem, X)  (src/lyapunov/residual.jl:3-31) */
 int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
                       const dre_dense* Vt, dre_ldlt* C, dre_ldlt* X, dre_ldlt** out);
+/* LyapunovOperator(E, F) * X = F'XE + E'XF as an LDL' object with factor [E'L, F'L] (src/lyapunov/gmres.jl:108-120); F as in dre_gale_solve */
+int dre_gale_apply(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
+                   const dre_ldlt* X, dre_ldlt** out);
 /* info: [0]=iters [1]=converged [2]=warnings [3]=number of recorded norms [4]=rhs columns;  dinfo: [0]=res_norm [1]=abstol [2]=initial norm */
 int dre_adi_result_info(const dre_adi_result* r, int64_t* info, double* dinfo);
 int dre_adi_result_history(const dre_adi_result* r, double* norms, int32_t* norm_iters, double* shifts_re, double* shifts_im);

@@ -57,3 +57,24 @@ def test_newton_with_fgmres_inner_solver(ctx, rail371):           # benchmark/be
         X, info = D.solve(are, D.Newton(gm, maxiters=20, reltol=1e-8), return_info=True)
     assert info["converged"]
     assert D.norm(D.residual(are, X)) < 1e-8 * D.norm(are.Q)
+
+
+def test_dot_and_lyapunov_operator_on_the_device(ctx):       # LDLt.jl:91-108, gmres.jl:108-120
+    """dre_ldlt_dot / dre_gale_apply against the dense definitions: <X1, X2>_F = tr(X1' X2) and L(X) = A'XE + E'XA, also for a
+    LowRankUpdate operator and lazily summed operands."""
+    from test_gpu_ldlt_gale import _rand_pencil
+    rng = np.random.default_rng(21)
+    n = 40
+    E, A = _rand_pencil(rng, n, True, False)
+    P = D.Pencil(E, A, ctx)
+    X1 = D.lowrank(rng.standard_normal((n, 3)), np.diag([1.0, -2.0, 0.5])) + 0.7 * D.lowrank(rng.standard_normal((n, 2)))
+    X2 = (-1.5) * D.lowrank(rng.standard_normal((n, 4)), rng.standard_normal((4, 4)) + 3 * np.eye(4))
+    X2 = D.LDLt(X2.alphas, X2.Ls, [0.5 * (d + d.T) for d in X2.Ds])
+    ref = float(np.sum(X1.dense() * X2.dense()))
+    assert abs(D.dot(X1, X2, ctx, P) - ref) <= 1e-12 * abs(ref) + 1e-12
+    assert abs(D.dot(X1, X2) - ref) <= 1e-12 * abs(ref) + 1e-12          # host fallback agrees
+    U, V = rng.random((n, 2)), rng.random((2, n))
+    for F, Fd in ((A, A.toarray()), (D.lr_update(A, -3.0, U, V), A.toarray() + U @ V / -3.0)):
+        W = D.lyapunov_apply(E, F, X1, ctx)
+        Wd = Fd.T @ X1.dense() @ E.toarray() + E.toarray().T @ X1.dense() @ Fd
+        assert np.linalg.norm(W.dense() - Wd) <= 1e-12 * np.linalg.norm(Wd)
