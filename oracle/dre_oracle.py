@@ -897,6 +897,93 @@ def solve_dense_ros2(prob: GDREProblem, dt, save_state=False):
     return DRESolution(Xs, Ks, tstops)
 
 
+def solve_dense_ros3(prob: GDREProblem, dt, save_state=False):
+    """riccati/dense_ros3.jl:3-86 (CPU oracle only).  The generalized Schur form + lyapcs! of the reference
+    (`lyapcs!(Fs, Es, R; adj=true)` solves F'XE + E'XF = -R in Schur coordinates, :44-49) is replaced by the dense GALE solver above."""
+    E, A, B, C = prob.E, prob.A, prob.B, prob.C
+    Ed = E.toarray() if sp.issparse(E) else np.asarray(E)
+    Ad = A.toarray() if sp.issparse(A) else np.asarray(A)
+    X = prob.X0
+    tstops = _tstops(prob.tspan, dt)
+    Xs = [X]
+    K = (B.T @ X) @ Ed
+    Ks = [K]
+    gamma = 7.886751345948129e-1                       # dense_ros3.jl:28-35
+    a21 = 1.267949192431123
+    c21, c31, c32 = -1.607695154586736, -3.464101615137755, -1.732050807568877
+    m1, m2, m3 = 2.0, 5.773502691896258e-1, 4.226497308103742e-1
+    CtC = C.T @ C
+    sym = lambda M: 0.5 * (M + M.T)
+    for i in range(1, len(tstops)):
+        tau = tstops[i - 1] - tstops[i]
+        gF = (Ad - B @ K) - Ed / (2.0 * gamma * tau)                   # :40
+        AXE = Ad.T @ X @ Ed
+        K1 = lyap_dense(gF, Ed, sym(CtC + AXE + AXE.T - K.T @ K))       # :44-50
+        RX = (Ad.T @ K1 - K.T @ (B.T @ K1)) @ Ed                        # :53
+        R23 = a21 * (RX + RX.T)
+        K21 = lyap_dense(gF, Ed, sym(R23 + (c21 / tau) * (Ed.T @ K1 @ Ed)))                                   # :55-60
+        K31 = lyap_dense(gF, Ed, sym(R23 + Ed.T @ (((c31 / tau) + (c32 / tau)) * K1 + (c32 / tau) * K21) @ Ed))   # :63-68
+        X = X + (m1 + m2 + m3) * K1 + m2 * K21 + m3 * K31               # :71
+        if save_state:
+            Xs.append(X)
+        K = (B.T @ X) @ Ed
+        Ks.append(K)
+    if not save_state:
+        Xs.append(X)
+    return DRESolution(Xs, Ks, tstops)
+
+
+def solve_dense_ros4(prob: GDREProblem, dt, save_state=False):
+    """riccati/dense_ros4.jl:3-94 (CPU oracle only; same replacement of schur + lyapcs! as in solve_dense_ros3)."""
+    E, A, B, C = prob.E, prob.A, prob.B, prob.C
+    Ed = E.toarray() if sp.issparse(E) else np.asarray(E)
+    Ad = A.toarray() if sp.issparse(A) else np.asarray(A)
+    X = prob.X0
+    tstops = _tstops(prob.tspan, dt)
+    Xs = [X]
+    K = (B.T @ X) @ Ed
+    Ks = [K]
+    CtC = C.T @ C
+    sym = lambda M: 0.5 * (M + M.T)
+    for i in range(1, len(tstops)):
+        tau = tstops[i - 1] - tstops[i]
+        gF = (tau * (Ad - B @ K) - Ed) / 2.0                             # :32
+        AXE = Ad.T @ X @ Ed
+        K1 = lyap_dense(gF, Ed, sym(CtC + AXE + AXE.T - K.T @ K))       # :36-42
+        EK1E = Ed.T @ K1 @ Ed
+        EK1B = Ed.T @ (K1 @ B)
+        K21 = lyap_dense(gF, Ed, sym(-tau ** 2 * (EK1B @ EK1B.T) - 2.0 * EK1E))     # :45-52
+        K2 = K21 - K1
+        al, be = (24.0 / 25.0) * tau, (3.0 / 25.0) * tau                 # :56-57
+        EK2E = Ed.T @ K2 @ Ed
+        EK2B = Ed.T @ (K2 @ B)
+        TMP = EK2B @ EK1B.T
+        R3 = (245.0 / 25.0) * EK1E + (36.0 / 25.0) * EK2E - (426.0 / 625.0) * tau ** 2 * (EK1B @ EK1B.T) - be ** 2 * (EK2B @ EK2B.T) - al * be * (TMP + TMP.T)
+        K31 = lyap_dense(gF, Ed, sym(R3))                                # :61-66
+        K3 = K31 - (17.0 / 25.0) * K1
+        R4 = -(981.0 / 125.0) * EK1E - (177.0 / 125.0) * EK2E - (1.0 / 5.0) * (Ed.T @ K3 @ Ed)
+        K41 = lyap_dense(gF, Ed, sym(R4))                                # :69-75
+        K4 = K41 + K3
+        X = X + tau * ((19.0 / 18.0) * K1 + 0.25 * K2 + (25.0 / 216.0) * K3 + (125.0 / 216.0) * K4)     # :78
+        if save_state:
+            Xs.append(X)
+        K = (B.T @ X) @ Ed
+        Ks.append(K)
+    if not save_state:
+        Xs.append(X)
+    return DRESolution(Xs, Ks, tstops)
+
+
+@dataclass
+class Ros3:
+    """DifferentialRiccatiEquations.jl:61 (dense only)"""
+
+
+@dataclass
+class Ros4:
+    """DifferentialRiccatiEquations.jl:62 (dense only)"""
+
+
 # --------------------------------------------------------------------------------------------
 # Low-rank FGMRES with (optional) ADI preconditioner (SURVEY §8f item 2)
 # --------------------------------------------------------------------------------------------
@@ -1137,4 +1224,8 @@ def solve(prob: GDREProblem, alg, dt, save_state=False, observer=None, stats=Non
         return solve_lowrank_ros2(prob, alg, dt, save_state, observer, stats)
     if isinstance(alg, Ros1):
         return solve_dense_ros1(prob, dt, save_state)
+    if isinstance(alg, Ros3):
+        return solve_dense_ros3(prob, dt, save_state)
+    if isinstance(alg, Ros4):
+        return solve_dense_ros4(prob, dt, save_state)
     return solve_dense_ros2(prob, dt, save_state)
