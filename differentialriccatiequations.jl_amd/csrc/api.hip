@@ -83,6 +83,9 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_RATIO")) ctx->c.compress_direct_ratio = std::atof(e);
         if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_N")) ctx->c.compress_factor_min_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_COLS")) ctx->c.compress_factor_min_cols = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH")) ctx->c.compress_sketch = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_MIN_COLS")) ctx->c.compress_sketch_min_cols = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_EXTRA")) ctx->c.compress_sketch_extra = std::atoi(e);
         if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
         if (const char* e = std::getenv("DRE_X_SIDE_STREAM")) ctx->c.x_side_stream = std::atoi(e);
         if (const char* e = std::getenv("DRE_DENSE_X_MAX_N")) ctx->c.dense_x_max_n = std::atoi(e);
@@ -127,6 +130,9 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "compress_direct_ratio") ctx->c.compress_direct_ratio = value;
         else if (key == "compress_factor_min_n") ctx->c.compress_factor_min_n = (int)value;
         else if (key == "compress_factor_min_cols") ctx->c.compress_factor_min_cols = (int)value;
+        else if (key == "compress_sketch") ctx->c.compress_sketch = (int)value;
+        else if (key == "compress_sketch_min_cols") ctx->c.compress_sketch_min_cols = (int)value;
+        else if (key == "compress_sketch_extra") ctx->c.compress_sketch_extra = (int)value;
         else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;

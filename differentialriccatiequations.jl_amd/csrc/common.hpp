@@ -122,6 +122,12 @@ struct Ctx {
     // compression in factor form (no QR of L, no n x n matrix) for n >= compress_factor_min_n and at least compress_factor_min_cols columns
     int compress_factor_min_n = 2561;
     int compress_factor_min_cols = 96;
+    // wide factors (c >= compress_sketch_min_cols and c >= 3 x sketch width) of a PSD-like sum are compressed through a randomized range
+    // finder (engine.hip, sketch_compress): three GEMM passes over the n x c factor instead of four per 16 columns of rank; the sketch width
+    // is the rank of the previous compression of this kind + compress_sketch_extra; 0 disables
+    int compress_sketch = 1;
+    int compress_sketch_min_cols = 768;
+    int compress_sketch_extra = 48;
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense
     // inverse of their Schur complement (reused real factors only; 0 disables)
     int top_inverse_max_rows = 1536;

@@ -3239,6 +3239,10 @@ __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* _
     const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
     out[idx % n + (idx / n) * (size_t)ld] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
+void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed) {
+    const size_t tot = (size_t)A.rows * A.cols;
+    if (tot) hipLaunchKernelGGL(k_fill_gauss, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, A.rows, A.cols, seed, A.p, A.ld);
+}
 struct LrBlockDev { int off, k, ldd, diag; const double* D; double alpha; };
 // RD = RB * blockdiag(alpha_b D_b)  (32 x c, ld 32);  colblk[j] = block of column j.  One thread per output entry.
 __global__ __launch_bounds__(256) void k_rows_blockdiag(int c, const double* __restrict__ RB, double* __restrict__ RD, const LrBlockDev* __restrict__ blocks,

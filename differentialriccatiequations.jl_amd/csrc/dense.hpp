@@ -50,6 +50,7 @@ struct CopyDesc { const double* src; double* dst; int rows, cols, lds, ldd; };
 void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                      // all blocks in one launch per 32
 void fill_mat(Ctx* ctx, Mat& dst, double v);
 void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
+void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed);   // independent standard normal entries (deterministic in seed and position)
 void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst);      // dst = src'
 void add_diag(Ctx* ctx, Mat& dst, const double* diag_dev, double scale);  // dst += scale*diag(v)
 void symmetrize(Ctx* ctx, Mat& S);                           // S = (S+S')/2

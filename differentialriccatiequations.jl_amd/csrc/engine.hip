@@ -124,6 +124,60 @@ static void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD) {
 }
 
 
+// Compression of a WIDE factor (c >> rank) through a randomized range finder (LDLt.jl:204-225 replaced for this regime; same result up
+// to the truncation tolerance).  With Om an n x s Gaussian test matrix, Y = X Om = L (Dt (L' Om)) spans the numerical range of
+// X = L Dt L' as soon as s exceeds the numerical rank by a modest oversampling, so  X ~ Q (Q'XQ) Q'  with Q = orth(Y):  three GEMM
+// passes over the n x c factor (L'Om, L W, Q'L) instead of four per 16 columns of rank in the factor-form band reduction.  The small
+// s x s matrix Q'XQ then goes through the usual band reduction, which fixes the final rank J.  Two independent acceptance tests:
+// (1) J leaves at least 32 of the s sketch directions unused (they carry nothing above the truncation tolerance), (2) 16 further
+// probe columns G, independent of Q:  ||(I - QQ') X G||_F <= 64 eps ||X G||_F  (the floor of that difference in f64 is ~ 20 eps).
+// A rejected sketch costs its three passes and the caller falls back to the factor-form reduction.  Only for sums without
+// cancellation (the ADI solution factors): the relative accuracy of Y is eps ||L||^2 ||Dt||.
+static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) {
+    const int n = X.n, c = X.rank(), sp = s + 16;
+    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    Mat Om(ctx, n, sp), W1(ctx, sp, c), W2(ctx, sp, c), Y(ctx, n, sp);
+    fill_gauss(ctx, Om, 0x2545F4914F6CDD1Dull);
+    gemm(ctx, true, false, 1.0, Om, Lcat, 0.0, W1, nullptr, "gemm_sketch");           // Om' L
+    mul_blockdiag(ctx, W1, X, W2);                                                     // Om' L Dt
+    gemm(ctx, false, true, 1.0, Lcat, W2, 0.0, Y, nullptr, "gemm_sketch");            // X Om  (Dt symmetric)
+    Mat Yr = Y.colsview(0, s), Z = Y.colsview(s, 16);
+    DevArr<double> nrm(ctx, 2);
+    frob2_device(ctx, Z, nrm.p);
+    QRFact qr = qr_factor(ctx, Yr);
+    Mat Q(ctx, n, s);
+    set_identity(ctx, Q, 1.0);
+    qr_apply_q(ctx, qr, Q, false);
+    {
+        Mat QtZ(ctx, s, 16);
+        gemm(ctx, true, false, 1.0, Q, Z, 0.0, QtZ, nullptr, "gemm_sketch");
+        gemm(ctx, false, false, -1.0, Q, QtZ, 1.0, Z, nullptr, "gemm_sketch");
+        frob2_device(ctx, Z, nrm.p + 1);
+    }
+    Mat B(ctx, s, c), BD(ctx, s, c), S(ctx, s, s);
+    gemm(ctx, true, false, 1.0, Q, Lcat, 0.0, B, nullptr, "gemm_sketch");             // Q' L
+    mul_blockdiag(ctx, B, X, BD);
+    gemm(ctx, false, true, 1.0, BD, B, 0.0, S, nullptr, "gemm_compress");             // Q' X Q
+    symmetrize(ctx, S);
+    SymBand sb = sym_band_reduce(ctx, S, tolfac);
+    double h[2] = {0.0, 0.0};
+    ctx_fetch(ctx, nrm.p, 2 * sizeof(double), h);
+    const double est = h[0] > 0.0 ? std::sqrt(h[1] / h[0]) : 0.0;
+    const bool ok = sb.J + 32 <= s && est <= 64.0 * EPS;
+    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d -> J=%d  probe residual %.2e  %s\n", n, c, s, sb.J, est, ok ? "accepted" : "REJECTED");
+    if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
+    ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += s; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
+    ctx->band_hint[skey] = sb.J;
+    X.blocks.clear();
+    if (sb.J == 0) { X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true}); return true; }
+    Mat Bq = sym_band_basis(ctx, sb);                 // s x J
+    Mat Lnew(ctx, n, sb.J);
+    gemm(ctx, false, false, 1.0, Q, Bq, 0.0, Lnew, nullptr, "gemm_sketch");
+    X.blocks.push_back({Lnew, sb.D, 1.0, false, true});
+    return true;
+}
+
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol) {
     const int n = X.n, c = X.rank();
     auto set_empty = [&]() {
@@ -135,6 +189,15 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     // (two thirds of all panel factorisations at n = 371) at the price of one GEMM.
     // (a handful of columns: the QR path keeps the rank <= c, the direct form can only stop at panel boundaries of the n x n problem)
     const bool wide = c >= n || (!exact && ((n <= 512 && c > 64) || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
+    const long skey = -(4000000000L + (long)n);          // band_hint: rank of the previous wide-factor compression at this order
+    const bool sketchable = !wide && !exact && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && c >= ctx->compress_sketch_min_cols && c + 64 <= n;
+    if (sketchable) {
+        auto hit = ctx->band_hint.find(skey);
+        if (hit != ctx->band_hint.end() && hit->second > 0) {
+            const int s = ((hit->second + ctx->compress_sketch_extra + 15) / 16) * 16;
+            if (c >= 3 * s && s + 80 <= n && sketch_compress(ctx, X, tolfac, s, skey)) return;
+        }
+    }
     if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {
         // large n: the band reduction works on the factor itself (dense.hip, lr_band_reduce): rank/16 panel steps on n x c data
         // instead of a QR of all c columns followed by the reduction of R D R'
@@ -153,6 +216,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         copy_batched(ctx, cd);
         SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
         ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += n; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
+        if (sketchable) ctx->band_hint[skey] = std::max(sb.J, 16);
         if (sb.J == 0) { set_empty(); return; }
         if (sb.J >= c) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
         Mat Bq = sym_band_basis(ctx, sb);
