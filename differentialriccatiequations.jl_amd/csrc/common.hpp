@@ -131,6 +131,10 @@ struct Ctx {
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense
     // inverse of their Schur complement (reused real factors only; 0 disables)
     int top_inverse_max_rows = 1536;
+    // multifrontal sweeps below the dense top: one workgroup per subtree and 16 right-hand-side columns (sparse.hip, SubPlan) instead of one
+    // launch per tree level; read when a pencil runs its first solve.  0 (default): level kernels everywhere — on the SteelProfile trees the
+    // two forms measure the same (sparse.hip)
+    int mf_subtree = 0;
     // Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments"; its compression runs on a second stream
     // beside the next time step (x_side_stream) or only every x_compress_every-th step (engine.hip, gdre_solve)
     // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps

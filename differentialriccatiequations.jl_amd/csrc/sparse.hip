@@ -739,6 +739,426 @@ __global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_beg
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Subtree sweeps (SubPlan, sparse.hpp).  The level kernels above pay one launch and one chain of dependent memory round trips per tree
+// level and direction (16-18 us each at n = 20209, 14 of them per solve below the dense top).  Below level Tsub a subtree is a contiguous
+// range of nodes and of pivot rows, small enough that its slice of the right-hand-side panel (16 columns) fits in LDS: ONE workgroup then
+// walks the whole subtree in postorder.  Forward: y_S = inv(L11) w_S, and -L21 y_S is scattered straight into the LDS rows of the
+// ancestors (supernodal form: no update vectors between the nodes of a subtree; what leaves the subtree is accumulated in the rows of the
+// root's boundary and written out as the root's update vector, so the dense top / the level kernels above see exactly what they saw
+// before).  Backward: reverse postorder, x_B gathered from LDS.  The factor entries are the only HBM/L2 traffic inside the loop; every
+// wave prefetches the A fragments of its tile of the NEXT node (8 MFMA K-steps, enough for pivot blocks up to 32) while the current node
+// computes, so the loop is bound by the MFMA chains and two (four) workgroup barriers per node, not by memory latency.
+// MEASURED (MI355X, n = 20209, 99 right-hand sides, wall-clock stamps inside the kernel): 2.2 us per node (0.4 issuing the prefetch,
+// 0.65 y tile, 0.9 update tile + scatter, 0.25 barriers and fragment hand-over) — a chain of two dependent 8-step f64 MFMA products
+// with their LDS operands; 43 nodes per subtree at Tsub = 5 give 110 us forward / 155 us backward against 122 / 122 us for the seven
+// level launches they replace, and deeper roots (shorter chains, more workgroups than CUs x occupancy) land at the same total.  The
+// subtree sweeps are therefore OFF by default (dre_ctx_set_option "mf_subtree"); they are kept, tested against the level kernels and
+// SuperLU, for pencils whose trees are deep and narrow.
+// ---------------------------------------------------------------------------------------------
+#define SUB_NW 8
+#define SUB_NT (SUB_NW * 64)
+#define SUB_LD 17
+struct SubArgs { const int* sub; const int* lmap; int prows_cap, nn_cap, lm_cap, b_cap, s_cap; };
+struct FragSrc {
+    const double* base;   // element (row, k) = base[row + k * ld]
+    int ld, nrow, kend, mode;      // valid: row < nrow, k < kend, and (mode 0: all | 1: k < row | 2: k >= row); everything else reads as 0
+};
+// Branch-free: every lane loads from a clamped (always valid) address; the predicate is applied by frag_mask when the values are CONSUMED,
+// so the eight loads of a batch are in flight together and a prefetched batch is not waited for before the node that uses it.
+__device__ __forceinline__ void frag_load(double (&av)[8], const FragSrc& f, int r0, int kb) {
+    const int lane = threadIdx.x & 63, row = r0 + (lane & 15), lk = lane >> 4;
+    const int rc = max(min(row, f.nrow - 1), 0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = kb + 4 * u + lk;
+        av[u] = f.base[rc + (size_t)max(min(k, f.kend - 1), 0) * f.ld];
+    }
+}
+__device__ __forceinline__ void frag_mask(double (&av)[8], const FragSrc& f, int r0, int kb) {
+    const int lane = threadIdx.x & 63, row = r0 + (lane & 15), lk = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = kb + 4 * u + lk;
+        const bool ok = row < f.nrow && k < f.kend && (f.mode == 0 || (f.mode == 1 ? k < row : k >= row));
+        av[u] = ok ? av[u] : 0.0;
+    }
+}
+__device__ __forceinline__ mf_v4d frag_mma(mf_v4d acc, const double (&av)[8], const double* __restrict__ Bs, int brow0, int kb, int kend) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (kb + 4 * u < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], Bs[(brow0 + kb + 4 * u + lk) * SUB_LD + lr], acc, 0, 0, 0);
+    return acc;
+}
+struct SubLds {
+    double* panel; long long* m_fo; long long* m_io; int* m_s; int* m_b; int* m_prow; int* m_lm; int* lml; double* extra;
+};
+__device__ __forceinline__ SubLds sub_carve(double* sm, const SubArgs& sa) {
+    SubLds L;
+    L.panel = sm;
+    L.m_fo = reinterpret_cast<long long*>(sm + (size_t)(sa.prows_cap + 4) * SUB_LD);
+    L.m_io = L.m_fo + sa.nn_cap;
+    L.m_s = reinterpret_cast<int*>(L.m_io + sa.nn_cap);
+    L.m_b = L.m_s + sa.nn_cap; L.m_prow = L.m_b + sa.nn_cap; L.m_lm = L.m_prow + sa.nn_cap;
+    L.lml = L.m_lm + sa.nn_cap;
+    L.extra = reinterpret_cast<double*>(L.lml + ((sa.lm_cap + 1) & ~1));
+    return L;
+}
+static size_t sub_lds_base(const SubArgs& sa) {
+    return (size_t)(sa.prows_cap + 4) * SUB_LD * 8 + (size_t)sa.nn_cap * (2 * 8 + 4 * 4) + (size_t)((sa.lm_cap + 1) & ~1) * 4;
+}
+// one prefetched batch (8 K-steps from kb) of a tile
+__device__ __forceinline__ mf_v4d tile_pf(mf_v4d acc, const FragSrc& f, int r0, int kb, const double* __restrict__ Bs, int brow0, const double (&pf)[8]) {
+    double av[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) av[u] = pf[u];
+    frag_mask(av, f, r0, kb);
+    return frag_mma(acc, av, Bs, brow0, kb, f.kend);      // (the branch-free variant with eight unconditional MFMAs measured 8-10 % slower)
+}
+// the rest of a tile's K range with loads issued on the spot (fronts beyond the prefetch depth; never instantiated in the SMALL kernels)
+__device__ __forceinline__ mf_v4d tile_rest(mf_v4d acc, const FragSrc& f, int r0, int kb, const double* __restrict__ Bs, int brow0) {
+    for (; kb < f.kend; kb += 32) {
+        double av[8];
+        frag_load(av, f, r0, kb);
+        frag_mask(av, f, r0, kb);
+        acc = frag_mma(acc, av, Bs, brow0, kb, f.kend);
+    }
+    return acc;
+}
+
+// SMALL: every node of every subtree has s <= 32 and b <= 256, so that all factor fragments of a node are covered by the prefetch (one
+// batch for the y tile, two update tiles per wave) and the node loop contains no other global load: the only vector-memory wait of an
+// iteration is the one at its top, for fragments requested one node earlier.
+template <bool SMALL>
+__global__ __launch_bounds__(SUB_NT) void k_mf_sub_forward(MfArgs a, SubArgs sa, const double* __restrict__ fronts, const double* __restrict__ inv,
+                                                           double* __restrict__ W, int ldw, int nrhs, double* __restrict__ upd, int64_t ldu,
+                                                           const AdiState* st, long long* probe) {
+    if (st && st->done) return;
+    int pslot = 0;
+#define SUB_STAMP() do { if (probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && pslot < 60) probe[pslot++] = (long long)wall_clock64(); } while (0)
+    SUB_STAMP();
+    extern __shared__ double sm[];
+    const SubLds L = sub_carve(sm, sa);
+    double* yb = L.extra;                                         // (round16(s_cap) + 4) x SUB_LD: y of the current node
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int n0 = sa.sub[4 * blockIdx.x], nn = sa.sub[4 * blockIdx.x + 1], row0 = sa.sub[4 * blockIdx.x + 2], nrows = sa.sub[4 * blockIdx.x + 3];
+    const int root = n0 + nn - 1, lm0 = a.bptr[n0], broot = a.bptr[root + 1] - a.bptr[root], prows = nrows + broot;
+    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    for (int i = tid; i < nn; i += SUB_NT) {
+        const int t = n0 + i;
+        L.m_s[i] = a.size[t]; L.m_b[i] = a.bptr[t + 1] - a.bptr[t]; L.m_prow[i] = a.first[t] - row0; L.m_lm[i] = a.bptr[t] - lm0;
+        L.m_fo[i] = a.front_off[t]; L.m_io[i] = a.inv_off[t];
+    }
+    for (int i = tid; i < a.bptr[root + 1] - lm0; i += SUB_NT) L.lml[i] = sa.lmap[lm0 + i];
+    for (int id0 = tid; id0 < (prows + 4) * MFM_KC; id0 += 8 * SUB_NT) {       // eight loads in flight per thread
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = id0 + u * SUB_NT, i = id % (prows + 4), c = id / (prows + 4);
+            const bool ok = i < nrows && c < kc;
+            v[u] = W[ok ? (size_t)(row0 + i) + (size_t)(c0 + c) * ldw : (size_t)row0];
+            v[u] = ok ? v[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = id0 + u * SUB_NT, i = id % (prows + 4), c = id / (prows + 4);
+            if (id < (prows + 4) * MFM_KC) L.panel[i * SUB_LD + c] = v[u];
+        }
+    }
+    __syncthreads();
+    SUB_STAMP();
+    const int r0 = wave * 16;
+    double nY[8], nU[8], nU2[8];
+    auto prefetch = [&](int i) {
+        const int s = L.m_s[i], b = L.m_b[i];
+        if (r0 < s) frag_load(nY, FragSrc{inv + L.m_io[i], s, s, min(s, r0 + 16), 1}, r0, 0);
+        if (r0 < b) frag_load(nU, FragSrc{fronts + L.m_fo[i] + s, s + b, b, s, 0}, r0, 0);
+        if (SMALL && r0 + 16 * SUB_NW < b) frag_load(nU2, FragSrc{fronts + L.m_fo[i] + s, s + b, b, s, 0}, r0 + 16 * SUB_NW, 0);
+    };
+    prefetch(0);
+    for (int i = 0; i < nn; ++i) {
+        double cY[8], cU[8], cU2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {     // the wait for this node's fragments sits HERE, before the next prefetch is issued (vmcnt counts in order)
+            cY[u] = nY[u]; cU[u] = nU[u]; cU2[u] = nU2[u];
+            asm volatile("" : "+v"(cY[u]), "+v"(cU[u]), "+v"(cU2[u]));
+        }
+        SUB_STAMP();
+        if (i + 1 < nn) prefetch(i + 1);
+        SUB_STAMP();
+        const int s = L.m_s[i], b = L.m_b[i], f = s + b, prow = L.m_prow[i], lm = L.m_lm[i];
+        const double* F = fronts + L.m_fo[i];
+        const double* Ti = inv + L.m_io[i];
+        // y_S = inv(L11) w_S  (unit diagonal: the accumulator starts at w; strictly lower part of Ti)
+        // (y goes to its own buffer: the tiles of a node read each other's w rows, and one barrier per phase is saved)
+        if (r0 < s) {
+            mf_v4d yacc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = r0 + lq + 4 * r; yacc[r] = row < s ? L.panel[(prow + row) * SUB_LD + lr] : 0.0; }
+            const FragSrc fy{Ti, s, s, min(s, r0 + 16), 1};
+            yacc = tile_pf(yacc, fy, r0, 0, L.panel, prow, cY);
+            if (!SMALL) yacc = tile_rest(yacc, fy, r0, 32, L.panel, prow);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yb[(r0 + lq + 4 * r) * SUB_LD + lr] = yacc[r];       // rows >= s of the last tile: never read with a nonzero A
+        }
+        SUB_STAMP();
+        __syncthreads();
+        SUB_STAMP();
+        for (int id = tid; id < s * MFM_KC; id += SUB_NT) { const int row = id >> 4, c = id & 15; L.panel[(prow + row) * SUB_LD + c] = yb[row * SUB_LD + c]; }
+        // rows of the ancestors -= L21 y_S   (the tile holds +L21 y_S)
+        const FragSrc fu{F + s, f, b, s, 0};
+        auto scatter = [&](int rt, const mf_v4d& acc) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = rt * 16 + lq + 4 * r; if (row < b) L.panel[L.lml[lm + row] * SUB_LD + lr] -= acc[r]; }
+        };
+        if (r0 < b) {
+            mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            acc = tile_pf(acc, fu, r0, 0, yb, 0, cU);
+            if (!SMALL) acc = tile_rest(acc, fu, r0, 32, yb, 0);
+            scatter(wave, acc);
+        }
+        if (SMALL) {
+            if (r0 + 16 * SUB_NW < b) {
+                mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+                acc = tile_pf(acc, fu, r0 + 16 * SUB_NW, 0, yb, 0, cU2);
+                scatter(wave + SUB_NW, acc);
+            }
+        } else {
+            for (int rt = wave + SUB_NW; rt * 16 < b; rt += SUB_NW) {
+                mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+                acc = tile_rest(acc, fu, rt * 16, 0, yb, 0);
+                scatter(rt, acc);
+            }
+        }
+        SUB_STAMP();
+        __syncthreads();
+        SUB_STAMP();
+    }
+    for (int id = tid; id < nrows * kc; id += SUB_NT) {
+        const int i = id % nrows, c = id / nrows;
+        W[(size_t)(row0 + i) + (size_t)(c0 + c) * ldw] = L.panel[i * SUB_LD + c];
+    }
+    double* ut = upd + a.upd_off[root];
+    for (int id = tid; id < broot * kc; id += SUB_NT) {
+        const int j = id % broot, c = id / broot;
+        ut[j + (size_t)(c0 + c) * ldu] = L.panel[(nrows + j) * SUB_LD + c];
+    }
+    SUB_STAMP();
+    if (probe && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) probe[63] = pslot;
+#undef SUB_STAMP
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__(SUB_NT) void k_mf_sub_backward(MfArgs a, SubArgs sa, const double* __restrict__ fronts, const double* __restrict__ inv,
+                                                            double* __restrict__ W, int ldw, int nrhs, const AdiState* st) {
+    if (st && st->done) return;
+    extern __shared__ double sm[];
+    const SubLds L = sub_carve(sm, sa);
+    double* xb = L.extra;                                         // (b_cap + 4) x SUB_LD: the boundary unknowns of the current node
+    double* zb = xb + (size_t)(sa.b_cap + 4) * SUB_LD;            // (s_cap + 4) x SUB_LD
+    double* part = zb + (size_t)(sa.s_cap + 4) * SUB_LD;          // SUB_NW x 256: K-split partial tiles
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+    const int n0 = sa.sub[4 * blockIdx.x], nn = sa.sub[4 * blockIdx.x + 1], row0 = sa.sub[4 * blockIdx.x + 2], nrows = sa.sub[4 * blockIdx.x + 3];
+    const int root = n0 + nn - 1, lm0 = a.bptr[n0], broot = a.bptr[root + 1] - a.bptr[root], prows = nrows + broot;
+    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    for (int i = tid; i < nn; i += SUB_NT) {
+        const int t = n0 + i;
+        L.m_s[i] = a.size[t]; L.m_b[i] = a.bptr[t + 1] - a.bptr[t]; L.m_prow[i] = a.first[t] - row0; L.m_lm[i] = a.bptr[t] - lm0;
+        L.m_fo[i] = a.front_off[t]; L.m_io[i] = a.inv_off[t];
+    }
+    for (int i = tid; i < a.bptr[root + 1] - lm0; i += SUB_NT) L.lml[i] = sa.lmap[lm0 + i];
+    const int* Broot = a.bidx + a.bptr[root];
+    for (int id0 = tid; id0 < (prows + 4) * MFM_KC; id0 += 8 * SUB_NT) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = id0 + u * SUB_NT, i = id % (prows + 4), c = id / (prows + 4);
+            const bool ok = i < prows && c < kc;
+            const int grow = i < nrows ? row0 + i : Broot[min(max(i - nrows, 0), max(broot - 1, 0))];
+            v[u] = W[ok ? (size_t)grow + (size_t)(c0 + c) * ldw : (size_t)row0];
+            v[u] = ok ? v[u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int id = id0 + u * SUB_NT, i = id % (prows + 4), c = id / (prows + 4);
+            if (id < (prows + 4) * MFM_KC) L.panel[i * SUB_LD + c] = v[u];
+        }
+    }
+    __syncthreads();
+    double nZ[8], nZ2[8], nX[8];
+    auto prefetch = [&](int i) {
+        const int s = L.m_s[i], b = L.m_b[i], f = s + b;
+        const int ny = (s + 15) >> 4, nch = max(1, SUB_NW / ny), ks = (b + 3) >> 2, cks = (ks + nch - 1) / nch;
+        const int tile = wave % ny, ch = wave / ny;
+        if (wave < ny * nch && b > 0) {
+            const int kb0 = ch * cks * 4, ke = min(b, (ch + 1) * cks * 4);
+            const FragSrc fz{fronts + L.m_fo[i] + (size_t)s * f, f, s, ke, 0};
+            if (kb0 < ke) frag_load(nZ, fz, tile * 16, kb0);
+            if (SMALL && kb0 + 32 < ke) frag_load(nZ2, fz, tile * 16, kb0 + 32);
+        }
+        if (wave < ny) frag_load(nX, FragSrc{inv + L.m_io[i], s, s, s, 2}, wave * 16, wave * 16);
+    };
+    prefetch(nn - 1);
+    for (int i = nn - 1; i >= 0; --i) {
+        double cZ[8], cZ2[8], cX[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            cZ[u] = nZ[u]; cZ2[u] = nZ2[u]; cX[u] = nX[u];
+            asm volatile("" : "+v"(cZ[u]), "+v"(cZ2[u]), "+v"(cX[u]));
+        }
+        if (i > 0) prefetch(i - 1);
+        const int s = L.m_s[i], b = L.m_b[i], f = s + b, prow = L.m_prow[i], lm = L.m_lm[i];
+        const double* F = fronts + L.m_fo[i];
+        const double* Ti = inv + L.m_io[i];
+        const int ny = (s + 15) >> 4, nch = max(1, SUB_NW / ny), ks = (b + 3) >> 2, cks = (ks + nch - 1) / nch;
+        const int bp = (b + 3) & ~3, sp = (s + 3) & ~3;
+        for (int id = tid; id < bp * MFM_KC; id += SUB_NT) {
+            const int k = id >> 4, c = id & 15;
+            xb[k * SUB_LD + c] = k < b ? L.panel[L.lml[lm + k] * SUB_LD + c] : 0.0;
+        }
+        __syncthreads();
+        // partial tiles of  U12 x_B,  K split over the waves (subtracted in the reduction below)
+        if (wave < ny * nch && b > 0) {
+            const int tile = wave % ny, ch = wave / ny;
+            const int kb0 = ch * cks * 4, ke = min(b, (ch + 1) * cks * 4);
+            mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            if (kb0 < ke) {
+                const FragSrc fz{F + (size_t)s * f, f, s, ke, 0};
+                acc = tile_pf(acc, fz, tile * 16, kb0, xb, 0, cZ);
+                if (SMALL) { if (kb0 + 32 < ke) acc = tile_pf(acc, fz, tile * 16, kb0 + 32, xb, 0, cZ2); }
+                else acc = tile_rest(acc, fz, tile * 16, kb0 + 32, xb, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave * 256 + (lq + 4 * r) * 16 + lr] = acc[r];
+        }
+        __syncthreads();
+        for (int id = tid; id < sp * MFM_KC; id += SUB_NT) {
+            const int row = id >> 4, c = id & 15;
+            double v = 0.0;
+            if (row < s) {
+                v = L.panel[(prow + row) * SUB_LD + c];
+                if (b > 0) { const int tile = row >> 4; for (int ch = 0; ch < nch; ++ch) v -= part[(tile + ch * ny) * 256 + (row & 15) * 16 + c]; }
+            }
+            zb[row * SUB_LD + c] = v;
+        }
+        __syncthreads();
+        // x_S = inv(U11) z : upper triangle of Ti including the diagonal
+        if (wave < ny) {
+            const int r0 = wave * 16;
+            mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const FragSrc fx{Ti, s, s, s, 2};
+            acc = tile_pf(acc, fx, r0, r0, zb, 0, cX);
+            if (!SMALL) acc = tile_rest(acc, fx, r0, r0 + 32, zb, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = r0 + lq + 4 * r; if (row < s) L.panel[(prow + row) * SUB_LD + lr] = acc[r]; }
+        }
+        __syncthreads();
+    }
+    for (int id = tid; id < nrows * kc; id += SUB_NT) {
+        const int i = id % nrows, c = id / nrows;
+        W[(size_t)(row0 + i) + (size_t)(c0 + c) * ldw] = L.panel[i * SUB_LD + c];
+    }
+}
+
+// host: choose the root level and build the per-subtree tables
+static void sub_plan_build(Ctx* ctx, const Pencil& P, int Tmin) {
+    SubPlan& sp = P.sub;
+    sp.built = true; sp.Tsub = -1;
+    if (!ctx->mf_subtree) return;
+    const Symbolic& S = P.sym;
+    const size_t lds_limit = 156 * 1024;
+    std::vector<int> nsubnodes((size_t)S.nnodes, 1);            // nodes of the subtree rooted at t (postorder: children first)
+    for (int t = 0; t < S.nnodes; ++t) if (S.parent[t] >= 0) nsubnodes[(size_t)S.parent[t]] += nsubnodes[(size_t)t];
+    // root level: the chain of a workgroup costs ~2.2 us per node (measured: MFMA / LDS latency of two dependent tile products) plus ~6 us of
+    // set-up, a level launch above the subtrees ~17.5 us; deeper roots mean shorter chains and more level launches
+    int forced = -1;
+    if (const char* e = std::getenv("DRE_MF_SUBTREE_LEVEL")) forced = std::atoi(e);
+    int bestL = -1; double bestcost = 1e300;
+    for (int Lv = std::max(Tmin, 1); Lv < S.nlevels; ++Lv) {
+        int nnmax = 0;
+        for (int q = S.lvl_ptr[Lv]; q < S.lvl_ptr[Lv + 1]; ++q) nnmax = std::max(nnmax, nsubnodes[(size_t)S.lvl_nodes[q]]);
+        const double cost = 6.0 + 2.2 * nnmax + 17.5 * (Lv - std::max(Tmin, 0));
+        if (cost < bestcost) { bestcost = cost; bestL = Lv; }
+    }
+    if (forced >= 0) bestL = std::max(forced, std::max(Tmin, 1));
+    for (int Lv = std::max(bestL, 1); Lv < S.nlevels; ++Lv) {
+        SubArgs sa{nullptr, nullptr, 0, 0, 0, 0, 0};
+        bool ok = true;
+        std::vector<int> tab;
+        for (int q = S.lvl_ptr[Lv]; q < S.lvl_ptr[Lv + 1] && ok; ++q) {
+            const int r = S.lvl_nodes[q], nn = nsubnodes[(size_t)r], n0 = r - nn + 1;
+            const int rowb = S.first[n0], nrows = S.first[r] + S.size[r] - rowb, broot = S.bptr[r + 1] - S.bptr[r];
+            sa.prows_cap = std::max(sa.prows_cap, nrows + broot); sa.nn_cap = std::max(sa.nn_cap, nn);
+            sa.lm_cap = std::max(sa.lm_cap, S.bptr[r + 1] - S.bptr[n0]);
+            for (int t = n0; t <= r; ++t) {
+                sa.b_cap = std::max(sa.b_cap, S.bptr[t + 1] - S.bptr[t]); sa.s_cap = std::max(sa.s_cap, S.size[t]);
+                if (S.level[t] < Lv) ok = false;                 // not a subtree in the postorder (cannot happen for a tree; guard)
+            }
+            tab.push_back(n0); tab.push_back(nn); tab.push_back(rowb); tab.push_back(nrows);
+        }
+        if (!ok || tab.empty() || sa.s_cap > 16 * SUB_NW) continue;
+        const size_t base = sub_lds_base(sa), fwd = base + (size_t)(((sa.s_cap + 15) & ~15) + 4) * SUB_LD * 8;
+        const size_t bwd = base + ((size_t)(sa.b_cap + 4) * SUB_LD + (size_t)(sa.s_cap + 4) * SUB_LD + (size_t)SUB_NW * 256) * 8;
+        if (bwd > lds_limit) continue;
+        // rows of the subtree's LDS panel for every boundary entry
+        std::vector<int> lmap((size_t)std::max<int>(S.bptr[S.nnodes], 1), 0);
+        for (size_t z = 0; z < tab.size(); z += 4) {
+            const int n0 = tab[z], nn = tab[z + 1], rowb = tab[z + 2], nrows = tab[z + 3], r = n0 + nn - 1;
+            const int* Br = S.bidx.data() + S.bptr[r];
+            const int broot = S.bptr[r + 1] - S.bptr[r];
+            for (int t = n0; t <= r; ++t)
+                for (int e = S.bptr[t]; e < S.bptr[t + 1]; ++e) {
+                    const int j = S.bidx[e];
+                    if (j < rowb + nrows) { lmap[(size_t)e] = j - rowb; continue; }
+                    const int* it = std::lower_bound(Br, Br + broot, j);
+                    if (it == Br + broot || *it != j) return;     // boundary entry outside the root's boundary: keep the level kernels
+                    lmap[(size_t)e] = nrows + (int)(it - Br);
+                }
+        }
+        sp.sub = DevArr<int>(ctx, tab.size()); sp.sub.upload(ctx, tab);
+        sp.lmap = DevArr<int>(ctx, lmap.size()); sp.lmap.upload(ctx, lmap);
+        sp.Tsub = Lv; sp.nsub = (int)(tab.size() / 4);
+        sp.prows_max = sa.prows_cap; sp.nn_max = sa.nn_cap; sp.lm_max = sa.lm_cap; sp.b_max = sa.b_cap; sp.s_max = sa.s_cap;
+        sp.lds_fwd = fwd; sp.lds_bwd = bwd;
+        if (std::getenv("DRE_TRACE_SUBTREE"))
+            std::fprintf(stderr, "[subtree sweeps] n=%d levels=%d Tsub=%d subtrees=%d panel rows<=%d nodes<=%d b<=%d s<=%d LDS fwd %zu bwd %zu\n", P.n, S.nlevels, Lv,
+                         sp.nsub, sa.prows_cap, sa.nn_cap, sa.b_cap, sa.s_cap, fwd, bwd);
+        return;
+    }
+}
+static void mf_sub_sweep(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, double* upd, int64_t ldu, const AdiState* st,
+                         bool forward) {
+    const SubPlan& sp = P.sub;
+    MfArgs a = mf_args(P);
+    SubArgs sa{sp.sub.p, sp.lmap.p, sp.prows_max, sp.nn_max, sp.lm_max, sp.b_max, sp.s_max};
+    const int ncb = ceil_div(nrhs, MFM_KC);
+    const bool small = sp.s_max <= 32 && sp.b_max <= 32 * SUB_NW;        // every fragment of every node fits the prefetch depth
+    static const bool probe_on = std::getenv("DRE_SUB_PROBE") != nullptr;   // debug: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
+    static int probe_count = 0;
+    DevArr<long long> probe;
+    long long* pp = nullptr;
+    if (probe_on && forward && nrhs >= 64 && probe_count < 3) { probe = DevArr<long long>(ctx, 64); DRE_HIP(hipMemsetAsync(probe.p, 0, 64 * 8, ctx->stream)); pp = probe.p; }
+    if (small) {
+        lds_attr(ctx, (const void*)k_mf_sub_forward<true>, 160 * 1024); lds_attr(ctx, (const void*)k_mf_sub_backward<true>, 160 * 1024);
+        if (forward) hipLaunchKernelGGL((k_mf_sub_forward<true>), dim3(sp.nsub, ncb), dim3(SUB_NT), sp.lds_fwd, ctx->stream, a, sa, Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st, pp);
+        else hipLaunchKernelGGL((k_mf_sub_backward<true>), dim3(sp.nsub, ncb), dim3(SUB_NT), sp.lds_bwd, ctx->stream, a, sa, Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+    } else {
+        lds_attr(ctx, (const void*)k_mf_sub_forward<false>, 160 * 1024); lds_attr(ctx, (const void*)k_mf_sub_backward<false>, 160 * 1024);
+        if (forward) hipLaunchKernelGGL((k_mf_sub_forward<false>), dim3(sp.nsub, ncb), dim3(SUB_NT), sp.lds_fwd, ctx->stream, a, sa, Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st, pp);
+        else hipLaunchKernelGGL((k_mf_sub_backward<false>), dim3(sp.nsub, ncb), dim3(SUB_NT), sp.lds_bwd, ctx->stream, a, sa, Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+    }
+    if (pp) {
+        long long h[64];
+        DRE_HIP(hipMemcpyAsync(h, pp, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        ++probe_count;
+        std::fprintf(stderr, "[sub probe] nrhs=%d stamps=%lld (us since start):", nrhs, h[63]);
+        for (int i = 1; i < (int)h[63] && i < 60; ++i) std::fprintf(stderr, " %.2f", (double)(h[i] - h[0]) * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+}
+
 // ---- top levels as one dense operator (TopPlan, sparse.hpp) --------------------------------------------------------
 static void top_plan_build(Ctx* ctx, const Pencil& P, int max_rows) {
     TopPlan& tp = P.top;
@@ -873,10 +1293,28 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     DevArr<double> upd(ctx, (size_t)ldu * nrhs);
     const double bytes = 2.0 * 8.0 * (double)S.factor_nnz + 4.0 * 8.0 * (double)P.n * nrhs;
     const double flops = 2.0 * 2.0 * (double)S.factor_nnz * nrhs;
+    // subtree sweeps below level Tsub (>= the number of dense top levels, so that both plans agree on who owns a level)
+    if (!P.sub.built) {
+        if (!P.top.built && ctx->top_inverse_max_rows > 0) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
+        sub_plan_build(ctx, P, P.top.T);
+    }
+    const int Tsub = P.sub.Tsub;            // -1: level kernels everywhere
+    auto forward_to = [&](int l_to) {        // levels nlevels-1 .. l_to
+        if (Tsub >= 0 && Tsub >= l_to) {
+            mf_sub_sweep(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true);
+            if (Tsub - 1 >= l_to) mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, Tsub - 1, l_to);
+        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, l_to);
+    };
+    auto backward_from = [&](int l_from) {   // levels l_from .. nlevels-1
+        if (Tsub >= 0 && Tsub >= l_from) {
+            if (Tsub - 1 >= l_from) mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, l_from, Tsub - 1);
+            mf_sub_sweep(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false);
+        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, l_from, S.nlevels - 1);
+    };
     if (Fc.topinv.empty()) {
         TimedScope ts(ctx, "mf_solve_real", bytes, flops);
-        mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, 0);
-        mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, 0, S.nlevels - 1);
+        forward_to(0);
+        backward_from(0);
     } else {
         const TopPlan& tp = P.top;
         const int ntop = tp.ntop, T = tp.T;
@@ -884,7 +1322,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
         const size_t tot = (size_t)ntop * nrhs;
         {
             TimedScope ts(ctx, "mf_solve_real", bytes, flops);
-            mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, T);
+            forward_to(T);
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st);
         }
@@ -893,7 +1331,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
             hipLaunchKernelGGL(k_top_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const double*)x.p, x.ld, W, ldw, st);
-            mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, T, S.nlevels - 1);
+            backward_from(T);
         }
     }
     DRE_HIP(hipGetLastError());

@@ -53,6 +53,21 @@ struct TopPlan {
     DevArr<int64_t> gsrc;       // row offsets into the update slab contributing to top variable p
 };
 
+// The subtrees below level Tsub of the elimination tree, each swept by ONE workgroup per 16 right-hand-side columns (sparse.hip,
+// k_mf_sub_forward / k_mf_sub_backward): nodes and pivot rows of a subtree are contiguous in the postorder, so its slice of the
+// right-hand-side panel (pivot rows + the rows of the root's boundary) stays in LDS for the whole sweep and the 2 x (nlevels - Tsub)
+// latency-bound level launches collapse into two launches.
+struct SubPlan {
+    bool built = false;
+    int Tsub = -1;              // level of the subtree roots; -1: no plan (the level kernels run everywhere)
+    int nsub = 0;
+    int prows_max = 0;          // largest panel (pivot rows of the subtree + boundary rows of its root)
+    int nn_max = 0, lm_max = 0, b_max = 0, s_max = 0;
+    size_t lds_fwd = 0, lds_bwd = 0;
+    DevArr<int> sub;            // 4 ints per subtree: first node, number of nodes, first pivot row, number of pivot rows
+    DevArr<int> lmap;           // per boundary entry (indexing of bidx): row of the subtree's LDS panel
+};
+
 // E' and A' (CSR == the caller's CSC of E and A) on one union pattern, permuted to the solver ordering.
 struct Pencil {
     int n = 0, nnz = 0;
@@ -66,6 +81,7 @@ struct Pencil {
     bool use_mfma_sweeps = true;    // real triangular sweeps on the matrix cores (env DRE_MF_SCALAR=1 selects the scalar kernels)
     bool has_device = false;
     mutable TopPlan top;            // built on first use
+    mutable SubPlan sub;            // built on first use (after the top plan)
 };
 
 // Build from CSC arrays (1-based or 0-based) of E and A as Julia's SparseMatrixCSC stores them.

@@ -58,6 +58,34 @@ def test_shifted_multifrontal_solve(ctx, pencil371, cA, cE):
     assert np.linalg.norm(X - ref) / np.linalg.norm(ref) < 1e-12
 
 
+@pytest.mark.parametrize("n,leaf", [(1357, 0), (5177, 0), (5177, 12), (20209, 0)])
+def test_subtree_sweeps_match_the_level_kernels_and_superlu(ctx, n, leaf):
+    """One workgroup per subtree below the dense top (sparse.hip, SubPlan) against the level-by-level sweeps and SuperLU: real shifts,
+    ragged column counts (the combination with the dense top inverse of reused factors is covered by the GDRE fixtures at n = 5177, 20209)."""
+    d = D.steel_profile(n)
+    rng = np.random.default_rng(n + leaf)
+    ctx.set_option("mf_subtree", 1)
+    P1 = D.Pencil(d.E, d.A, ctx, leaf_size=leaf)
+    lu = spla.splu((d.A.T - 0.37 * d.E.T).tocsc())
+    F1 = P1.factor(1.0, -0.37)
+    outs = []
+    for k in (1, 16, 37, 99):
+        B = rng.standard_normal((n, k))
+        X = F1.solve(B)
+        ref = lu.solve(B)
+        assert np.linalg.norm(X - ref) / np.linalg.norm(ref) < 1e-11, (n, leaf, k)
+        outs.append((B, X))
+    ctx.set_option("mf_subtree", 0)
+    try:
+        P0 = D.Pencil(d.E, d.A, ctx, leaf_size=leaf)
+        F0 = P0.factor(1.0, -0.37)
+        for B, X in outs:
+            X0 = F0.solve(B)
+            assert np.linalg.norm(X - X0) / np.linalg.norm(X0) < 1e-12
+    finally:
+        ctx.set_option("mf_subtree", 0)          # the default
+
+
 def test_shifted_solve_nonsymmetric_and_empty_rhs(ctx):
     rng = np.random.default_rng(2)
     n = 90
