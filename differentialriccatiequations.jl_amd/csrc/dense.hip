@@ -1,5 +1,6 @@
 // Dense f64 kernels for gfx950: MFMA GEMM, Householder QR, symmetric eigensolver, small helpers.
 #include "dense.hpp"
+#include <functional>
 #include "profiling.hpp"
 #include <atomic>
 #include <chrono>
@@ -417,6 +418,58 @@ __global__ void k_symmetrize(int n, double* __restrict__ S, int ld) {
         S[c + (size_t)r * ld] = m;
     }
 }
+// X <- sym(X + A B')  (A, B: n x K): the split-K slabs of A B' are reduced, added and symmetrised in one pass (same arithmetic as
+// gemm(beta = 1) followed by symmetrize)
+// one workgroup per pair of mirror tiles (32 x 32): both are reduced with coalesced reads and exchanged through LDS
+__global__ __launch_bounds__(256) void k_reduce_sym_update(int n, int splits, const double* __restrict__ partial, double* __restrict__ X, int ldx) {
+    __shared__ double sa[32][33], sb[32][33];
+    const int I = blockIdx.x, J = blockIdx.y;
+    if (I < J) return;
+    const int tr = threadIdx.x & 31, tc0 = threadIdx.x >> 5;
+    const size_t slab = (size_t)n * n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tc = tc0 + 8 * q;
+        {
+            const int r = I * 32 + tr, c = J * 32 + tc;
+            double v = 0.0;
+            if (r < n && c < n) { for (int z = 0; z < splits; ++z) v += partial[z * slab + r + (size_t)c * n]; v += X[r + (size_t)c * ldx]; }
+            sa[tr][tc] = v;
+        }
+        if (I != J) {
+            const int r = J * 32 + tr, c = I * 32 + tc;
+            double v = 0.0;
+            if (r < n && c < n) { for (int z = 0; z < splits; ++z) v += partial[z * slab + r + (size_t)c * n]; v += X[r + (size_t)c * ldx]; }
+            sb[tr][tc] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tc = tc0 + 8 * q;
+        {
+            const int r = I * 32 + tr, c = J * 32 + tc;
+            if (r < n && c < n) {
+                const double a = sa[tr][tc], b = (I == J) ? sa[tc][tr] : sb[tc][tr];
+                X[r + (size_t)c * ldx] = (r == c) ? a : 0.5 * (a + b);
+            }
+        }
+        if (I != J) {
+            const int r = J * 32 + tr, c = I * 32 + tc;
+            if (r < n && c < n) X[r + (size_t)c * ldx] = 0.5 * (sb[tr][tc] + sa[tc][tr]);
+        }
+    }
+}
+void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag) {
+    const int n = X.rows;
+    DRE_REQUIRE(X.cols == n && A.rows == n && B.rows == n && A.cols == B.cols, "gemm_sym_update: shape mismatch");
+    if (A.cols == 0) return;
+    int splits = 1;
+    BufP pb = gemm_partials(ctx, false, true, n, n, A.cols, A.p, A.ld, B.p, B.ld, &splits, nullptr, tag);
+    const int nt = ceil_div(n, 32);
+    hipLaunchKernelGGL(k_reduce_sym_update, dim3(nt, nt), dim3(256), 0, ctx->stream, n, splits, (const double*)pb->p, X.p, X.ld);
+    DRE_HIP(hipGetLastError());
+}
 void symmetrize(Ctx* ctx, Mat& S) {
     DRE_REQUIRE(S.rows == S.cols, "symmetrize: square matrix expected");
     size_t tot = (size_t)S.rows * S.rows;
@@ -511,6 +564,10 @@ __global__ __launch_bounds__(256) void k_fetch(FetchSrc s, unsigned long long* _
     if (threadIdx.x == 0) __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1, const void* d2, size_t b2, void* h2) {
+    ctx_fetch_overlap(ctx, std::function<void()>(), d0, b0, h0, d1, b1, h1, d2, b2, h2);
+}
+void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1,
+                       const void* d2, size_t b2, void* h2) {
     static const bool spin_on = !(std::getenv("DRE_FETCH_SPIN") && std::atoi(std::getenv("DRE_FETCH_SPIN")) == 0);   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
     const size_t tot = (b0 + b1 + b2) / 8;
     DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
@@ -528,6 +585,7 @@ void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, si
         if (b0) DRE_HIP(hipMemcpyAsync(h0, d0, b0, hipMemcpyDeviceToHost, ctx->stream));
         if (b1) DRE_HIP(hipMemcpyAsync(h1, d1, b1, hipMemcpyDeviceToHost, ctx->stream));
         if (b2) DRE_HIP(hipMemcpyAsync(h2, d2, b2, hipMemcpyDeviceToHost, ctx->stream));
+        if (between) between();
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         return;
     }
@@ -538,6 +596,7 @@ void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, si
     const unsigned long long want = ++ctx->fetch_seq;
     hipLaunchKernelGGL(k_fetch, dim3(1), dim3(256), 0, ctx->stream, s, (unsigned long long*)ctx->fetch_dev->words, (unsigned long long*)&ctx->fetch_dev->seq, want);
     DRE_HIP(hipGetLastError());
+    if (between) between();          // work the host enqueues while the words are on their way (the device runs it right behind the signal kernel)
     // bounded spin on the host-visible sequence number, then the plain synchronisation as a safety net
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = false;
@@ -2156,7 +2215,7 @@ template <int NR>
 __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int lda, int rows, double* __restrict__ V, int ldv,
                                                     double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, AdiState* st,
                                                     const double* __restrict__ part, int nparts, int kpanel, double tolfac,
-                                                    double* __restrict__ part_out) {
+                                                    double* __restrict__ part_out, int zero_above) {
     if (st && st->done) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (part) {
@@ -2244,6 +2303,8 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
         }
         if (c0 <= jj + 1 && jj + 1 < c0 + 4) sig = wave_sum(nn);        // the next owner's look-ahead norm
     }
+    // the rows of V above this panel (the caller's columns start zero_above rows higher): zeroed here instead of a fill of the whole matrix
+    for (int id = tid; id < zero_above * 16; id += 256) V[(long)(id % zero_above) - zero_above + (long)(id / zero_above) * ldv] = 0.0;
     // V (explicit) to LDS and global, the panel (R above, reflectors below) back to A
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -2336,17 +2397,17 @@ static bool qr_panel16_enabled() {
 
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
-                            double tolfac = 0.0, double* part_out = nullptr) {
+                            double tolfac = 0.0, double* part_out = nullptr, int zero_above = 0) {
     const int rows = m - j0;
     if (rows <= 512 && rows >= 16 && jb == 16 && j0 == 0 && qr_panel16_enabled()) {
         TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = ((size_t)1024 + (size_t)rows * 17) * sizeof(double);
         if (rows <= 256) {
             lds_attr(ctx, (const void*)k_qr_panel16<4>, 96 * 1024);
-            hipLaunchKernelGGL((k_qr_panel16<4>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
+            hipLaunchKernelGGL((k_qr_panel16<4>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out, zero_above);
         } else {
             lds_attr(ctx, (const void*)k_qr_panel16<8>, 96 * 1024);
-            hipLaunchKernelGGL((k_qr_panel16<8>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out);
+            hipLaunchKernelGGL((k_qr_panel16<8>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out, zero_above);
         }
         return;
     }
@@ -3096,12 +3157,17 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
     D[oi + (size_t)oj * ldd] = v;
 }
 
-__global__ void k_set_abstol(AdiState* st, const double* __restrict__ tol) { st->abstol = tol[0]; }
+// control block of a reduction set up on the device (abs_tol_dev: the tolerance only exists in device memory)
+__global__ void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev) {
+    st->done = 0; st->iters = 0; st->maxiters = 0; st->smw_singular = 0;
+    st->abstol = abs_tol_dev ? abs_tol_dev[0] : abs_tol;
+    st->res_norm = 0.0;
+}
 static bool band_fused_enabled() {
     static const bool v = !(std::getenv("DRE_BAND_FUSED") && std::atoi(std::getenv("DRE_BAND_FUSED")) == 0);
     return v;
 }
-SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev) {
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev, BandSpec* spec, const double* ext_part, int ext_nparts) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
     SymBand out;
     const int q = S.rows, b = QR_NB;
@@ -3110,21 +3176,16 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     out.V = Mat(ctx, q, q);
     out.VT = Mat(ctx, q, q);
     out.T = Mat(ctx, b, q);
-    fill_mat(ctx, out.V, 0.0);
+    // small orders: every panel goes through the 16-column register kernel, which zeroes the rows of V above its panel itself
+    const bool panel_zeroes = q - b <= 512 && q - b >= 16 && qr_panel16_enabled();
+    if (!panel_zeroes) fill_mat(ctx, out.V, 0.0);
     // all panels factored by a single-workgroup panel kernel: the termination norm of the next panel is assembled from the update
     // GEMM's per-tile sums of squares plus the coupling term written by the panel kernel — no separate norm launch
     const bool fused_rem = q - b <= 1536;            // single-workgroup panel kernels (LDS and register variants), not the TSQR panels
     DevArr<double> part(ctx, (size_t)std::max(BAND_REM_BLOCKS, 1 + gemm_num_tiles(q, q)));
     int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
-    {
-        AdiState h;
-        std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
-        h.abstol = abs_tol;
-        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
-        // absolute tolerance that only exists in device memory (no host round trip for it)
-        if (abs_tol_dev) hipLaunchKernelGGL(k_set_abstol, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol_dev);
-    }
+    hipLaunchKernelGGL(k_band_init, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol, abs_tol_dev);
     // Panels are enqueued speculatively: every kernel returns at once after the device-side decision `done`, and the
     // host looks at the flag only every few panels.
     int k = 0, np = 0, J = q;
@@ -3134,25 +3195,28 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0);
     auto hit = ctx->band_hint.find(hkey);
     int chunk = hit != ctx->band_hint.end() ? std::max(4, hit->second + 1) : 4;
+    bool first_round = true;
     while (!finished) {
         int issued = 0;
         while (issued < chunk && k < q) {
-            if (!fused_rem || k == 0) {
+            const double* cur_part = part.p;
+            if (k == 0 && ext_part && fused_rem) { cur_part = ext_part; nparts = ext_nparts; }      // ||S||_F^2 came with the assembly of S
+            else if (!fused_rem || k == 0) {
                 TimedScope ts(ctx, "band_rem", 8.0 * (q - k) * (q - k), 2.0 * (q - k) * (q - k));
                 hipLaunchKernelGGL(k_band_rem, dim3(BAND_REM_BLOCKS), dim3(256), 0, ctx->stream, q, k, b, S.p, S.ld, part.p, st.p);
                 nparts = BAND_REM_BLOCKS;
             }
             const int m = q - k - b;            // rows below the diagonal block of this panel
             if (m < b) {                        // the last rows stay unreduced: D is stored dense, band form is not required
-                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, nparts, part.p, tolfac, st.p);
+                hipLaunchKernelGGL(k_band_decide, dim3(1), dim3(1), 0, ctx->stream, k, nparts, cur_part, tolfac, st.p);
                 k = q;
                 break;
             }
             // the panel kernel evaluates the termination test in its prologue
             launch_qr_panel(ctx, S.p + (size_t)(k + b) + (size_t)k * S.ld, S.ld, m, 0, b,
                             out.V.p + (size_t)(k + b) + (size_t)k * out.V.ld, out.V.ld, out.T.p + (size_t)k * out.T.ld, out.T.ld,
-                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p, part.p, nparts, k, tolfac,
-                            fused_rem ? part.p : nullptr);
+                            out.VT.p + (size_t)(k + b) + (size_t)k * out.VT.ld, out.VT.ld, st.p, cur_part, nparts, k, tolfac,
+                            fused_rem ? part.p : nullptr, panel_zeroes ? k + b : 0);
             // two-sided update of S22 = S[k+b:, k+b:]:  S22 <- S22 - W V' - V W',  W = Z - V N / 2,  Z = S22 (V T),  N = T' (V' Z)
             Mat S22 = S.view(k + b, k + b, m, m);
             Mat Vp = out.V.view(k + b, k, m, b);
@@ -3202,13 +3266,32 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
             k += b; ++np; ++issued;
         }
         AdiState h;
-        ctx_fetch(ctx, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
+        // Speculation on the result (same number of panels as the previous reduction of this kind): the band matrix and the basis are
+        // enqueued right behind the read-back kernel, so the device works on them while the control block travels to the host; they
+        // are used if the prediction holds and dropped otherwise.
+        std::function<void()> between;
+        if (spec && first_round && hit != ctx->band_hint.end() && hit->second > 0 && hit->second * b <= k && hit->second * b < q) {
+            const int Js = hit->second * b, nps = hit->second;
+            between = [&, Js, nps]() {
+                SymBand tmp = out;
+                tmp.J = Js; tmp.npanels = nps;
+                tmp.D = Mat(ctx, Js, Js);
+                const size_t tots = (size_t)Js * Js;
+                hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tots + 255) / 256)), dim3(256), 0, ctx->stream, Js, b, nps * b, S.p, S.ld, tmp.D.p, tmp.D.ld);
+                spec->B = sym_band_basis(ctx, tmp);
+                spec->D = tmp.D; spec->J = Js;
+            };
+        }
+        ctx_fetch_overlap(ctx, between, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
+        first_round = false;
         if (h.done) { J = h.iters; np = J / b; finished = true; }
         else if (k >= q) { J = q; finished = true; }
         chunk = 4;
     }
     ctx->band_hint[hkey] = np;
     out.J = J; out.npanels = np;
+    if (spec && spec->J == J && J > 0) { out.D = spec->D; spec->hit = true; DRE_HIP(hipGetLastError()); return out; }
+    if (spec) { spec->hit = false; spec->B = Mat(); spec->D = Mat(); }
     out.D = Mat(ctx, J, J);
     size_t tot = (size_t)J * J;
     if (tot) hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, J, b, np * b, S.p, S.ld, out.D.p, out.D.ld);

@@ -2,6 +2,7 @@
 // blocked Householder QR, symmetric eigensolver with early-terminating tridiagonalisation.
 #pragma once
 #include <cstdlib>
+#include <functional>
 #include "common.hpp"
 
 namespace dre {
@@ -60,6 +61,10 @@ double frob_norm_host(Ctx* ctx, const Mat& A);               // synchronising
 // on the critical path): up to three device ranges (multiples of 8 bytes, together at most 8 KB) land in the given host buffers.
 void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1 = nullptr, size_t b1 = 0, void* h1 = nullptr,
                const void* d2 = nullptr, size_t b2 = 0, void* h2 = nullptr);
+// the same with work enqueued by `between` right after the signal kernel, before the host starts waiting for the words
+void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const void* d0, size_t b0, void* h0, const void* d1 = nullptr, size_t b1 = 0,
+                       void* h1 = nullptr, const void* d2 = nullptr, size_t b2 = 0, void* h2 = nullptr);
+void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag = "gemm_f64_mfma");   // X <- sym(X + A B')
 void frob2_device(Ctx* ctx, const Mat& A, double* out_dev);   // ||A||_F^2 into device memory (no synchronisation)
 bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (small)
 
@@ -172,7 +177,12 @@ struct SymBand {
     Mat V0, VT0; // optional leading reflector block Q0 = I - VT0 V0' (factor-form reduction with a warm start): Qb <- Q0 Qb
 };
 // abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
-SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr);   // abs_tol_dev: the tolerance lives in device memory
+// spec (optional): the band matrix and the basis for the predicted result are enqueued while the control block is read back (spec->hit
+// tells whether they are valid: then out.D == spec->D and spec->B == sym_band_basis(out)); ext_part: ext_nparts partial sums of
+// ||S||_F^2 that came with the assembly of S (saves the first norm launch)
+struct BandSpec { int J = -1; bool hit = false; Mat B, D; };
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr, BandSpec* spec = nullptr,
+                        const double* ext_part = nullptr, int ext_nparts = 0);   // abs_tol_dev: the tolerance lives in device memory
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 // The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
 // neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).

@@ -872,10 +872,26 @@ LDLtP lyapunov_apply(Ctx* ctx, const GaleOperator& op, const LDLtP& X) {
 // =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
 // =============================================================================================
+// Dense inverses whose acceptance test (condition estimate ||M||_F ||inv(M)||_F, two norms in device memory) is still outstanding: a run
+// over all shifts of a cycle enqueues every factorisation and inverse first and reads all norms back with ONE synchronisation
+// (finalize_dense) instead of two per shift.
+struct PendingDense { std::shared_ptr<FactorEntry<double>> fe; Mat W; };
+struct DeferredDense { std::vector<PendingDense> items; DevArr<double> norms; int cap = 0; };
+static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
+    const int cnt = (int)dd.items.size();
+    if (!cnt) return;
+    std::vector<double> h((size_t)2 * cnt);
+    ctx_fetch(ctx, dd.norms.p, (size_t)2 * cnt * sizeof(double), h.data());
+    for (int i = 0; i < cnt; ++i) {
+        const double cond_est = std::sqrt(h[2 * i]) * std::sqrt(h[2 * i + 1]);
+        if (cond_est == cond_est && cond_est < 1e7) { dd.items[i].fe->dinv = dd.items[i].W; dd.items[i].fe->dense = true; }
+    }
+    dd.items.clear();
+}
 template <typename T>
 static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
                                                   std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
-                                                  std::complex<double> mu, bool want_dense = true) {
+                                                  std::complex<double> mu, bool want_dense = true, DeferredDense* defer = nullptr) {
     auto key = std::make_tuple(op.tag, mu.real(), mu.imag());
     if (cache->enabled) {
         auto it = store.find(key);
@@ -895,8 +911,15 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
             mf_solve<double>(ctx, *op.P, fe->f, W.p, W.ld, n, nullptr);
             Mat fv(ctx, op.P->nnz, 1);
             vals_axpby(ctx, op.P->nnz, 1.0, op.valFt.p, mu.real(), op.P->valEt.p, fv.p);
-            const double cond_est = frob_norm_host(ctx, fv) * frob_norm_host(ctx, W);
-            if (cond_est == cond_est && cond_est < 1e7) { fe->dinv = W; fe->dense = true; }
+            if (defer && (int)defer->items.size() < defer->cap) {
+                const size_t slot = defer->items.size();
+                frob2_device(ctx, fv, defer->norms.p + 2 * slot);
+                frob2_device(ctx, W, defer->norms.p + 2 * slot + 1);
+                defer->items.push_back({fe, W});
+            } else {
+                const double cond_est = frob_norm_host(ctx, fv) * frob_norm_host(ctx, W);
+                if (cond_est == cond_est && cond_est < 1e7) { fe->dinv = W; fe->dense = true; }
+            }
         }
     }
     if (cache->enabled) { store[key] = fe; cache->fresh.push_back(key); }
@@ -1754,23 +1777,30 @@ __global__ __launch_bounds__(256) void k_dense_residual(int n, int q, int m, con
                                                         double* __restrict__ Res, int ldres, double* __restrict__ part) {
     __shared__ double red[17];
     const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
-    double s = 0.0;
+    double s = 0.0, s2 = 0.0;
     if (i < n && j < n) {
         double cc = 0.0, kk = 0.0;
         for (int l = 0; l < q; ++l) cc += Ct[i + (size_t)l * ldc] * Ct[j + (size_t)l * ldc];
         for (int l = 0; l < m; ++l) kk += Kt[i + (size_t)l * ldk] * Kt[j + (size_t)l * ldk];
         const double mm = M[i + (size_t)j * ldm] + M[j + (size_t)i * ldm];
         const double ey = 0.5 * (EY[i + (size_t)j * ldey] + EY[j + (size_t)i * ldey]);
-        Res[i + (size_t)j * ldres] = (cc - kk) + mm;
+        const double res = (cc - kk) + mm;
+        Res[i + (size_t)j * ldres] = res;
         const double rhs = (cc + kk) + inv_tau * ey;              // right-hand side of the step's Lyapunov equation (lowrank_ros1.jl:42-43)
         s = rhs * rhs;
+        s2 = res * res;
     }
     // block_sum (dense.hip) is not visible here: fixed-order reduction through LDS
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     s = wave_sum_t<double>(s);
-    if (lane == 0) red[wave] = s;
+    s2 = wave_sum_t<double>(s2);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = s2; }
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x + (size_t)gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const size_t slot = blockIdx.x + (size_t)gridDim.x * blockIdx.y, ntot = (size_t)gridDim.x * gridDim.y;
+        part[slot] = (red[0] + red[1]) + (red[2] + red[3]);
+        part[ntot + slot] = (red[4] + red[5]) + (red[6] + red[7]);      // ||Res||_F^2: the first termination norm of the band reduction
+    }
 }
 // tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F
 __global__ __launch_bounds__(64) void k_dense_tols(int nparts, const double* __restrict__ part, double reltol, double abstol_given, double frac, double* __restrict__ tols) {
@@ -1827,8 +1857,16 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
     std::vector<GemmBatchDesc> descs;
     std::vector<SmwBatch> hb;
     std::vector<const double*> stacks, wks; std::vector<double*> outs;
+    for (auto& mu : values) if (mu.imag() != 0.0) return false;
+    {
+        // every factorisation and dense inverse of the cycle is enqueued before the single read-back of the acceptance norms
+        DeferredDense dd;
+        dd.cap = std::min<int>((int)values.size(), 256);
+        dd.norms = DevArr<double>(ctx, (size_t)2 * dd.cap);
+        for (auto& mu : values) (void)get_factor<double>(ctx, op, cache, cache->real, mu, true, &dd);
+        finalize_dense(ctx, dd);
+    }
     for (auto& mu : values) {
-        if (mu.imag() != 0.0) return false;
         auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, true);
         if (!fe->dense) return false;
         ensure_stack(ctx, op, *fe);
@@ -1916,28 +1954,32 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // SMW products and the folded stacks depend on K only: they are built on the side stream while the main stream assembles and
     // compresses the residual; the ADI chain waits for them through an event
     Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
-    if (wctx != ctx) {
-        DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
-        DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
-    }
-    CycleOps co;
-    if (!cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co)) return false;
-    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));          // K of the previous step is ready here
     sx.mark(ctx, 0);
-    // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side
+    // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
+    // The main stream's kernels are enqueued BEFORE the side stream is set up: the host calls for the side stream (event wait, six
+    // launches) would otherwise sit in front of them while the main stream idles.
     Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
     transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
     spmm(ctx, P, P.valAt.p, Y, Mx, 1.0, 0.0);                 // A' X E
     spmm(ctx, P, P.valEt.p, Y, EY, 1.0, 0.0);                 // E' X E
     const int nt = ceil_div(n, 16);
-    DevArr<double> part(ctx, (size_t)nt * nt), tols(ctx, 4);
+    DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 4);
     hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
                        (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
     hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
     sx.mark(ctx, 1);
+    if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+    CycleOps co;
+    if (!cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co)) {
+        DRE_HIP(hipStreamSynchronize(ctx->stream));         // the kernels above read buffers that go out of scope with this frame
+        return false;
+    }
+    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
     // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
-    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1);
+    BandSpec spec;
+    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     sx.mark(ctx, 2);
     const int k = sb.J;
     DevArr<AdiState> st(ctx, 1);
@@ -1951,7 +1993,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     int acc_total = 0;
     std::vector<double> coef;
     if (k > 0) {
-        Mat R = sym_band_basis(ctx, sb);
+        Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
         Mat Tm = sb.D;
         hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p);
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
@@ -2044,8 +2086,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             }
             gemm_batched(ctx, descs, "gemm_xupdate");
             Mat Vacc = Vall.colsview(0, k * acc_total);
-            gemm(ctx, false, true, 1.0, Wall, Vacc, 1.0, sx.X, nullptr, "gemm_xupdate");
-            symmetrize(ctx, sx.X);
+            gemm_sym_update(ctx, Wall, Vacc, sx.X, "gemm_xupdate");
         }
     } else {
         // zero residual: read the tolerances back for the record
@@ -2139,7 +2180,12 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     DenseXState sx;
     bool sx_init = false, x_is_dense = false;
 
+    const bool wall_on = std::getenv("DRE_PHASE_TIMING") != nullptr;
+    auto wall_now = [&]() { if (wall_on) DRE_HIP(hipStreamSynchronize(ctx->stream)); return std::chrono::steady_clock::now(); };
+    const auto w_begin = wall_now();
+    auto w_first = w_begin;
     for (int i = 1; i <= nsteps; ++i) {
+        if (wall_on && i == 2) w_first = wall_now();
         const double tau = out.t[i - 1] - out.t[i];
         GaleOperator op;
         op.P = &P;
@@ -2329,10 +2375,16 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         fb = feedback(ctx, prob, *X, ctf, cex);
         out.Kt.push_back(fb.Kt);
     }
+    const auto w_loop = wall_now();
     sx.report();
     if (x_is_dense) X = dense_to_ldlt(ctx, n, sx.X, ctf);
     if (!save_state) out.X.push_back(X);
     out.nfactor = cache.nfactor;
+    if (wall_on) {
+        const auto w_end = wall_now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[wall, ms] first step %.2f | steps 2..%d %.2f | final form %.2f\n", ms(w_begin, w_first), nsteps, ms(w_first, w_loop), ms(w_loop, w_end));
+    }
     return out;
 }
 

@@ -50,3 +50,16 @@ if len(marks) > 12:
         last[q] = r["e"]
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dre::", "")[:34]
         print(f"  q{q} +{(r['s']-w0)/1e3:8.1f} us  dur {(r['e']-r['s'])/1e3:6.1f}  gap {gap:6.1f}  {name}")
+
+# optional: the first N kernels of the analysed solve (both queues), e.g. the set-up step:  TIMELINE_HEAD=200
+import os
+nh = int(os.environ.get("TIMELINE_HEAD", "0"))
+if nh:
+    print(f"\nfirst {nh} kernels of the solve:")
+    last = {}
+    for r in seg[:nh]:
+        q = r[qkey]
+        gap = (r["s"] - last[q]) / 1e3 if q in last else 0.0
+        last[q] = r["e"]
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("dre::", "")[:40]
+        print(f"  q{q} +{(r['s']-t0)/1e3:8.1f} us  dur {(r['e']-r['s'])/1e3:6.1f}  gap {gap:6.1f}  {name}")
