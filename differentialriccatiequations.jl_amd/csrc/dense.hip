@@ -3194,8 +3194,28 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     // panel after the last one is the one whose prologue detects termination
     const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0);
     auto hit = ctx->band_hint.find(hkey);
-    int chunk = hit != ctx->band_hint.end() ? std::max(4, hit->second + 1) : 4;
+    int chunk = hit != ctx->band_hint.end() ? std::max(2, hit->second + 1) : 4;
     bool first_round = true;
+    int deferred_k = -1;
+    auto fused_update = [&](int kk) {      // S22 <- S22 - W V' - V W' for the panel at kk (k_band_z + k_band_upd)
+        const int m = q - kk - b;
+        Mat S22 = S.view(kk + b, kk + b, m, m);
+        Mat Vp = out.V.view(kk + b, kk, m, b);
+        Mat VTp = out.VT.view(kk + b, kk, m, b);
+        Mat Tp = out.T.view(0, kk, b, b);
+        Mat Z(ctx, m, b);
+        {
+            TimedScope ts(ctx, "band_z", 8.0 * ((double)m * m + 2.0 * m * b), 2.0 * m * (double)m * b);
+            hipLaunchKernelGGL(k_band_z, dim3(ceil_div(m, 16)), dim3(256), 0, ctx->stream, m, (const double*)S22.p, S22.ld, (const double*)VTp.p, VTp.ld, Z.p, Z.ld,
+                               (const AdiState*)st.p);
+        }
+        {
+            TimedScope ts(ctx, "band_upd", 8.0 * (2.0 * m * m + 2.0 * m * b), 4.0 * m * (double)m * b);
+            hipLaunchKernelGGL(k_band_upd, dim3(ceil_div(m, 64), ceil_div(m, 64)), dim3(256), 0, ctx->stream, m, S22.p, S22.ld, (const double*)Vp.p, Vp.ld,
+                               (const double*)Z.p, Z.ld, (const double*)Tp.p, Tp.ld, fused_rem ? part.p + 1 : (double*)nullptr, (const AdiState*)st.p);
+        }
+        if (fused_rem) nparts = 1 + gemm_num_tiles(m, m);
+    };
     while (!finished) {
         int issued = 0;
         while (issued < chunk && k < q) {
@@ -3233,18 +3253,10 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 hipLaunchKernelGGL(k_band_w_rows, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, m, ms, Z.p, Z.ld, (const double*)mpart->p,
                                    Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
             } else if (band_fused_enabled()) {
-                Mat Z(ctx, m, b);
-                {
-                    TimedScope ts(ctx, "band_z", 8.0 * ((double)m * m + 2.0 * m * b), 2.0 * m * (double)m * b);
-                    hipLaunchKernelGGL(k_band_z, dim3(ceil_div(m, 16)), dim3(256), 0, ctx->stream, m, (const double*)S22.p, S22.ld, (const double*)VTp.p, VTp.ld, Z.p, Z.ld,
-                                       (const AdiState*)st.p);
-                }
-                {
-                    TimedScope ts(ctx, "band_upd", 8.0 * (2.0 * m * m + 2.0 * m * b), 4.0 * m * (double)m * b);
-                    hipLaunchKernelGGL(k_band_upd, dim3(ceil_div(m, 64), ceil_div(m, 64)), dim3(256), 0, ctx->stream, m, S22.p, S22.ld, (const double*)Vp.p, Vp.ld,
-                                       (const double*)Z.p, Z.ld, (const double*)Tp.p, Tp.ld, fused_rem ? part.p + 1 : (double*)nullptr, (const AdiState*)st.p);
-                }
-                if (fused_rem) nparts = 1 + gemm_num_tiles(m, m);
+                // the last panel of a speculative chunk is the one whose prologue is expected to detect termination: its two-sided update
+                // is only enqueued if the read-back says the reduction goes on
+                if (first_round && hit != ctx->band_hint.end() && issued == chunk - 1 && issued >= 1) { deferred_k = k; break; }
+                fused_update(k);
                 k += b; ++np; ++issued;
                 continue;
             } else {
@@ -3285,7 +3297,9 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
         ctx_fetch_overlap(ctx, between, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
         first_round = false;
         if (h.done) { J = h.iters; np = J / b; finished = true; }
+        else if (deferred_k >= 0) { fused_update(deferred_k); k += b; ++np; }       // the prediction was short: the reduction continues
         else if (k >= q) { J = q; finished = true; }
+        deferred_k = -1;
         chunk = 4;
     }
     ctx->band_hint[hkey] = np;

@@ -1961,8 +1961,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // launches) would otherwise sit in front of them while the main stream idles.
     Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
     transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
-    spmm(ctx, P, P.valAt.p, Y, Mx, 1.0, 0.0);                 // A' X E
-    spmm(ctx, P, P.valEt.p, Y, EY, 1.0, 0.0);                 // E' X E
+    spmm_dual(ctx, P, P.valAt.p, P.valEt.p, Y, Mx, EY);       // A' X E and E' X E in one pass over X E
     const int nt = ceil_div(n, 16);
     DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 4);
     hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,

@@ -99,6 +99,8 @@ void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, co
 inline void spmm(Ctx* ctx, const Pencil& P, const double* val, const Mat& X, Mat& Y, double alpha, double beta, const AdiState* st = nullptr) {
     spmm(ctx, P.n, P.ptr.p, P.idx.p, val, X, Y, alpha, beta, st, P.nnz);
 }
+// Y1 = M1 X and Y2 = M2 X for two value arrays on the pencil's pattern in one pass over X
+void spmm_dual(Ctx* ctx, const Pencil& P, const double* val1, const double* val2, const Mat& X, Mat& Y1, Mat& Y2);
 // out = a*x + b*y on value arrays of the shared pattern (shifted-operator assembly K4, values only)
 void vals_axpby(Ctx* ctx, int nnz, double a, const double* x, double b, const double* y, double* out);
 // row permutation helpers: dst(i,:) = src(map[i],:)
