@@ -1,3 +1,4 @@
+#include <functional>
 // C ABI of libdre_hip (declared in include/dre_hip.h).
 #include "../../include/dre_hip.h"
 
@@ -104,12 +105,34 @@ int dre_ctx_destroy(dre_ctx* ctx) {
     if (ctx->c.side) {
         Ctx& sc = *ctx->c.side;
         (void)hipStreamSynchronize(sc.stream);
+        for (size_t h = 0; h < sc.helpers.size(); ++h) {
+            Ctx& hc = *sc.helpers[h];
+            (void)hipStreamSynchronize(hc.stream);
+            hc.timer.reset(); hc.pool.trim();
+            (void)hipEventDestroy(sc.helper_ev[h]);
+            (void)hipStreamDestroy(hc.stream);
+        }
+        sc.helpers.clear(); sc.helper_ev.clear();
+        if (sc.helper_e0) { (void)hipEventDestroy(sc.helper_e0); sc.helper_e0 = nullptr; }
         sc.timer.reset(); sc.pool.trim();
         if (sc.fetch_host) { (void)hipHostFree((void*)sc.fetch_host); sc.fetch_host = nullptr; }
         (void)hipEventDestroy(ctx->c.side_e1); (void)hipEventDestroy(ctx->c.side_e2);
         (void)hipStreamDestroy(sc.stream);
         ctx->c.side.reset();
     }
+    auto drop_helpers = [](Ctx& owner) {
+        for (size_t h = 0; h < owner.helpers.size(); ++h) {
+            Ctx& hc = *owner.helpers[h];
+            (void)hipStreamSynchronize(hc.stream);
+            hc.timer.reset(); hc.pool.trim();
+            if (hc.fetch_host) { (void)hipHostFree((void*)hc.fetch_host); hc.fetch_host = nullptr; }
+            (void)hipEventDestroy(owner.helper_ev[h]);
+            (void)hipStreamDestroy(hc.stream);
+        }
+        owner.helpers.clear(); owner.helper_ev.clear();
+        if (owner.helper_e0) { (void)hipEventDestroy(owner.helper_e0); owner.helper_e0 = nullptr; }
+    };
+    drop_helpers(ctx->c);
     ctx->c.timer.reset();
     ctx->c.pool.trim();
     if (ctx->c.fetch_host) { (void)hipHostFree((void*)ctx->c.fetch_host); ctx->c.fetch_host = nullptr; }
@@ -146,28 +169,31 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
 }
 // Both contexts of a library context are timed (the side context carries the work that runs beside the main stream): enable/reset act on
 // both, count/get see the per-class sums.
+// every context that carries work of this library context: main, side, and the helper contexts of both
+static void for_each_timed(dre_ctx* ctx, const std::function<void(Ctx&)>& f) {
+    auto visit = [&](Ctx& c) { f(c); for (auto& h : c.helpers) if (h && h->timer) f(*h); };
+    visit(ctx->c);
+    if (ctx->c.side && ctx->c.side->timer) visit(*ctx->c.side);
+}
 static void prof_collect_merge(dre_ctx* ctx) {
-    ctx->c.timer->collect(&ctx->c);
-    ctx->merged = ctx->c.timer->stats;
-    if (ctx->c.side && ctx->c.side->timer) {
-        ctx->c.side->timer->collect(ctx->c.side.get());
-        for (auto& kv : ctx->c.side->timer->stats) {
+    ctx->merged.clear();
+    for_each_timed(ctx, [&](Ctx& c) {
+        c.timer->collect(&c);
+        for (auto& kv : c.timer->stats) {
             auto& d = ctx->merged[kv.first];
             d.ms += kv.second.ms; d.launches += kv.second.launches; d.bytes += kv.second.bytes; d.flops += kv.second.flops;
         }
-    }
+    });
 }
 int dre_prof_enable(dre_ctx* ctx, int on) {
     return guarded(ctx, [&] {
-        ctx->c.timer->collect(&ctx->c); ctx->c.timer->enabled = on != 0;
         ctx->c.prof_side = on != 0;
-        if (ctx->c.side && ctx->c.side->timer) { ctx->c.side->timer->collect(ctx->c.side.get()); ctx->c.side->timer->enabled = on != 0; }
+        for_each_timed(ctx, [&](Ctx& c) { c.timer->collect(&c); c.timer->enabled = on != 0; });
     });
 }
 int dre_prof_reset(dre_ctx* ctx) {
     return guarded(ctx, [&] {
-        ctx->c.timer->collect(&ctx->c); ctx->c.timer->stats.clear();
-        if (ctx->c.side && ctx->c.side->timer) { ctx->c.side->timer->collect(ctx->c.side.get()); ctx->c.side->timer->stats.clear(); }
+        for_each_timed(ctx, [&](Ctx& c) { c.timer->collect(&c); c.timer->stats.clear(); });
         ctx->merged.clear();
     });
 }

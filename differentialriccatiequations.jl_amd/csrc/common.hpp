@@ -151,6 +151,12 @@ struct Ctx {
     // created on first use, lives as long as this context
     std::unique_ptr<Ctx> side;
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
+    // helper contexts (own stream and pool each) for independent chains of small kernels that would otherwise queue up behind each other
+    // on one stream — the factorisations and dense inverses of the shifts of a cycle (engine.hip, cycle_ops_prepare); created on first use
+    std::vector<std::unique_ptr<Ctx>> helpers;
+    std::vector<hipEvent_t> helper_ev;
+    hipEvent_t helper_e0 = nullptr;
+    int setup_streams = 5;      // 0 / 1: everything on the calling context's stream
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
     bool attr_adi_fast = false;
     // host-visible landing zone for small device->host reads on the critical path (ctx_fetch, dense.hip): a tiny kernel copies the words

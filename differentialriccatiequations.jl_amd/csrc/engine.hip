@@ -1859,11 +1859,47 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
     std::vector<const double*> stacks, wks; std::vector<double*> outs;
     for (auto& mu : values) if (mu.imag() != 0.0) return false;
     {
-        // every factorisation and dense inverse of the cycle is enqueued before the single read-back of the acceptance norms
+        // Every factorisation and dense inverse of the cycle is enqueued before the single read-back of the acceptance norms.  Each of
+        // them is a chain of ~25 small kernels (assembly, one factorisation launch per tree level, n unit right-hand sides, norms) that
+        // uses a few CUs: the chains of different shifts go to different helper streams and run side by side.
         DeferredDense dd;
         dd.cap = std::min<int>((int)values.size(), 256);
         dd.norms = DevArr<double>(ctx, (size_t)2 * dd.cap);
-        for (auto& mu : values) (void)get_factor<double>(ctx, op, cache, cache->real, mu, true, &dd);
+        int todo = 0;
+        for (auto& mu : values) if (!cache->enabled || !cache->real.count(std::make_tuple(op.tag, mu.real(), mu.imag()))) ++todo;
+        const int nh = (cache->enabled && todo > 1) ? std::min(todo, std::max(0, ctx->setup_streams)) : 0;
+        if (nh > 1) {
+            while ((int)ctx->helpers.size() < nh) {
+                auto hc = std::make_unique<Ctx>();
+                hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+                DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+                hc->timer = std::make_unique<KernelTimer>();
+                hipEvent_t ev;
+                DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+            }
+            if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
+            DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));         // the operator's value arrays are ready here
+            for (int h = 0; h < nh; ++h) {
+                Ctx* hc = ctx->helpers[(size_t)h].get();
+                hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->mf_subtree = ctx->mf_subtree;
+                hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
+                hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+                DRE_HIP(hipStreamWaitEvent(hc->stream, ctx->helper_e0, 0));
+            }
+            int j = 0;
+            for (auto& mu : values) {
+                if (cache->real.count(std::make_tuple(op.tag, mu.real(), mu.imag()))) continue;
+                (void)get_factor<double>(ctx->helpers[(size_t)(j % nh)].get(), op, cache, cache->real, mu, true, &dd);
+                ++j;
+            }
+            for (int h = 0; h < nh; ++h) {
+                DRE_HIP(hipEventRecord(ctx->helper_ev[(size_t)h], ctx->helpers[(size_t)h]->stream));
+                DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->helper_ev[(size_t)h], 0));
+            }
+        } else {
+            for (auto& mu : values) (void)get_factor<double>(ctx, op, cache, cache->real, mu, true, &dd);
+        }
         finalize_dense(ctx, dd);
     }
     for (auto& mu : values) {
