@@ -171,8 +171,9 @@ template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
                                               int lda, const double* __restrict__ B, int ldb, double beta,
                                               double* __restrict__ C, int ldc, int kchunk,
-                                              double* __restrict__ partial, const AdiState* st, double* __restrict__ tile_sumsq) {
+                                              double* __restrict__ partial, const AdiState* st, double* __restrict__ tile_sumsq, DevCount dc) {
     if (st && st->done) return;
+    if (dc.st) K = min(K, dc.per * dev_count(dc));          // inner dimension decided on the device (accepted ADI iterations x columns)
     const int kbeg = blockIdx.z * kchunk;
     gemm_tile<TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.x * GB_M, blockIdx.y * GB_N, kbeg, min(K, kbeg + kchunk),
                       partial ? partial + (size_t)blockIdx.z * M * N : nullptr,
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(256) void k_gemm_batched(const GemmBatchDesc* __res
     gemm_tile<false, false>(d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb, 0.0, d.C, d.ldc, m0, n0, 0, d.K, nullptr);
 }
 // up to 48 products: the descriptors travel as kernel arguments (no upload, no staging copy on the host)
-struct GemmBatchArgs { GemmBatchDesc d[48]; };
+struct GemmBatchArgs { GemmBatchDesc d[48]; DevCount dc; };
 __global__ __launch_bounds__(256) void k_gemm_batched_args(GemmBatchArgs a) {
+    if (a.dc.st && (int)blockIdx.z >= dev_count(a.dc)) return;       // products beyond the device-side count are not formed
     const GemmBatchDesc d = a.d[blockIdx.z];
     const int m0 = blockIdx.x * GB_M, n0 = blockIdx.y * GB_N;
     if (m0 >= d.M) return;
@@ -209,10 +211,12 @@ __global__ __launch_bounds__(256) void k_gemm_batched_args(GemmBatchArgs a) {
     if (n0 >= d.N) return;
     gemm_tile<false, false>(d.M, d.N, d.K, d.alpha, d.A, d.lda, d.B, d.ldb, 0.0, d.C, d.ldc, m0, n0, 0, d.K, nullptr);
 }
-void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag) {
+void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag, DevCount dc) {
+    DRE_REQUIRE(!dc.st || descs.size() <= 48, "gemm_batched: a device-side count needs at most 48 products");
     if (!descs.empty() && descs.size() <= 48) {
         int maxM = 0, maxN = 0; double fl = 0.0, by = 0.0;
         GemmBatchArgs a;
+        a.dc = dc;
         for (size_t i = 0; i < descs.size(); ++i) {
             const auto& d = descs[i];
             a.d[i] = d;
@@ -286,10 +290,10 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
         pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
         partial = (double*)pb->p;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
     if (splits > 1) {
         size_t tot = (size_t)M * N;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, M, N, splits, alpha, partial, beta, C, ldc, st);
@@ -298,7 +302,7 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
 }
 
 BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
-                   int* splits_out, const AdiState* st, const char* tag) {
+                   int* splits_out, const AdiState* st, const char* tag, DevCount dc) {
     TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
     const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
     int splits = 1;
@@ -312,10 +316,10 @@ BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double
     auto pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
     double* partial = (double*)pb->p;
     double* none = nullptr;
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
     DRE_HIP(hipGetLastError());
     *splits_out = splits;
     return pb;
@@ -460,12 +464,12 @@ __global__ __launch_bounds__(256) void k_reduce_sym_update(int n, int splits, co
         }
     }
 }
-void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag) {
+void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag, DevCount dc) {
     const int n = X.rows;
     DRE_REQUIRE(X.cols == n && A.rows == n && B.rows == n && A.cols == B.cols, "gemm_sym_update: shape mismatch");
     if (A.cols == 0) return;
     int splits = 1;
-    BufP pb = gemm_partials(ctx, false, true, n, n, A.cols, A.p, A.ld, B.p, B.ld, &splits, nullptr, tag);
+    BufP pb = gemm_partials(ctx, false, true, n, n, A.cols, A.p, A.ld, B.p, B.ld, &splits, nullptr, tag, dc);
     const int nt = ceil_div(n, 32);
     hipLaunchKernelGGL(k_reduce_sym_update, dim3(nt, nt), dim3(256), 0, ctx->stream, n, splits, (const double*)pb->p, X.p, X.ld);
     DRE_HIP(hipGetLastError());

@@ -20,6 +20,14 @@ struct AdiState {
     double norms[512];   // residual norm after iteration i (index = shifts consumed)
 };
 
+// A count that only exists in device memory when the consumer is enqueued: the number of ADI iterations of a speculatively enqueued
+// chunk that were accepted, clamp(st->iters - base, 0, nmax).  Kernels that take one either skip the products beyond it (batched GEMM)
+// or shorten their inner dimension to per * count (split-K GEMM), so that the update of X can be enqueued before the host knows
+// how many increments there are.
+struct DevCount { const AdiState* st = nullptr; int base = 0, nmax = 0, per = 1; };
+#if defined(__HIPCC__)
+__device__ __forceinline__ int dev_count(const DevCount& dc) { const int c = dc.st->iters - dc.base; return c < 0 ? 0 : (c > dc.nmax ? dc.nmax : c); }
+#endif
 // C = alpha*op(A)*op(B) + beta*C   (M x N, inner K).  `st` may be null.
 void gemm(Ctx* ctx, bool transA, bool transB, int M, int N, int K, double alpha, const double* A, int lda,
           const double* B, int ldb, double beta, double* C, int ldc, const AdiState* st = nullptr,
@@ -43,9 +51,9 @@ struct GemmBatchDesc {
     double alpha;
     int M, N, K, lda, ldb, ldc, ldcopy;
 };
-void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag = "gemm_batched");
+void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag = "gemm_batched", DevCount dc = DevCount{});
 BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
-                   int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma");
+                   int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma", DevCount dc = DevCount{});
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src
 struct CopyDesc { const double* src; double* dst; int rows, cols, lds, ldd; };
 void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                      // all blocks in one launch per 32
@@ -64,7 +72,7 @@ void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1 = n
 // the same with work enqueued by `between` right after the signal kernel, before the host starts waiting for the words
 void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const void* d0, size_t b0, void* h0, const void* d1 = nullptr, size_t b1 = 0,
                        void* h1 = nullptr, const void* d2 = nullptr, size_t b2 = 0, void* h2 = nullptr);
-void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag = "gemm_f64_mfma");   // X <- sym(X + A B')
+void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag = "gemm_f64_mfma", DevCount dc = DevCount{});   // X <- sym(X + A B')
 void frob2_device(Ctx* ctx, const Mat& A, double* out_dev);   // ||A||_F^2 into device memory (no synchronisation)
 bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (small)
 

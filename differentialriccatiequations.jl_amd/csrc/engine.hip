@@ -2044,8 +2044,13 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         const int cap = std::max(1, adi.maxiters);
         Vall = Mat(ctx, n, k * std::min(cap, std::max(adi.compression_interval, sx.hint + 1) + 64));
         int vcols_used = 0;
+        // specx: every chunk's update of X is enqueued during its read-back (the batched product takes its descriptors as kernel arguments,
+        // 48 at most; chunks never grow within a solve)
+        const bool specx = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters) <= 48;
+        bool any_plain = false;
         while (!finished) {
             const int base_it = iters_host;
+            const size_t cyc0 = cyc;
             int nit = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters - iters_host);
             nit = std::min(nit, (Vall.cols - vcols_used) / k);
             if (nit <= 0) break;
@@ -2092,15 +2097,34 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             chain_ts.reset();
             sx.mark(ctx, 4);
             {
-                // control block (header + the norms of this chunk), tolerances and the SMW breakdown flag in ONE read-back
+                // control block (header + the norms of this chunk), tolerances and the SMW breakdown flag in ONE read-back.  The update
+                //   X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated: one batched product + one GEMM)
+                // of this chunk is enqueued right behind the read-back kernel: how many of the speculatively enqueued iterations count is
+                // read from the control block ON THE DEVICE (DevCount), so the device works on X while the host waits for the words.
                 const size_t stb = sizeof(int) * 4 + sizeof(double) * (2 + (size_t)std::min(511, base_it + nit + 1));
                 long long serr8 = 0;
-                ctx_fetch(ctx, st.p, stb, &sx.land->st, tols.p, 4 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
+                std::function<void()> between;
+                if (specx) between = [&]() {
+                    DevCount dc{st.p, base_it, nit, k};
+                    Mat Wc(ctx, n, k * nit);
+                    std::vector<GemmBatchDesc> descs;
+                    for (int j = 0; j < nit; ++j) {
+                        Mat Vj = Vall.colsview(vcols_used + j * k, k), Wj = Wc.colsview(j * k, k);
+                        const double cj = -2.0 * adi.shifts.values[(cyc0 + (size_t)j) % adi.shifts.values.size()].real();
+                        descs.push_back({Vj.p, Tm.p, Wj.p, nullptr, cj, n, k, k, Vj.ld, Tm.ld, Wj.ld, 0});
+                    }
+                    DevCount dcb = dc; dcb.per = 1;
+                    gemm_batched(ctx, descs, "gemm_xupdate", dcb);
+                    Mat Vch = Vall.colsview(vcols_used, k * nit);
+                    gemm_sym_update(ctx, Wc, Vch, sx.X, "gemm_xupdate", dc);
+                };
+                ctx_fetch_overlap(ctx, between, st.p, stb, &sx.land->st, tols.p, 4 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
                 sx.land->serr = (int)serr8;
             }
             h = sx.land->st;
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
             for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[base_it + j]); ar.norm_iters.push_back(base_it + j); }
+            if (!specx && acc_it > 0) any_plain = true;
             iters_host = base_it + acc_it;
             vcols_used += acc_it * k;
             cyc = cyc - nit + acc_it;
@@ -2111,8 +2135,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         acc_total = iters_host;
         for (auto& f : co.fe) if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; }
         if (sx.land->serr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
-        // X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated, one GEMM)
-        if (acc_total > 0) {
+        // chunks whose update was not enqueued during the read-back (more than 48 iterations at once): all increments in one go
+        if (acc_total > 0 && any_plain) {
             Wall = Mat(ctx, n, k * acc_total);
             std::vector<GemmBatchDesc> descs;
             for (int j = 0; j < acc_total; ++j) {
