@@ -89,6 +89,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_EXTRA")) ctx->c.compress_sketch_extra = std::atoi(e);
         if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
         if (const char* e = std::getenv("DRE_MF_SUBTREE")) ctx->c.mf_subtree = std::atoi(e);
+        if (const char* e = std::getenv("DRE_SETUP_STREAMS")) ctx->c.setup_streams = std::atoi(e);
         if (const char* e = std::getenv("DRE_X_SIDE_STREAM")) ctx->c.x_side_stream = std::atoi(e);
         if (const char* e = std::getenv("DRE_DENSE_X_MAX_N")) ctx->c.dense_x_max_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_X_COMPRESS_EVERY")) ctx->c.x_compress_every = std::atoi(e);
@@ -159,6 +160,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "compress_sketch_extra") ctx->c.compress_sketch_extra = (int)value;
         else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
         else if (key == "mf_subtree") ctx->c.mf_subtree = (int)value;
+        else if (key == "setup_streams") ctx->c.setup_streams = (int)value;
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
         else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
