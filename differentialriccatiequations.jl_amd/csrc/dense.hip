@@ -167,6 +167,10 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
 }
 
 
+// (A 128 x 128-tile variant — 4 x 4 MFMA tiles per wave, 16 flop per byte staged through LDS — was built and measured in round 2:
+// 45.1 TFLOP/s at 4096^3 against 47.9 for this kernel, 22-30 against 29-34 on the skinny passes of the randomized compression
+// (tools/gemm_probe.py).  With one wave per SIMD its global round trips are not covered; the 64 x 64 tiles keep four workgroups per CU.
+// It was removed again.)
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
                                               int lda, const double* __restrict__ B, int ldb, double beta,

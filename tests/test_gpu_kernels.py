@@ -17,7 +17,8 @@ def _gemm(ctx, tA, tB, alpha, A, B, beta, Cm):
     return Cd.numpy()
 
 
-@pytest.mark.parametrize("shape", [(16, 16, 4), (64, 64, 16), (37, 53, 29), (7, 110, 371), (130, 130, 2000), (371, 371, 1279), (1, 1, 1), (200, 3, 5)])
+@pytest.mark.parametrize("shape", [(16, 16, 4), (64, 64, 16), (37, 53, 29), (7, 110, 371), (130, 130, 2000), (371, 371, 1279), (1, 1, 1), (200, 3, 5),
+                                   (300, 3500, 5177), (5177, 320, 2100), (777, 1234, 600), (1357, 1357, 1357)])      # the last four: the shapes of the randomized compression and of S = L D L'
 def test_gemm_f64_mfma_all_transposes(ctx, shape):
     M, N, K = shape
     rng = np.random.default_rng(M * N + K)
