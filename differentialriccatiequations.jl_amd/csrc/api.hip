@@ -538,6 +538,7 @@ int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldl
 int dre_ldlt_compress_tol(dre_ctx* ctx, dre_ldlt* x, double abs_tol) {
     return guarded(ctx, [&] { ldlt_compress(&ctx->c, *x->x, 4.0, false, abs_tol > 0.0 ? abs_tol : -1.0); });
 }
+int dre_ldlt_compress_fast(dre_ctx* ctx, dre_ldlt* x) { return guarded(ctx, [&] { ldlt_compress(&ctx->c, *x->x, 4.0, false, -1.0); }); }
 int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x) {
     return guarded(ctx, [&] {
         LDLt& X = *x->x;

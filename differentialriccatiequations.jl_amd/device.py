@@ -287,8 +287,12 @@ class DeviceLDLt:
     def concatenate(self):
         self.ctx.chk(self.ctx.lib.dre_ldlt_concatenate(self.ctx.ptr, self.ptr))
 
-    def compress(self, abs_tol=None):
-        if abs_tol is not None and abs_tol > 0:
+    def compress(self, abs_tol=None, fast=False):
+        """compress!: exact (eigenvalue truncation, the reference's arithmetic) by default; fast=True: the engine's early-terminating
+        compression (dre_ldlt_compress_fast); abs_tol: absolute truncation tolerance."""
+        if fast:
+            self.ctx.chk(self.ctx.lib.dre_ldlt_compress_fast(self.ctx.ptr, self.ptr))
+        elif abs_tol is not None and abs_tol > 0:
             self.ctx.chk(self.ctx.lib.dre_ldlt_compress_tol(self.ctx.ptr, self.ptr, float(abs_tol)))
         else:
             self.ctx.chk(self.ctx.lib.dre_ldlt_compress(self.ctx.ptr, self.ptr))

@@ -68,7 +68,12 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               (default 2560; n <= 512 always);  "compress_direct_ratio" (default 8)
  *   "compress_factor_min_n"     n >= value: band reduction in factor form, reflectors applied to L, randomized termination estimate
  *                               (default 2561; a huge value disables);  "compress_factor_min_cols" (default 96) fewer columns: QR path
- *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS)
+ *   "compress_sketch"           wide factors (columns >= "compress_sketch_min_cols", default 768, and >= 3 x the sketch width) of sums without
+ *                               cancellation: randomized range finder, three GEMM passes over the factor; sketch width = rank of the previous
+ *                               compression of this kind + "compress_sketch_extra" (48); rejected sketches fall back (default 1, 0 disables)
+ *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS, DRE_COMPRESS_SKETCH*)
+ *   "mf_subtree"                1: the multifrontal sweeps below the dense top run as one workgroup per subtree (default 0: one launch per level)
+ *   "setup_streams"             helper streams for the factorisations / dense inverses of the shifts of a Cyclic list (default 5; 0, 1: none)
  *   "top_inverse_max_rows"      multifrontal solves with a real factor that keeps being reused (third multi-column solve on): the top
  *                               levels of the elimination tree with at most this many pivot variables are applied as ONE dense inverse
  *                               of their Schur complement (MFMA GEMM) instead of level-by-level sweeps (default 1536, 0 disables;
@@ -157,8 +162,12 @@ int dre_ldlt_concatenate(dre_ctx* ctx, dre_ldlt* x);                            
 int dre_ldlt_compress(dre_ctx* ctx, dre_ldlt* x);                                              /* LDLt.jl:204-225 */
 /* compress! with an ABSOLUTE truncation tolerance (Frobenius norm of what may be dropped) instead of the relative one: used where the
  * caller only compares norm(x) with a tolerance (Riccati / Lyapunov residuals near convergence are pure cancellation noise relative to
- * their own size, so a relative criterion keeps all of it).  abs_tol <= 0 behaves like dre_ldlt_compress. */
+ * their own size, so a relative criterion keeps all of it).  abs_tol <= 0 behaves like dre_ldlt_compress_fast. */
 int dre_ldlt_compress_tol(dre_ctx* ctx, dre_ldlt* x, double abs_tol);
+/* The engine's own compression (what the ADI and Rosenbrock loops use between the API boundaries): early-terminating band reduction — on
+ * S = L D L', in factor form, or through a randomized range finder for wide factors — truncated at 4 eps ||X||_F; the result has an
+ * orthonormal factor and a band matrix D instead of diag(eigenvalues).  Same X up to that tolerance. */
+int dre_ldlt_compress_fast(dre_ctx* ctx, dre_ldlt* x);
 int dre_ldlt_norm(dre_ctx* ctx, dre_ldlt* x, double* out);                                     /* LDLt.jl:77-89 */
 /* bring an engine result to the reference's canonical form: one component, D = diag(eigenvalues), |lambda| >= 100 eps max|lambda| */
 int dre_ldlt_canonicalize(dre_ctx* ctx, dre_ldlt* x);

@@ -100,15 +100,62 @@ def test_factor_form_compression(ctx, n, c, r, nblk):
     remainder; sums of diagonal-D and dense-D blocks, indefinite, numerical rank r."""
     rng = np.random.default_rng(n + c)
     Ls, Ds = _blocks(rng, n, c, r, nblk)
-    X = D.lowrank(Ls[0], Ds[0])
-    for L, Dd in zip(Ls[1:], Ds[1:]):
-        X = X + D.lowrank(L, Dd)
     ref = sum(L @ Dd @ L.T for L, Dd in zip(Ls, Ds))
-    D.compress_(X)
-    assert X.rank() <= r + 32
-    assert np.linalg.norm(X.dense() - ref) < 1e-12 * np.linalg.norm(ref)
-    Q = X.Ls[0]
-    assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() < 1e-12
+    for fast in (True, False):                  # the engine's own compression (factor form at these sizes) and the exact one of the API boundary
+        Xd = D.DeviceLDLt.create(ctx, None, Ls[0], Ds[0])
+        for L, Dd in zip(Ls[1:], Ds[1:]):
+            Xd = Xd.add(D.DeviceLDLt.create(ctx, None, L, Dd))
+        Xd.compress(fast=fast)
+        assert Xd.info()[1] <= r + 32
+        a, Q, Dc = Xd.destructure()
+        assert np.linalg.norm(a * Q @ Dc @ Q.T - ref) < 1e-12 * np.linalg.norm(ref), fast
+        if Q.shape[1] < c:                       # (a compression that cannot gain hands the concatenated summands back)
+            assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() < 1e-12
+
+
+def test_randomized_compression_of_wide_factors(ctx):
+    """engine.hip sketch_compress: from the second compression of a wide factor (c >= 768, c >= 3 s) at an order n >= 2561 on, the range is found
+    with a Gaussian sketch whose width is the previous rank + 48.  Same rank: accepted; rank far beyond the sketch: rejected (fewer than 32
+    unused sketch directions) and the factor-form reduction takes over.  Both against the dense sum and against the engine with the sketch off."""
+    rng = np.random.default_rng(7)
+    n, c = 3100, 1000
+
+    def psd_sum(r, seed):
+        g = np.random.default_rng(seed)
+        U, _ = np.linalg.qr(g.standard_normal((n, r)))
+        w = 10.0 ** (-14.0 * np.arange(r) / r)                      # eigenvalues 1 ... 1e-14
+        Ls, Ds = [], []
+        for b in range(4):                                           # four PSD summands with the same range
+            M = g.standard_normal((r, c // 4))
+            Ls.append((U * np.sqrt(w)) @ M / np.sqrt(c // 4)); Ds.append(np.eye(c // 4))
+        return Ls, Ds
+
+    def run(r, seed):
+        Ls, Ds = psd_sum(r, seed)
+        Xd = D.DeviceLDLt.create(ctx, None, Ls[0], Ds[0])
+        for L, Dd in zip(Ls[1:], Ds[1:]):
+            Xd = Xd.add(D.DeviceLDLt.create(ctx, None, L, Dd))
+        ref = sum(L @ Dd @ L.T for L, Dd in zip(Ls, Ds))
+        Xd.compress(fast=True)                                       # the engine's own compression (dre_ldlt_compress_fast)
+        _, rank, nblk = Xd.info()
+        assert nblk == 1
+        a, Q, Dc = Xd.destructure()                                  # canonical form of the same X (D = diag(eigenvalues))
+        assert np.abs(Q.T @ Q - np.eye(Q.shape[1])).max() < 1e-12
+        err = np.linalg.norm(a * Q @ Dc @ Q.T - ref) / np.linalg.norm(ref)
+        assert err < 2e-13, (r, err)
+        return rank
+
+    ctx.set_option("compress_sketch", 1)
+    r1 = run(60, 1)             # first compression at this order: factor form, leaves the rank hint
+    r2 = run(60, 2)             # sketch of width r1 + 48: accepted
+    r3 = run(200, 3)            # rank far beyond the sketch: rejected, factor form again
+    r4 = run(200, 4)            # sketch with the new hint
+    ctx.set_option("compress_sketch", 0)
+    try:
+        q2, q4 = run(60, 2), run(200, 4)
+    finally:
+        ctx.set_option("compress_sketch", 1)
+    assert abs(r2 - q2) <= 16 and abs(r4 - q4) <= 16 and r1 <= 76 and 150 <= r3 <= 232
 
 
 def test_factor_form_compression_edge_cases(ctx):
