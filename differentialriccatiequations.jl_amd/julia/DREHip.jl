@@ -335,6 +335,38 @@ function residual(prob::GALEProblem, X::LDLᵀ; ctx::Context=default_context())
     R
 end
 
+"dot(X, Y) = tr(X'Y) for two LDLᵀ objects — src/LDLt.jl:91-108 (dre_ldlt_dot: block-wise trace form on the device)"
+function LinearAlgebra.dot(X::LDLᵀ, Y::LDLᵀ; ctx::Context=default_context())
+    hx = to_device(ctx, nothing, X); hy = to_device(ctx, nothing, Y)
+    out = Ref{Cdouble}(0.0)
+    chk(ctx, ccall((:dre_ldlt_dot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cdouble}), ctx.ptr, hx, hy, out))
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, hx)
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, hy)
+    out[]
+end
+
+"LyapunovOperator(E, A) * X = A'XE + E'XA as an LDLᵀ object — src/lyapunov/gmres.jl:108-120 (dre_gale_apply)"
+function lyapunov_apply(prob::GALEProblem, X::LDLᵀ; ctx::Context=default_context())
+    o = gale_operands(ctx, prob, X)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    chk(ctx, ccall((:dre_gale_apply, LIB), Cint,
+                   (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                   ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Xh, out))
+    R = from_device(ctx, out[])
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, out[])
+    R
+end
+
+"compress_fast!(X): the engine's own early-terminating compression (dre_ldlt_compress_fast); same X up to 4 eps ‖X‖, orthonormal factor, band D"
+function compress_fast!(X::LDLᵀ; ctx=default_context())
+    h = to_device(ctx, nothing, X)
+    chk(ctx, ccall((:dre_ldlt_compress_fast, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, h))
+    Y = from_device(ctx, h)
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, h)
+    X.alphas, X.Ls, X.Ds = Y.alphas, Y.Ls, Y.Ds
+    X
+end
+
 "concatenate!(X)  — src/LDLt.jl:174-191 (host side: hcat of the factors, block-diagonal of the scaled inner matrices)"
 function concatenate!(X::LDLᵀ)
     length(X.Ls) <= 1 && return X
@@ -417,7 +449,7 @@ function CommonSolve.solve(prob::GDREProblem{LDLᵀ}, alg::Union{Ros1,Ros2}; dt:
     DRESolution(Xs, Ks, t)
 end
 
-export Context, Pencil, LDLᵀ, lowrank, compress!, concatenate!, residual, ADI, Shifts, Callbacks, GALEProblem, GDREProblem, DRESolution, Ros1, Ros2,
+export Context, Pencil, LDLᵀ, lowrank, compress!, compress_fast!, concatenate!, residual, lyapunov_apply, ADI, Shifts, Callbacks, GALEProblem, GDREProblem, DRESolution, Ros1, Ros2,
        LowRankUpdate, lr_update, ADISolver, isdone, solve
 
 end # module
