@@ -428,44 +428,42 @@ __global__ void k_symmetrize(int n, double* __restrict__ S, int ld) {
 }
 // X <- sym(X + A B')  (A, B: n x K): the split-K slabs of A B' are reduced, added and symmetrised in one pass (same arithmetic as
 // gemm(beta = 1) followed by symmetrize)
-// one workgroup per pair of mirror tiles (32 x 32): both are reduced with coalesced reads and exchanged through LDS
+// one workgroup per pair of mirror tiles (16 x 16, one entry of each per thread): both are reduced with eight slab loads in flight and
+// exchanged through LDS
 __global__ __launch_bounds__(256) void k_reduce_sym_update(int n, int splits, const double* __restrict__ partial, double* __restrict__ X, int ldx) {
-    __shared__ double sa[32][33], sb[32][33];
+    __shared__ double sa[16][17], sb[16][17];
     const int I = blockIdx.x, J = blockIdx.y;
     if (I < J) return;
-    const int tr = threadIdx.x & 31, tc0 = threadIdx.x >> 5;
+    const int tr = threadIdx.x & 15, tc = threadIdx.x >> 4;
     const size_t slab = (size_t)n * n;
+    auto reduce_at = [&](int r, int c) {
+        if (r >= n || c >= n) return 0.0;
+        const double* p = partial + r + (size_t)c * n;
+        double v = 0.0;
+        int z = 0;
+        for (; z + 7 < splits; z += 8) {
+            double q[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tc = tc0 + 8 * q;
-        {
-            const int r = I * 32 + tr, c = J * 32 + tc;
-            double v = 0.0;
-            if (r < n && c < n) { for (int z = 0; z < splits; ++z) v += partial[z * slab + r + (size_t)c * n]; v += X[r + (size_t)c * ldx]; }
-            sa[tr][tc] = v;
+            for (int u = 0; u < 8; ++u) q[u] = p[(size_t)(z + u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += q[u];
         }
-        if (I != J) {
-            const int r = J * 32 + tr, c = I * 32 + tc;
-            double v = 0.0;
-            if (r < n && c < n) { for (int z = 0; z < splits; ++z) v += partial[z * slab + r + (size_t)c * n]; v += X[r + (size_t)c * ldx]; }
-            sb[tr][tc] = v;
+        for (; z < splits; ++z) v += p[(size_t)z * slab];
+        return v + X[r + (size_t)c * ldx];
+    };
+    sa[tr][tc] = reduce_at(I * 16 + tr, J * 16 + tc);
+    if (I != J) sb[tr][tc] = reduce_at(J * 16 + tr, I * 16 + tc);
+    __syncthreads();
+    {
+        const int r = I * 16 + tr, c = J * 16 + tc;
+        if (r < n && c < n) {
+            const double a = sa[tr][tc], b = (I == J) ? sa[tc][tr] : sb[tc][tr];
+            X[r + (size_t)c * ldx] = (r == c) ? a : 0.5 * (a + b);
         }
     }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tc = tc0 + 8 * q;
-        {
-            const int r = I * 32 + tr, c = J * 32 + tc;
-            if (r < n && c < n) {
-                const double a = sa[tr][tc], b = (I == J) ? sa[tc][tr] : sb[tc][tr];
-                X[r + (size_t)c * ldx] = (r == c) ? a : 0.5 * (a + b);
-            }
-        }
-        if (I != J) {
-            const int r = J * 32 + tr, c = I * 32 + tc;
-            if (r < n && c < n) X[r + (size_t)c * ldx] = 0.5 * (sb[tr][tc] + sa[tc][tr]);
-        }
+    if (I != J) {
+        const int r = J * 16 + tr, c = I * 16 + tc;
+        if (r < n && c < n) X[r + (size_t)c * ldx] = 0.5 * (sb[tr][tc] + sa[tc][tr]);
     }
 }
 void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* tag, DevCount dc) {
@@ -474,7 +472,7 @@ void gemm_sym_update(Ctx* ctx, const Mat& A, const Mat& B, Mat& X, const char* t
     if (A.cols == 0) return;
     int splits = 1;
     BufP pb = gemm_partials(ctx, false, true, n, n, A.cols, A.p, A.ld, B.p, B.ld, &splits, nullptr, tag, dc);
-    const int nt = ceil_div(n, 32);
+    const int nt = ceil_div(n, 16);
     hipLaunchKernelGGL(k_reduce_sym_update, dim3(nt, nt), dim3(256), 0, ctx->stream, n, splits, (const double*)pb->p, X.p, X.ld);
     DRE_HIP(hipGetLastError());
 }
@@ -3061,6 +3059,29 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
     __shared__ double red[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
+    // everything the later phases read from global memory is requested NOW, so that its latency hides behind the M = V'Z product:
+    // the rows of V and Z of the tile's row and column block, and the old values of the tile itself
+    const int rr_ = tid & 63, cq_ = tid >> 6;
+    double vrow2[2][16], zrow2[2][4], cold[2][2][4];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int r = (side == 0 ? i0 : j0) + rr_, rc = min(r, m - 1);
+#pragma unroll
+        for (int l = 0; l < 16; ++l) vrow2[side][l] = V[rc + (size_t)l * ldv];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) zrow2[side][cc] = Z[rc + (size_t)(cq_ * 4 + cc) * ldz];
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = min(i0 + wm + x * 16 + lk + 4 * r, m - 1), col = min(j0 + wn + y * 16 + lr, m - 1);
+                cold[x][y][r] = S22[row + (size_t)col * lds_];
+            }
     {   // M = V' Z  (16 x 16, K = m)
         const int kst = (m + 3) >> 2, per = (kst + 3) >> 2, t0 = wv * per, t1 = min(kst, t0 + per);
         v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -3091,19 +3112,18 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
         Nsh[i][j] = a0;
     }
     __syncthreads();
-    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
     {   // rows of [W V] for the tile's row block and of [V W] for its column block
-        const int rr = tid & 63, cq = tid >> 6;
+        const int rr = rr_, cq = cq_;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const int r = (side == 0 ? i0 : j0) + rr;
             double vrow[16];
 #pragma unroll
-            for (int l = 0; l < 16; ++l) vrow[l] = r < m ? V[r + (size_t)l * ldv] : 0.0;
+            for (int l = 0; l < 16; ++l) vrow[l] = r < m ? vrow2[side][l] : 0.0;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const int c = cq * 4 + cc;
-                double a0 = r < m ? Z[r + (size_t)c * ldz] : 0.0, a1 = 0.0;
+                double a0 = r < m ? zrow2[side][cc] : 0.0, a1 = 0.0;
 #pragma unroll
                 for (int l = 0; l < 16; l += 2) { a0 -= 0.5 * vrow[l] * Nsh[l][c]; a1 -= 0.5 * vrow[l + 1] * Nsh[l + 1][c]; }
                 const double w = a0 + a1;
@@ -3113,7 +3133,6 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
         }
     }
     __syncthreads();
-    const int wm = (wave & 1) * 32, wn = (wave >> 1) * 32;
     v4d acc[2][2];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -3137,9 +3156,8 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wm + x * 16 + lk + 4 * r, col = j0 + wn + y * 16 + lr;
                 if (row < m && col < m) {
-                    double* c = S22 + row + (size_t)col * lds_;
-                    const double v = *c - acc[x][y][r];
-                    *c = v;
+                    const double v = cold[x][y][r] - acc[x][y][r];
+                    S22[row + (size_t)col * lds_] = v;
                     ssq += v * v;
                 }
             }

@@ -1814,8 +1814,10 @@ __global__ __launch_bounds__(64) void k_dense_tols(int nparts, const double* __r
     }
 }
 // control block of the Lyapunov solve: residual = R D R' with orthonormal R, so its norm is ||D||_F
-__global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st) {
+__global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st,
+                                                        double* __restrict__ nws, int nws_n) {
     __shared__ double red[4];
+    for (int i = threadIdx.x; i < nws_n; i += 256) nws[i] = 0.0;        // meeting point of the fast chain's norm workgroups (was a memset of its own)
     double s = 0.0;
     for (int id = threadIdx.x; id < J * J; id += 256) { const double x = D[id % J + (size_t)(id / J) * ldd]; s += x * x; }
     s = wave_sum_t<double>(s);
@@ -2031,13 +2033,12 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     if (k > 0) {
         Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
         Mat Tm = sb.D;
-        hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p);
+        DevArr<double> nws(ctx, ADI_FAST_NWS);
+        hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p, nws.p, ADI_FAST_NWS);
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
         sx.mark(ctx, 3);
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
         Mat Gm(ctx, k * k, 2);
-        DevArr<double> nws(ctx, ADI_FAST_NWS);
-        DRE_HIP(hipMemsetAsync(nws.p, 0, (ADI_FAST_NWS) * sizeof(double), ctx->stream));
         // the whole solve is enqueued at once (one more iteration than the previous step needed); further chunks only if that was not enough
         int iters_host = 0;
         size_t cyc = 0;
