@@ -2,6 +2,7 @@
 #include "symbolic.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -57,8 +58,12 @@ struct Dissector {
     }
     void restamp(const std::vector<int>& verts, int st) { for (int v : verts) mark[v] = st; }
 
-    int dissect(std::vector<int>& verts) {
-        if ((int)verts.size() <= leaf_size) return new_node(std::move(verts), {});
+    // depth cap: below the depth of a balanced tree (log2(n / leaf_size)) a subdomain of up to four leaf sizes becomes a (dense) leaf, so
+    // that the few deep branches of an unbalanced dissection do not add tree levels — every level is one launch per sweep direction
+    // (sparse.hip), whatever the number of its nodes
+    int depth_cap = 1 << 30;
+    int dissect(std::vector<int>& verts, int depth = 0) {
+        if ((int)verts.size() <= leaf_size || (depth >= depth_cap && (int)verts.size() <= 4 * leaf_size)) return new_node(std::move(verts), {});
         // stamps: st = member, st+1 = visited
         int st = (stamp += 2);
         restamp(verts, st);
@@ -78,8 +83,8 @@ struct Dissector {
                 auto& g = (g1.size() <= g2.size()) ? g1 : g2;
                 g.insert(g.end(), c.begin(), c.end());
             }
-            int c1 = dissect(g1);
-            int c2 = dissect(g2);
+            int c1 = dissect(g1, depth + 1);
+            int c2 = dissect(g2, depth + 1);
             return new_node({}, {c1, c2});   // empty separator
         }
         // pseudo-peripheral vertex: two sweeps
@@ -119,8 +124,8 @@ struct Dissector {
         if (p1.empty() || p2.empty()) return new_node(std::move(verts), {});
         verts.clear();
         verts.shrink_to_fit();
-        int c1 = dissect(p1);
-        int c2 = dissect(p2);
+        int c1 = dissect(p1, depth + 1);
+        int c2 = dissect(p2, depth + 1);
         return new_node(std::move(sep), {c1, c2});
     }
 };
@@ -150,6 +155,12 @@ Symbolic symbolic_analyze(int n, const std::vector<int>& ptr, const std::vector<
     for (int i = 0; i < n; ++i) aidx.insert(aidx.end(), adj[i].begin(), adj[i].end());
 
     Dissector D(n, aptr, aidx, std::max(1, leaf_size));
+    {
+        int dc = 0;
+        while (((long)std::max(1, leaf_size) << (dc + 1)) <= (long)n) ++dc;        // floor(log2(n / leaf_size))
+        if (const char* e = std::getenv("DRE_ND_DEPTH_CAP")) dc = std::atoi(e);    // tuning knob (a huge value: no cap)
+        D.depth_cap = std::max(1, dc);
+    }
     std::vector<int> all(n);
     for (int i = 0; i < n; ++i) all[i] = i;
     D.dissect(all);
