@@ -165,6 +165,43 @@ Symbolic symbolic_analyze(int n, const std::vector<int>& ptr, const std::vector<
     for (int i = 0; i < n; ++i) all[i] = i;
     D.dissect(all);
 
+    // Supernode amalgamation (2:1): every tree level costs one launch per sweep direction and one per factorisation whatever its width
+    // (sparse.hip), and on these meshes the levels are latency bound, so two levels of bisection are merged into one four-way node: a node
+    // at odd depth hands its separator (a leaf: its whole subdomain) to its parent, its children become children of the parent.  The merged
+    // front treats the (structurally zero) coupling between the two absorbed separators as dense — a few percent more factor entries for half
+    // the launches.  Vertices of the absorbed nodes come first inside the merged node (they are eliminated first).
+    // MEASURED (round 2) and therefore OFF by default: n = 20209 goes from 12 to 5 levels and from 132 to 236 ms (factor entries +58 %, fronts
+    // of up to 187 pivots: their factorisation and their sweeps cost far more than the launches saved); n = 5177: 137.7 -> 142.5 ms.
+    {
+        int amalg = 0;
+        if (const char* e = std::getenv("DRE_ND_AMALGAMATE")) amalg = std::atoi(e);
+        if (amalg) {
+            const int T0 = (int)D.node_verts.size();
+            int root = -1;
+            for (int t = 0; t < T0; ++t) if (D.node_parent[t] < 0) root = t;       // the dissection returns one root (created last)
+            std::vector<std::vector<int>> nverts; std::vector<int> nparent; std::vector<std::vector<int>> nchildren;
+            // recursive build in postorder (explicit stack: depth is only ~log2 n, recursion is fine)
+            struct Rec {
+                Dissector& D; std::vector<std::vector<int>>& nv; std::vector<int>& np; std::vector<std::vector<int>>& nc;
+                int build(int t) {
+                    std::vector<int> verts, kids;
+                    for (int c : D.node_children[t]) {
+                        verts.insert(verts.end(), D.node_verts[c].begin(), D.node_verts[c].end());     // absorbed (odd depth)
+                        for (int g : D.node_children[c]) kids.push_back(build(g));
+                    }
+                    verts.insert(verts.end(), D.node_verts[t].begin(), D.node_verts[t].end());
+                    const int id = (int)nv.size();
+                    nv.push_back(std::move(verts)); np.push_back(-1); nc.push_back(kids);
+                    for (int k : kids) np[(size_t)k] = id;
+                    return id;
+                }
+            } rec{D, nverts, nparent, nchildren};
+            if (root >= 0) {
+                rec.build(root);
+                D.node_verts = std::move(nverts); D.node_parent = std::move(nparent); D.node_children = std::move(nchildren);
+            }
+        }
+    }
     // nodes were created in postorder already (children before parents)
     const int T = (int)D.node_verts.size();
     S.nnodes = T;
