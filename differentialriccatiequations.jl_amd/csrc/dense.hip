@@ -3189,6 +3189,14 @@ __global__ void k_band_init(AdiState* st, double abs_tol, const double* __restri
     st->abstol = abs_tol_dev ? abs_tol_dev[0] : abs_tol;
     st->res_norm = 0.0;
 }
+// debug (DRE_CLOCK_PROBE=1): shader clock while the solve runs = delta s_memtime / delta s_memrealtime x 100 MHz over ~10 us of dependent ALU work
+__global__ void k_clock_probe(long long* out) {
+    const long long c0 = clock64(), w0 = wall_clock64();
+    double x = 1.0 + threadIdx.x;
+    for (int i = 0; i < 4000; ++i) x = x * 1.0000001 + 1e-9;
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
+}
 static bool band_fused_enabled() {
     static const bool v = !(std::getenv("DRE_BAND_FUSED") && std::atoi(std::getenv("DRE_BAND_FUSED")) == 0);
     return v;
@@ -3212,6 +3220,18 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
     hipLaunchKernelGGL(k_band_init, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol, abs_tol_dev);
+    {
+        static const bool cp = std::getenv("DRE_CLOCK_PROBE") != nullptr;
+        static int cp_count = 0;
+        if (cp && q > 300 && (++cp_count % 40) == 20) {
+            DevArr<long long> o(ctx, 4);
+            hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, ctx->stream, o.p);
+            long long h[4];
+            DRE_HIP(hipMemcpyAsync(h, o.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            std::fprintf(stderr, "[clock probe] %lld shader cycles in %lld x 10 ns -> %.0f MHz\n", h[0], h[1], h[1] > 0 ? (double)h[0] / (double)h[1] * 100.0 : 0.0);
+        }
+    }
     // Panels are enqueued speculatively: every kernel returns at once after the device-side decision `done`, and the
     // host looks at the flag only every few panels.
     int k = 0, np = 0, J = q;
