@@ -10,6 +10,10 @@ the shift sequence are replicated.  The Gram matrix of the residual norm (src/LD
 reduces its row block, a k x k all_reduce (tiny) completes it.  Sparse factorisations are replicated (they are opaque device
 objects behind the C ABI; a farm that factors shift j on rank j mod P and ships the factor is future work).
 
+`RowShardedCompress` is SURVEY.md §8e item 3: `compress!` (src/LDLt.jl:204-225) of the replicated increment slab with the ROWS of the factor
+sharded, in the randomized form the single-GPU engine uses for wide factors (engine.hip, sketch_compress): two all_reduces of c x s
+matrices (L'Om and Q'L), one all_gather of the s x s triangles of a TSQR and two scalar reductions; the n x c factor itself never moves.
+
 Layering: `ColumnShardedADI` is backend agnostic — the per-rank operator work goes through an `ops` object (HipOps: the C ABI of
 libdre_hip on this rank's GPU; NumpyOps: SciPy stand-in used by the world-size-2 gloo test on CPU), the exchange through
 `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU).  With world size 1 the collectives are no-ops.
@@ -62,8 +66,20 @@ class Comm:
 
     def all_reduce_sum(self, G: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
+            G = G.contiguous()
             dist.all_reduce(G, op=dist.ReduceOp.SUM)
+            self.bytes_reduced = getattr(self, "bytes_reduced", 0) + G.numel() * G.element_size()
         return G
+
+    def all_gather_stack(self, T: torch.Tensor) -> torch.Tensor:
+        """The equal-shaped blocks of all ranks stacked along the first dimension (rank order)."""
+        if self.world == 1:
+            return T
+        T = T.contiguous()
+        recv = [torch.empty_like(T) for _ in range(self.world)]
+        dist.all_gather(recv, T)
+        self.bytes_gathered += T.numel() * T.element_size() * (self.world - 1)
+        return torch.cat(recv, dim=0)
 
 
 class NumpyOps:
@@ -103,6 +119,19 @@ class NumpyOps:
         Rb = R[r0:r1].numpy()
         return torch.from_numpy(Rb.T @ Rb)
 
+    # dense pieces of the row-sharded compression (plain NumPy on this stand-in)
+    def mm(self, A: torch.Tensor, B: torch.Tensor, tA=False, tB=False) -> torch.Tensor:
+        a, b = A.numpy(), B.numpy()
+        return torch.from_numpy(np.ascontiguousarray((a.T if tA else a) @ (b.T if tB else b)))
+
+    def qr(self, A: torch.Tensor):
+        q, r = np.linalg.qr(A.numpy())
+        return torch.from_numpy(np.ascontiguousarray(q)), torch.from_numpy(np.ascontiguousarray(r))
+
+    def eigh(self, S: torch.Tensor):
+        w, v = np.linalg.eigh(S.numpy())
+        return w, torch.from_numpy(np.ascontiguousarray(v))
+
 
 class HipOps:
     """The same per-rank work on this rank's GPU through the C ABI (libdre_hip): multifrontal LU + Sherman-Morrison-Woodbury for the
@@ -122,6 +151,8 @@ class HipOps:
     def _to_lib(self, T: torch.Tensor):
         """column-major library matrix from an (n x c) torch tensor view with unit row stride (device-to-device copy)"""
         Tc = T.t().contiguous()                       # (c, n) row-major == n x c column-major
+        if Tc.is_cuda:
+            torch.cuda.current_stream(Tc.device).synchronize()      # torch fills the exchange buffer on ITS stream; the library reads it on its own
         return self.ctx.from_device(Tc.data_ptr(), T.shape[0], T.shape[1], T.shape[0]), Tc
 
     def _from_lib(self, M, rows, cols) -> torch.Tensor:
@@ -152,6 +183,37 @@ class HipOps:
         Rb, keep = self._to_lib(R[r0:r1])
         G = self.ctx.gemm(True, False, 1.0, Rb, Rb)
         return self._from_lib(G, k, k)
+
+    # dense pieces of the row-sharded compression through the C ABI: f64 MFMA GEMM, blocked Householder QR (dre_orthf), symmetric
+    # eigensolver (dre_sym_eig); the tensors are exchange buffers only
+    def mm(self, A: torch.Tensor, B: torch.Tensor, tA=False, tB=False) -> torch.Tensor:
+        M = A.shape[1] if tA else A.shape[0]
+        N = B.shape[0] if tB else B.shape[1]
+        if M == 0 or N == 0 or (A.shape[0] if tA else A.shape[1]) == 0:
+            return torch.zeros((M, N), dtype=torch.float64, device=self.device)
+        Ad, k1 = self._to_lib(A)
+        Bd, k2 = self._to_lib(B)
+        return self._from_lib(self.ctx.gemm(tA, tB, 1.0, Ad, Bd), M, N)
+
+    def qr(self, A: torch.Tensor):
+        import ctypes as C
+        from . import device as dev
+        Ad, keep = self._to_lib(A)
+        q, r = C.c_void_p(), C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_orthf(self.ctx.ptr, Ad.ptr, C.byref(q), C.byref(r)))
+        k = min(A.shape)
+        return self._from_lib(dev.DenseMatrix(self.ctx, q), A.shape[0], k), self._from_lib(dev.DenseMatrix(self.ctx, r), k, A.shape[1])
+
+    def eigh(self, S: torch.Tensor):
+        import ctypes as C
+        from . import device as dev
+        Sd, keep = self._to_lib(S)
+        w, v = C.c_void_p(), C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_sym_eig(self.ctx.ptr, Sd.ptr, 4.0, C.byref(w), C.byref(v)))
+        wv = dev.DenseMatrix(self.ctx, w).numpy().ravel()
+        Vd = dev.DenseMatrix(self.ctx, v)
+        rows, cols = Vd.shape
+        return wv, self._from_lib(Vd, rows, cols)
 
 
 class ColumnShardedADI:
@@ -191,6 +253,85 @@ class ColumnShardedADI:
             it += 1
             norms.append(self._norm(R, St))
         return dict(increments=incs, T=S, iters=it, norms=norms, abstol=abstol, converged=norms[-1] <= abstol, residual_factor=R)
+
+
+class RowShardedCompress:
+    """compress!(X) (src/LDLt.jl:204-225) for X = sum_b alpha_b L_b D_b L_b' with the rows of every L_b sharded over the ranks (this rank
+    passes its row block of each factor).  Randomized range finder as in engine.hip sketch_compress, every contraction over the state
+    dimension n done on the local rows and completed by a collective on a SMALL matrix:
+
+        W  = sum_r L_r' Om_r                      all_reduce  (c x (s + 16))
+        Y_r = L_r (Dt W)                          local       (rows_r x (s + 16))
+        TSQR: Y_r = Q_r R_r,  all_gather R_r,  QR of the stack,  Q_r <- Q_r Qtop_r          all_gather ((s x s) per rank)
+        B  = sum_r Q_r' L_r                       all_reduce  (s x c)
+        T  = B Dt B'  (s x s, replicated),  eigen-decomposition with the reference's threshold 100 eps max|lambda|
+        Lnew_r = Q_r Z                            local       (rows_r x J)
+
+    plus the acceptance test on 16 probe columns (two scalar all_reduces).  Returns this rank's rows of the new orthonormal factor, the
+    eigenvalues, and the diagnostics; `gather_rows` assembles the replicated factor when a caller needs it."""
+
+    def __init__(self, ops, comm: Comm, seed=0x2545F491):
+        self.ops, self.comm, self.seed = ops, comm, seed
+
+    def compress(self, blocks, n: int, sketch: int):
+        """blocks: list of (L_rows [rows_r x k_b tensor], D_b [k_b x k_b ndarray], alpha_b); sketch: range-finder width s (a multiple of 16)."""
+        ops, comm = self.ops, self.comm
+        dev = ops.device
+        r0, r1 = row_range(n, comm.rank, comm.world)
+        Lr = torch.cat([b[0] for b in blocks], dim=1).contiguous()                      # rows_r x c
+        assert Lr.shape[0] == r1 - r0
+        c, sp = Lr.shape[1], sketch + 16
+        Dt = np.zeros((c, c))
+        off = 0
+        for _, Db, ab in blocks:
+            k = Db.shape[0]
+            Dt[off:off + k, off:off + k] = ab * np.asarray(Db)
+            off += k
+        Dt_t = torch.from_numpy(Dt).to(dev)
+        Om = torch.from_numpy(np.random.default_rng(self.seed).standard_normal((n, sp))[r0:r1]).to(dev)     # same stream of numbers on every rank
+        W = comm.all_reduce_sum(ops.mm(Lr, Om, tA=True))                                # c x sp
+        Y = ops.mm(Lr, ops.mm(Dt_t, W))                                                 # rows_r x sp  (this rank's rows of X Om)
+        Yr, Z = Y[:, :sketch].contiguous(), Y[:, sketch:].contiguous()
+        # TSQR over the ranks (a rank with fewer rows than columns pads its triangle with zero rows)
+        Qloc, Rloc = ops.qr(Yr) if Yr.shape[0] > 0 else (Yr, torch.zeros((0, sketch), dtype=torch.float64, device=dev))
+        Rpad = torch.zeros((sketch, sketch), dtype=torch.float64, device=dev)
+        Rpad[: Rloc.shape[0]] = Rloc
+        Rall = comm.all_gather_stack(Rpad)                                              # (P s) x s
+        Qtop, _ = ops.qr(Rall)
+        Qt_r = Qtop[comm.rank * sketch: comm.rank * sketch + Rloc.shape[0]]
+        Q = ops.mm(Qloc, Qt_r) if Yr.shape[0] > 0 else Yr                                # rows_r x s, orthonormal across the ranks
+        # acceptance test: ||(I - QQ') X G||_F / ||X G||_F on the 16 probe columns
+        QtZ = comm.all_reduce_sum(ops.mm(Q, Z, tA=True))
+        E = Z - ops.mm(Q, QtZ)
+        nz = comm.all_reduce_sum(torch.tensor([float((Z * Z).sum()), float((E * E).sum())], dtype=torch.float64, device=dev))
+        est = float(torch.sqrt(nz[1] / nz[0])) if float(nz[0]) > 0 else 0.0
+        B = comm.all_reduce_sum(ops.mm(Q, Lr, tA=True))                                 # s x c
+        T = ops.mm(ops.mm(B, Dt_t), B, tB=True)
+        T = 0.5 * (T + T.t())
+        w, Zv = ops.eigh(T.contiguous())
+        w = np.asarray(w)
+        wmax = np.abs(w).max() if w.size else 0.0
+        keep = np.where(np.abs(w) >= 100.0 * np.finfo(float).eps * wmax)[0] if wmax > 0 else np.array([], dtype=int)     # LDLt.jl:216-217
+        Zk = Zv[:, torch.from_numpy(keep).to(Zv.device)] if keep.size else Zv[:, :0]
+        Lnew = ops.mm(Q, Zk.contiguous()) if keep.size and Q.shape[0] > 0 else torch.zeros((Q.shape[0], int(keep.size)), dtype=torch.float64, device=dev)
+        ok = (keep.size + 32 <= sketch) and est <= 64.0 * np.finfo(float).eps
+        return dict(L_rows=Lnew, eigenvalues=w[keep], rank=int(keep.size), probe_residual=est, accepted=bool(ok), row_range=(r0, r1))
+
+    def gather_rows(self, L_rows: torch.Tensor, n: int) -> torch.Tensor:
+        """the replicated n x J factor from the row blocks (all_gather of n J 8 bytes in total)"""
+        comm = self.comm
+        if comm.world == 1:
+            return L_rows
+        J = L_rows.shape[1]
+        hmax = max(row_range(n, r, comm.world)[1] - row_range(n, r, comm.world)[0] for r in range(comm.world))
+        pad = torch.zeros((hmax, J), dtype=L_rows.dtype, device=L_rows.device)
+        pad[: L_rows.shape[0]] = L_rows
+        allr = comm.all_gather_stack(pad)
+        parts = []
+        for r in range(comm.world):
+            a, b = row_range(n, r, comm.world)
+            parts.append(allr[r * hmax: r * hmax + (b - a)])
+        return torch.cat(parts, dim=0)
 
 
 def dense_solution(res) -> np.ndarray:

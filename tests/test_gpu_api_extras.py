@@ -298,3 +298,36 @@ def test_column_sharded_adi_device_ops_single_rank(ctx):
     for k, w in ((12, 8), (5, 8), (200, 3)):
         rs = [col_range(k, r, w) for r in range(w)]
         assert rs[0][0] == 0 and rs[-1][1] == k and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+
+
+def test_row_sharded_compression_device_ops_single_rank(ctx):
+    """dre_amd.sharded.RowShardedCompress with HipOps (GEMM, Householder QR and the symmetric eigensolver through the C ABI, tensors as
+    device-to-device exchange buffers) at world size 1: the increments of a device ADI run compress to the same X as the SciPy stand-in
+    and as the dense sum (the world-size-2 exchange pattern is covered by the gloo test on CPU)."""
+    import torch
+    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, NumpyOps, RowShardedCompress
+    d = D.steel_profile(371)
+    L, Dm = D.initial_value(d)
+    tau = 100.0
+    P = D.Pencil(d.E, d.A, ctx)
+    K0 = (d.B.T @ L) @ Dm @ (L.T @ d.E)
+    G = np.hstack([d.C.T, d.E.T @ L])
+    BtLD = (d.B.T @ L) @ Dm
+    S = np.zeros((12, 12)); S[:6, :6] = np.eye(6); S[6:, 6:] = BtLD.T @ BtLD + Dm / tau
+    shifts = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    comm = Comm(rank=0, world=1)
+    hops = HipOps(ctx, P, 1.0, -1.0 / (2 * tau), d.B, K0, alpha=-1.0, device=torch.device("cuda", 0))
+    res = ColumnShardedADI(hops, comm, shifts).solve(G, S)
+    assert res["converged"]
+    blocks_dev = [(V, S, c) for V, c in res["increments"]]                       # X = sum_j c_j V_j S V_j'  (c = 12 x iters columns)
+    ref = sum(c * (V.cpu().numpy() @ S @ V.cpu().numpy().T) for V, c in res["increments"])
+    out = RowShardedCompress(hops, comm).compress(blocks_dev, 371, sketch=192)
+    Lh = out["L_rows"].cpu().numpy()
+    assert out["accepted"] and out["rank"] <= 160, (out["rank"], out["probe_residual"])
+    assert np.abs(Lh.T @ Lh - np.eye(out["rank"])).max() < 1e-12
+    Xh = (Lh * out["eigenvalues"]) @ Lh.T
+    assert np.linalg.norm(Xh - ref) < 1e-12 * np.linalg.norm(ref)
+    cops = NumpyOps(d.E, d.A)
+    outc = RowShardedCompress(cops, comm).compress([(V.cpu(), S, c) for V, c in res["increments"]], 371, sketch=192)
+    Lc = outc["L_rows"].numpy()
+    assert abs(outc["rank"] - out["rank"]) <= 2 and np.linalg.norm((Lc * outc["eigenvalues"]) @ Lc.T - Xh) < 1e-12 * np.linalg.norm(ref)

@@ -116,6 +116,18 @@ def test_column_sharded_adi_over_gloo_world_size_2():
     assert "SHARDED_OK world=2" in r.stdout
 
 
+def test_row_sharded_compression_over_gloo_world_size_2():
+    """compress! of the increment slab with the rows of the factor sharded (dre_amd.sharded.RowShardedCompress,
+    randomized range finder + TSQR over the ranks): two CPU processes over gloo reproduce the dense sum, the single-rank result and the
+    eigenvalues the oracle's compress! keeps; the factor is orthonormal across the ranks; a too narrow sketch is rejected."""
+    script = os.path.join(ROOT, "tests", "_gloo_rowshard_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29543", script], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ROWSHARD_OK world=2" in r.stdout
+
+
 def test_bench_refuses_a_world_size_mismatch():
     """bench.py --gpus N under a torchrun environment of another size must fail loudly instead of printing n_gpus = 1."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
