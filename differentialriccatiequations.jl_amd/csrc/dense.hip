@@ -3338,7 +3338,10 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tots + 255) / 256)), dim3(256), 0, ctx->stream, Js, b, nps * b, S.p, S.ld, tmp.D.p, tmp.D.ld);
                 spec->B = sym_band_basis(ctx, tmp);
                 spec->D = tmp.D; spec->J = Js;
+                if (spec->extra && !spec->ran) { spec->ran = true; spec->extra(); }
             };
+        } else if (spec && first_round && spec->extra && !spec->ran) {
+            between = [&]() { spec->ran = true; spec->extra(); };
         }
         ctx_fetch_overlap(ctx, between, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
         first_round = false;

@@ -188,7 +188,12 @@ struct SymBand {
 // spec (optional): the band matrix and the basis for the predicted result are enqueued while the control block is read back (spec->hit
 // tells whether they are valid: then out.D == spec->D and spec->B == sym_band_basis(out)); ext_part: ext_nparts partial sums of
 // ||S||_F^2 that came with the assembly of S (saves the first norm launch)
-struct BandSpec { int J = -1; bool hit = false; Mat B, D; };
+struct BandSpec {
+    int J = -1; bool hit = false; Mat B, D;
+    // further host work to slot into the wait for the control block (runs once, after the speculative kernels were enqueued; ran = true)
+    std::function<void()> extra;
+    bool ran = false;
+};
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr, BandSpec* spec = nullptr,
                         const double* ext_part = nullptr, int ext_nparts = 0);   // abs_tol_dev: the tolerance lives in device memory
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb

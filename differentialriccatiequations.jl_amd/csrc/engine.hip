@@ -2008,16 +2008,27 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
     hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
     sx.mark(ctx, 1);
-    if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+    // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
+    // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
     CycleOps co;
-    if (!cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co)) {
+    bool co_ok = true;
+    auto side_setup = [&]() {
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+        co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co);
+        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+    };
+    // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
+    BandSpec spec;
+    static const bool side_in_fetch = !(std::getenv("DRE_SIDE_IN_FETCH") && std::atoi(std::getenv("DRE_SIDE_IN_FETCH")) == 0);
+    const bool defer_side = wctx != ctx && side_in_fetch;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
+    if (defer_side) spec.extra = side_setup;
+    else side_setup();
+    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
+    if (defer_side && !spec.ran) side_setup();
+    if (!co_ok) {
         DRE_HIP(hipStreamSynchronize(ctx->stream));         // the kernels above read buffers that go out of scope with this frame
         return false;
     }
-    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
-    // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
-    BandSpec spec;
-    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     sx.mark(ctx, 2);
     const int k = sb.J;
     DevArr<AdiState> st(ctx, 1);
