@@ -176,3 +176,21 @@ def test_largest_steel_profile_size(ctx):
     K = (d.B.T @ Lx) @ (a * Dx) @ (Lx.T @ d.E)
     assert D.delta(K, sol.K[-1]) < 1e-10
     assert np.abs(Lx.T @ Lx - np.eye(Lx.shape[1])).max() < 1e-10
+
+
+def test_dense_x_loop_with_short_speculation_chunks(ctx, rail371):
+    """The dense-X time loop enqueues max(compression_interval, previous count + 1) ADI iterations at a time and adds every chunk's increments to X
+    on the device before the host knows how many of them count (DevCount).  compression_interval = 2 forces several chunks per Lyapunov
+    solve in the first steps (and whenever the count grows by more than one): same iteration counts and K(t) as the default chunking and as
+    the oracle's fixture."""
+    d, L, Dm = rail371
+    g = np.load(os.path.join(GOLDEN, "ros1_371.npz"))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4000.0))
+    ref, st0 = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(371)))), dt=-100.0, return_stats=True)
+    sol, st = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(371)), compression_interval=2)), dt=-100.0, return_stats=True)
+    assert [x["iters"] for x in st["gales"]] == [x["iters"] for x in st0["gales"]] == list(g["iters"])
+    for i in range(len(sol.K)):
+        assert D.delta(sol.K[i], ref.K[i]) < 1e-10 and D.delta(sol.K[i], g["K"][i]) < 1e-7
+    a, Lx, Dx = sol.X[-1]
+    a0, L0, D0 = ref.X[-1]
+    assert np.linalg.norm(a * Lx @ Dx @ Lx.T - a0 * L0 @ D0 @ L0.T) < 1e-10 * np.linalg.norm(L0 @ D0 @ L0.T)
