@@ -103,6 +103,8 @@ PROTOTYPES = {
     "dre_gale_solve": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
     "dre_ldlt_dot": (C.c_int, [_vp, _vp, _vp, _pd]),
     "dre_ldlt_compress_fast": (C.c_int, [_vp, _vp]),
+    "dre_gare_residual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_double, _vp, _vp, C.c_double, _pvp]),
+    "dre_ldlt_feedback": (C.c_int, [_vp, _vp, _vp, _vp, _pvp]),
     "dre_gale_apply": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _pvp]),
     "dre_adi_init": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, C.POINTER(AdiOptionsC), _pvp]),
     "dre_adi_step": (C.c_int, [_vp, _vp]),

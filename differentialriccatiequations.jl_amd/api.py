@@ -1019,26 +1019,37 @@ def _spT_mul(M, L):
 
 def gare_residual(prob: GAREProblem, X: LDLt, ctx=None, drop_below=None) -> LDLt:
     """residual(::GAREProblem, ::LDLᵀ)  (riccati/residual.jl:5-52): the factors R = [C', A'L, E'L] and the small T are assembled on
-    the host (n x (h + 2 z) doubles), the compression — the expensive part — runs on the device."""
+    the DEVICE from the factors of X (dre_gare_residual) and compressed there; nothing of size n x rank crosses the bus."""
     if X.iszero():
         g, Ct, S = prob.Q
         return g * lowrank(Ct.copy(), np.array(S, dtype=float))
     gamma, Ct, S = prob.Q
     beta, B, Rinv = prob.G
-    alpha, L, D = X._factors_any_form()
-    h, z = Ct.shape[1], L.shape[1]
-    BtLD = (B.T @ L) @ D * (alpha * beta)
-    R = np.hstack([Ct, _spT_mul(prob.A, L), _spT_mul(prob.E, L)])
-    T = np.zeros((h + 2 * z, h + 2 * z))
-    T[:h, :h] = gamma * np.asarray(S)
-    T[h:h + z, h + z:] = alpha * D
-    T[h + z:, h:h + z] = alpha * D
-    T[h + z:, h + z:] = -(BtLD.T @ np.asarray(Rinv) @ BtLD)
     ctx = ctx or dev.default_context()
     pencil = _pencil_for(prob.E, prob.A, ctx)
-    h = lowrank(R, T)._to_device(ctx, pencil)        # compressed on the device; the factors stay there until somebody looks at them
+    hx = X._to_device(ctx, pencil)                   # the factors of X stay where the ADI left them (no download of L)
+    Ctd, Sd = ctx.upload(np.asarray(Ct, dtype=float)), ctx.upload(np.asarray(S, dtype=float))
+    Bd, Rd = ctx.upload(np.asarray(B, dtype=float)), ctx.upload(np.asarray(Rinv, dtype=float))
+    out = C.c_void_p()
+    ctx.chk(ctx.lib.dre_gare_residual(ctx.ptr, pencil.ptr, hx.ptr, Ctd.ptr, Sd.ptr, float(gamma), Bd.ptr, Rd.ptr, float(beta), C.byref(out)))
+    h = dev.DeviceLDLt(ctx, out, pencil)             # [C', A'L, E'L] T [...]' assembled on the device (dre_gare_residual)
     h.compress(drop_below)                           # drop_below: absolute truncation (the Newton loop passes a fraction of its tolerance)
     return LDLt([], [], [], _handle=h)
+
+
+def gare_feedback(prob: GAREProblem, X: LDLt, ctx=None) -> np.ndarray:
+    """K = B'XE (newton.jl:104-112) from the device factors of X (dre_ldlt_feedback); only the m x n result comes back."""
+    beta, B, Rinv = prob.G
+    n = prob.A.shape[0]
+    if X.rank() == 0:
+        return np.zeros((B.shape[1], n))
+    ctx = ctx or dev.default_context()
+    pencil = _pencil_for(prob.E, prob.A, ctx)
+    hx = X._to_device(ctx, pencil)
+    Bd = ctx.upload(np.asarray(B, dtype=float))
+    out = C.c_void_p()
+    ctx.chk(ctx.lib.dre_ldlt_feedback(ctx.ptr, pencil.ptr, hx.ptr, Bd.ptr, C.byref(out)))
+    return np.ascontiguousarray(dev.DenseMatrix(ctx, out).numpy().T)
 
 
 def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_info=False):
@@ -1061,13 +1072,10 @@ def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_i
     history, adi_iters, i = [], 0, 0
 
     def aux(Xc):
-        alpha, L, D = Xc._factors_any_form()
-        EtL = _spT_mul(prob.E, L)
-        BtLD = (B.T @ L) @ D * alpha
-        return EtL, BtLD, BtLD @ EtL.T
+        return gare_feedback(prob, Xc, ctx)              # K = B'XE, formed on the device
 
     while True:
-        EtL, BtLD, K = aux(X)
+        K = aux(X)
         res = gare_residual(prob, X, ctx, drop_below=1e-3 * abstol)
         res_norm_prev, res_norm = res_norm, norm(res)
         if i > 0 and alg.linesearch and res_norm > (1 - 0.1) * res_norm_prev:      # Armijo, newton.jl:50-92
@@ -1077,13 +1085,13 @@ def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_i
                 res = gare_residual(prob, X, ctx, drop_below=1e-3 * abstol)
                 res_norm = norm(res)
                 if res_norm < (1 - lam * 0.1) * res_norm_prev:
-                    EtL, BtLD, K = aux(X)
+                    K = aux(X)
                     break
                 lam *= 0.5
                 if lam < np.finfo(float).eps:
                     warnings.warn("Line search failed; using un-modified iterate")
                     X, lam = Xt, 1.0
-                    EtL, BtLD, K = aux(X)
+                    K = aux(X)
                     break
             _call(observer, "observe_gare_metadata", "line search", lam)
         _call(observer, "observe_gare_step", i, X, res, res_norm)
@@ -1096,7 +1104,7 @@ def solve_gare(prob: GAREProblem, alg: Newton, observer=None, ctx=None, return_i
             break
         i += 1
         F = lr_update(prob.A, -1.0, B, K)                                        # newton.jl:104
-        G = np.hstack([Ct, EtL @ BtLD.T])                                        # newton.jl:107-112
+        G = np.hstack([Ct, K.T])                                                 # newton.jl:107-112  (E'XB = K')
         lyap = GALEProblem(prob.E, F, lowrank(G, np.eye(G.shape[1])))
         if alg.inexact:                                                          # newton.jl:116-133
             inner_abstol = alg.inexact_forcing(i, res_norm) * res_norm

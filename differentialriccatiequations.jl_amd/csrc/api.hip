@@ -702,6 +702,32 @@ int dre_gale_apply(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, doub
         *out = h;
     });
 }
+int dre_gare_residual(dre_ctx* ctx, const dre_pencil* p, dre_ldlt* X, const dre_dense* Ct, const dre_dense* S, double gamma, const dre_dense* B,
+                      const dre_dense* Rinv, double beta, dre_ldlt** out) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        DRE_REQUIRE(X->pen == p, "LDLt operand must be created with the same pencil");
+        DRE_REQUIRE(Ct->m.rows == p->p->n && B->m.rows == p->p->n && S->m.rows == Ct->m.cols && Rinv->m.rows == B->m.cols, "dre_gare_residual: shape mismatch");
+        Mat Cs = to_solver_order(c, p, Ct->m), Bs = to_solver_order(c, p, B->m);
+        auto* h = new dre_ldlt();
+        h->pen = p;
+        try { h->x = gare_residual_dev(c, *p->p, *X->x, Cs, S->m, gamma, Bs, Rinv->m, beta); } catch (...) { delete h; throw; }
+        *out = h;
+    });
+}
+int dre_ldlt_feedback(dre_ctx* ctx, const dre_pencil* p, dre_ldlt* X, const dre_dense* B, dre_dense** Kt) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
+        DRE_REQUIRE(X->pen == p && B->m.rows == p->p->n, "dre_ldlt_feedback: operand mismatch");
+        Mat Bs = to_solver_order(c, p, B->m);
+        Mat Ks = ldlt_feedback_dev(c, *p->p, *X->x, Bs);
+        auto* K = new dre_dense();
+        Mat Ku = to_user_order(c, p, Ks);
+        K->m = Mat(c, Ku.rows, Ku.cols);
+        copy_mat(c, Ku, K->m);
+        *Kt = K;
+    });
+}
 int dre_adi_result_info(const dre_adi_result* r, int64_t* info, double* dinfo) {
     info[0] = r->r.iters; info[1] = r->r.converged; info[2] = r->r.warnings; info[3] = (int64_t)r->r.norms.size(); info[4] = r->r.rhs_cols;
     dinfo[0] = r->r.res_norm; dinfo[1] = r->r.abstol; dinfo[2] = r->r.initial_norm;

@@ -871,6 +871,50 @@ LDLtP lyapunov_apply(Ctx* ctx, const GaleOperator& op, const LDLtP& X) {
 }
 
 // =============================================================================================
+// Algebraic Riccati pieces on the device (riccati/residual.jl:5-52, newton.jl:104-112): the residual
+//   R(X) = gamma C'S C + A'XE + E'XA - beta^2 E'XB Rinv B'XE   as ONE LDL' block  [C', A'L, E'L] T [...]'
+// and the feedback K' = E'XB, both from the factors of X where they live (no download of L).
+// =============================================================================================
+static void single_block(Ctx* ctx, LDLt& X) { if (X.blocks.size() > 1) ldlt_concatenate(ctx, X); }
+LDLtP gare_residual_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& Ct, const Mat& S, double gamma, const Mat& B, const Mat& Rinv, double beta) {
+    const int n = P.n, h = Ct.cols, m = B.cols;
+    single_block(ctx, X);
+    const int z = X.blocks.empty() ? 0 : X.blocks[0].L.cols;
+    Mat R(ctx, n, h + 2 * z), T(ctx, h + 2 * z, h + 2 * z);
+    fill_mat(ctx, T, 0.0);
+    { Mat d = R.colsview(0, h); copy_mat(ctx, Ct, d); }
+    { Mat d = T.view(0, 0, h, h); copy_mat(ctx, S, d, gamma); }
+    if (z > 0) {
+        auto& b = X.blocks[0];
+        { Mat d = R.colsview(h, z); spmm(ctx, P, P.valAt.p, b.L, d, 1.0, 0.0); }
+        { Mat d = R.colsview(h + z, z); spmm(ctx, P, P.valEt.p, b.L, d, 1.0, 0.0); }
+        { Mat d = T.view(h, h + z, z, z); copy_mat(ctx, b.D, d, b.alpha); }
+        { Mat d = T.view(h + z, h, z, z); copy_mat(ctx, b.D, d, b.alpha); }
+        Mat BtL(ctx, m, z), BtLD(ctx, m, z), RB(ctx, m, z);
+        gemm(ctx, true, false, 1.0, B, b.L, 0.0, BtL);
+        gemm(ctx, false, false, b.alpha * beta, BtL, b.D, 0.0, BtLD);
+        gemm(ctx, false, false, 1.0, Rinv, BtLD, 0.0, RB);
+        Mat d = T.view(h + z, h + z, z, z);
+        gemm(ctx, true, false, -1.0, BtLD, RB, 0.0, d);
+    }
+    return ldlt_make(ctx, n, R, T, 1.0, false);
+}
+Mat ldlt_feedback_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& B) {
+    const int n = P.n, m = B.cols;
+    Mat Kt(ctx, n, m);
+    single_block(ctx, X);
+    if (X.blocks.empty() || X.blocks[0].L.cols == 0) { fill_mat(ctx, Kt, 0.0); return Kt; }
+    auto& b = X.blocks[0];
+    const int z = b.L.cols;
+    Mat LtB(ctx, z, m), DLtB(ctx, z, m), XB(ctx, n, m);
+    gemm(ctx, true, false, 1.0, b.L, B, 0.0, LtB);
+    gemm(ctx, false, false, b.alpha, b.D, LtB, 0.0, DLtB);
+    gemm(ctx, false, false, 1.0, b.L, DLtB, 0.0, XB);
+    spmm(ctx, P, P.valEt.p, XB, Kt, 1.0, 0.0);
+    return Kt;
+}
+
+// =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
 // =============================================================================================
 // Dense inverses whose acceptance test (condition estimate ||M||_F ||inv(M)||_F, two norms in device memory) is still outstanding: a run

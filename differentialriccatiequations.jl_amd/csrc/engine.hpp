@@ -41,6 +41,9 @@ void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-
 // exact = false (engine default): the early-terminated Householder reduction alone, D := T_j (tridiagonal); the
 // dropped part is below tolfac*eps*||S||_F, i.e. not larger than what the reference's threshold discards.
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
+// residual(::GAREProblem, ::LDLt) and the feedback E'XB from the device factors of X (solver ordering throughout)
+LDLtP gare_residual_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& Ct, const Mat& S, double gamma, const Mat& B, const Mat& Rinv, double beta);
+Mat ldlt_feedback_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& B);
 double ldlt_norm(Ctx* ctx, LDLt& X);                             // LDLt.jl:77-89 (concatenates, synchronises)
 double ldlt_norm_accurate(Ctx* ctx, const LDLt& X);   // QR/compression based like LDLt.jl:77-89 (robust to cancellation); X unchanged
 void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true);   // LDLt.jl:54-60: compress iff more than one block

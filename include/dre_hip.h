@@ -242,6 +242,11 @@ int dre_heuristic_ritz(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, 
 int dre_gale_residual(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U,
                       const dre_dense* Vt, dre_ldlt* C, dre_ldlt* X, dre_ldlt** out);
 /* LyapunovOperator(E, F) * X = F'XE + E'XF as an LDL' object with factor [E'L, F'L] (src/lyapunov/gmres.jl:108-120); F as in dre_gale_solve */
+/* residual(::GAREProblem, ::LDLt) = gamma C'SC + A'XE + E'XA - beta^2 E'XB Rinv B'XE as one LDL' object [C', A'L, E'L] T [...]'
+ * (src/riccati/residual.jl:5-52), and the feedback K' = E'XB (newton.jl:104-112), both formed from the device factors of X */
+int dre_gare_residual(dre_ctx* ctx, const dre_pencil* p, dre_ldlt* X, const dre_dense* Ct, const dre_dense* S, double gamma, const dre_dense* B,
+                      const dre_dense* Rinv, double beta, dre_ldlt** out);
+int dre_ldlt_feedback(dre_ctx* ctx, const dre_pencil* p, dre_ldlt* X, const dre_dense* B, dre_dense** Kt);
 int dre_gale_apply(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
                    const dre_ldlt* X, dre_ldlt** out);
 /* info: [0]=iters [1]=converged [2]=warnings [3]=number of recorded norms [4]=rhs columns;  dinfo: [0]=res_norm [1]=abstol [2]=initial norm */
