@@ -3385,6 +3385,87 @@ __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* _
     const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
     out[idx % n + (idx / n) * (size_t)ld] = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
+// Upper Cholesky factor R of a symmetric positive semidefinite b x b matrix G (b <= 64) and Rinv = inv(R), one workgroup:  G = R'R, so
+// that Y Rinv has orthonormal columns when G = Y'Y (Cholesky QR).  Right-looking in LDS with ONE barrier per column (the scaling by
+// 1/sqrt(pivot) is folded into the rank-1 update).  Two thresholds:
+//   * a pivot at or below `floor` is a NULL column — what is left of it after the earlier columns is rounding noise relative to the whole
+//     sketch — and gets a zero column in Rinv (a zero column of Q: it contributes nothing instead of a normalised noise vector that is
+//     not orthogonal to anything).  mode 0: floor = relfloor x this block's largest diagonal entry, which is also written to *ref (first
+//     block of a sketch); mode 1: floor = relfloor x *ref; mode 2: floor = 1e-20 (second pass: the block is orthonormal up to 1e-8);
+//   * a pivot above the floor but at or below 1e-13 x the block's largest diagonal entry (cond(Y_b) beyond ~3e6: Cholesky QR would lose
+//     orthogonality) raises *flag: the caller falls back to Householder panels.
+//   nullmask (optional, b entries): 1 for a null column, so that the caller can put a fresh random direction there (k_fill_gauss_masked).
+__global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restrict__ G, int ldg, double* __restrict__ Rinv, int ldr, int* __restrict__ flag,
+                                                  double* __restrict__ ref, int mode, int* __restrict__ nullmask, double relfloor) {
+    extern __shared__ double chol_lds[];            // 3 x 64 x 65 doubles (dynamic: beyond the 64 KB static limit)
+    double (*A)[65] = reinterpret_cast<double (*)[65]>(chol_lds);
+    double (*Lm)[65] = A + 64;
+    double (*Li)[65] = Lm + 64;
+    __shared__ double dmax_s;
+    const int tid = threadIdx.x;
+    for (int id = tid; id < 64 * 64; id += 256) { const int i = id & 63, j = id >> 6; A[i][j] = (i < b && j < b) ? G[i + (size_t)j * ldg] : 0.0; Lm[i][j] = 0.0; Li[i][j] = 0.0; }
+    __syncthreads();
+    if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0) *ref = m; }
+    __syncthreads();
+    const double floor_abs = mode == 2 ? 1e-20 : relfloor * (mode == 0 ? dmax_s : *ref);
+    const double thr = 1e-13 * dmax_s;
+    bool bad = false;
+    for (int k = 0; k < b; ++k) {
+        const double piv = A[k][k];
+        const bool live = piv > floor_abs;           // (NaN: not live)
+        if (live && !(piv > thr)) bad = true;
+        const double rd = live ? 1.0 / sqrt(piv) : 0.0, rp = rd * rd;
+        if (nullmask && tid == 0) nullmask[k] = live ? 0 : 1;
+        for (int i = k + tid; i < b; i += 256) Lm[i][k] = A[i][k] * rd;          // column k of L (a null column: zero)
+        const int m = b - k - 1;                                                   // trailing block (k+1 .. b-1)^2, lower triangle incl. diagonal
+        for (int id = tid; id < m * m; id += 256) {
+            const int i = k + 1 + id % m, j = k + 1 + id / m;
+            if (i >= j) A[i][j] -= A[i][k] * A[j][k] * rp;
+        }
+        __syncthreads();
+    }
+    // inv(L) column by column (thread j owns column j; a null column j gives a zero column), then Rinv = inv(L)'
+    if (tid < b) {
+        const int j = tid;
+        const bool livej = Lm[j][j] != 0.0;
+        Li[j][j] = livej ? 1.0 / Lm[j][j] : 0.0;
+        for (int i = j + 1; i < b; ++i) {
+            double acc = 0.0;
+            for (int l = j; l < i; ++l) acc += Lm[i][l] * Li[l][j];
+            Li[i][j] = (livej && Lm[i][i] != 0.0) ? -acc / Lm[i][i] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int id = tid; id < b * b; id += 256) { const int r = id % b, c = id / b; Rinv[r + (size_t)c * ldr] = (r <= c) ? Li[c][r] : 0.0; }
+    if (bad && tid == 0) atomicOr(flag, 1);
+}
+// Unit-scale Gaussian entries (variance 1/n) into the columns of T that mask marks
+__global__ void k_fill_gauss_masked(int n, int cols, unsigned long long seed, double* __restrict__ out, int ld, const int* __restrict__ mask, double scale) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * cols) return;
+    const int col = (int)(idx / n);
+    if (!mask[col]) return;
+    auto mix = [](unsigned long long z) {
+        z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+    };
+    const unsigned long long a = mix(seed + 2 * idx), b = mix(seed + 2 * idx + 1);
+    const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+    out[idx % n + (size_t)col * ld] = scale * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+}
+void fill_gauss_masked(Ctx* ctx, Mat& A, unsigned long long seed, const int* mask_dev) {
+    const size_t tot = (size_t)A.rows * A.cols;
+    if (tot) hipLaunchKernelGGL(k_fill_gauss_masked, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, A.rows, A.cols, seed, A.p, A.ld, mask_dev,
+                                1.0 / std::sqrt((double)A.rows));
+}
+void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev) {
+    DRE_REQUIRE(G.rows == G.cols && G.rows <= 64 && Rinv.rows == G.rows && Rinv.cols == G.rows, "chol_inv: order <= 64 expected");
+    if (G.rows == 0) return;
+    const size_t shm = (size_t)3 * 64 * 65 * sizeof(double);
+    const double relfloor = 1e-30;        // measured on the rail sketches: 1e-28 leaves a probe residual of 1e-14, 1e-30 and below 2.4e-15 (Householder: 1.9e-15)
+    lds_attr(ctx, (const void*)k_chol_inv, (int)shm);
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor);
+    DRE_HIP(hipGetLastError());
+}
 void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed) {
     const size_t tot = (size_t)A.rows * A.cols;
     if (tot) hipLaunchKernelGGL(k_fill_gauss, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, A.rows, A.cols, seed, A.p, A.ld);

@@ -59,7 +59,13 @@ struct CopyDesc { const double* src; double* dst; int rows, cols, lds, ldd; };
 void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                      // all blocks in one launch per 32
 void fill_mat(Ctx* ctx, Mat& dst, double v);
 void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
-void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed);   // independent standard normal entries (deterministic in seed and position)
+void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed);
+// Rinv = inv(R) for the upper Cholesky factor R of the symmetric positive semidefinite G (order <= 64), null columns (pivot below the floor
+// selected by mode / *ref_dev, see k_chol_inv) zeroed; *flag_dev |= 1 when a live pivot is too small for Cholesky QR
+// nullmask_dev (optional, order entries): 1 where a null column was found
+void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev = nullptr);
+// Gaussian entries of variance 1/rows into the columns of A that mask_dev marks (the others are left alone)
+void fill_gauss_masked(Ctx* ctx, Mat& A, unsigned long long seed, const int* mask_dev);   // independent standard normal entries (deterministic in seed and position)
 void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst);      // dst = src'
 void add_diag(Ctx* ctx, Mat& dst, const double* diag_dev, double scale);  // dst += scale*diag(v)
 void symmetrize(Ctx* ctx, Mat& S);                           // S = (S+S')/2

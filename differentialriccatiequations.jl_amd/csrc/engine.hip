@@ -133,6 +133,42 @@ static void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD) {
 // probe columns G, independent of Q:  ||(I - QQ') X G||_F <= 64 eps ||X G||_F  (the floor of that difference in f64 is ~ 20 eps).
 // A rejected sketch costs its three passes and the caller falls back to the factor-form reduction.  Only for sums without
 // cancellation (the ADI solution factors): the relative accuracy of Y is eps ||L||^2 ||Dt||.
+// Orthonormal basis of the columns of Y (n x s, destroyed) into Q (n x s) without Householder panels: 64-column blocks, each projected
+// against the finished blocks and orthonormalised by Cholesky QR (Gram matrix -> k_chol_inv -> GEMM with inv(R)), both TWICE (block
+// Gram-Schmidt with re-orthogonalisation, the second round on the already well-conditioned block).  Everything is a GEMM over the n rows plus a 64 x 64 workgroup
+// kernel, 14 launches per block, against 16 dependent latency-bound column steps per 16 columns of a Householder/TSQR panel.  Valid
+// while every block has cond <= ~3e6 AFTER the projections (columns of X Om: the decay of the spectrum over 64 indices); k_chol_inv raises
+// *flag otherwise and the caller redoes the factorisation with Householder panels.
+static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
+    const int n = Y.rows, s = Y.cols, bs = 64;
+    Mat G(ctx, bs, bs), Ri(ctx, bs, bs), T(ctx, n, bs);
+    DevArr<double> ref(ctx, 1);              // scale of the sketch: largest squared column norm of the first block
+    DevArr<int> nullmask(ctx, bs);
+    for (int j0 = 0; j0 < s; j0 += bs) {
+        const int b = std::min(bs, s - j0);
+        Mat Yb = Y.colsview(j0, b), Qb = Q.colsview(j0, b), Tb = T.colsview(0, b), Gb = G.view(0, 0, b, b), Rb = Ri.view(0, 0, b, b);
+        // project, normalise, project AGAIN, normalise again: the second projection acts on the well-conditioned T, so the loss of
+        // orthogonality against the earlier blocks is O(eps) instead of O(eps cond(Y_b))
+        auto project = [&](Mat& V) {
+            if (j0 == 0) return;
+            Mat Qp = Q.colsview(0, j0), W(ctx, j0, b);
+            gemm(ctx, true, false, 1.0, Qp, V, 0.0, W, nullptr, "gemm_orth");
+            gemm(ctx, false, false, -1.0, Qp, W, 1.0, V, nullptr, "gemm_orth");
+        };
+        project(Yb);
+        gemm(ctx, true, false, 1.0, Yb, Yb, 0.0, Gb, nullptr, "gemm_orth");
+        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, j0 == 0 ? 0 : 1, nullmask.p);
+        gemm(ctx, false, false, 1.0, Yb, Rb, 0.0, Tb, nullptr, "gemm_orth");
+        // a column that was rounding noise relative to the whole sketch (sketch wider than the numerical rank) becomes a fresh random direction:
+        // Q stays orthonormal in all its columns, as a Householder Q would, and the band reduction of Q'XQ sorts the direction out
+        fill_gauss_masked(ctx, Tb, 0x9E3779B97F4A7C15ull + (unsigned long long)j0, nullmask.p);
+        project(Tb);
+        gemm(ctx, true, false, 1.0, Tb, Tb, 0.0, Gb, nullptr, "gemm_orth");
+        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, 2);
+        gemm(ctx, false, false, 1.0, Tb, Rb, 0.0, Qb, nullptr, "gemm_orth");
+    }
+}
+
 static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) {
     const int n = X.n, c = X.rank(), sp = s + 16;
     static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
@@ -145,10 +181,17 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     Mat Yr = Y.colsview(0, s), Z = Y.colsview(s, 16);
     DevArr<double> nrm(ctx, 2);
     frob2_device(ctx, Z, nrm.p);
-    QRFact qr = qr_factor(ctx, Yr);
     Mat Q(ctx, n, s);
-    set_identity(ctx, Q, 1.0);
-    qr_apply_q(ctx, qr, Q, false);
+    DevArr<long long> cflag(ctx, 1);
+    DRE_HIP(hipMemsetAsync(cflag.p, 0, sizeof(long long), ctx->stream));
+    const long ckey = skey - 1;                        // band_hint: Cholesky-QR breakdowns seen at this order (two strikes: Householder panels from then on)
+    const bool use_chol = ctx->compress_sketch_cholqr && ctx->band_hint[ckey] < 2;
+    if (use_chol) orth_cholqr(ctx, Yr, Q, reinterpret_cast<int*>(cflag.p));
+    else {
+        QRFact qr = qr_factor(ctx, Yr);
+        set_identity(ctx, Q, 1.0);
+        qr_apply_q(ctx, qr, Q, false);
+    }
     {
         Mat QtZ(ctx, s, 16);
         gemm(ctx, true, false, 1.0, Q, Z, 0.0, QtZ, nullptr, "gemm_sketch");
@@ -162,10 +205,14 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     symmetrize(ctx, S);
     SymBand sb = sym_band_reduce(ctx, S, tolfac);
     double h[2] = {0.0, 0.0};
-    ctx_fetch(ctx, nrm.p, 2 * sizeof(double), h);
+    long long cf = 0;
+    ctx_fetch(ctx, nrm.p, 2 * sizeof(double), h, cflag.p, sizeof(long long), &cf);
     const double est = h[0] > 0.0 ? std::sqrt(h[1] / h[0]) : 0.0;
-    const bool ok = sb.J + 32 <= s && est <= 64.0 * EPS;
-    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d -> J=%d  probe residual %.2e  %s\n", n, c, s, sb.J, est, ok ? "accepted" : "REJECTED");
+    const bool chol_bad = use_chol && (cf & 1) != 0;
+    const bool ok = !chol_bad && sb.J + 32 <= s && est <= 64.0 * EPS;
+    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d (%s) -> J=%d  probe residual %.2e  %s\n", n, c, s, use_chol ? "CholQR2 blocks" : "Householder",
+                            sb.J, est, ok ? "accepted" : (chol_bad ? "REJECTED (Cholesky breakdown)" : "REJECTED"));
+    if (chol_bad) { ctx->band_hint[ckey] += 1; return false; }
     if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
     ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += s; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
     ctx->band_hint[skey] = sb.J;

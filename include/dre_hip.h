@@ -71,6 +71,9 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *   "compress_sketch"           wide factors (columns >= "compress_sketch_min_cols", default 768, and >= 3 x the sketch width) of sums without
  *                               cancellation: randomized range finder, three GEMM passes over the factor; sketch width = rank of the previous
  *                               compression of this kind + "compress_sketch_extra" (48); rejected sketches fall back (default 1, 0 disables)
+ *   "compress_sketch_cholqr"    1 (default): the sketch is orthonormalised in 64-column blocks by block Gram-Schmidt + Cholesky QR, both twice
+ *                               (GEMMs and a 64 x 64 Cholesky kernel); a block with cond > ~3e6 is detected on the device and the compression
+ *                               redone, after two such events at an order n Householder/TSQR panels are used (0: always)
  *   (env: DRE_COMPRESS_DIRECT_MAX_N, DRE_COMPRESS_DIRECT_RATIO, DRE_COMPRESS_FACTOR_MIN_N, DRE_COMPRESS_FACTOR_MIN_COLS, DRE_COMPRESS_SKETCH*)
  *   "mf_subtree"                1: the multifrontal sweeps below the dense top run as one workgroup per subtree (default 0: one launch per level)
  *   "setup_streams"             helper streams for the factorisations / dense inverses of the shifts of a Cyclic list (default 5; 0, 1: none)

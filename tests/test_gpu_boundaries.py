@@ -149,7 +149,15 @@ def test_randomized_compression_of_wide_factors(ctx):
     r1 = run(60, 1)             # first compression at this order: factor form, leaves the rank hint
     r2 = run(60, 2)             # sketch of width r1 + 48: accepted
     r3 = run(200, 3)            # rank far beyond the sketch: rejected, factor form again
-    r4 = run(200, 4)            # sketch with the new hint
+    r4 = run(200, 4)            # sketch with the new hint, orthonormalised by blocked Cholesky QR (engine.hip orth_cholqr)
+    ctx.set_option("compress_sketch_cholqr", 0)
+    r4h = run(200, 4)           # the same sketch through Householder panels
+    ctx.set_option("compress_sketch_cholqr", 1)
+    assert abs(r4 - r4h) <= 16
+    # 14 decades within one 64-column block: Cholesky QR breaks down (k_chol_inv raises its flag, the compression is redone in factor form);
+    # after the second breakdown at this order the sketches go through Householder panels
+    r5, r6 = run(60, 5), run(60, 6)
+    assert r5 <= 76 and r6 <= 76
     ctx.set_option("compress_sketch", 0)
     try:
         q2, q4 = run(60, 2), run(200, 4)
