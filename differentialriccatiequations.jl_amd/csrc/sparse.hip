@@ -139,6 +139,35 @@ __global__ __launch_bounds__(256) void k_spmm_lds(int n, const int* __restrict__
     double acc[SPMM_CB];
 #pragma unroll
     for (int c = 0; c < SPMM_CB; ++c) acc[c] = 0.0;
+    if (staged && c1 - c0 == SPMM_CB) {
+        // full column block: no predicate inside the loop, so the 8 gathers of an entry (and, two entries at a time, 16) are issued
+        // back to back and the old values of Y are requested before the loop — the predicated form made the compiler wait per load
+        double yold[SPMM_CB];
+#pragma unroll
+        for (int c = 0; c < SPMM_CB; ++c) yold[c] = (beta != 0.0) ? Y[i + (size_t)(c0 + c) * ldy] : 0.0;
+        const double* __restrict__ xb = X + (size_t)c0 * ldx;
+        int p = pb - p0;
+        const int pend = pe - p0;
+        for (; p + 1 < pend; p += 2) {
+            const double v0 = vs[p], v1 = vs[p + 1];
+            const double* x0 = xb + is[p];
+            const double* x1 = xb + is[p + 1];
+            double t0[SPMM_CB], t1[SPMM_CB];
+#pragma unroll
+            for (int c = 0; c < SPMM_CB; ++c) { t0[c] = x0[(size_t)c * ldx]; t1[c] = x1[(size_t)c * ldx]; }
+#pragma unroll
+            for (int c = 0; c < SPMM_CB; ++c) { acc[c] += v0 * t0[c]; acc[c] += v1 * t1[c]; }
+        }
+        if (p < pend) {
+            const double v0 = vs[p];
+            const double* x0 = xb + is[p];
+#pragma unroll
+            for (int c = 0; c < SPMM_CB; ++c) acc[c] += v0 * x0[(size_t)c * ldx];
+        }
+#pragma unroll
+        for (int c = 0; c < SPMM_CB; ++c) Y[i + (size_t)(c0 + c) * ldy] = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * yold[c];
+        return;
+    }
     for (int p = pb; p < pe; ++p) {
         const double v = staged ? vs[p - p0] : val[p];
         const double* x = X + (staged ? is[p - p0] : idx[p]) + (size_t)c0 * ldx;
@@ -188,6 +217,32 @@ __global__ __launch_bounds__(SPMM2_ROWS) void k_spmm_dual(int n, const int* __re
     double a1[SPMM2_CB], a2[SPMM2_CB];
 #pragma unroll
     for (int c = 0; c < SPMM2_CB; ++c) { a1[c] = 0.0; a2[c] = 0.0; }
+    if (staged && c1 - c0 == SPMM2_CB) {
+        // full column block, predicate-free (see k_spmm_lds): the gathers of two entries in flight together
+        const double* __restrict__ xb = X + (size_t)c0 * ldx;
+        int p = pb - p0;
+        const int pend = pe - p0;
+        for (; p + 1 < pend; p += 2) {
+            const double* x0 = xb + is[p];
+            const double* x1 = xb + is[p + 1];
+            double t0[SPMM2_CB], t1[SPMM2_CB];
+#pragma unroll
+            for (int c = 0; c < SPMM2_CB; ++c) { t0[c] = x0[(size_t)c * ldx]; t1[c] = x1[(size_t)c * ldx]; }
+#pragma unroll
+            for (int c = 0; c < SPMM2_CB; ++c) {
+                a1[c] += v1s[p] * t0[c]; a2[c] += v2s[p] * t0[c];
+                a1[c] += v1s[p + 1] * t1[c]; a2[c] += v2s[p + 1] * t1[c];
+            }
+        }
+        if (p < pend) {
+            const double* x0 = xb + is[p];
+#pragma unroll
+            for (int c = 0; c < SPMM2_CB; ++c) { const double xv = x0[(size_t)c * ldx]; a1[c] += v1s[p] * xv; a2[c] += v2s[p] * xv; }
+        }
+#pragma unroll
+        for (int c = 0; c < SPMM2_CB; ++c) { Y1[i + (size_t)(c0 + c) * ldy1] = a1[c]; Y2[i + (size_t)(c0 + c) * ldy2] = a2[c]; }
+        return;
+    }
     for (int p = pb; p < pe; ++p) {
         const double w1 = staged ? v1s[p - p0] : val1[p], w2 = staged ? v2s[p - p0] : val2[p];
         const double* x = X + (staged ? is[p - p0] : idx[p]) + (size_t)c0 * ldx;
@@ -648,6 +703,11 @@ __global__ __launch_bounds__(256) void k_mf_backward(MfArgs a, int lvl_begin, co
 typedef double mf_v4d __attribute__((ext_vector_type(4)));
 #define MFM_KC 16
 
+// THROUGHPUT form (the forward kernel, and the backward kernel of levels with many fronts: thousands of workgroups, the memory round trips
+// of one workgroup hide behind the others): predicated loads, so masked lanes (outside the triangle / past the end of the K range) generate
+// no traffic, element-per-thread staging, fewer registers.  The LATENCY form of the backward kernel further down wins where a level has few
+// fronts (measured at n = 20209, 10 column blocks: up to ~1300 workgroups 16 vs 22 us, 320 workgroups 10 vs 28 us; at the 504-leaf level the
+// throughput form is 34 vs 71 us).
 // acc += A(rows r0.., K range [kbeg, kend)) * Bs   with A(row, k) = sign * Aglob[row + k * lda] where keep(row, k), else 0
 template <typename Keep>
 __device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restrict__ Aglob, int lda, int r0, int kbeg, int kend, double sign,
@@ -735,7 +795,7 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+__global__ __launch_bounds__(1024) void k_mf_backward_tp(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
                                                            double* __restrict__ W, int ldw, int nrhs, const AdiState* st) {
     if (st && st->done) return;
     extern __shared__ double sm[];
@@ -775,6 +835,146 @@ __global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_beg
         const int r0 = rt * 16;
         mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
         acc = mfma_rowtile(acc, Ti, s, r0, r0, s, 1.0, z, ldz, [s](int row, int k) { return row < s && k >= row; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r0 + lq + 4 * r;
+            if (row < s && lr < kc) W[(first + row) + (size_t)(c0 + lr) * ldw] = acc[r];
+        }
+    }
+}
+
+// LATENCY form (backward levels with few fronts).
+// A operand of a 16-row tile: element (row, k) = A[row + k * lda]; addressable for row < nrow and k < kcap (both >= 1).
+struct RtSrc { const double* A; int lda, nrow, kcap; };
+// One batch = 8 K-steps (32 columns of the factor block) of the tile at rows r0..r0+15, starting at column k0.  BRANCH-FREE: every lane
+// loads from a clamped, always valid address and the predicate (range, triangle, sign) is applied when the value is consumed (rt_mma) —
+// with predicated loads the compiler waits for each load before it issues the next one (the in-order vmcnt counter cannot express "maybe
+// issued"), which made a batch cost eight memory round trips instead of one.
+__device__ __forceinline__ void rt_load(double (&raw)[8], const RtSrc& s, int r0, int k0, int kend) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const double* __restrict__ p = s.A + min(r0 + lr, s.nrow - 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (k0 + 4 * u < kend) raw[u] = p[(size_t)min(k0 + 4 * u + lk, s.kcap - 1) * s.lda];       // wave-uniform guard: K-steps past the end are not requested
+}
+// acc += sign * A(tile rows, [k0, k0 + 32) below kend, where keep(row, k)) * Bs
+template <typename Keep>
+__device__ __forceinline__ mf_v4d rt_mma(mf_v4d acc, const double (&raw)[8], int r0, int k0, int kend, double sign, const double* __restrict__ Bs, int ldb,
+                                         Keep keep) {
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int row = r0 + lr;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = k0 + 4 * u + lk;
+        if (k0 + 4 * u < kend) {
+            const double v = (k < kend && keep(row, k)) ? sign * raw[u] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, Bs[k + lr * ldb], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+// The whole K range [kbeg, kend) of one tile, software pipelined: `cur` holds the batch at kbeg (issued by the caller, as early as it
+// likes); while a batch multiplies the next one is in flight (two register sets, no copies).
+template <typename Keep>
+__device__ __forceinline__ mf_v4d rt_tile(mf_v4d acc, const RtSrc& s, int r0, int kbeg, int kend, double sign, const double* __restrict__ Bs, int ldb,
+                                          Keep keep, double (&cur)[8]) {
+    double nxt[8];
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        rt_load(nxt, s, r0, k0 + 32, kend);
+        acc = rt_mma(acc, cur, r0, k0, kend, sign, Bs, ldb, keep);
+        rt_load(cur, s, r0, k0 + 64, kend);
+        acc = rt_mma(acc, nxt, r0, k0 + 32, kend, sign, Bs, ldb, keep);
+    }
+    return acc;
+}
+
+// Backward: the long product is z = w_S - U12 x_B (K = b, the boundary: up to several hundred near the top of the tree) on only
+// ceil(s / 16) row tiles, so the waves of a workgroup SPLIT K: G = nw / tiles waves per tile, each over a 32-aligned share of the
+// boundary, partial tiles summed in a fixed order through LDS (`part`, nw x 256 doubles behind z).
+__global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st, int split) {
+    if (st && st->done) return;
+    extern __shared__ double sm[];
+    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
+    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
+    const int sp = (s + 15) & ~15, ldx = (b + 36) | 1, ldz = (sp + 36) | 1;
+    double* xb = sm;                          // (b + pad) x 16: the already known ancestor unknowns, zero padded
+    double* z = sm + (size_t)ldx * MFM_KC;    // (sp + pad) x 16
+    double* part = z + (size_t)ldz * MFM_KC;  // nw x 256: K-split partial tiles
+    const double* F = fronts + a.front_off[t];
+    const double* Ti = inv + a.inv_off[t];
+    const int* B = a.bidx + a.bptr[t];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int nts = sp >> 4, G = split ? max(1, nw / nts) : 1;        // split = 0: no room for the partial tiles in LDS (huge fronts)
+    // split form (G >= 2): wave -> (tile, share of K);  plain form: wave -> tiles wave, wave + nw, ...
+    const int ztile = G >= 2 ? wv / G : wv, zpart = G >= 2 ? wv - ztile * G : 0;
+    const int kshare = G >= 2 ? ((((b + G - 1) / G) + 31) & ~31) : b;
+    const int zk0 = zpart * kshare, zk1 = min(b, zk0 + kshare);
+    const bool zwork = ztile < nts && zk0 < zk1;
+    const RtSrc sz{F + (size_t)s * f, f, s, max(b, 1)}, sx{Ti, s, s, s};
+    double za[8], xa[8];
+    if (zwork) rt_load(za, sz, ztile * 16, zk0, zk1);
+    if (wv * 16 < s) rt_load(xa, sx, wv * 16, wv * 16, s);
+    // staging: one row per thread, 16 columns in flight (see the forward kernel)
+    for (int i = tid; i < b; i += nt) {
+        double v[MFM_KC];
+        const double* __restrict__ src = W + B[i] + (size_t)c0 * ldw;
+#pragma unroll
+        for (int c = 0; c < MFM_KC; ++c) v[c] = src[(size_t)min(c, kc - 1) * ldw];
+#pragma unroll
+        for (int c = 0; c < MFM_KC; ++c) xb[i + c * ldx] = c < kc ? v[c] : 0.0;
+    }
+    for (int id = tid; id < (ldx - b) * MFM_KC; id += nt) { const int i = b + id % (ldx - b), c = id / (ldx - b); xb[i + c * ldx] = 0.0; }
+    for (int i = tid; i < s; i += nt) {
+        double v[MFM_KC];
+        const double* __restrict__ src = W + (first + i) + (size_t)c0 * ldw;
+#pragma unroll
+        for (int c = 0; c < MFM_KC; ++c) v[c] = src[(size_t)min(c, kc - 1) * ldw];
+#pragma unroll
+        for (int c = 0; c < MFM_KC; ++c) z[i + c * ldz] = c < kc ? v[c] : 0.0;
+    }
+    for (int id = tid; id < (ldz - s) * MFM_KC; id += nt) { const int i = s + id % (ldz - s), c = id / (ldz - s); z[i + c * ldz] = 0.0; }
+    __syncthreads();
+    const int lr = lane & 15, lq = lane >> 4;
+    // z = w_S - U12 x_B   (in place in LDS: every tile reads and writes only its own rows of z)
+    if (G >= 2) {
+        mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+        const int r0 = ztile * 16;
+        if (zwork) acc = rt_tile(acc, sz, r0, zk0, zk1, -1.0, xb, ldx, [s](int row, int) { return row < s; }, za);
+        if (ztile < nts && zpart > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[(size_t)wv * 256 + r * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (ztile < nts && zpart == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = z[(r0 + lq + 4 * r) + lr * ldz] + acc[r];
+                for (int g = 1; g < G; ++g) v += part[(size_t)(wv + g) * 256 + r * 64 + lane];
+                z[(r0 + lq + 4 * r) + lr * ldz] = v;
+            }
+        }
+    } else {
+        for (int rt = wv; rt * 16 < s; rt += nw) {
+            const int r0 = rt * 16;
+            if (rt != wv && b > 0) rt_load(za, sz, r0, 0, b);
+            mf_v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = z[(r0 + lq + 4 * r) + lr * ldz];
+            acc = rt_tile(acc, sz, r0, 0, b, -1.0, xb, ldx, [s](int row, int) { return row < s; }, za);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[(r0 + lq + 4 * r) + lr * ldz] = acc[r];
+        }
+    }
+    __syncthreads();
+    // x_S = inv(U11) z : upper triangle of Ti including the diagonal
+    for (int rt = wv; rt * 16 < s; rt += nw) {
+        const int r0 = rt * 16;
+        if (rt != wv) rt_load(xa, sx, r0, r0, s);
+        mf_v4d acc = {0.0, 0.0, 0.0, 0.0};
+        acc = rt_tile(acc, sx, r0, r0, s, 1.0, z, ldz, [s](int row, int k) { return row < s && k >= row; }, xa);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = r0 + lq + 4 * r;
@@ -1276,6 +1476,14 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
 // inv(S) = (M^-1)[top, top]: unit right-hand sides on the top variables, sweeps over the top levels only (everything below stays zero)
 static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc);
 
+// Backward levels with at most this many workgroups (fronts x column blocks) run the latency variant of the sweep kernel (env
+// DRE_MF_LAT_BWD overrides; 0 = throughput variant everywhere).  Sweep at n = 20209 / 5177 (tools/mf_latency_sweep.sh): 700, 1500 and 3000 are
+// within 2 % of each other, 0 costs 15 % / 9 % of the solve time.  A latency variant of the FORWARD kernel (same loads, early prefetch)
+// was built and lost at every threshold (its K ranges are short: s <= 64), so the forward sweep has the one kernel.
+static long mf_latency_max_wg(bool) {
+    static const long b = std::getenv("DRE_MF_LAT_BWD") ? std::atol(std::getenv("DRE_MF_LAT_BWD")) : 1500;
+    return b;
+}
 static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, double* upd, int64_t ldu,
                             const AdiState* st, bool forward, int l_from, int l_to) {
     // forward: levels l_from down to l_to (l_from >= l_to);  backward: levels l_from up to l_to
@@ -1283,21 +1491,37 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc,
     MfArgs a = mf_args(P);
     const int ncb = ceil_div(nrhs, MFM_KC);
     lds_attr(ctx, (const void*)k_mf_forward_mfma, 150 * 1024); lds_attr(ctx, (const void*)k_mf_backward_mfma, 150 * 1024);
+    lds_attr(ctx, (const void*)k_mf_backward_tp, 150 * 1024);
     if (forward) {
         for (int l = l_from; l >= l_to; --l) {
             const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
             const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
             const size_t shm = ((size_t)((std::max(fm + 16, spm) + 4) | 1) + (size_t)((spm + 4) | 1)) * MFM_KC * sizeof(double);
-            const int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
+            // wide levels (more workgroups than the chip holds at once) are throughput bound: four waves per front keep more fronts resident
+            // (n = 20209: 32.9 -> 31.5 ms of sweeps per 4 steps against 512 threads, 34.2 ms with 1024)
+            static const int tp_threads = std::getenv("DRE_MF_FWD_TP_THREADS") ? std::atoi(std::getenv("DRE_MF_FWD_TP_THREADS")) : 256;
+            int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
+            if (tp_threads > 0 && (long)nb * ncb > 2000) nthreads = tp_threads;
             hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st);
         }
     } else {
         for (int l = l_from; l <= l_to; ++l) {
             const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
             const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
-            const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
-            const int nthreads = sm_ > 64 ? 512 : 256;
-            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+            if ((long)nb * ncb > mf_latency_max_wg(false)) {
+                const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
+                const int nthreads = sm_ > 64 ? 512 : 256;
+                hipLaunchKernelGGL(k_mf_backward_tp, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+                continue;
+            }
+            // waves: one per 16-row tile of the separator times up to four shares of the boundary (K-split of z = w_S - U12 x_B)
+            const int nts = spm / 16, bmax = std::max(fm - 1, 0);
+            const int nwv = std::min(16, std::max(sm_ > 64 ? 8 : 4, nts * std::min(4, std::max(1, bmax / 64))));
+            const int nthreads = 64 * nwv;
+            const size_t base = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double), parts = (size_t)nwv * 256 * sizeof(double);
+            const int split = base + parts <= (size_t)150 * 1024;
+            const size_t shm = base + (split ? parts : 0);
+            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st, split);
         }
     }
 }
