@@ -3397,46 +3397,41 @@ __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* _
 //   nullmask (optional, b entries): 1 for a null column, so that the caller can put a fresh random direction there (k_fill_gauss_masked).
 __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restrict__ G, int ldg, double* __restrict__ Rinv, int ldr, int* __restrict__ flag,
                                                   double* __restrict__ ref, int mode, int* __restrict__ nullmask, double relfloor) {
-    extern __shared__ double chol_lds[];            // 3 x 64 x 65 doubles (dynamic: beyond the 64 KB static limit)
+    extern __shared__ double chol_lds[];            // 2 x 64 x 65 doubles (dynamic: beyond the 64 KB static limit)
     double (*A)[65] = reinterpret_cast<double (*)[65]>(chol_lds);
-    double (*Lm)[65] = A + 64;
-    double (*Li)[65] = Lm + 64;
-    __shared__ double dmax_s;
-    const int tid = threadIdx.x;
-    for (int id = tid; id < 64 * 64; id += 256) { const int i = id & 63, j = id >> 6; A[i][j] = (i < b && j < b) ? G[i + (size_t)j * ldg] : 0.0; Lm[i][j] = 0.0; Li[i][j] = 0.0; }
+    double (*Y)[65] = A + 64;                       // forward substitution on the identity, carried along: inv(L) = diag(rd) Y at the end
+    __shared__ double dmax_s, rds[64];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (int id = tid; id < 64 * 64; id += 256) { const int i = id & 63, j = id >> 6; A[i][j] = (i < b && j < b) ? G[i + (size_t)j * ldg] : 0.0; Y[i][j] = (i == j) ? 1.0 : 0.0; }
     __syncthreads();
     if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0) *ref = m; }
     __syncthreads();
     const double floor_abs = mode == 2 ? 1e-20 : relfloor * (mode == 0 ? dmax_s : *ref);
     const double thr = 1e-13 * dmax_s;
     bool bad = false;
+    // step k (one barrier): with l_ik = A_ik / pivot,   A_ij -= l_ik A_jk  (k < j <= i: the Schur complement)   and
+    //                                                   Y_ij -= l_ik Y_kj  (j <= k: rows of inv(L), unscaled; Y_kk = 1)
+    // on a 16 x 16 thread grid; the first version inverted L afterwards with one thread per column (b^3/6 dependent steps: 100 of its 107 us)
     for (int k = 0; k < b; ++k) {
         const double piv = A[k][k];
         const bool live = piv > floor_abs;           // (NaN: not live)
         if (live && !(piv > thr)) bad = true;
         const double rd = live ? 1.0 / sqrt(piv) : 0.0, rp = rd * rd;
-        if (nullmask && tid == 0) nullmask[k] = live ? 0 : 1;
-        for (int i = k + tid; i < b; i += 256) Lm[i][k] = A[i][k] * rd;          // column k of L (a null column: zero)
-        const int m = b - k - 1;                                                   // trailing block (k+1 .. b-1)^2, lower triangle incl. diagonal
-        for (int id = tid; id < m * m; id += 256) {
-            const int i = k + 1 + id % m, j = k + 1 + id / m;
-            if (i >= j) A[i][j] -= A[i][k] * A[j][k] * rp;
+        if (tid == 0) { rds[k] = rd; if (nullmask) nullmask[k] = live ? 0 : 1; }
+        for (int i = k + 1 + ty; i < b; i += 16) {
+            const double lik = A[i][k] * rp;
+            for (int j = tx; j <= i; j += 16) {
+                if (j > k) A[i][j] -= lik * A[j][k];
+                else Y[i][j] -= lik * Y[k][j];
+            }
         }
         __syncthreads();
     }
-    // inv(L) column by column (thread j owns column j; a null column j gives a zero column), then Rinv = inv(L)'
-    if (tid < b) {
-        const int j = tid;
-        const bool livej = Lm[j][j] != 0.0;
-        Li[j][j] = livej ? 1.0 / Lm[j][j] : 0.0;
-        for (int i = j + 1; i < b; ++i) {
-            double acc = 0.0;
-            for (int l = j; l < i; ++l) acc += Lm[i][l] * Li[l][j];
-            Li[i][j] = (livej && Lm[i][i] != 0.0) ? -acc / Lm[i][i] : 0.0;
-        }
+    // Rinv = inv(L)':  Rinv(r, c) = rd_c Y(c, r) for r <= c  (a null column c: rd_c = 0)
+    for (int id = tid; id < 64 * 64; id += 256) {
+        const int r = id & 63, c = id >> 6;
+        if (r < b && c < b) Rinv[r + (size_t)c * ldr] = (r <= c) ? Y[c][r] * rds[c] : 0.0;
     }
-    __syncthreads();
-    for (int id = tid; id < b * b; id += 256) { const int r = id % b, c = id / b; Rinv[r + (size_t)c * ldr] = (r <= c) ? Li[c][r] : 0.0; }
     if (bad && tid == 0) atomicOr(flag, 1);
 }
 // Unit-scale Gaussian entries (variance 1/n) into the columns of T that mask marks
@@ -3460,7 +3455,7 @@ void fill_gauss_masked(Ctx* ctx, Mat& A, unsigned long long seed, const int* mas
 void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev) {
     DRE_REQUIRE(G.rows == G.cols && G.rows <= 64 && Rinv.rows == G.rows && Rinv.cols == G.rows, "chol_inv: order <= 64 expected");
     if (G.rows == 0) return;
-    const size_t shm = (size_t)3 * 64 * 65 * sizeof(double);
+    const size_t shm = (size_t)2 * 64 * 65 * sizeof(double);
     const double relfloor = 1e-30;        // measured on the rail sketches: 1e-28 leaves a probe residual of 1e-14, 1e-30 and below 2.4e-15 (Householder: 1.9e-15)
     lds_attr(ctx, (const void*)k_chol_inv, (int)shm);
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor);

@@ -719,12 +719,14 @@ __device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restr
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + 4 * u + lk;
-            av[u] = (k < kend && keep(row, k)) ? sign * Aglob[row + (size_t)k * lda] : 0.0;
+            av[u] = (k < kend && keep(row, k)) ? Aglob[row + (size_t)k * lda] : 0.0;
         }
+        // the sign is applied when the value is consumed: `sign * load` inside the predicated region made the compiler wait for every
+        // single load (eight memory round trips in a row per batch)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + 4 * u + lk;
-            if (k0 + 4 * u < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], Bs[k + lr * ldb], acc, 0, 0, 0);
+            if (k0 + 4 * u < kend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sign * av[u], Bs[k + lr * ldb], acc, 0, 0, 0);
         }
     }
     return acc;
