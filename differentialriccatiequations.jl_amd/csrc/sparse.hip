@@ -746,9 +746,17 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
     double* y = sm + (size_t)ldl * MFM_KC;   // (sp + 4) x 16 (ld ldy), zero padded
     const double* F = fronts + a.front_off[t];
     const double* Ti = inv + a.inv_off[t];
-    for (int id = tid; id < ldl * MFM_KC; id += nt) {
-        const int i = id % ldl, c = id / ldl;
-        w[id] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+    // staging, four elements per thread and pass: the four (predicated) loads are issued together and waited for once — one load per pass
+    // made every pass a memory round trip of its own (ldl * 16 / nt = 6..10 in a row on a narrow level)
+    for (int id0 = tid; id0 < ldl * MFM_KC; id0 += 4 * nt) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = id0 + q * nt, i = id % ldl, c = id / ldl;
+            v[q] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int id = id0 + q * nt; if (id < ldl * MFM_KC) w[id] = v[q]; }
     }
     for (int id = tid; id < ldy * MFM_KC; id += nt) y[id] = 0.0;
     __syncthreads();
@@ -757,9 +765,19 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
         const int bc = a.bptr[ch + 1] - a.bptr[ch];
         const int* map = a.cmap + a.cmap_ptr[ch];
         const double* uc = upd + a.upd_off[ch];
-        for (int id = tid; id < bc * kc; id += nt) {
-            const int i = id % bc, c = id / bc;
-            w[map[i] + c * ldl] += uc[i + (size_t)(c0 + c) * ldu];
+        for (int id0 = tid; id0 < bc * kc; id0 += 4 * nt) {
+            double v[4];
+            int mi[4], cc[4];
+            // (no arithmetic on a loaded value inside its predicate: the eight loads go out together)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int id = min(id0 + q * nt, bc * kc - 1), i = id % bc;
+                cc[q] = id / bc;
+                v[q] = uc[i + (size_t)(c0 + cc[q]) * ldu];
+                mi[q] = map[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (id0 + q * nt < bc * kc) w[mi[q] + cc[q] * ldl] += v[q];
         }
         __syncthreads();
     }
@@ -811,13 +829,26 @@ __global__ __launch_bounds__(1024) void k_mf_backward_tp(MfArgs a, int lvl_begin
     const double* F = fronts + a.front_off[t];
     const double* Ti = inv + a.inv_off[t];
     const int* B = a.bidx + a.bptr[t];
-    for (int id = tid; id < ldx * MFM_KC; id += nt) {
-        const int i = id % ldx, c = id / ldx;
-        xb[id] = (i < b && c < kc) ? W[B[i] + (size_t)(c0 + c) * ldw] : 0.0;
+    // staging: four predicated loads in flight per thread and pass (see the forward kernel)
+    for (int id0 = tid; id0 < ldx * MFM_KC; id0 += 4 * nt) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = id0 + q * nt, i = id % ldx, c = id / ldx;
+            v[q] = (i < b && c < kc) ? W[B[i] + (size_t)(c0 + c) * ldw] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int id = id0 + q * nt; if (id < ldx * MFM_KC) xb[id] = v[q]; }
     }
-    for (int id = tid; id < ldz * MFM_KC; id += nt) {
-        const int i = id % ldz, c = id / ldz;
-        z[id] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+    for (int id0 = tid; id0 < ldz * MFM_KC; id0 += 4 * nt) {
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = id0 + q * nt, i = id % ldz, c = id / ldz;
+            v[q] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int id = id0 + q * nt; if (id < ldz * MFM_KC) z[id] = v[q]; }
     }
     __syncthreads();
     const int lr = lane & 15, lq = lane >> 4;
