@@ -88,6 +88,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_MIN_COLS")) ctx->c.compress_sketch_min_cols = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_EXTRA")) ctx->c.compress_sketch_extra = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_CHOLQR")) ctx->c.compress_sketch_cholqr = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_SPARSE")) ctx->c.compress_sketch_sparse = std::atoi(e);
         if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
         if (const char* e = std::getenv("DRE_MF_SUBTREE")) ctx->c.mf_subtree = std::atoi(e);
         if (const char* e = std::getenv("DRE_SETUP_STREAMS")) ctx->c.setup_streams = std::atoi(e);
@@ -160,6 +161,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "compress_sketch_min_cols") ctx->c.compress_sketch_min_cols = (int)value;
         else if (key == "compress_sketch_extra") ctx->c.compress_sketch_extra = (int)value;
         else if (key == "compress_sketch_cholqr") ctx->c.compress_sketch_cholqr = (int)value;
+        else if (key == "compress_sketch_sparse") ctx->c.compress_sketch_sparse = (int)value;
         else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
         else if (key == "mf_subtree") ctx->c.mf_subtree = (int)value;
         else if (key == "setup_streams") ctx->c.setup_streams = (int)value;

@@ -128,6 +128,7 @@ struct Ctx {
     int compress_sketch = 1;
     int compress_sketch_min_cols = 768;
     int compress_sketch_extra = 48;
+    int compress_sketch_sparse = 1;     // sketch with the structured sparse sign test matrix (one pass over the factor) instead of a Gaussian one (dense GEMM)
     int compress_sketch_cholqr = 1;     // orthonormalise the sketch by blocked Cholesky QR (GEMMs) instead of Householder/TSQR panels; falls back on breakdown
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense
     // inverse of their Schur complement (reused real factors only; 0 disables)

@@ -3461,6 +3461,73 @@ void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev,
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor);
     DRE_HIP(hipGetLastError());
 }
+// Structured sparse sign test matrix Om (n x s) for the range finder of engine.hip sketch_compress: row i has SKETCH_ZETA entries
+// +-1/sqrt(SKETCH_ZETA), in the columns (i + off_t) mod s with independent pseudo-random signs (one byte of sign bits per row, k_sign_bits).
+// W(0:s, j) = Om' L(:, j): one workgroup per column of L, thread h owns the rows i = h (mod s) — coalesced reads of the column, ZETA private
+// accumulators, which are the buckets (h + off_t) mod s; they meet through LDS in a fixed order (deterministic, no atomics).  One pass over
+// L at HBM speed (8 n c bytes) instead of a dense GEMM with a Gaussian matrix (2 n c s flop: 1.5 ms per sketch at n = 20209, c = 4500).
+__global__ void k_sign_bits(int n, unsigned long long seed, unsigned char* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    out[i] = (unsigned char)(z >> 24);
+}
+struct SketchOffsets { int off[SKETCH_ZETA]; };
+__global__ __launch_bounds__(1024) void k_sketch_sign(int n, int s, const double* __restrict__ L, int ldl, double* __restrict__ W, int ldw, SketchOffsets so,
+                                                      const unsigned char* __restrict__ bits) {
+    extern __shared__ double sk_slot[];                 // SKETCH_ZETA x s
+    const int j = blockIdx.x, h = threadIdx.x;
+    double acc[SKETCH_ZETA];
+#pragma unroll
+    for (int t = 0; t < SKETCH_ZETA; ++t) acc[t] = 0.0;
+    if (h < s) {
+        const double* __restrict__ col = L + (size_t)j * ldl;
+        for (int i0 = h; i0 < n; i0 += 8 * s) {
+            double v[8];
+            unsigned char sb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = min(i0 + q * s, n - 1); v[q] = col[i]; sb[q] = bits[i]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double x = (i0 + q * s < n) ? v[q] : 0.0;
+#pragma unroll
+                for (int t = 0; t < SKETCH_ZETA; ++t) acc[t] += ((sb[q] >> t) & 1) ? x : -x;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < SKETCH_ZETA; ++t) { int b = h + so.off[t]; if (b >= s) b -= s; sk_slot[t * s + b] = acc[t]; }
+    }
+    __syncthreads();
+    if (h < s) {
+        double r = 0.0;
+#pragma unroll
+        for (int t = 0; t < SKETCH_ZETA; ++t) r += sk_slot[t * s + h];
+        W[h + (size_t)j * ldw] = r * 0.35355339059327373;          // 1 / sqrt(8)
+    }
+}
+static_assert(SKETCH_ZETA == 8, "k_sketch_sign: one sign byte per row, scale 1/sqrt(8)");
+void sketch_sign(Ctx* ctx, const Mat& L, Mat& W, unsigned long long seed) {
+    const int n = L.rows, c = L.cols, s = W.rows;
+    DRE_REQUIRE(W.cols == c && s >= SKETCH_ZETA && s <= 1024 && n >= 1, "sketch_sign: shape out of range");
+    if (c == 0) return;
+    SketchOffsets so;
+    so.off[0] = 0;
+    for (int t = 1; t < SKETCH_ZETA; ++t) {
+        unsigned long long z = seed + 0xD1B54A32D192ED03ull * (unsigned long long)t;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        int o = (int)(z % (unsigned long long)s);
+        for (bool clash = true; clash;) { clash = false; for (int u = 0; u < t; ++u) if (so.off[u] == o) { o = (o + 1) % s; clash = true; } }
+        so.off[t] = o;
+    }
+    DevArr<unsigned char> bits(ctx, (size_t)n);
+    hipLaunchKernelGGL(k_sign_bits, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, n, seed, bits.p);
+    TimedScope ts(ctx, "sketch_sign", 8.0 * n * c + 8.0 * s * c, 8.0 * (double)n * c);
+    const size_t shm = (size_t)SKETCH_ZETA * s * sizeof(double);
+    if (shm > 48 * 1024) lds_attr(ctx, (const void*)k_sketch_sign, 64 * 1024);
+    hipLaunchKernelGGL(k_sketch_sign, dim3(c), dim3((s + 63) & ~63), shm, ctx->stream, n, s, (const double*)L.p, L.ld, W.p, W.ld, so, (const unsigned char*)bits.p);
+    DRE_HIP(hipGetLastError());
+}
 void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed) {
     const size_t tot = (size_t)A.rows * A.cols;
     if (tot) hipLaunchKernelGGL(k_fill_gauss, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, A.rows, A.cols, seed, A.p, A.ld);

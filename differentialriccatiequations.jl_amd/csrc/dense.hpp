@@ -60,6 +60,9 @@ void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                
 void fill_mat(Ctx* ctx, Mat& dst, double v);
 void set_identity(Ctx* ctx, Mat& dst, double v = 1.0);       // dst = v*I (square or rectangular)
 void fill_gauss(Ctx* ctx, Mat& A, unsigned long long seed);
+// W (s x c) = Om' L for the structured sparse sign test matrix Om (n x s, SKETCH_ZETA entries +-1/sqrt(SKETCH_ZETA) per row; deterministic in seed)
+#define SKETCH_ZETA 8
+void sketch_sign(Ctx* ctx, const Mat& L, Mat& W, unsigned long long seed);
 // Rinv = inv(R) for the upper Cholesky factor R of the symmetric positive semidefinite G (order <= 64), null columns (pivot below the floor
 // selected by mode / *ref_dev, see k_chol_inv) zeroed; *flag_dev |= 1 when a live pivot is too small for Cholesky QR
 // nullmask_dev (optional, order entries): 1 where a null column was found

@@ -173,9 +173,20 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     const int n = X.n, c = X.rank(), sp = s + 16;
     static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
     Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
-    Mat Om(ctx, n, sp), W1(ctx, sp, c), W2(ctx, sp, c), Y(ctx, n, sp);
-    fill_gauss(ctx, Om, 0x2545F4914F6CDD1Dull);
-    gemm(ctx, true, false, 1.0, Om, Lcat, 0.0, W1, nullptr, "gemm_sketch");           // Om' L
+    Mat W1(ctx, sp, c), W2(ctx, sp, c), Y(ctx, n, sp);
+    const long spkey = skey - 2;                       // band_hint: sketches with the sparse sign test matrix the probe rejected at this order (two strikes: Gaussian)
+    const bool use_sparse = ctx->compress_sketch_sparse && s <= 1024 && ctx->band_hint[spkey] < 2;
+    if (use_sparse) {
+        // Om = [sparse sign matrix (s columns) | Gaussian probe (16 columns, independent of it)]
+        Mat Ws = W1.view(0, 0, s, c), Wg = W1.view(s, 0, 16, c), G(ctx, n, 16);
+        sketch_sign(ctx, Lcat, Ws, 0x2545F4914F6CDD1Dull);
+        fill_gauss(ctx, G, 0x5851F42D4C957F2Dull);
+        gemm(ctx, true, false, 1.0, G, Lcat, 0.0, Wg, nullptr, "gemm_sketch");
+    } else {
+        Mat Om(ctx, n, sp);
+        fill_gauss(ctx, Om, 0x2545F4914F6CDD1Dull);
+        gemm(ctx, true, false, 1.0, Om, Lcat, 0.0, W1, nullptr, "gemm_sketch");       // Om' L
+    }
     mul_blockdiag(ctx, W1, X, W2);                                                     // Om' L Dt
     gemm(ctx, false, true, 1.0, Lcat, W2, 0.0, Y, nullptr, "gemm_sketch");            // X Om  (Dt symmetric)
     Mat Yr = Y.colsview(0, s), Z = Y.colsview(s, 16);
@@ -210,9 +221,10 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     const double est = h[0] > 0.0 ? std::sqrt(h[1] / h[0]) : 0.0;
     const bool chol_bad = use_chol && (cf & 1) != 0;
     const bool ok = !chol_bad && sb.J + 32 <= s && est <= 64.0 * EPS;
-    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d (%s) -> J=%d  probe residual %.2e  %s\n", n, c, s, use_chol ? "CholQR2 blocks" : "Householder",
-                            sb.J, est, ok ? "accepted" : (chol_bad ? "REJECTED (Cholesky breakdown)" : "REJECTED"));
+    if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d (%s, %s) -> J=%d  probe residual %.2e  %s\n", n, c, s, use_sparse ? "sparse sign" : "Gaussian",
+                            use_chol ? "CholQR2 blocks" : "Householder", sb.J, est, ok ? "accepted" : (chol_bad ? "REJECTED (Cholesky breakdown)" : "REJECTED"));
     if (chol_bad) { ctx->band_hint[ckey] += 1; return false; }
+    if (use_sparse && !ok && sb.J + 32 <= s) ctx->band_hint[spkey] += 1;       // enough room in the sketch, yet the probe sees a miss: the test matrix's fault
     if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
     ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += s; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
     ctx->band_hint[skey] = sb.J;

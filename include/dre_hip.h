@@ -71,6 +71,9 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *   "compress_sketch"           wide factors (columns >= "compress_sketch_min_cols", default 768, and >= 3 x the sketch width) of sums without
  *                               cancellation: randomized range finder, three GEMM passes over the factor; sketch width = rank of the previous
  *                               compression of this kind + "compress_sketch_extra" (48); rejected sketches fall back (default 1, 0 disables)
+ *   "compress_sketch_sparse"    1 (default): the test matrix of the sketch is a structured sparse sign matrix (8 entries +-1/sqrt(8) per row), applied
+ *                               in one pass over the factor; 0: Gaussian (dense GEMM).  The acceptance test uses 16 independent Gaussian probe
+ *                               columns either way; two probe rejections at an order n switch that order to the Gaussian matrix
  *   "compress_sketch_cholqr"    1 (default): the sketch is orthonormalised in 64-column blocks by block Gram-Schmidt + Cholesky QR, both twice
  *                               (GEMMs and a 64 x 64 Cholesky kernel); a block with cond > ~3e6 is detected on the device and the compression
  *                               redone, after two such events at an order n Householder/TSQR panels are used (0: always)

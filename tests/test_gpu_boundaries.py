@@ -153,7 +153,10 @@ def test_randomized_compression_of_wide_factors(ctx):
     ctx.set_option("compress_sketch_cholqr", 0)
     r4h = run(200, 4)           # the same sketch through Householder panels
     ctx.set_option("compress_sketch_cholqr", 1)
-    assert abs(r4 - r4h) <= 16
+    ctx.set_option("compress_sketch_sparse", 0)
+    r4g = run(200, 4)           # Gaussian test matrix (dense GEMM) instead of the structured sparse sign matrix (dense.hip k_sketch_sign)
+    ctx.set_option("compress_sketch_sparse", 1)
+    assert abs(r4 - r4h) <= 16 and abs(r4 - r4g) <= 16
     # 14 decades within one 64-column block: Cholesky QR breaks down (k_chol_inv raises its flag, the compression is redone in factor form);
     # after the second breakdown at this order the sketches go through Householder panels
     r5, r6 = run(60, 5), run(60, 6)
