@@ -3392,11 +3392,11 @@ __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* _
 //     sketch — and gets a zero column in Rinv (a zero column of Q: it contributes nothing instead of a normalised noise vector that is
 //     not orthogonal to anything).  mode 0: floor = relfloor x this block's largest diagonal entry, which is also written to *ref (first
 //     block of a sketch); mode 1: floor = relfloor x *ref; mode 2: floor = 1e-20 (second pass: the block is orthonormal up to 1e-8);
-//   * a pivot above the floor but at or below 1e-13 x the block's largest diagonal entry (cond(Y_b) beyond ~3e6: Cholesky QR would lose
-//     orthogonality) raises *flag: the caller falls back to Householder panels.
+//   * a live pivot at or below 1e-15 x the block's largest diagonal entry in the first pass, or below 1/4 in the second pass (the first
+//     pass lost more orthogonality than the second repairs: cond(Y_b) beyond ~1e7), raises *flag: the caller falls back to Householder panels.
 //   nullmask (optional, b entries): 1 for a null column, so that the caller can put a fresh random direction there (k_fill_gauss_masked).
 __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restrict__ G, int ldg, double* __restrict__ Rinv, int ldr, int* __restrict__ flag,
-                                                  double* __restrict__ ref, int mode, int* __restrict__ nullmask, double relfloor) {
+                                                  double* __restrict__ ref, int mode, int* __restrict__ nullmask, double relfloor, double* __restrict__ dbg) {
     extern __shared__ double chol_lds[];            // 2 x 64 x 65 doubles (dynamic: beyond the 64 KB static limit)
     double (*A)[65] = reinterpret_cast<double (*)[65]>(chol_lds);
     double (*Y)[65] = A + 64;                       // forward substitution on the identity, carried along: inv(L) = diag(rd) Y at the end
@@ -3407,8 +3407,14 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
     if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0) *ref = m; }
     __syncthreads();
     const double floor_abs = mode == 2 ? 1e-20 : relfloor * (mode == 0 ? dmax_s : *ref);
-    const double thr = 1e-13 * dmax_s;
+    // breakdown: judged where it shows.  First pass (modes 0, 1): only a pivot that is all rounding (<= 1e-15 of the block's scale; the Gram
+    // matrix carries cond^2) is hopeless.  Second pass (mode 2): the block entered orthonormal up to the error of the first pass, so every live
+    // pivot of its Gram matrix is ~1; one below 1/4 says the first pass lost more than CholeskyQR2 repairs.  (Measured on the rail
+    // sketches: first-pass ratios down to 3e-14 still give second-pass pivots >= 0.99 and a probe residual of 2e-15; the earlier
+    // first-pass bound of 1e-13 struck there and sent every later sketch of the run to Householder panels: 27 % of a 45-step run.)
+    const double thr = (mode == 2 ? 0.25 : 1e-15) * dmax_s;
     bool bad = false;
+    double minratio = 1.0;                           // smallest live pivot / largest diagonal entry (trace only)
     // step k (one barrier): with l_ik = A_ik / pivot,   A_ij -= l_ik A_jk  (k < j <= i: the Schur complement)   and
     //                                                   Y_ij -= l_ik Y_kj  (j <= k: rows of inv(L), unscaled; Y_kk = 1)
     // on a 16 x 16 thread grid; the first version inverted L afterwards with one thread per column (b^3/6 dependent steps: 100 of its 107 us)
@@ -3416,6 +3422,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
         const double piv = A[k][k];
         const bool live = piv > floor_abs;           // (NaN: not live)
         if (live && !(piv > thr)) bad = true;
+        if (live) minratio = fmin(minratio, piv / dmax_s);
         const double rd = live ? 1.0 / sqrt(piv) : 0.0, rp = rd * rd;
         if (tid == 0) { rds[k] = rd; if (nullmask) nullmask[k] = live ? 0 : 1; }
         for (int i = k + 1 + ty; i < b; i += 16) {
@@ -3433,6 +3440,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
         if (r < b && c < b) Rinv[r + (size_t)c * ldr] = (r <= c) ? Y[c][r] * rds[c] : 0.0;
     }
     if (bad && tid == 0) atomicOr(flag, 1);
+    if (dbg && tid == 0) *dbg = minratio;
 }
 // Unit-scale Gaussian entries (variance 1/n) into the columns of T that mask marks
 __global__ void k_fill_gauss_masked(int n, int cols, unsigned long long seed, double* __restrict__ out, int ld, const int* __restrict__ mask, double scale) {
@@ -3452,13 +3460,13 @@ void fill_gauss_masked(Ctx* ctx, Mat& A, unsigned long long seed, const int* mas
     if (tot) hipLaunchKernelGGL(k_fill_gauss_masked, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, A.rows, A.cols, seed, A.p, A.ld, mask_dev,
                                 1.0 / std::sqrt((double)A.rows));
 }
-void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev) {
+void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev, double* dbg_dev) {
     DRE_REQUIRE(G.rows == G.cols && G.rows <= 64 && Rinv.rows == G.rows && Rinv.cols == G.rows, "chol_inv: order <= 64 expected");
     if (G.rows == 0) return;
     const size_t shm = (size_t)2 * 64 * 65 * sizeof(double);
     const double relfloor = 1e-30;        // measured on the rail sketches: 1e-28 leaves a probe residual of 1e-14, 1e-30 and below 2.4e-15 (Householder: 1.9e-15)
     lds_attr(ctx, (const void*)k_chol_inv, (int)shm);
-    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor);
+    hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor, dbg_dev);
     DRE_HIP(hipGetLastError());
 }
 // Structured sparse sign test matrix Om (n x s) for the range finder of engine.hip sketch_compress: row i has SKETCH_ZETA entries

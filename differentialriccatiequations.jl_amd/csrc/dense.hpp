@@ -66,7 +66,8 @@ void sketch_sign(Ctx* ctx, const Mat& L, Mat& W, unsigned long long seed);
 // Rinv = inv(R) for the upper Cholesky factor R of the symmetric positive semidefinite G (order <= 64), null columns (pivot below the floor
 // selected by mode / *ref_dev, see k_chol_inv) zeroed; *flag_dev |= 1 when a live pivot is too small for Cholesky QR
 // nullmask_dev (optional, order entries): 1 where a null column was found
-void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev = nullptr);
+// dbg_dev (optional): receives the smallest live pivot relative to the largest diagonal entry (conditioning trace)
+void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev, int mode, int* nullmask_dev = nullptr, double* dbg_dev = nullptr);
 // Gaussian entries of variance 1/rows into the columns of A that mask_dev marks (the others are left alone)
 void fill_gauss_masked(Ctx* ctx, Mat& A, unsigned long long seed, const int* mask_dev);   // independent standard normal entries (deterministic in seed and position)
 void transpose_mat(Ctx* ctx, const Mat& src, Mat& dst);      // dst = src'

@@ -144,6 +144,9 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
     Mat G(ctx, bs, bs), Ri(ctx, bs, bs), T(ctx, n, bs);
     DevArr<double> ref(ctx, 1);              // scale of the sketch: largest squared column norm of the first block
     DevArr<int> nullmask(ctx, bs);
+    static const bool trace = std::getenv("DRE_TRACE_CHOLQR") != nullptr;
+    DevArr<double> dbg(ctx, 64);
+    int nblk = 0;
     for (int j0 = 0; j0 < s; j0 += bs) {
         const int b = std::min(bs, s - j0);
         Mat Yb = Y.colsview(j0, b), Qb = Q.colsview(j0, b), Tb = T.colsview(0, b), Gb = G.view(0, 0, b, b), Rb = Ri.view(0, 0, b, b);
@@ -157,15 +160,23 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
         };
         project(Yb);
         gemm(ctx, true, false, 1.0, Yb, Yb, 0.0, Gb, nullptr, "gemm_orth");
-        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, j0 == 0 ? 0 : 1, nullmask.p);
+        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, j0 == 0 ? 0 : 1, nullmask.p, trace && nblk < 32 ? dbg.p + 2 * nblk : nullptr);
         gemm(ctx, false, false, 1.0, Yb, Rb, 0.0, Tb, nullptr, "gemm_orth");
         // a column that was rounding noise relative to the whole sketch (sketch wider than the numerical rank) becomes a fresh random direction:
         // Q stays orthonormal in all its columns, as a Householder Q would, and the band reduction of Q'XQ sorts the direction out
         fill_gauss_masked(ctx, Tb, 0x9E3779B97F4A7C15ull + (unsigned long long)j0, nullmask.p);
         project(Tb);
         gemm(ctx, true, false, 1.0, Tb, Tb, 0.0, Gb, nullptr, "gemm_orth");
-        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, 2);
+        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, 2, nullptr, trace && nblk < 32 ? dbg.p + 2 * nblk + 1 : nullptr);
+        ++nblk;
         gemm(ctx, false, false, 1.0, Tb, Rb, 0.0, Qb, nullptr, "gemm_orth");
+    }
+    if (trace) {
+        double h[64];
+        ctx_fetch(ctx, dbg.p, sizeof(double) * 2 * std::min(nblk, 32), h);
+        std::fprintf(stderr, "[cholqr] n=%d s=%d  min pivot / max diagonal per block (pass 1, pass 2):", n, s);
+        for (int b2 = 0; b2 < std::min(nblk, 32); ++b2) std::fprintf(stderr, "  %.1e %.1e", h[2 * b2], h[2 * b2 + 1]);
+        std::fprintf(stderr, "\n");
     }
 }
 
