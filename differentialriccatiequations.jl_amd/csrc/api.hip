@@ -89,6 +89,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_EXTRA")) ctx->c.compress_sketch_extra = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_CHOLQR")) ctx->c.compress_sketch_cholqr = std::atoi(e);
         if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_SPARSE")) ctx->c.compress_sketch_sparse = std::atoi(e);
+        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_RATIO")) ctx->c.compress_sketch_ratio = std::atof(e);
         if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
         if (const char* e = std::getenv("DRE_MF_SUBTREE")) ctx->c.mf_subtree = std::atoi(e);
         if (const char* e = std::getenv("DRE_SETUP_STREAMS")) ctx->c.setup_streams = std::atoi(e);
@@ -162,6 +163,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "compress_sketch_extra") ctx->c.compress_sketch_extra = (int)value;
         else if (key == "compress_sketch_cholqr") ctx->c.compress_sketch_cholqr = (int)value;
         else if (key == "compress_sketch_sparse") ctx->c.compress_sketch_sparse = (int)value;
+        else if (key == "compress_sketch_ratio") ctx->c.compress_sketch_ratio = value;
         else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
         else if (key == "mf_subtree") ctx->c.mf_subtree = (int)value;
         else if (key == "setup_streams") ctx->c.setup_streams = (int)value;
@@ -612,6 +614,14 @@ static GaleOperator make_operator(Ctx* c, const dre_pencil* p, double cA, double
     }
     return op;
 }
+// The sketch of a wide factor (engine.hip sketch_compress) is chosen from what earlier compressions at the same order left in the context:
+// the rank hint and the fallback counters.  A solve entered through the ABI starts from a clean slate, so that two identical calls return
+// identical bits whatever ran on the context before (the explicit compression entry dre_ldlt_compress_fast keeps the history: that is
+// its documented behaviour).
+static void reset_sketch_history(Ctx* c, int n) {
+    const long skey = -(4000000000L + (long)n);
+    c->band_hint.erase(skey); c->band_hint.erase(skey - 1); c->band_hint.erase(skey - 2);
+}
 int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double lr_alpha, const dre_dense* U, const dre_dense* Vt,
                    dre_ldlt* C, const dre_ldlt* X0, const dre_adi_options* opt, dre_adi_result** out) {
     return guarded(ctx, [&] {
@@ -621,6 +631,7 @@ int dre_gale_solve(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, doub
         AdiOptions ao = convert_options(opt);
         auto* r = new dre_adi_result();
         r->pen = p;
+        reset_sketch_history(c, p->p->n);
         try { r->r = adi_solve(c, op, *C->x, X0 ? X0->x : nullptr, ao, nullptr); } catch (...) { delete r; throw; }
         *out = r;
     });
@@ -639,6 +650,7 @@ int dre_adi_init(dre_ctx* ctx, const dre_pencil* p, double cA, double cE, double
         AdiOptions ao = convert_options(opt);
         auto* s = new dre_adi_solver();
         s->pen = p;
+        reset_sketch_history(c, p->p->n);
         try { s->run = adi_begin(c, op, *C->x, X0 ? X0->x : nullptr, ao, nullptr); } catch (...) { delete s; throw; }
         *out = s;
     });
@@ -770,6 +782,7 @@ int dre_gdre_solve(dre_ctx* ctx, const dre_pencil* p, const dre_dense* B, const 
         AdiOptions ao = convert_options(opt);
         auto* r = new dre_gdre_result();
         r->pen = p; r->m = B->m.cols;
+        reset_sketch_history(c, p->p->n);
         try { r->r = gdre_solve(c, prob, order, dt, save_state != 0, ao); } catch (...) { delete r; throw; }
         *out = r;
     });

@@ -122,12 +122,13 @@ struct Ctx {
     // compression in factor form (no QR of L, no n x n matrix) for n >= compress_factor_min_n and at least compress_factor_min_cols columns
     int compress_factor_min_n = 2561;
     int compress_factor_min_cols = 96;
-    // wide factors (c >= compress_sketch_min_cols and c >= 3 x sketch width) of a PSD-like sum are compressed through a randomized range
+    // wide factors (c >= compress_sketch_min_cols and c >= compress_sketch_ratio x sketch width) of a PSD-like sum are compressed through a randomized range
     // finder (engine.hip, sketch_compress): three GEMM passes over the n x c factor instead of four per 16 columns of rank; the sketch width
     // is the rank of the previous compression of this kind + compress_sketch_extra; 0 disables
     int compress_sketch = 1;
-    int compress_sketch_min_cols = 768;
+    int compress_sketch_min_cols = 320;
     int compress_sketch_extra = 48;
+    double compress_sketch_ratio = 1.25; // columns >= ratio x sketch width (sweep at n = 5177 / 20209, 45 / 12 steps: 3.0 -> 257 / 246 ms, 2.0 -> 252 / 233, 1.25 -> 241 / 234)
     int compress_sketch_sparse = 1;     // sketch with the structured sparse sign test matrix (one pass over the factor) instead of a Gaussian one (dense GEMM)
     int compress_sketch_cholqr = 1;     // orthonormalise the sketch by blocked Cholesky QR (GEMMs) instead of Householder/TSQR panels; falls back on breakdown
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense

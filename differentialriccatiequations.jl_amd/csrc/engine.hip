@@ -266,7 +266,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         auto hit = ctx->band_hint.find(skey);
         if (hit != ctx->band_hint.end() && hit->second > 0) {
             const int s = ((hit->second + ctx->compress_sketch_extra + 15) / 16) * 16;
-            if (c >= 3 * s && s + 80 <= n && sketch_compress(ctx, X, tolfac, s, skey)) return;
+            if ((double)c >= ctx->compress_sketch_ratio * s && s + 80 <= n && sketch_compress(ctx, X, tolfac, s, skey)) return;
         }
     }
     if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {

@@ -68,7 +68,7 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               (default 2560; n <= 512 always);  "compress_direct_ratio" (default 8)
  *   "compress_factor_min_n"     n >= value: band reduction in factor form, reflectors applied to L, randomized termination estimate
  *                               (default 2561; a huge value disables);  "compress_factor_min_cols" (default 96) fewer columns: QR path
- *   "compress_sketch"           wide factors (columns >= "compress_sketch_min_cols", default 768, and >= 3 x the sketch width) of sums without
+ *   "compress_sketch"           wide factors (columns >= "compress_sketch_min_cols", default 320, and >= "compress_sketch_ratio", default 1.25, x the sketch width) of sums without
  *                               cancellation: randomized range finder, three GEMM passes over the factor; sketch width = rank of the previous
  *                               compression of this kind + "compress_sketch_extra" (48); rejected sketches fall back (default 1, 0 disables)
  *   "compress_sketch_sparse"    1 (default): the test matrix of the sketch is a structured sparse sign matrix (8 entries +-1/sqrt(8) per row), applied

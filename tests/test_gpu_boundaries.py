@@ -114,7 +114,7 @@ def test_factor_form_compression(ctx, n, c, r, nblk):
 
 
 def test_randomized_compression_of_wide_factors(ctx):
-    """engine.hip sketch_compress: from the second compression of a wide factor (c >= 768, c >= 3 s) at an order n >= 2561 on, the range is found
+    """engine.hip sketch_compress: from the second compression of a wide factor (c >= 320, c >= 1.25 s) at an order n >= 2561 on, the range is found
     with a Gaussian sketch whose width is the previous rank + 48.  Same rank: accepted; rank far beyond the sketch: rejected (fewer than 32
     unused sketch directions) and the factor-form reduction takes over.  Both against the dense sum and against the engine with the sketch off."""
     rng = np.random.default_rng(7)
