@@ -1508,10 +1508,10 @@ void adi_advance(AdiRun& run, int budget) {
                     }
                 } else {
                     Mat W(ctx, n, ncols);
-                    { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
+                    if (user_inner) { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
                     if (op.has_lr && !have) { Mat d = W.colsview(k, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
                     if (user_inner) user_block_solve(ctx, op, opt, mu, W, nullptr);
-                    else mf_solve<double>(ctx, P, fe->f, W.p, W.ld, ncols, dst);
+                    else mf_solve_from(ctx, P, fe->f, R.p, R.ld, k, W.p, W.ld, ncols, dst);     // the residual block is read where it is
                     if (op.has_lr) {
                         V1 = Mat(ctx, n, k);
                         Mat small(ctx, m, ncols);

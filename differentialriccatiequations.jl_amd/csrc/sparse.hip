@@ -732,9 +732,12 @@ __device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restr
     return acc;
 }
 
+// Win / ldwin / nin: the first nin right-hand-side columns are READ from Win (the caller's residual block) instead of W, so that the
+// caller does not have to copy them into the work panel first; everything is written to W (every row of the panel belongs to exactly one
+// front or to the dense top, so the sweeps write all of it).
 __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
                                                           double* __restrict__ W, int ldw, int nrhs, double* __restrict__ upd, int64_t ldu,
-                                                          const AdiState* st) {
+                                                          const AdiState* st, const double* __restrict__ Win, int ldwin, int nin) {
     if (st && st->done) return;
     extern __shared__ double sm[];
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
@@ -753,7 +756,8 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int id = id0 + q * nt, i = id % ldl, c = id / ldl;
-            v[q] = (i < s && c < kc) ? W[(first + i) + (size_t)(c0 + c) * ldw] : 0.0;
+            const double* __restrict__ src = (c0 + c < nin) ? Win + (size_t)(c0 + c) * ldwin : W + (size_t)(c0 + c) * ldw;
+            v[q] = (i < s && c < kc) ? src[first + i] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) { const int id = id0 + q * nt; if (id < ldl * MFM_KC) w[id] = v[q]; }
@@ -1474,15 +1478,20 @@ static void top_plan_build(Ctx* ctx, const Pencil& P, int max_rows) {
     tp.gsrc = DevArr<int64_t>(ctx, std::max<size_t>(gsrc.size(), 1)); tp.gsrc.upload(ctx, gsrc);
     tp.T = T; tp.ntop = rows;
 }
+__global__ void k_copy_cols(int n, const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd, const AdiState* st) {
+    if (st && st->done) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i + (size_t)blockIdx.y * ldd] = src[i + (size_t)blockIdx.y * lds_];
+}
 // g[p, c] = W[topidx[p], c] + sum of the update rows that the level-T nodes send to top variable p
 __global__ void k_top_gather(int ntop, int nrhs, const int* __restrict__ topidx, const int* __restrict__ gptr, const int64_t* __restrict__ gsrc,
                              const double* __restrict__ W, int ldw, const double* __restrict__ upd, int64_t ldu, double* __restrict__ g, int ldg,
-                             const AdiState* st) {
+                             const AdiState* st, const double* __restrict__ Win, int ldwin, int nin) {
     if (st && st->done) return;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)ntop * nrhs) return;
     const int p = idx % ntop; const size_t c = idx / ntop;
-    double v = W[topidx[p] + c * ldw];
+    double v = (int)c < nin ? Win[topidx[p] + c * ldwin] : W[topidx[p] + c * ldw];
     for (int j = gptr[p]; j < gptr[p + 1]; ++j) v += upd[gsrc[j] + c * (size_t)ldu];
     g[p + c * ldg] = v;
 }
@@ -1505,7 +1514,8 @@ __global__ void k_top_collect(int ntop, int nrhs, int c0, const int* __restrict_
     Ti[p + (c0 + c) * ldt] = W[topidx[p] + c * ldw];
 }
 
-static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st);
+struct MfIn;
+static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st, const MfIn* inp = nullptr);
 // inv(S) = (M^-1)[top, top]: unit right-hand sides on the top variables, sweeps over the top levels only (everything below stays zero)
 static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc);
 
@@ -1517,8 +1527,9 @@ static long mf_latency_max_wg(bool) {
     static const long b = std::getenv("DRE_MF_LAT_BWD") ? std::atol(std::getenv("DRE_MF_LAT_BWD")) : 1500;
     return b;
 }
+struct MfIn { const double* p = nullptr; int ld = 0, n = 0; };       // leading right-hand-side columns that live outside the work panel
 static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, double* upd, int64_t ldu,
-                            const AdiState* st, bool forward, int l_from, int l_to) {
+                            const AdiState* st, bool forward, int l_from, int l_to, MfIn in = MfIn()) {
     // forward: levels l_from down to l_to (l_from >= l_to);  backward: levels l_from up to l_to
     const Symbolic& S = P.sym;
     MfArgs a = mf_args(P);
@@ -1535,7 +1546,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc,
             static const int tp_threads = std::getenv("DRE_MF_FWD_TP_THREADS") ? std::atoi(std::getenv("DRE_MF_FWD_TP_THREADS")) : 256;
             int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
             if (tp_threads > 0 && (long)nb * ncb > 2000) nthreads = tp_threads;
-            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st);
+            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n);
         }
     } else {
         for (int l = l_from; l <= l_to; ++l) {
@@ -1584,8 +1595,9 @@ static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc)
     Fc.topinv = Ti;
 }
 
-static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st) {
+static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, const AdiState* st, const MfIn* inp) {
     const Symbolic& S = P.sym;
+    MfIn in = inp ? *inp : MfIn();
     const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
     if (Fc.allow_topinv && ctx->top_inverse_max_rows > 0 && nrhs >= 8 && Fc.topinv.empty() && ++Fc.uses == 3) {
         if (!P.top.built) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
@@ -1600,11 +1612,16 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
         sub_plan_build(ctx, P, P.top.T);
     }
     const int Tsub = P.sub.Tsub;            // -1: level kernels everywhere
+    if (in.n > 0 && Tsub >= 0) {
+        // the subtree kernels read their panel in place: bring the outside columns in first
+        hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div(P.n, 256), in.n), dim3(256), 0, ctx->stream, P.n, in.p, in.ld, W, ldw, st);
+        in = MfIn();
+    }
     auto forward_to = [&](int l_to) {        // levels nlevels-1 .. l_to
         if (Tsub >= 0 && Tsub >= l_to) {
             mf_sub_sweep(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true);
             if (Tsub - 1 >= l_to) mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, Tsub - 1, l_to);
-        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, l_to);
+        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, l_to, in);
     };
     auto backward_from = [&](int l_from) {   // levels l_from .. nlevels-1
         if (Tsub >= 0 && Tsub >= l_from) {
@@ -1625,7 +1642,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             TimedScope ts(ctx, "mf_solve_real", bytes, flops);
             forward_to(T);
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
-                               (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st);
+                               (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n);
         }
         gemm(ctx, false, false, 1.0, Fc.topinv, g, 0.0, x, st, "gemm_mf_top");
         {
@@ -1638,6 +1655,19 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     DRE_HIP(hipGetLastError());
 }
 
+// W = F^-1 [Win(:, 0:nin) | W(:, nin:nrhs)]: the leading right-hand sides are read where they are (no copy into the panel) when the
+// matrix-core sweeps run; otherwise they are copied in and the in-place solve follows.
+void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs, const AdiState* st) {
+    if (nrhs <= 0) return;
+    DRE_REQUIRE(nin >= 0 && nin <= nrhs && Win != W, "mf_solve_from: bad column split");
+    if (P.use_mfma_sweeps) {
+        MfIn in; in.p = Win; in.ld = ldwin; in.n = nin;
+        mf_solve_mfma(ctx, P, Fc, W, ldw, nrhs, st, &in);
+        return;
+    }
+    if (nin > 0) hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div(P.n, 256), nin), dim3(256), 0, ctx->stream, P.n, Win, ldwin, W, ldw, st);
+    mf_solve<double>(ctx, P, Fc, W, ldw, nrhs, st);
+}
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st) {
     if (nrhs <= 0) return;

@@ -129,5 +129,8 @@ double mf_check(Ctx* ctx, const Factor<T>& F);
 // In-place solve  M * X = W  for the n x nrhs panel W (column-major, leading dimension ldw), solver ordering.
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& F, T* W, int ldw, int nrhs, const AdiState* st = nullptr);
+// W = F^-1 [Win(:, 0:nin) | W(:, nin:nrhs)] — the leading right-hand sides are read in place (no copy into the work panel)
+void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& F, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs,
+                   const AdiState* st = nullptr);
 
 }  // namespace dre
