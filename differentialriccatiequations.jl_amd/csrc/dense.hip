@@ -1064,9 +1064,76 @@ __global__ __launch_bounds__(256) void k_eff_stack(int n, int m, int nstrip, int
     }
     bt.out[blockIdx.z][((size_t)b * kst + t) * 64 + lane] = v;
 }
+// The same on the matrix cores (m <= 8): a wave owns 16 x 16 tiles (16 rows of a strip x 4 K-steps of the packed layout).  The correction
+// is computed TRANSPOSED,  D = (U' inv)(:, cols)' (WKS(rows, :))'  (16 x m times m x 16: two v_mfma_f64_16x16x4), because the accumulator
+// layout of D — lane = 16 lk + lr holds D[lk + 4 r][lr] = (col 4 r + lk, row lr) — IS the packed layout: acc[r] is the entry of K-step
+// t0 + r at position `lane`.  Two loads per output entry instead of fifteen (the scalar kernel re-reads the m entries of WKS and of U' inv
+// for every entry and is bound by the vector-memory instruction rate: 317 us per step for ten shifts at n = 1357, 590 MB).
+#define EFF_TPW 4
+__global__ __launch_bounds__(256) void k_eff_stack_mfma(int n, int m, int nstrip, int kst, int lds_, int ldwk, EffStackBatch bt) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;
+    const int b = blockIdx.y, half = b / nstrip, s = b - half * nstrip;
+    const double* __restrict__ stack = bt.stack[blockIdx.z];
+    const double* __restrict__ WKS = bt.WKS[blockIdx.z];
+    double* __restrict__ out = bt.out[blockIdx.z];
+    const int ntile = (kst + 3) >> 2;
+    const int row = s * 16 + lr;
+    const size_t r = (size_t)half * n + min(row, n - 1);
+    // B operand (shared by all tiles of the strip): B[k][j = row] = WKS(row, k)
+    double bw[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int k = 4 * kk + lk;
+        const double v = WKS[r + (size_t)min(k, m - 1) * ldwk];
+        bw[kk] = (k < m && row < n) ? v : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < EFF_TPW; ++i) {
+        const int tt = (blockIdx.x * EFF_TPW + i) * 4 + wave;           // tile = K-steps 4 tt .. 4 tt + 3 = columns 16 tt .. 16 tt + 15
+        if (tt >= ntile) break;                                          // wave-uniform
+        // A operand: A[i = col][k] = (U' inv)(k, col), col = 16 tt + lr
+        const int colA = 16 * tt + lr;
+        double au[2], sv[4];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = 4 * kk + lk;
+            const double v = stack[2 * (size_t)n + min(k, m - 1) + (size_t)min(colA, n - 1) * lds_];
+            au[kk] = (k < m && colA < n) ? v : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = 16 * tt + 4 * q + lk;
+            const double v = stack[r + (size_t)min(col, n - 1) * lds_];
+            sv[q] = (row < n && col < n) ? v : 0.0;
+        }
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au[0], bw[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(au[1], bw[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int t = 4 * tt + q;
+            if (t < kst) out[((size_t)b * kst + t) * 64 + lane] = sv[q] - acc[q];
+        }
+    }
+}
 void adi_fast_build(Ctx* ctx, int n, int m, const std::vector<const double*>& stacks, int lds_, const std::vector<const double*>& wks, int ldwk,
                     const std::vector<double*>& outs) {
     const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+    bool all_lr = m >= 1 && m <= 8;
+    for (auto w : wks) if (!w) all_lr = false;
+    static const bool use_mfma = !(std::getenv("DRE_EFF_STACK_MFMA") && std::atoi(std::getenv("DRE_EFF_STACK_MFMA")) == 0);
+    if (all_lr && use_mfma) {
+        const int ntile = (kst + 3) >> 2;
+        for (size_t b0 = 0; b0 < stacks.size(); b0 += 16) {
+            EffStackBatch bt;
+            const int nb = (int)std::min<size_t>(16, stacks.size() - b0);
+            for (int i = 0; i < 16; ++i) { const int j = i < nb ? i : 0; bt.stack[i] = stacks[b0 + j]; bt.WKS[i] = wks[b0 + j]; bt.out[i] = outs[b0 + j]; }
+            TimedScope ts(ctx, "adi_eff_stack", 8.0 * nb * (2.0 * n * n + (double)m * n + 2.0 * n * m + 2.0 * nstrip * 16.0 * kst * 4.0), 4.0 * nb * n * n * (double)m);
+            hipLaunchKernelGGL(k_eff_stack_mfma, dim3(ceil_div(ntile, 4 * EFF_TPW), 2 * nstrip, nb), dim3(256), 0, ctx->stream, n, m, nstrip, kst, lds_, ldwk, bt);
+        }
+        DRE_HIP(hipGetLastError());
+        return;
+    }
     for (size_t b0 = 0; b0 < stacks.size(); b0 += 16) {
         EffStackBatch bt;
         const int nb = (int)std::min<size_t>(16, stacks.size() - b0);
