@@ -132,14 +132,18 @@ struct AdiFastArgs {
 // column tiles per workgroup: as many as keep at least ~2 tile workgroups per CU in the launch
 inline int adi_fast_pick_nt(int n, int k) {
     const long tiles = 2L * adi_fast_nstrip(n) * ((k + 15) / 16);
-    return tiles > 2048 ? 4 : (tiles > 512 ? 2 : 1);
+    // n = 1357 (170 half strips), sweep with DRE_ADI_FAST_NT: 1 -> 40.9 us per launch, 2 -> 35.1, 4 -> 37.6; n = 371 (48 half strips): 7.65 / 8.7 / 11.1
+    return tiles > 2048 ? 4 : (tiles > 400 ? 2 : 1);
 }
 // kernel variant and column tiles per workgroup: the K-split tiles win while a launch is latency bound (n < 768 or residuals narrower than 128 columns); beyond that the LDS-staged
 // full-K strips with two column tiles per wave keep >= 1 wave per SIMD busy without re-gathering R
 inline void adi_fast_pick(int n, int k, int* mode, int* nt) {
     static const int wide_min_n = std::getenv("DRE_ADI_WIDE_MIN_N") ? std::atoi(std::getenv("DRE_ADI_WIDE_MIN_N")) : 768;
     if (n >= wide_min_n && k >= 128) { *mode = 1; *nt = 2; }       // measured at n = 1357: k = 64: 41 us (K-split) vs 53 us; k = 160: 77 vs 55 us; k = 294: 131 vs 80 us
-    else { *mode = 0; *nt = adi_fast_pick_nt(n, k); }
+    else {
+        static const int force_nt = std::getenv("DRE_ADI_FAST_NT") ? std::atoi(std::getenv("DRE_ADI_FAST_NT")) : 0;
+        *mode = 0; *nt = force_nt > 0 ? force_nt : adi_fast_pick_nt(n, k);
+    }
 }
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
 void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops);     // algorithmic bytes / flops of one launch
