@@ -1209,7 +1209,9 @@ __device__ __forceinline__ void gram_norm_global(int k, const double* __restrict
 // 16 x 16 output tile  C = A_strip B  over the K-steps [t0, t1) of this wave:  A packed (64 consecutive doubles per K-step),
 // B = X[4 t + lk, col] column-major; all loads of a batch of 24 K-steps are issued before its first MFMA.
 #define ADI_FAST_KB 24
-__device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, const double* __restrict__ bp, bool colok, int lk, int n, int t0, int t1) {
+// PACKED: bp points at (column tile, lane) of the packed residual, K-step stride pstride doubles
+template <bool PACKED>
+__device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, const double* __restrict__ bp, bool colok, int lk, int n, int t0, int t1, size_t pstride) {
     // branch-free: every load address is clamped into range (the packed A strip is padded, rows of B are clamped to n - 1) and
     // out-of-range operands are zeroed by a select, so the 48 loads of a batch issue back to back without exec-mask branches
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -1221,7 +1223,7 @@ __device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, cons
             const int t = min(tb + u, t1 - 1);
             const int row = 4 * t + lk;
             av[u] = ap[(size_t)t * 64];
-            bv[u] = bp[min(row, n - 1) - lk];
+            bv[u] = PACKED ? bp[(size_t)t * pstride] : bp[min(row, n - 1) - lk];
         }
 #pragma unroll
         for (int u = 0; u < ADI_FAST_KB; ++u) {
@@ -1235,9 +1237,9 @@ __device__ __forceinline__ v4d adi_fast_tile(const double* __restrict__ ap, cons
 }
 // The same for NT column tiles per wave (wide residuals / larger n): one A fragment feeds NT MFMAs, so the packed strip is read once per
 // NT tiles, and the operand batches are double buffered — the loads of batch i + 1 are in flight while batch i multiplies.
-template <int NT>
+template <int NT, bool PACKED>
 __device__ __forceinline__ void adi_fast_tiles(const double* __restrict__ ap, const double* __restrict__ R, int ldr, int col0, int k, int lk, int lr, int n,
-                                               int t0, int t1, v4d (&acc)[NT]) {
+                                               int t0, int t1, v4d (&acc)[NT], const double* __restrict__ Rp, size_t pstride) {
     constexpr int KB = 24 / NT;
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -1248,7 +1250,7 @@ __device__ __forceinline__ void adi_fast_tiles(const double* __restrict__ ap, co
     for (int j = 0; j < NT; ++j) {
         const int col = col0 + j * 16 + lr;
         cok[j] = col < k;
-        bp[j] = R + (size_t)(cok[j] ? col : 0) * ldr;
+        bp[j] = PACKED ? Rp + ((size_t)(col0 / 16 + j)) * 64 + (threadIdx.x & 63) : R + (size_t)(cok[j] ? col : 0) * ldr;
     }
     double a0[KB], a1[KB], b0[NT][KB], b1[NT][KB];
     auto load = [&](double (&av)[KB], double (&bv)[NT][KB], int tb) {
@@ -1258,7 +1260,7 @@ __device__ __forceinline__ void adi_fast_tiles(const double* __restrict__ ap, co
             const int row = min(4 * t + lk, n - 1);
             av[u] = ap[(size_t)t * 64];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j][u] = bp[j][row];
+            for (int j = 0; j < NT; ++j) bv[j][u] = PACKED ? bp[j][(size_t)t * pstride] : bp[j][row];
         }
     };
     auto mma = [&](const double (&av)[KB], const double (&bv)[NT][KB], int tb) {
@@ -1294,7 +1296,9 @@ __device__ __forceinline__ void adi_fast_strip_group(const AdiFastArgs& a, int h
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
     v4d acc[NT];
-    adi_fast_tiles<NT>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur, a.ldr, col0, k, lk, lr, n, t0, t1, acc);
+    const int ctp = (k + 15) >> 4;
+    if (a.Rpc) adi_fast_tiles<NT, true>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur, a.ldr, col0, k, lk, lr, n, t0, t1, acc, a.Rpc, (size_t)ctp * 64);
+    else adi_fast_tiles<NT, false>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur, a.ldr, col0, k, lk, lr, n, t0, t1, acc, nullptr, 0);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1305,10 +1309,14 @@ __device__ __forceinline__ void adi_fast_strip_group(const AdiFastArgs& a, int h
         const int col = col0 + j * 16 + lr;
         const size_t o = ((size_t)j * 4 + wave) * 64 + lane, ws = (size_t)4 * NT * 64;
         const double v = ((part[o] + part[ws + o]) + part[2 * ws + o]) + part[3 * ws + o];
-        if (col < k && erow < n) {
+        const bool ok = col < k && erow < n;
+        const double rnew = rold[j] - a.two_mu * v;
+        if (ok) {
             if (half == 0) a.V[erow + (size_t)col * a.ldv] = v;
-            else a.Rnext[erow + (size_t)col * a.ldr_next] = rold[j] - a.two_mu * v;
+            else a.Rnext[erow + (size_t)col * a.ldr_next] = rnew;
         }
+        // this wave's 64 results are K-step 4 s + wave of column tile col0 / 16 + j of the packed residual
+        if (half == 1 && a.Rpn && col0 / 16 + j < ctp) a.Rpn[((size_t)(4 * s + wave) * ctp + (col0 / 16 + j)) * 64 + lane] = ok ? rnew : 0.0;
     }
 }
 // Large n (mode 1): every wave owns one 16-row strip over the FULL K range and NT column tiles; the four waves of a workgroup share the
@@ -1428,16 +1436,20 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
         const double rold = (half == 1 && colok && erow < n) ? a.Rcur[erow + (size_t)col * a.ldr] : 0.0;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
-        const v4d acc = adi_fast_tile(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur + (size_t)(colok ? col : 0) * a.ldr + lk, colok, lk, n, t0, t1);
+        const v4d acc = a.Rpc ? adi_fast_tile<true>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rpc + (size_t)tc * 64 + lane, colok, lk, n, t0, t1, (size_t)ct * 64)
+                              : adi_fast_tile<false>(a.Apack + (size_t)hs * a.kst * 64 + lane, a.Rcur + (size_t)(colok ? col : 0) * a.ldr + lk, colok, lk, n, t0, t1, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
         __syncthreads();
         // thread (wave = r, lane) finishes element (row lk + 4 r, column lane & 15) of the tile: fixed-order sum over the K quarters
         const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
-        if (colok && erow < n) {
+        const bool ok = colok && erow < n;
+        const double rnew = rold - a.two_mu * v;
+        if (ok) {
             if (half == 0) a.V[erow + (size_t)col * a.ldv] = v;
-            else a.Rnext[erow + (size_t)col * a.ldr_next] = rold - a.two_mu * v;
+            else a.Rnext[erow + (size_t)col * a.ldr_next] = rnew;
         }
+        if (half == 1 && a.Rpn) a.Rpn[((size_t)(4 * s + wave) * ct + tc) * 64 + lane] = ok ? rnew : 0.0;
         return;
     }
     b -= nsw;
@@ -1459,8 +1471,13 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
             for (int u = 0; u < ADI_FAST_KB; ++u) {
                 const int t = min(tb0 + u, t1 - 1);
                 const int off = min(4 * t + lk, n - 1) - lk;
-                av[u] = pa[off];
-                bv[u] = pb[off];
+                if (a.Rpc) {                                   // (launch-uniform)
+                    av[u] = a.Rpc[((size_t)t * ct + ta) * 64 + lane];
+                    bv[u] = a.Rpc[((size_t)t * ct + tb) * 64 + lane];
+                } else {
+                    av[u] = pa[off];
+                    bv[u] = pb[off];
+                }
             }
 #pragma unroll
             for (int u = 0; u < ADI_FAST_KB; ++u) {
@@ -1538,6 +1555,16 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
 void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops) {
     *flops = (a.do_strips ? 4.0 * a.n * (double)a.n * a.k : 0.0) + (a.G_prev ? 2.0 * a.n * (double)a.k * a.k : 0.0);
     *bytes = a.do_strips ? 8.0 * (2.0 * a.nstrip * 16.0 * a.kst * 4.0 + 3.0 * a.n * a.k) : 8.0 * (double)a.n * a.k;
+}
+__global__ void k_adi_pack_r(int n, int k, int ct, const double* __restrict__ R, int ldr, double* __restrict__ Rp, const AdiState* st) {
+    if (st && st->done) return;
+    const int t = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const int row = 4 * t + (lane >> 4), col = 16 * j + (lane & 15);
+    Rp[((size_t)t * ct + j) * 64 + lane] = (row < n && col < k) ? R[row + (size_t)col * ldr] : 0.0;
+}
+void adi_fast_pack_r(Ctx* ctx, int n, int k, const double* R, int ldr, double* Rp, const AdiState* st) {
+    const int ct = (k + 15) >> 4;
+    hipLaunchKernelGGL(k_adi_pack_r, dim3(4 * adi_fast_nstrip(n), ct), dim3(64), 0, ctx->stream, n, k, ct, R, ldr, Rp, st);
 }
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     DRE_REQUIRE(a.k >= 1 && a.k <= ADI_FAST_MAX_K, "adi_fast_iter: residual too wide");

@@ -116,6 +116,11 @@ struct AdiFastArgs {
     const double* Apack;        // packed effective stack of this iteration's shift
     const double* Rcur; int ldr;
     double* Rnext; int ldr_next;
+    // the residual ALSO in the lane order of the MFMA B operand ("packed": K-step t, column tile j -> 64 consecutive doubles, element
+    // (row 4 t + (lane >> 4), column 16 j + (lane & 15)) at ((t * ct + j) * 64 + lane), zero padded to 4 nstrip K-steps): written by the
+    // epilogue of the launch that produces it (each wave's 64 results ARE one such block), read by the next launch as single coalesced
+    // 512-byte fragment loads instead of 16 separate 32-byte pieces per load.  Null: column-major gathers (mode 1, the general GALE chain).
+    const double* Rpc; double* Rpn;
     double* V; int ldv;
     double two_mu;
     double* G_prev;             // receives Rcur' Rcur (Gram matrix of the residual the previous launch produced), or null
@@ -146,6 +151,8 @@ inline void adi_fast_pick(int n, int k, int* mode, int* nt) {
     }
 }
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
+inline size_t adi_fast_rpack_doubles(int n, int k) { return (size_t)4 * adi_fast_nstrip(n) * ((k + 15) / 16) * 64; }
+void adi_fast_pack_r(Ctx* ctx, int n, int k, const double* R, int ldr, double* Rp, const AdiState* st);      // column-major -> packed
 void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops);     // algorithmic bytes / flops of one launch
 double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha);  // synchronising
 

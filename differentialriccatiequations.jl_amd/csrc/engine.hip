@@ -1381,6 +1381,12 @@ void adi_advance(AdiRun& run, int budget) {
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p; a.nws = nws.p;
+            // the residual also in the B-operand lane order (dense.hpp, AdiFastArgs::Rpc): slot 0 = the chunk's input, slot j = after iteration j
+            static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
+            const bool use_pk = packed_r && a.mode == 0;
+            const size_t rpd = adi_fast_rpack_doubles(n, k);
+            DevArr<double> Rpk(ctx, use_pk ? rpd * (size_t)(nit + 1) : 1);
+            if (use_pk) adi_fast_pack_r(ctx, n, k, R.p, R.ld, Rpk.p, st.p);
             for (int j = 1; j <= nit; ++j) {
                 const std::complex<double> mu = opt.shifts.values[cyc % opt.shifts.values.size()];
                 all_shifts.push_back(mu);
@@ -1388,6 +1394,8 @@ void adi_advance(AdiRun& run, int budget) {
                 a.Apack = fast_pack[cyc % fast_pack.size()];
                 if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
                 a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
+                a.Rpc = use_pk ? Rpk.p + (size_t)(j - 1) * rpd : nullptr;
+                a.Rpn = use_pk ? Rpk.p + (size_t)j * rpd : nullptr;
                 Mat Vj = Vall.colsview((j - 1) * k, k);
                 a.V = Vj.p; a.ldv = Vj.ld;
                 a.two_mu = 2.0 * mu.real();
@@ -1403,6 +1411,7 @@ void adi_advance(AdiRun& run, int budget) {
             {   // drain the norm pipeline: Gram matrix of the last residual, decisions for the last two iterations of the chunk
                 const int g = base_it + nit;
                 a.do_strips = 0; a.Apack = nullptr; a.Rnext = nullptr; a.V = nullptr;
+                a.Rpc = use_pk ? Rpk.p + (size_t)nit * rpd : nullptr; a.Rpn = nullptr;
                 a.Rcur = Rring.p + (size_t)(nit - 1) * k * Rring.ld; a.ldr = Rring.ld;
                 a.G_prev = Gm.p + (size_t)(g & 1) * k * k;
                 a.G_prev2 = nit >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
@@ -2186,6 +2195,12 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
+            // the residual also in the B-operand lane order (dense.hpp, AdiFastArgs::Rpc): slot 0 = the chunk's input, slot j = after iteration j
+            static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
+            const bool use_pk = packed_r && a.mode == 0;
+            const size_t rpd = adi_fast_rpack_doubles(n, k);
+            DevArr<double> Rpk(ctx, use_pk ? rpd * (size_t)(nit + 1) : 1);
+            if (use_pk) adi_fast_pack_r(ctx, n, k, R.p, R.ld, Rpk.p, st.p);
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
             a.chain_timed = 1; a.do_strips = 1; a.G_prev = Gm.p;
             double by1 = 0.0, fl1 = 0.0;
@@ -2196,6 +2211,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 a.Apack = co.pack[cyc % co.pack.size()];
                 if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
                 a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
+                a.Rpc = use_pk ? Rpk.p + (size_t)(j - 1) * rpd : nullptr;
+                a.Rpn = use_pk ? Rpk.p + (size_t)j * rpd : nullptr;
                 Mat Vj = Vall.colsview(vcols_used + (j - 1) * k, k);
                 a.V = Vj.p; a.ldv = Vj.ld;
                 a.two_mu = 2.0 * mu.real();
@@ -2211,6 +2228,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             {
                 const int g = base_it + nit;
                 a.do_strips = 0; a.Apack = nullptr; a.Rnext = nullptr; a.V = nullptr;
+                a.Rpc = use_pk ? Rpk.p + (size_t)nit * rpd : nullptr; a.Rpn = nullptr;
                 a.Rcur = Rring.p + (size_t)(nit - 1) * k * Rring.ld; a.ldr = Rring.ld;
                 a.G_prev = Gm.p + (size_t)(g & 1) * k * k;
                 a.G_prev2 = nit >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
