@@ -1937,8 +1937,19 @@ __global__ __launch_bounds__(64) void k_dense_tols(int nparts, const double* __r
     }
 }
 // control block of the Lyapunov solve: residual = R D R' with orthonormal R, so its norm is ||D||_F
+// Workgroup 0: control block of the Lyapunov solve.  Workgroups 1..: the initial residual R (n x J) in the B-operand lane order of the fast
+// chain (dense.hpp, AdiFastArgs::Rpc; four 64-entry blocks per workgroup) — rides on this launch instead of a launch of its own.
 __global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st,
-                                                        double* __restrict__ nws, int nws_n) {
+                                                        double* __restrict__ nws, int nws_n, int n, int ct, int nblk, const double* __restrict__ R, int ldr,
+                                                        double* __restrict__ Rp) {
+    if (blockIdx.x > 0) {
+        const int blk = (blockIdx.x - 1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (blk >= nblk) return;
+        const int t = blk / ct, j = blk - t * ct;
+        const int row = 4 * t + (lane >> 4), col = 16 * j + (lane & 15);
+        Rp[(size_t)blk * 64 + lane] = (row < n && col < J) ? R[row + (size_t)col * ldr] : 0.0;
+        return;
+    }
     __shared__ double red[4];
     for (int i = threadIdx.x; i < nws_n; i += 256) nws[i] = 0.0;        // meeting point of the fast chain's norm workgroups (was a memset of its own)
     double s = 0.0;
@@ -2168,7 +2179,15 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
         Mat Tm = sb.D;
         DevArr<double> nws(ctx, ADI_FAST_NWS);
-        hipLaunchKernelGGL(k_adi_init_state, dim3(1), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p, nws.p, ADI_FAST_NWS);
+        static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
+        int mode0 = 0, nt0 = 0;
+        adi_fast_pick(n, k, &mode0, &nt0);
+        const bool use_pk = packed_r && mode0 == 0;
+        const size_t rpd = adi_fast_rpack_doubles(n, k);
+        DevArr<double> Rp0(ctx, use_pk ? rpd : 1);                  // the initial residual in the fast chain's B-operand order (slot 0 of the first chunk)
+        const int pk_ct = (k + 15) / 16, pk_nblk = use_pk ? 4 * adi_fast_nstrip(n) * pk_ct : 0;
+        hipLaunchKernelGGL(k_adi_init_state, dim3(1 + (pk_nblk + 3) / 4), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p, nws.p,
+                           ADI_FAST_NWS, n, pk_ct, pk_nblk, (const double*)R.p, R.ld, Rp0.p);
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
         sx.mark(ctx, 3);
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
@@ -2195,12 +2214,9 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
-            // the residual also in the B-operand lane order (dense.hpp, AdiFastArgs::Rpc): slot 0 = the chunk's input, slot j = after iteration j
-            static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
-            const bool use_pk = packed_r && a.mode == 0;
-            const size_t rpd = adi_fast_rpack_doubles(n, k);
             DevArr<double> Rpk(ctx, use_pk ? rpd * (size_t)(nit + 1) : 1);
-            if (use_pk) adi_fast_pack_r(ctx, n, k, R.p, R.ld, Rpk.p, st.p);
+            const double* slot0 = Rp0.p;                        // first chunk: packed by the init launch
+            if (use_pk && base_it > 0) { adi_fast_pack_r(ctx, n, k, R.p, R.ld, Rpk.p, st.p); slot0 = Rpk.p; }
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
             a.chain_timed = 1; a.do_strips = 1; a.G_prev = Gm.p;
             double by1 = 0.0, fl1 = 0.0;
@@ -2211,7 +2227,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 a.Apack = co.pack[cyc % co.pack.size()];
                 if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
                 a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
-                a.Rpc = use_pk ? Rpk.p + (size_t)(j - 1) * rpd : nullptr;
+                a.Rpc = use_pk ? (j == 1 ? slot0 : Rpk.p + (size_t)(j - 1) * rpd) : nullptr;
                 a.Rpn = use_pk ? Rpk.p + (size_t)j * rpd : nullptr;
                 Mat Vj = Vall.colsview(vcols_used + (j - 1) * k, k);
                 a.V = Vj.p; a.ldv = Vj.ld;
