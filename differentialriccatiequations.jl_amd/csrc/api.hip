@@ -169,6 +169,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "setup_streams") ctx->c.setup_streams = (int)value;
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
+        else if (key == "dense_x_max_k") ctx->c.dense_x_max_k = (int)value;
         else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
         else if (key == "pivot_growth_warn") ctx->c.pivot_growth_warn = value;
         else if (key == "pivot_growth_fail") ctx->c.pivot_growth_fail = value;

@@ -143,6 +143,9 @@ struct Ctx {
     // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps
     // (engine.hip, ros1_dense_step); 0 disables
     int dense_x_max_n = 1536;
+    // residual factors wider than this leave the dense-X loop for the factored path (0: the fast chain's own limit ADI_FAST_MAX_K); also the
+    // switch the tests use to force that fallback in the middle of a run
+    int dense_x_max_k = 0;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;

@@ -2159,10 +2159,15 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     else side_setup();
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     if (defer_side && !spec.ran) side_setup();
-    if (!co_ok) {
-        DRE_HIP(hipStreamSynchronize(ctx->stream));         // the kernels above read buffers that go out of scope with this frame
-        return false;
-    }
+    // Leaving early (refusal or exception) after the side stream was set up: the caller falls back to the generic ADI on the MAIN stream
+    // with the same factor cache, whose entries (stacks, dense inverses, SMW products) and op.Vt the side stream may still be touching
+    // (ADVICE round 2).  Join both streams on the host before anything of this frame is released or reused.
+    auto join_side = [&]() {
+        if (wctx != ctx) (void)hipStreamSynchronize(wctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    };
+    struct SideGuard { std::function<void()> f; bool armed = true; ~SideGuard() { if (armed) f(); } } side_guard{join_side};
+    if (!co_ok) return false;
     sx.mark(ctx, 2);
     const int k = sb.J;
     DevArr<AdiState> st(ctx, 1);
@@ -2170,7 +2175,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 3);
     ar = AdiResult();
     ar.rhs_cols = k;
-    if (k > ADI_FAST_MAX_K) return false;
+    if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return false;
     std::vector<Mat> keepV;
     Mat Vall, Wall;
     int acc_total = 0;
@@ -2330,6 +2335,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     gemm(ctx, false, false, 1.0, sx.P1, prob.B, 0.0, Kt);
     sx.Kt = Kt;
     sx.mark(ctx, 6);
+    side_guard.armed = false;          // the main stream waited for side_e2 above: nothing of the side stream is pending
     return true;
 }
 

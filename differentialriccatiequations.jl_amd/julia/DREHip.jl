@@ -106,6 +106,12 @@ Base.:+(X::LDLᵀ, Y::LDLᵀ) = LDLᵀ(vcat(X.alphas, Y.alphas), vcat(X.Ls, Y.Ls
 function to_device(ctx::Context, p::Union{Nothing,Pencil}, X::LDLᵀ)
     pp = p === nothing ? C_NULL : p.ptr
     h = C_NULL
+    if isempty(X.Ls)                  # zero(X): no blocks (src/LDLt.jl:62-66) -> an explicit zero object, never a NULL handle
+        p === nothing && throw(ArgumentError("a zero LDLᵀ (no blocks) takes its dimension from a pencil"))
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        chk(ctx, ccall((:dre_ldlt_zero, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ref{Ptr{Cvoid}}), ctx.ptr, pp, p.n, out))
+        return out[]
+    end
     for (a, L, D) in zip(X.alphas, X.Ls, X.Ds)
         Ld, Dd = upload(ctx, L), upload(ctx, D)
         out = Ref{Ptr{Cvoid}}(C_NULL)
@@ -254,6 +260,12 @@ function gale_operands(ctx, prob::GALEProblem, X0)
     Xh = X0 === nothing ? C_NULL : to_device(ctx, pencil, X0)
     (; pencil, α, Ud, Vd, Ch, Xh)
 end
+"device LDLᵀ handles made by gale_operands belong to the call that made them (ADVICE round 2: they leaked n×k doubles per call)"
+function free_operands(ctx, o)
+    o.Ch == C_NULL || ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, o.Ch)
+    o.Xh == C_NULL || ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, o.Xh)
+    nothing
+end
 dptr(x) = x === nothing ? C_NULL : x.ptr
 
 "iteration record of a finished ADI run (dre_adi_result_info / dre_adi_result_history)"
@@ -302,7 +314,7 @@ function CommonSolve.init(prob::GALEProblem, alg::ADI; initial_guess=nothing, ob
         (Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{AdiOptionsC}, Ref{Ptr{Cvoid}}),
         ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Ch, o.Xh, Ref(opt), out))
     s = ADISolver(retain!(ctx), out[], prob, alg, observer, (o, keep))
-    finalizer(x -> (ccall((:dre_adi_free, LIB), Cint, (Ptr{Cvoid},), x.ptr); release!(x.ctx)), s)
+    finalizer(x -> (ccall((:dre_adi_free, LIB), Cint, (Ptr{Cvoid},), x.ptr); free_operands(x.ctx, x.keep[1]); release!(x.ctx)), s)
 end
 isdone(s::ADISolver) = (d = Ref{Cint}(0); ccall((:dre_adi_isdone, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), s.ptr, d); d[] != 0)
 CommonSolve.step!(s::ADISolver) = (chk(s.ctx, ccall((:dre_adi_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, s.ptr)); s)
@@ -332,6 +344,7 @@ function residual(prob::GALEProblem, X::LDLᵀ; ctx::Context=default_context())
                    ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Ch, o.Xh, out))
     R = from_device(ctx, out[])
     ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, out[])
+    free_operands(ctx, o)
     R
 end
 
@@ -354,6 +367,7 @@ function lyapunov_apply(prob::GALEProblem, X::LDLᵀ; ctx::Context=default_conte
                    ctx.ptr, o.pencil.ptr, 1.0, 0.0, o.α, dptr(o.Ud), dptr(o.Vd), o.Xh, out))
     R = from_device(ctx, out[])
     ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.ptr, out[])
+    free_operands(ctx, o)
     R
 end
 

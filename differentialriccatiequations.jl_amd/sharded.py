@@ -229,8 +229,8 @@ class ColumnShardedADI:
     def _norm(self, R: torch.Tensor, S: torch.Tensor) -> float:
         r0, r1 = row_range(R.shape[0], self.comm.rank, self.comm.world)
         G = self.comm.all_reduce_sum(self.ops.gram_rows(R, r0, r1).contiguous())       # k x k all_reduce
-        M = (S.to(G.device) @ G).cpu().numpy() if S.shape[0] <= 2048 else None
-        return float(np.sqrt(max(np.sum(M * M.T), 0.0)))
+        M = S.to(G.device) @ G                  # ||R S R'||_F^2 = tr((S G)^2) = sum_ij M_ij M_ji, any width
+        return float(torch.sqrt(torch.clamp(torch.sum(M * M.T), min=0.0)).item())
 
     def solve(self, G: np.ndarray, S: np.ndarray):
         ops, comm = self.ops, self.comm

@@ -217,7 +217,8 @@ def steel_profile(n: int, convection: float = 0.0) -> SteelProfileData:
     if key in _CACHE:
         return _CACHE[key]
     d = os.environ.get("DRE_RAIL_DIR")
-    if d and os.path.exists(os.path.join(d, f"rail_{n}.npz")):
+    # the convection variant is a property of the SURROGATE (its mesh): real Rail files are symmetric and are never substituted for it
+    if d and convection == 0.0 and os.path.exists(os.path.join(d, f"rail_{n}.npz")):
         z = np.load(os.path.join(d, f"rail_{n}.npz"))
         E = sp.csc_matrix((z["E_data"], z["E_indices"], z["E_indptr"]), shape=(n, n))
         A = sp.csc_matrix((z["A_data"], z["A_indices"], z["A_indptr"]), shape=(n, n))
