@@ -40,11 +40,129 @@ def parse():
     ap.add_argument("--n", type=int, default=371, help="SteelProfile size (371 = the configuration the metric is quoted on)")
     ap.add_argument("--nsteps", type=int, default=45, help="Rosenbrock time steps per solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-path", action="store_true", help="skip the SteelProfile(5177) general-path leg (rank 0 at N = 1, n = 371 only)")
     ap.add_argument("--mode", choices=["replicas", "strong"], default="replicas",
                     help="replicas (default, weak scaling): one independent GDRE solve per GPU; strong: ONE Lyapunov solve of the first Rosenbrock "
                          "step column-sharded over the GPUs (dre_amd.sharded: all_gather of V per ADI step over RCCL)")
     ap.add_argument("--cpu-steps", type=int, default=8, help="Rosenbrock time steps of the bounded CPU-baseline sample")
     return ap.parse_args()
+
+
+def roofline_record(stats, n, m, pencil, its_solve, kw, wall):
+    """Dominant kernel class (largest share of device time over BOTH streams of the context; dre_prof_* merges the side context) with its
+    algorithmic bytes / flops per launch over the HIP-event time per launch, plus the whole solve against SURVEY 8(d) B_iter."""
+    if not stats:
+        return None
+    name, s = max(stats.items(), key=lambda kv: kv[1]["ms"])
+    total_ms = sum(v["ms"] for v in stats.values())
+    avg_s = s["ms"] * 1e-3 / max(s["launches"], 1)
+    if s["flops"] > 0 and s["bytes"] > 0 and s["flops"] / s["bytes"] > 12.0:
+        ach = s["flops"] / max(s["launches"], 1) / avg_s / 1e12
+        roof = dict(bound="mfma", kernel=name, achieved=ach, peak=78.6, unit="TFLOP/s", frac=ach / 78.6, traffic=None)
+    else:
+        ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
+        roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
+    roof["algorithmic_bytes_per_launch"] = s["bytes"] / max(s["launches"], 1)
+    roof["algorithmic_flops_per_launch"] = s["flops"] / max(s["launches"], 1)
+    for rnd in ("r03", "r02"):
+        try:
+            pmc_file = f"pmc_traffic_{rnd}_n{n}.json"
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
+            sym = KERNEL_SYMBOL.get(name)
+            hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
+            if hits:
+                tot_l = sum(h["launches"] for h in hits)
+                roof["traffic"] = sum(h["fabric_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
+                roof["traffic_source"] = (f"profiles/{pmc_file}: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE in separate passes; these are L2-fabric "
+                                          "bytes, Infinity-Cache hits included (the working set of this size is MALL resident), not pure HBM bytes")
+                break
+        except Exception:
+            pass
+    roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
+                measured_on="one extra profiled solve after the timed region (HIP events on the library's streams, main + side context merged)")
+    roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    # whole solve against the HBM roofline: SURVEY.md 8(d) B_iter per ADI iteration, summed with the measured residual widths
+    pinfo = pencil.info()
+    z, nnzF = float(pinfo["nnz"]), float(pinfo["factor_nnz"])
+    kavg = kw / max(its_solve, 1.0)
+    b_iter = 24.0 * z + 8.0 * n + 48.0 * n * kavg + 24.0 * n * m + 24.0 * nnzF + 32.0 * n * (kavg + m)
+    ws = b_iter * its_solve / wall / 1e9
+    roof["whole_solve"] = dict(bytes_per_iteration=b_iter, avg_residual_width=kavg, achieved=ws, unit="GB/s", peak=8000.0, frac=ws / 8000.0,
+                               note="SURVEY.md 8(d) B_iter (algorithmic bytes of one real-shift ADI iteration) x ADI iterations / measured wall-clock of one solve")
+    return roof
+
+
+def parity_check(n, nsteps, Kdev_host, its):
+    """K(t) of the solve that was just timed against the oracle's committed trajectory (tests/golden/make_fixtures_r03.py): delta of
+    Stuff.jl:21 at the last time step (criterion of test/cuda.jl:95-99: < 1e-7) and the worst over all steps, plus the ADI iteration counts
+    of every Lyapunov solve.  Fixtures exist for the metric's configuration (n = 371, 45 steps), n = 1357 (45 steps) and n = 5177 (12 steps)."""
+    name = {(371, 45): "ros1_371_full", (1357, 45): "ros1_1357_full", (5177, 12): "ros1_5177_long"}.get((n, nsteps))
+    if name is None:
+        return None
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+    def delta(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(a), np.linalg.norm(b)))
+    K = [Kdev_host[i].T for i in range(nsteps + 1)]          # block i holds the m x n matrix K(t_i) column-major
+    if "K" in g.files:
+        ds = [delta(K[i], g["K"][i]) for i in range(1, nsteps + 1)]
+    else:
+        ds = [delta(K[i][:, ::16], g["K_cols"][i]) for i in range(1, nsteps + 1)]
+    rec = dict(fixture=f"tests/golden/{name}.npz", delta_K_end=ds[-1], delta_K_worst=max(ds), criterion="delta < 1e-7 (test/cuda.jl:95-99)",
+               iteration_counts_equal_oracle=bool(list(its) == [int(v) for v in g["iters"]]))
+    if not (rec["delta_K_worst"] < 1e-7 and rec["iteration_counts_equal_oracle"]):
+        raise SystemExit(f"bench.py: PARITY FAILURE against {name}: {rec}")
+    return rec
+
+
+def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1):
+    """The general sparse path (multifrontal sweeps, factored X, sketch compression — everything the n <= 1536 dense special case is not),
+    measured in the same run: SteelProfile(5177) Ros1 LRSIF, 12 time steps, Cyclic real shifts; parity against ros1_5177_long.npz."""
+    import torch
+    lib = ctx.lib
+    d = D.steel_profile(n)
+    L, Dm = D.initial_value(d)
+    shifts = np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy"))
+    pencil = D.Pencil(d.E, d.A, ctx)
+    Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
+    X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm, 1.0)
+    opt, keep = D.device.make_adi_options(shift_kind=0, shifts=list(shifts), maxiters=200)
+    m = d.B.shape[1]
+    Kdev = torch.empty((nsteps + 1, n, m), dtype=torch.float64, device="cuda")
+    t0, dt = 4500.0, -100.0
+    rec = {}
+
+    def one():
+        r = C.c_void_p()
+        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, t0 + dt * nsteps, dt, 1, 0, C.byref(opt), C.byref(r)))
+        ii = (C.c_int64 * 7)()
+        lib.dre_gdre_result_info(r, ii)
+        ctx.chk(lib.dre_gdre_result_K_device(ctx.ptr, r, C.c_void_p(Kdev.data_ptr())))
+        its, kw = [], 0.0
+        for j in range(ii[4]):
+            gi = (C.c_int64 * 4)(); gd = (C.c_double * 2)()
+            lib.dre_gdre_result_gale(r, j, gi, gd)
+            its.append(int(gi[0])); kw += float(gi[0]) * float(gi[3])
+        lib.dre_gdre_result_free(r)
+        rec.update(its=its, kw=kw, nfac=int(ii[3]))
+        return int(ii[2])
+    for _ in range(warmup):
+        one()
+    ctx.sync(); torch.cuda.synchronize()
+    ts = time.perf_counter()
+    iters = sum(one() for _ in range(steps))
+    ctx.sync(); torch.cuda.synchronize()
+    el = time.perf_counter() - ts
+    ctx.prof_reset(); ctx.prof_enable(True)
+    one()
+    stats = ctx.prof_stats()
+    ctx.prof_enable(False)
+    roof = roofline_record(stats, n, m, pencil, iters / steps, rec["kw"], el / steps)
+    par = parity_check(n, nsteps, Kdev.cpu().numpy(), rec["its"])
+    return dict(workload=f"SteelProfile({n}) surrogate, Ros1 LRSIF, Cyclic real shifts, {nsteps} time steps (tspan=(4500,{t0 + dt * nsteps:g}), dt=-100): "
+                         "multifrontal sweeps + factored X + sketch compression", n=n, nsteps=nsteps, steps=steps, warmup=warmup,
+                value=iters / el, unit="ADI iterations/s", ms_per_step=el / steps * 1e3, adi_iterations_per_solve=iters / steps,
+                sparse_factorizations_per_solve=rec["nfac"], roofline=roof, parity=par)
 
 
 def launch_ranks(args):
@@ -160,12 +278,14 @@ def main():
         ngale = ii[4]
         nconv = 0
         kw = 0.0                      # sum over Lyapunov solves of iterations x residual width (for the whole-solve byte count)
+        its = []
         for j in range(ngale):
             gi = (C.c_int64 * 4)(); gd = (C.c_double * 2)()
             lib.dre_gdre_result_gale(r, j, gi, gd)
             nconv += int(gi[1])
             kw += float(gi[0]) * float(gi[3])
-        width["kw"] = kw
+            its.append(int(gi[0]))
+        width["kw"] = kw; width["its"] = its
         lib.dre_gdre_result_free(r)
         if world > 1 and gather:
             gather_trajectories(Kdev, world)     # RCCL over xGMI: the K(t) feedback trajectories of all replicas
@@ -191,51 +311,20 @@ def main():
 
     out = None
     if rank == 0:
+        its_last = width["its"]
         # ---- roofline leg: one extra identical solve with per-kernel HIP-event timing on the library stream
         ctx.prof_reset()
         ctx.prof_enable(True)
         one_solve(gather=False)      # collectives stay matched across ranks: the profiled solve does not gather
         stats = ctx.prof_stats()
         ctx.prof_enable(False)
-        roof = None
-        if stats:
-            # dominant kernel class over BOTH streams of the context (dre_prof_* merges the side context)
-            name, s = max(stats.items(), key=lambda kv: kv[1]["ms"])
-            total_ms = sum(v["ms"] for v in stats.values())
-            avg_s = s["ms"] * 1e-3 / max(s["launches"], 1)
-            if s["flops"] > 0 and s["bytes"] > 0 and s["flops"] / s["bytes"] > 12.0:
-                ach = s["flops"] / max(s["launches"], 1) / avg_s / 1e12
-                roof = dict(bound="mfma", kernel=name, achieved=ach, peak=78.6, unit="TFLOP/s", frac=ach / 78.6, traffic=None)
-            else:
-                ach = s["bytes"] / max(s["launches"], 1) / avg_s / 1e9
-                roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
-            roof["algorithmic_bytes_per_launch"] = s["bytes"] / max(s["launches"], 1)
-            roof["algorithmic_flops_per_launch"] = s["flops"] / max(s["launches"], 1)
-            try:
-                pmc_file = f"pmc_traffic_r02_n{n}.json"
-                pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-                sym = KERNEL_SYMBOL.get(name)
-                hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
-                if hits:
-                    tot_l = sum(h["launches"] for h in hits)
-                    roof["traffic"] = sum(h["fabric_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
-                    roof["traffic_source"] = (f"profiles/{pmc_file}: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE in separate passes; these are L2-fabric "
-                                              "bytes, Infinity-Cache hits included (the working set of this size is MALL resident), not pure HBM bytes")
-            except Exception:
-                pass
-            roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
-                        measured_on="one extra profiled solve after the timed region (HIP events on the library's streams, main + side context merged)")
-            roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
-            # whole solve against the HBM roofline: SURVEY.md §8(d) B_iter per ADI iteration, summed with the measured residual widths
-            pinfo = pencil.info()
-            z, nnzF = float(pinfo["nnz"]), float(pinfo["factor_nnz"])
-            its_solve = total_iters / (args.steps * world)
-            kavg = width["kw"] / max(its_solve, 1.0)
-            b_iter = 24.0 * z + 8.0 * n + 48.0 * n * kavg + 24.0 * n * m + 24.0 * nnzF + 32.0 * n * (kavg + m)
-            wall = elapsed / args.steps
-            ws = b_iter * its_solve / wall / 1e9
-            roof["whole_solve"] = dict(bytes_per_iteration=b_iter, avg_residual_width=kavg, achieved=ws, unit="GB/s", peak=8000.0, frac=ws / 8000.0,
-                                       note="SURVEY.md §8(d) B_iter (algorithmic bytes of one real-shift ADI iteration) x ADI iterations / measured wall-clock of one solve")
+        roof = roofline_record(stats, n, m, pencil, total_iters / (args.steps * world), width["kw"], elapsed / args.steps)
+        # ---- parity leg (after the timed region): the K(t) trajectory of the last timed solve of rank 0 against the committed oracle fixture
+        parity = parity_check(n, args.nsteps, Kdev.cpu().numpy(), its_last)
+        # ---- general path leg: the sparse multifrontal path north_star names, in the driver-timed record
+        general = None
+        if world == 1 and n == 371 and not args.no_general_path:
+            general = general_path(D, ctx, args)
         # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample.
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
         # so a two-step probe picks the fastest of a few thread counts and the sample runs with that one.
@@ -299,9 +388,11 @@ def main():
                        "adi_iterations_per_solve": total_iters / (args.steps * world),
                        "lyapunov_solves_converged": f"{nconv}/{ngale}",
                        "sparse_factorizations_per_solve": nfac,
+                       "parity": parity,
                        "parallelism": f"replicas x{world}" + (" + RCCL all_gather of K(t)" if world > 1 else "")},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "general_path": general,
         }
     if world > 1:
         dist.barrier()

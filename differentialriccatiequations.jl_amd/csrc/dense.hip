@@ -6,6 +6,16 @@
 #include <chrono>
 
 namespace dre {
+// Termination tolerance of the band reductions.  st->abstol > 0: absolute; <= 0: relative, tolfac * eps * ||S||_F.  Floor mode
+// (st->maxiters == BAND_TOL_FLOOR, set by k_band_init / lr_band_reduce): max(relative, st->abstol) — the caller's estimate of the rounding
+// noise with which S was FORMED (sums with cancellation: ||S|| << ||L||^2 ||D||, where the relative tolerance alone would keep the noise
+// as signal; engine.hip, ldlt_compress COMPRESS_NOISE_FLOOR).
+#define BAND_TOL_FLOOR 0x7F100D
+__device__ inline double band_tol(const AdiState* st, double tolfac, double base) {
+    const double rel = tolfac * 2.220446049250313e-16 * sqrt(base), a = st->abstol;
+    if (st->maxiters == BAND_TOL_FLOOR) return fmax(rel, a);
+    return a > 0.0 ? a : rel;
+}
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -1925,12 +1935,12 @@ __global__ __launch_bounds__(1024) void k_qr_panel(double* __restrict__ A, int l
     if (part) {
         // fused termination test of the band reduction (was a kernel of its own): the previous launch left `nparts`
         // partial sums of the not-yet-reduced norm; every thread evaluates the same fixed-order sum.
-        const double resn = st->res_norm, atol = st->abstol;
+        const double resn = st->res_norm;
         double r2 = 0.0;
         for (int i = (threadIdx.x & 63); i < nparts; i += 64) r2 += part[i];
         r2 = wave_sum(r2);
         const double base = (kpanel == 0) ? r2 : resn;
-        const double tol = atol > 0.0 ? atol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const double tol = band_tol(st, tolfac, base);
         const bool stop = r2 <= tol * tol;
         __syncthreads();          // everybody has read res_norm / done before thread 0 updates them
         if (threadIdx.x == 0) {
@@ -2319,12 +2329,12 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
     if (st && st->done) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (part) {
-        const double resn = st->res_norm, atol = st->abstol;
+        const double resn = st->res_norm;
         double r2 = 0.0;
         for (int i = lane; i < nparts; i += 64) r2 += part[i];
         r2 = wave_sum(r2);
         const double base = (kpanel == 0) ? r2 : resn;
-        const double tol = atol > 0.0 ? atol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const double tol = band_tol(st, tolfac, base);
         const bool stop = r2 <= tol * tol;
         __syncthreads();
         if (tid == 0) {
@@ -2671,7 +2681,7 @@ struct TridiagInfo { int jdim; int nref; double snorm; };
 // V(:, j) receives reflector j (v[j+1] = 1, zeros above; V pre-zeroed), d/e the tridiagonal.
 __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S, int lds_, double* __restrict__ V, int ldv,
                                                   double* __restrict__ tau_out, double* __restrict__ d, double* __restrict__ e,
-                                                  double tolfac, double abs_tol, TridiagInfo* info) {
+                                                  double tolfac, double abs_tol, TridiagInfo* info, int floor_mode) {
     extern __shared__ double sm[];
     double* v = sm;          // q
     double* w = sm + q;      // q
@@ -2686,7 +2696,7 @@ __global__ __launch_bounds__(1024) void k_tridiag(int q, double* __restrict__ S,
     }
     double rem2 = block_sum(s, red);          // ||S[j:, j:]||_F^2 for j = 0
     const double snorm = sqrt(rem2);
-    const double tol = abs_tol > 0.0 ? abs_tol : tolfac * 2.220446049250313e-16 * snorm;
+    const double tol = floor_mode ? fmax(tolfac * 2.220446049250313e-16 * snorm, abs_tol) : (abs_tol > 0.0 ? abs_tol : tolfac * 2.220446049250313e-16 * snorm);
     const double tol2 = tol * tol;
     int jdim = q, nref = 0;
     double eprev = 0.0;
@@ -2869,7 +2879,7 @@ __global__ void k_tri_to_dense(int n, const double* __restrict__ d, const double
     A[r + (size_t)c * lda] = v;
 }
 
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol) {
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol, bool tol_is_floor) {
     DRE_REQUIRE(S.rows == S.cols, "sym_eig: square matrix expected");
     SymEig out;
     const int q = S.rows;
@@ -2889,7 +2899,7 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol) {
         if (shm > 60 * 1024) {
             lds_attr(ctx, (const void*)k_tridiag, 140 * 1024);
         }
-        hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, abs_tol, info.p);
+        hipLaunchKernelGGL(k_tridiag, dim3(1), dim3(1024), shm, ctx->stream, q, S.p, S.ld, out.V.p, out.V.ld, out.tau.p, d.p, e.p, tolfac, abs_tol, info.p, tol_is_floor ? 1 : 0);
     }
     TridiagInfo hi;
     DRE_HIP(hipMemcpyAsync(&hi, info.p, sizeof(hi), hipMemcpyDeviceToHost, ctx->stream));
@@ -3001,7 +3011,7 @@ __global__ void k_band_decide(int k, int nparts, const double* __restrict__ part
     double r2 = 0.0;
     for (int i = 0; i < nparts; ++i) r2 += part[i];
     if (k == 0) st->res_norm = r2;
-    const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(st->res_norm);
+    const double tol = band_tol(st, tolfac, st->res_norm);
     if (r2 <= tol * tol) { st->done = 1; st->iters = k; }
 }
 // Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup.
@@ -3278,8 +3288,8 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
 }
 
 // control block of a reduction set up on the device (abs_tol_dev: the tolerance only exists in device memory)
-__global__ void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev) {
-    st->done = 0; st->iters = 0; st->maxiters = 0; st->smw_singular = 0;
+__global__ void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev, int floor_mode) {
+    st->done = 0; st->iters = 0; st->maxiters = floor_mode ? BAND_TOL_FLOOR : 0; st->smw_singular = 0;
     st->abstol = abs_tol_dev ? abs_tol_dev[0] : abs_tol;
     st->res_norm = 0.0;
 }
@@ -3295,7 +3305,8 @@ static bool band_fused_enabled() {
     static const bool v = !(std::getenv("DRE_BAND_FUSED") && std::atoi(std::getenv("DRE_BAND_FUSED")) == 0);
     return v;
 }
-SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev, BandSpec* spec, const double* ext_part, int ext_nparts) {
+SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev, BandSpec* spec, const double* ext_part, int ext_nparts,
+                        bool tol_is_floor) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
     SymBand out;
     const int q = S.rows, b = QR_NB;
@@ -3313,7 +3324,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     DevArr<double> part(ctx, (size_t)std::max(BAND_REM_BLOCKS, 1 + gemm_num_tiles(q, q)));
     int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
-    hipLaunchKernelGGL(k_band_init, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol, abs_tol_dev);
+    hipLaunchKernelGGL(k_band_init, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol, abs_tol_dev, tol_is_floor ? 1 : 0);
     {
         static const bool cp = std::getenv("DRE_CLOCK_PROBE") != nullptr;
         static int cp_count = 0;
@@ -3332,7 +3343,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     bool finished = false;
     // speculation depth: the previous reduction of the same kind (same order, same tolerance mode) needed `hint` panels; the
     // panel after the last one is the one whose prologue detects termination
-    const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0);
+    const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0) + (tol_is_floor ? 1000003L : 0L);
     auto hit = ctx->band_hint.find(hkey);
     int chunk = hit != ctx->band_hint.end() ? std::max(2, hit->second + 1) : 4;
     bool first_round = true;
@@ -3722,7 +3733,7 @@ __global__ __launch_bounds__(256) void k_lr_decide(int k, const double* __restri
         const double r2 = s;
         if (k == 0) st->res_norm = s / safety;
         const double base = (k == 0) ? s / safety : st->res_norm;
-        const double tol = st->abstol > 0.0 ? st->abstol : tolfac * 2.220446049250313e-16 * sqrt(base);
+        const double tol = band_tol(st, tolfac, base);
         if (r2 <= tol * tol || !(s == s)) { st->done = 1; st->iters = k; }
     }
 }
@@ -3765,7 +3776,7 @@ void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B) {      //
     gemm(ctx, false, false, -1.0, VT0, W, 1.0, B, nullptr, "gemm_band");
 }
 
-SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol) {
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol, bool tol_is_floor) {
     // Lx = [L | 16 spare columns]: the probe vectors live next to the factor and are transformed with it
     const int n = Lx.rows, c = Lx.cols - 16, b = QR_NB;
     Mat Lw = Lx.colsview(0, c);
@@ -3791,6 +3802,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
         AdiState h;
         std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
         h.abstol = abs_tol;
+        if (tol_is_floor) h.maxiters = BAND_TOL_FLOOR;
         DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipMemcpyAsync(dblocks.p, hb.data(), hb.size() * sizeof(LrBlockDev), hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipMemcpyAsync(dcol.p, hcol.data(), hcol.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));

@@ -189,7 +189,7 @@ struct SymEig {
 // Householder tridiagonalisation of S (q x q, full symmetric storage, destroyed) that stops as soon as
 // the not-yet-reduced trailing block is below tolfac*eps*||S||_F, then implicit QL on the tridiagonal.
 // want_eig = false stops after the reduction: S ~ Q_h(:,1:j) T_j Q_h(:,1:j)' with T_j = tridiag(d, e).
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true, double abs_tol = -1.0);
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true, double abs_tol = -1.0, bool tol_is_floor = false);
 Mat sym_tridiag_dense(Ctx* ctx, const SymEig& e);    // T_j as a dense j x j matrix
 // B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host); with an empty Z the identity is used
 Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids);
@@ -216,7 +216,8 @@ struct BandSpec {
     bool ran = false;
 };
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr, BandSpec* spec = nullptr,
-                        const double* ext_part = nullptr, int ext_nparts = 0);   // abs_tol_dev: the tolerance lives in device memory
+                        const double* ext_part = nullptr, int ext_nparts = 0, bool tol_is_floor = false);   // abs_tol_dev: the tolerance lives in device memory;
+                        // tol_is_floor: tolerance = max(relative, abs_tol) (formation noise of sums with cancellation)
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 // The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
 // neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).
@@ -224,6 +225,6 @@ bool lead_rotation_enabled();
 void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0);                        // L <- Q0' L,  Q0 = I - VT0 V0' from QR(L[:, 0:16])
 void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B);      // B <- Q0 B
 struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };
-SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0);   // Lx = [L | 16 spare columns]
+SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0, bool tol_is_floor = false);   // Lx = [L | 16 spare columns]
 
 }  // namespace dre

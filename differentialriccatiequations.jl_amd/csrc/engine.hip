@@ -248,8 +248,43 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     return true;
 }
 
-void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol) {
+// Rounding noise of forming S = A B' (A, B: n x c) in the probabilistic model: entry (i, j) is off by ~ eps sqrt(sum_k (a_ik b_jk)^2), hence
+// ||noise||_F^2 ~ eps^2 sum_k ||A[:,k]||^2 ||B[:,k]||^2 — the pairing of the columns matters (for Ros2's stage-1 right-hand side the large
+// blocks A'L never meet each other: a bound by ||A||_F ||B||_F overestimates the noise by orders of magnitude and truncates signal).
+__global__ __launch_bounds__(256) void k_colpair_noise(int n, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb, double* __restrict__ part) {
+    __shared__ double red[8];
+    const int k = blockIdx.x;
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double a = A[i + (size_t)k * lda], b = B[i + (size_t)k * ldb]; sa += a * a; sb += b * b; }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sa; red[4 + (threadIdx.x >> 6)] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) part[k] = ((red[0] + red[1]) + (red[2] + red[3])) * ((red[4] + red[5]) + (red[6] + red[7]));
+}
+__global__ __launch_bounds__(256) void k_noise_floor(int c, double fac, const double* __restrict__ part, double* __restrict__ floor_out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < c; i += 256) s += part[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) floor_out[0] = fac * 2.220446049250313e-16 * sqrt((red[0] + red[1]) + (red[2] + red[3]));
+}
+static double noise_floor_fac() {
+    static const double f = std::getenv("DRE_NOISE_FLOOR_FAC") ? std::atof(std::getenv("DRE_NOISE_FLOOR_FAC")) : 4.0;    // 0.03 ... 4: same K(t) to 2e-14 (tools/dbg_ros2_full.py)
+    return f;
+}
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode) {
     const int n = X.n, c = X.rank();
+    const bool nfloor = !exact && (mode & COMPRESS_NOISE_FLOOR), keep_result = !exact && (mode & COMPRESS_KEEP_RESULT);
+    if (nfloor) abs_tol = -1.0;
+    DevArr<double> nf;                       // [0] the floor, [1..] per-column products
+    auto floor_of = [&](const Mat& A, const Mat& B) {       // device-side floor for S = A B'
+        nf = DevArr<double>(ctx, (size_t)A.cols + 1);
+        hipLaunchKernelGGL(k_colpair_noise, dim3(A.cols), dim3(256), 0, ctx->stream, A.rows, (const double*)A.p, A.ld, (const double*)B.p, B.ld, nf.p + 1);
+        hipLaunchKernelGGL(k_noise_floor, dim3(1), dim3(256), 0, ctx->stream, A.cols, noise_floor_fac(), (const double*)(nf.p + 1), nf.p);
+    };
+    auto floor_host = [&]() { double h = 0.0; DRE_HIP(hipMemcpyAsync(&h, nf.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream)); DRE_HIP(hipStreamSynchronize(ctx->stream)); return h; };
     auto set_empty = [&]() {
         X.blocks.clear();
         X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true});
@@ -261,7 +296,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
     const bool wide = c >= n || (!exact && ((n <= 512 && c > 64) || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
     if (std::getenv("DRE_TRACE_COMPRESS")) std::fprintf(stderr, "[compress enter] n=%d c=%d wide=%d exact=%d abs_tol=%g factor_min_n=%d min_cols=%d sketch=%d/%d\n", n, c, (int)wide, (int)exact, abs_tol, ctx->compress_factor_min_n, ctx->compress_factor_min_cols, ctx->compress_sketch, ctx->compress_sketch_min_cols);
     const long skey = -(4000000000L + (long)n);          // band_hint: rank of the previous wide-factor compression at this order
-    const bool sketchable = !wide && !exact && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && c >= ctx->compress_sketch_min_cols && c + 64 <= n;
+    const bool sketchable = !wide && !exact && !nfloor && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && c >= ctx->compress_sketch_min_cols && c + 64 <= n;
     if (sketchable) {
         auto hit = ctx->band_hint.find(skey);
         if (hit != ctx->band_hint.end() && hit->second > 0) {
@@ -285,11 +320,19 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
             off += k;
         }
         copy_batched(ctx, cd);
-        SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, abs_tol);
+        double lr_tol = abs_tol;
+        if (nfloor) {
+            // noise of  L blockdiag(alpha_b D_b) L'  (host value: the factor-form reduction keeps its control block on the host side anyway)
+            Mat Lc = Lw.colsview(0, c), LDc(ctx, n, c);
+            mul_blockdiag(ctx, Lc, X, LDc);
+            floor_of(LDc, Lc);
+            lr_tol = floor_host();
+        }
+        SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, lr_tol, nfloor);
         ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += n; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
         if (sketchable) ctx->band_hint[skey] = std::max(sb.J, 16);
         if (sb.J == 0) { set_empty(); return; }
-        if (sb.J >= c) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
+        if (sb.J >= c && !keep_result) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
         Mat Bq = sym_band_basis(ctx, sb);
         X.blocks.clear();
         X.blocks.push_back({Bq, sb.D, 1.0, false, true});
@@ -313,6 +356,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         else { LD = Mat(ctx, n, c); Lcat = Mat(ctx, n, c); hcat_scale_blocks(ctx, X, Lcat, LD); }
         S = Mat(ctx, n, n);
         gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, S, nullptr, "gemm_compress");
+        if (nfloor) floor_of(LD, Lcat);
     } else {
         Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
         Mat A(ctx, n, c);
@@ -322,6 +366,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         mul_blockdiag(ctx, qr.R, X, RD);
         S = Mat(ctx, c, c);
         gemm(ctx, false, true, 1.0, RD, qr.R, 0.0, S, nullptr, "gemm_compress");
+        if (nfloor) floor_of(RD, qr.R);
     }
     symmetrize(ctx, S);
     Mat B, Dnew;
@@ -350,7 +395,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         if (S.rows <= 64) {
             // small problems: unblocked reduction with per-column termination gives the exact truncation rank
             // (the blocked variant can only stop at multiples of the panel width)
-            SymEig e = sym_eig(ctx, S, tolfac, false, abs_tol);
+            SymEig e = nfloor ? sym_eig(ctx, S, tolfac, false, floor_host(), true) : sym_eig(ctx, S, tolfac, false, abs_tol);
             ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += e.j;
             r = e.j;
             ctx->cstats.rank_out += r;
@@ -360,7 +405,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
             B = sym_eig_backtransform(ctx, e, ids);
             Dnew = sym_tridiag_dense(ctx, e);
         } else {
-            SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
+            SymBand sb = nfloor ? sym_band_reduce(ctx, S, tolfac, -1.0, nf.p, nullptr, nullptr, 0, true) : sym_band_reduce(ctx, S, tolfac, abs_tol);
             ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += sb.J;
             r = sb.J;
             ctx->cstats.rank_out += r;
@@ -380,7 +425,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol)
         copy_mat(ctx, B, top);
         qr_apply_q(ctx, qr, Lnew, false);
     }
-    if (!exact && r >= c) {
+    if (!exact && r >= c && !keep_result) {
         // nothing gained (numerical rank = number of columns, or a remainder that stays above the tolerance because S itself
         // carries cancellation): keep the summands as they are, concatenated
         ldlt_concatenate(ctx, X);
@@ -2571,7 +2616,13 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);
             // lowrank_ros2.jl:58 compresses here; [C', A'L, E'L] has full numerical rank q + 2r generically, so the engine's
             // compression would run to the end and hand G back (ldlt_compress): it is only attempted in the literal (exact) mode
+            // Default mode (round 3; found by the 45-step fixture): R1 is the Riccati residual at X, whose terms cancel as X approaches the steady
+            // state (||R1|| / (||G||^2 ||S||) falls below 1e-8 within ~20 steps).  The Gram form of the norm inside the ADI loop is only accurate
+            // relative to the largest term, so on the raw summands abstol = n eps ||R1|| and every residual norm became rounding noise (the solves
+            // stopped after 0 iterations and K(t) froze 1e-6 away from the oracle).  R1 is therefore always brought to ONE block with orthonormal
+            // factor, truncated at max(relative tolerance, formation noise of G S G'): nothing can cancel in that form.
             if (cex) ldlt_compress(ctx, *R1, ctf, cex);
+            else ldlt_compress(ctx, *R1, ctf, false, -1.0, COMPRESS_NOISE_FLOOR | COMPRESS_KEEP_RESULT);
             AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
             LDLtP K1 = a1.X;
             // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)

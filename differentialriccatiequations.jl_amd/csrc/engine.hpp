@@ -40,7 +40,14 @@ void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-
 // LDLt.jl:204-225.  exact = true: eigen-decomposition + threshold 100*eps*max|lambda| exactly as the reference.
 // exact = false (engine default): the early-terminated Householder reduction alone, D := T_j (tridiagonal); the
 // dropped part is below tolfac*eps*||S||_F, i.e. not larger than what the reference's threshold discards.
-void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0);
+// mode bits (engine's own compression only, exact = false):
+//   COMPRESS_NOISE_FLOOR  the truncation tolerance is max(relative, rounding noise of FORMING the sum) — for sums whose terms cancel
+//                         (||X|| << ||L||^2 ||D||: the Riccati residual that is Ros2's stage-1 right-hand side near the steady state), where
+//                         the relative tolerance alone would keep the formation noise as signal; abs_tol is ignored
+//   COMPRESS_KEEP_RESULT  never hand the summands back when nothing was gained: the result is always ONE block with orthonormal L, on which
+//                         the Gram form of the norm (adi loop) is accurate whatever cancelled in the summands
+enum { COMPRESS_NOISE_FLOOR = 1, COMPRESS_KEEP_RESULT = 2 };
+void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0, int mode = 0);
 // residual(::GAREProblem, ::LDLt) and the feedback E'XB from the device factors of X (solver ordering throughout)
 LDLtP gare_residual_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& Ct, const Mat& S, double gamma, const Mat& B, const Mat& Rinv, double beta);
 Mat ldlt_feedback_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& B);
