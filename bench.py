@@ -42,8 +42,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-path", action="store_true", help="skip the SteelProfile(5177) general-path leg (rank 0 at N = 1, n = 371 only)")
     ap.add_argument("--mode", choices=["replicas", "strong"], default="replicas",
-                    help="replicas (default, weak scaling): one independent GDRE solve per GPU; strong: ONE Lyapunov solve of the first Rosenbrock "
-                         "step column-sharded over the GPUs (dre_amd.sharded: all_gather of V per ADI step over RCCL)")
+                    help="replicas (default, weak scaling): one independent GDRE solve per GPU, K(t) gathered over RCCL; strong: ONE GDRE solve, the "
+                         "same device-resident time loop on every rank with the shifted solves of every ADI step column-sharded inside the library "
+                         "(dre_comm_init: one in-place RCCL all-gather of V per ADI step); meant for --n 5177 / 20209 (BASELINE configs[3], [4])")
+    ap.add_argument("--gather", choices=["lib", "torch"], default="lib",
+                    help="replicas mode, N > 1: gather K(t) with the library's own communicator (dre_comm_allgather, default) or torch.distributed")
+    ap.add_argument("--save-state", action="store_true", help="save_state=true (BASELINE configs[4]): every X(t) is kept, X stays factored")
     ap.add_argument("--cpu-steps", type=int, default=8, help="Rosenbrock time steps of the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -181,50 +185,6 @@ def launch_ranks(args):
     raise SystemExit(proc.returncode)
 
 
-def strong_mode(args, D, d, L, Dm, shifts, ctx, pencil, rank, world, local_rank, torch, dist):
-    """Strong scaling: ONE Lyapunov solve (the first Rosenbrock-1 step's equation, zero initial guess) per "step", its residual block
-    column-sharded over the ranks (dre_amd/sharded.py).  The loop is host driven per ADI step (one all_gather each), so at small n it is
-    far slower than the device-resident single-GPU engine; it exists to measure the exchange pattern at n >= 5177."""
-    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps
-    n, tau = args.n, 100.0
-    K0 = (d.B.T @ L) @ Dm @ (L.T @ d.E)
-    G = np.hstack([d.C.T, d.E.T @ L])
-    BtLD = (d.B.T @ L) @ Dm
-    q = d.C.shape[0]
-    S = np.zeros((G.shape[1],) * 2); S[:q, :q] = np.eye(q); S[q:, q:] = BtLD.T @ BtLD + Dm / tau
-    comm = Comm()
-    ops = HipOps(ctx, pencil, 1.0, -1.0 / (2 * tau), d.B, K0, alpha=-1.0, device=torch.device("cuda", local_rank))
-    solver = ColumnShardedADI(ops, comm, list(shifts), maxiters=200)
-
-    def barrier():
-        ctx.sync(); torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-    for _ in range(args.warmup):
-        res = solver.solve(G, S)
-    barrier()
-    t_start = time.perf_counter()
-    iters = 0
-    for _ in range(args.steps):
-        res = solver.solve(G, S)
-        iters += res["iters"]
-    barrier()
-    elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.barrier(); dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps({"metric": "ADI iterations/sec (one Lyapunov solve, column-sharded)", "value": iters / float(el.item()), "unit": "ADI iterations/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(el.item()) / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"SteelProfile({n}) surrogate, first Ros1 Lyapunov equation (zero initial guess, {G.shape[1]} residual columns), "
-                                                 f"Cyclic real shifts, column-sharded ADI", "adi_iterations_per_solve": iters / args.steps,
-                                     "converged": bool(res["converged"]), "parallelism": f"columns x{world}, all_gather of V per ADI step",
-                                     "bytes_gathered_per_rank_per_solve": comm.bytes_gathered / max(args.steps + args.warmup, 1)},
-                          "roofline": None, "cpu_baseline": None}))
-
-
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -257,21 +217,29 @@ def main():
     ctx = D.Context(local_rank)
     lib = ctx.lib
     pencil = D.Pencil(d.E, d.A, ctx)
-    if args.mode == "strong":
-        return strong_mode(args, D, d, L, Dm, shifts, ctx, pencil, rank, world, local_rank, torch, dist)
-    # independent replicas: rank r starts from a slightly different X0 (0.01 * (1 + r/8) * L L')
+    strong = args.mode == "strong"
+    # The communicator lives INSIDE the library (RCCL over xGMI on the library stream).  replicas: it gathers the K(t) trajectories;
+    # strong: it carries the one all-gather of V per ADI step of the column-sharded solve.  torch.distributed only hands the unique id around.
+    from dre_amd.replicas import attach_communicator
+    use_lib_comm = strong or (world > 1 and args.gather == "lib")
+    if use_lib_comm:
+        attach_communicator(ctx, rank, world)
+        if not strong:
+            ctx.set_option("shard_min_cols", 1 << 30)        # replicas: the communicator only gathers K(t), every rank solves its own problem
+    # replicas: rank r starts from a slightly different X0 (0.01 * (1 + r/8) * L L'); strong: the SAME problem on every rank
     Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
-    X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm * (1.0 + rank / 8.0), 1.0)
-    opt, keep = D.device.make_adi_options(shift_kind=0, shifts=list(shifts))
+    X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm * (1.0 if strong else 1.0 + rank / 8.0), 1.0)
+    opt, keep = D.device.make_adi_options(shift_kind=0, shifts=list(shifts), maxiters=100 if n <= 371 else 200)
     m = d.B.shape[1]
     nt = args.nsteps + 1
     Kdev = torch.empty((nt, n, m), dtype=torch.float64, device="cuda")       # nt blocks of m x n column-major
+    Kall = torch.empty((world, nt, n, m), dtype=torch.float64, device="cuda") if (world > 1 and not strong) else None
 
     width = {"kw": 0.0}
 
     def one_solve(gather=True):
         r = C.c_void_p()
-        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, tf, dt, 1, 0, C.byref(opt), C.byref(r)))
+        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, tf, dt, 1, 1 if args.save_state else 0, C.byref(opt), C.byref(r)))
         ii = (C.c_int64 * 7)()
         lib.dre_gdre_result_info(r, ii)
         ctx.chk(lib.dre_gdre_result_K_device(ctx.ptr, r, C.c_void_p(Kdev.data_ptr())))
@@ -287,8 +255,8 @@ def main():
             its.append(int(gi[0]))
         width["kw"] = kw; width["its"] = its
         lib.dre_gdre_result_free(r)
-        if world > 1 and gather:
-            gather_trajectories(Kdev, world)     # RCCL over xGMI: the K(t) feedback trajectories of all replicas
+        if Kall is not None and gather:
+            gather_trajectories(ctx if use_lib_comm else None, Kdev, Kall, world)     # RCCL over xGMI: the K(t) trajectories of all replicas
         return int(ii[2]), int(ii[3]), nconv, ngale
 
     def barrier():
@@ -308,6 +276,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed, total_iters = reduce_timing(elapsed, float(iters), torch.device('cuda', local_rank), world)
+    if strong:
+        total_iters /= world          # ONE problem: every rank counted the same iterations
 
     out = None
     if rank == 0:
@@ -318,12 +288,12 @@ def main():
         one_solve(gather=False)      # collectives stay matched across ranks: the profiled solve does not gather
         stats = ctx.prof_stats()
         ctx.prof_enable(False)
-        roof = roofline_record(stats, n, m, pencil, total_iters / (args.steps * world), width["kw"], elapsed / args.steps)
+        roof = roofline_record(stats, n, m, pencil, total_iters / (args.steps * (1 if strong else world)), width["kw"], elapsed / args.steps)
         # ---- parity leg (after the timed region): the K(t) trajectory of the last timed solve of rank 0 against the committed oracle fixture
         parity = parity_check(n, args.nsteps, Kdev.cpu().numpy(), its_last)
         # ---- general path leg: the sparse multifrontal path north_star names, in the driver-timed record
         general = None
-        if world == 1 and n == 371 and not args.no_general_path:
+        if world == 1 and n == 371 and not strong and not args.no_general_path:
             general = general_path(D, ctx, args)
         # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample.
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
@@ -379,17 +349,21 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "gdre_wall_clock_s": elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"SteelProfile({n}) surrogate, Ros1 LRSIF (LDL' X0), Cyclic real shifts (10 heuristic values), "
                                    f"tspan=(4500,{tf:g}), dt=-100, {args.nsteps} time steps",
-                       "adi_iterations_per_solve": total_iters / (args.steps * world),
+                       "adi_iterations_per_solve": total_iters / (args.steps * (1 if strong else world)),
                        "lyapunov_solves_converged": f"{nconv}/{ngale}",
                        "sparse_factorizations_per_solve": nfac,
                        "parity": parity,
-                       "parallelism": f"replicas x{world}" + (" + RCCL all_gather of K(t)" if world > 1 else "")},
+                       "save_state": bool(args.save_state),
+                       "parallelism": (f"ONE solve, ADI solves column-sharded x{world} inside the library (RCCL all-gather of V per ADI step)" if strong else
+                                       f"replicas x{world}" + ((" + K(t) gathered by " + ("dre_comm_allgather (RCCL inside the library)" if use_lib_comm
+                                                                                          else "torch.distributed all_gather")) if world > 1 else "")),
+                       "comm": ctx.comm_info() if use_lib_comm else None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "general_path": general,

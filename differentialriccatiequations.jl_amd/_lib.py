@@ -112,6 +112,14 @@ PROTOTYPES = {
     "dre_adi_isdone": (C.c_int, [_vp, _pint]),
     "dre_adi_state": (C.c_int, [_vp, _pi64, _pd, _pd]),
     "dre_adi_finish": (C.c_int, [_vp, _vp, _pvp]),
+    "dre_comm_unique_id": (C.c_int, [_vp, _vp]),
+    "dre_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "dre_comm_free": (C.c_int, [_vp]),
+    "dre_comm_info": (C.c_int, [_vp, _pi64]),
+    "dre_comm_allgather": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "dre_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "dre_adi_snapshot": (C.c_int, [_vp, _vp, _pvp, _pvp]),
+    "dre_adi_shifts": (C.c_int, [_vp, C.c_int64, _pi64, _pd, _pd]),
     "dre_adi_free": (C.c_int, [_vp]),
     "dre_heuristic_ritz": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, C.c_int, C.c_int, _pd, _pd, _pd, _pd]),
     "dre_gale_residual": (C.c_int, [_vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _pvp]),

@@ -468,6 +468,8 @@ def _inner_solver_callback(inner_alg, E, A0):
     alg = inner_alg.alg_sparse if isinstance(inner_alg, ShermanMorrisonWoodbury) else inner_alg
     if alg is None or type(alg) is Backslash:
         return None, None
+    if isinstance(A0, ScaledPencil):          # the library hands the trampoline the combined coefficients of the base pencil (E, A)
+        A0 = A0.A
     Et, At = sp.csc_matrix(E).T.tocsc(), sp.csc_matrix(A0).T.tocsc()
     errors = []
 
@@ -574,6 +576,41 @@ def _split_operator(E, A):
     return A, None
 
 
+@dataclass
+class ScaledPencil:
+    """`cA*A + cE*E` held lazily on the pencil of (E, A): the sparse part of the Rosenbrock operators (lowrank_ros1.jl:39 `A - E/(2τ)`,
+    lowrank_ros2.jl:41 `γτA - E/2`).  The library takes the two coefficients directly (dre_adi_init cA, cE), so a time loop driven from
+    the host re-uses ONE symbolic analysis instead of building a new sparse matrix and pencil per step."""
+    A: Any
+    cA: float
+    E: Any
+    cE: float
+
+    @property
+    def shape(self):
+        return self.A.shape
+
+    def tocsc(self):
+        return (self.cA * self.A + self.cE * self.E).tocsc()
+
+
+def _needs_state(observer) -> bool:
+    """Observers that look at `X` / `residual` of intermediate ADI iterations (observe_gale_step!, adi.jl:119, Callbacks.jl:97-107) say so
+    with a truthy attribute `needs_state`: the solve is then driven through the stepwise protocol and every call gets LDLᵀ handles that
+    materialise on first access.  Without it the loop stays device resident and the hooks are replayed with norms and shifts only."""
+    return observer is not None and bool(getattr(observer, "needs_state", False))
+
+
+def _gale_operands(prob, ctx):
+    """(pencil, cA, cE, sparse part as a matrix-like, low-rank triple) of a GALE coefficient."""
+    A0, lr = _split_operator(prob.E, prob.A)
+    if isinstance(A0, ScaledPencil):
+        if A0.E is not prob.E:
+            raise ValueError("ScaledPencil: E must be the GALE's own E")
+        return _pencil_for(prob.E, A0.A, ctx), float(A0.cA), float(A0.cE), A0, lr
+    return _pencil_for(prob.E, A0, ctx), 1.0, 0.0, A0, lr
+
+
 def _adi_options(alg: ADI, pencil, lr=None, E=None, A0=None):
     kind, nh, vals = _resolve_shifts(alg.shifts, pencil, lr)
     cb, keep_cb = _inner_solver_callback(getattr(alg, "inner_alg", None), E, A0) if E is not None else (None, None)
@@ -621,8 +658,15 @@ def _adi_result_info(ctx, rptr):
 def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, observer=None, ctx=None, return_info=False):
     """solve(::GALEProblem{<:LDLᵀ}, ::ADI; initial_guess, observer)  (adi.jl:29-89)"""
     ctx = ctx or dev.default_context()
-    A0, lr = _split_operator(prob.E, prob.A)
-    pencil = _pencil_for(prob.E, A0, ctx)
+    if _needs_state(observer):
+        # the observer wants X / residual of every iteration: stepwise protocol with live hooks (same bits as the one-shot solve)
+        solver = ADISolver(prob, alg, initial_guess, observer, ctx)
+        X = solver.solve()
+        info = solver.info
+        if not info["converged"] and alg.warn_convergence:
+            warnings.warn(f"ADI did not converge: residual={info['res_norm']} abstol={info['abstol']} maxiters={alg.maxiters}")
+        return (X, info) if return_info else X
+    pencil, cA, cE, A0, lr = _gale_operands(prob, ctx)
     opt, keep = _adi_options(alg, pencil, lr, prob.E, A0)
     Cd = prob.C._to_device(ctx, pencil)
     X0d = initial_guess._to_device(ctx, pencil) if initial_guess is not None else None
@@ -632,7 +676,7 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
         alpha, Uh, Vh = lr
         U, Vt = ctx.upload(Uh), ctx.upload(np.asarray(Vh).T)
     r = C.c_void_p()
-    ctx.chk(ctx.lib.dre_gale_solve(ctx.ptr, pencil.ptr, 1.0, 0.0, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
+    ctx.chk(ctx.lib.dre_gale_solve(ctx.ptr, pencil.ptr, cA, cE, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
                                    Cd.ptr, X0d.ptr if X0d else None, C.byref(opt), C.byref(r)))
     try:
         info = _adi_result_info(ctx, r)
@@ -656,9 +700,10 @@ class ADISolver:
     def __init__(self, prob, alg, initial_guess=None, observer=None, ctx=None):
         self.ctx = ctx or dev.default_context()
         self.prob, self.alg, self.observer = prob, alg, observer
-        A0, lr = _split_operator(prob.E, prob.A)
-        self.pencil = _pencil_for(prob.E, A0, self.ctx)
+        self.pencil, cA, cE, A0, lr = _gale_operands(prob, self.ctx)
         opt, self._keep = _adi_options(alg, self.pencil, lr, prob.E, A0)
+        self._live = _needs_state(observer)
+        self._seen = 0                      # shifts already reported to a live observer
         self._Cd = prob.C._to_device(self.ctx, self.pencil)
         self._X0d = initial_guess._to_device(self.ctx, self.pencil) if initial_guess is not None else None
         self._U = self._Vt = None
@@ -667,10 +712,29 @@ class ADISolver:
             alpha, Uh, Vh = lr
             self._U, self._Vt = self.ctx.upload(Uh), self.ctx.upload(np.asarray(Vh).T)
         self._ptr = C.c_void_p()
-        self.ctx.chk(self.ctx.lib.dre_adi_init(self.ctx.ptr, self.pencil.ptr, 1.0, 0.0, float(alpha), self._U.ptr if self._U else None,
+        self.ctx.chk(self.ctx.lib.dre_adi_init(self.ctx.ptr, self.pencil.ptr, cA, cE, float(alpha), self._U.ptr if self._U else None,
                                                self._Vt.ptr if self._Vt else None, self._Cd.ptr, self._X0d.ptr if self._X0d else None,
                                                C.byref(opt), C.byref(self._ptr)))
         self._result = None
+        if self._live:                      # adi.jl:37,65: start, then the initial state as "step 0"
+            _call(observer, "observe_gale_start", prob, alg)
+            X, R = self.snapshot()
+            _call(observer, "observe_gale_step", 0, X, R, self.state()["res_norm"])
+
+    def snapshot(self):
+        """(X, residual) of the current iteration as LDLᵀ handles (dre_adi_snapshot; adi.jl:119).  Nothing is downloaded until a handle is
+        looked at (`rank()` and `norm` never download)."""
+        xp, rp = C.c_void_p(), C.c_void_p()
+        self.ctx.chk(self.ctx.lib.dre_adi_snapshot(self.ctx.ptr, self._ptr, C.byref(xp), C.byref(rp)))
+        return (LDLt([], [], [], _handle=dev.DeviceLDLt(self.ctx, xp, self.pencil)),
+                LDLt([], [], [], _handle=dev.DeviceLDLt(self.ctx, rp, self.pencil)))
+
+    def _shifts_since(self, start):
+        cnt = C.c_int64(0)
+        self.ctx.lib.dre_adi_shifts(self._ptr, int(start), C.byref(cnt), None, None)
+        re, im = np.zeros(max(cnt.value, 1)), np.zeros(max(cnt.value, 1))
+        self.ctx.lib.dre_adi_shifts(self._ptr, int(start), C.byref(cnt), re.ctypes.data_as(C.POINTER(C.c_double)), im.ctypes.data_as(C.POINTER(C.c_double)))
+        return [complex(a, b) if b != 0.0 else float(a) for a, b in zip(re[:cnt.value], im[:cnt.value])]
 
     def __del__(self):
         try:
@@ -692,10 +756,22 @@ class ADISolver:
 
     def step(self):
         self.ctx.chk(self.ctx.lib.dre_adi_step(self.ctx.ptr, self._ptr))
+        if self._live:                      # adi.jl:103,119,192: the shift(s) of this step, then the step itself with its state
+            st = self.state()
+            for mu in self._shifts_since(self._seen):
+                _call(self.observer, "observe_gale_metadata", "ADI shifts", mu)
+            if st["iters"] > self._seen:
+                X, R = self.snapshot()
+                _call(self.observer, "observe_gale_step", int(st["iters"]), X, R, st["res_norm"])
+            self._seen = st["iters"]
         return self
 
     def solve(self):
-        self.ctx.chk(self.ctx.lib.dre_adi_solve(self.ctx.ptr, self._ptr))
+        if self._live:
+            while not self.isdone():
+                self.step()
+        else:
+            self.ctx.chk(self.ctx.lib.dre_adi_solve(self.ctx.ptr, self._ptr))
         return self.X
 
     def __iter__(self):
@@ -714,8 +790,14 @@ class ADISolver:
             finally:
                 self.ctx.lib.dre_adi_result_free(r)
             self._result = (X, info)
-            _replay_gale(self.observer, self.prob, self.alg, info)
-            _call(self.observer, "observe_gale_done", info["iters"], X, None, info["res_norm"])
+            if self._live:
+                if not info["converged"]:
+                    _call(self.observer, "observe_gale_failed")
+                R = None
+            else:
+                _replay_gale(self.observer, self.prob, self.alg, info)
+                R = None
+            _call(self.observer, "observe_gale_done", info["iters"], X, R, info["res_norm"])
         return self._result
 
     @property
@@ -780,6 +862,8 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
         raise TypeError("only Ros1 and Ros2 have a low-rank formulation")
     ctx = ctx or dev.default_context()
     inner = alg.inner_alg if alg.inner_alg is not None else ADI()
+    if _needs_state(observer):
+        return _solve_gdre_observed(prob, alg, order, inner, dt, save_state, observer, ctx, return_stats)
     _call(observer, "observe_gdre_start", prob, alg)
     pencil = _pencil_for(prob.E, prob.A, ctx)
     opt, keep = _adi_options(inner, pencil, None, prob.E, prob.A)
@@ -837,6 +921,81 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     sol = DRESolution(Xs, Ks, t)
     if return_stats:
         return sol, dict(adi_iters=iters, factorizations=nfac, gales=gales)
+    return sol
+
+
+def _solve_gdre_observed(prob, alg, order, inner, dt, save_state, observer, ctx, return_stats):
+    """The Rosenbrock time loop driven from the host for observers that look at the state of every ADI iteration
+    (src/riccati/lowrank_ros1.jl:19-63, lowrank_ros2.jl:19-86): every Lyapunov solve is a device-resident stepwise solver
+    (`ADISolver`) whose hooks fire live with (X, residual) handles; feedback, right-hand sides and their compression are the library's
+    (`dre_ldlt_feedback`, `compress_`).  Same equations as the device-resident loop (`dre_gdre_solve`), which is what runs when the
+    observer does not ask for state."""
+    E, A, B, Cm = prob.E, prob.A, np.asarray(prob.B, float), np.asarray(prob.C, float)
+    q = Cm.shape[0]
+    nsteps = int(np.floor((prob.tspan[1] - prob.tspan[0]) / dt + 1e-9))
+    t = prob.tspan[0] + dt * np.arange(nsteps + 1)
+    gamma = 1.0 + 1.0 / np.sqrt(2.0)
+    _call(observer, "observe_gdre_start", prob, alg)
+
+    def feedback(X):
+        a, L, Dm = X                                   # destructuring compresses a multi-component X (LDLt.jl:54-57)
+        BtLD = a * ((B.T @ L) @ Dm)
+        EtL = np.asarray(E.T @ L)
+        return L, Dm, BtLD, EtL, BtLD @ EtL.T          # K = (B'L D)(L'E)   (lowrank_ros1.jl:25-28)
+
+    X = prob.X0
+    Xs = [X]
+    L, Dm, BtLD, EtL, K = feedback(X)
+    Ks = [K]
+    _call(observer, "observe_gdre_step", t[0], X, K)
+    gales = []
+
+    def lyap(F, rhs, guess):
+        solver = ADISolver(GALEProblem(E, F, rhs), inner, guess, observer, ctx)
+        Xn = solver.solve()
+        info = solver.info
+        gales.append(info)
+        if not info["converged"] and inner.warn_convergence:
+            warnings.warn(f"ADI did not converge: residual={info['res_norm']} abstol={info['abstol']} maxiters={inner.maxiters}")
+        return Xn
+
+    for i in range(1, nsteps + 1):
+        tau = t[i - 1] - t[i]
+        if order == 1:
+            F = lr_update(ScaledPencil(A, 1.0, E, -1.0 / (2.0 * tau)), -1.0, B, K)                       # lowrank_ros1.jl:39
+            G = np.hstack([Cm.T, EtL])
+            S = np.zeros((G.shape[1],) * 2)
+            S[:q, :q] = np.eye(q)
+            S[q:, q:] = BtLD.T @ BtLD + Dm / tau                                                          # lowrank_ros1.jl:42-43
+            rhs = compress_(lowrank(G, S))                                                                # :44
+            X = lyap(F, rhs, X)                                                                           # :47-49 (warm start)
+        else:
+            F = lr_update(ScaledPencil(A, gamma * tau, E, -0.5), -gamma * tau, B, K)                     # lowrank_ros2.jl:41
+            r = L.shape[1]
+            G = np.hstack([Cm.T, np.asarray(A.T @ L), EtL])
+            S = np.zeros((q + 2 * r,) * 2)
+            S[:q, :q] = np.eye(q)
+            S[q:q + r, q + r:] = Dm
+            S[q + r:, q:q + r] = Dm
+            S[q + r:, q + r:] = -(BtLD.T @ BtLD)                                                          # :44-55
+            K1 = lyap(F, compress_(lowrank(G, S)), None)                                                  # :58
+            a1, T1, D1 = K1
+            BtT1D1 = a1 * ((B.T @ T1) @ D1)
+            G2 = np.asarray(E.T @ T1)
+            S2 = tau * tau * (BtT1D1.T @ BtT1D1) + (2.0 - 1.0 / gamma) * (a1 * D1)                        # :61-66
+            K2 = lyap(F, lowrank(G2, S2), None)                                                           # :69
+            X = X + ((2.0 - 1.0 / (2.0 * gamma)) * tau) * K1 + (-tau / 2.0) * K2                          # :72
+        L, Dm, BtLD, EtL, K = feedback(X)
+        Ks.append(K)
+        if save_state:
+            Xs.append(X)
+        _call(observer, "observe_gdre_step", t[i], X, K)
+    if not save_state:
+        Xs.append(X)
+    _call(observer, "observe_gdre_done")
+    sol = DRESolution(Xs, Ks, t)
+    if return_stats:
+        return sol, dict(adi_iters=sum(g["iters"] for g in gales), factorizations=None, gales=gales)
     return sol
 
 

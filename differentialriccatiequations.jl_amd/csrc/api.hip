@@ -6,6 +6,7 @@
 #include <atomic>
 #include <cstring>
 
+#include "comm.hpp"
 #include "engine.hpp"
 #include "hostla.hpp"
 #include "profiling.hpp"
@@ -106,6 +107,7 @@ int dre_ctx_destroy(dre_ctx* ctx) {
     if (!ctx) return DRE_OK;
     (void)hipSetDevice(ctx->c.device);
     (void)hipStreamSynchronize(ctx->c.stream);
+    ctx->c.comm.reset();
     if (ctx->c.side) {
         Ctx& sc = *ctx->c.side;
         (void)hipStreamSynchronize(sc.stream);
@@ -170,6 +172,12 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
         else if (key == "dense_x_max_k") ctx->c.dense_x_max_k = (int)value;
+        else if (key == "shard_min_cols") ctx->c.shard_min_cols = (int)value;
+        else if (key == "shard_emulate") {
+            // ONE process plays `value` ranks of the column-sharded ADI step one after the other (tests of the blocking logic on one GPU)
+            if (!ctx->c.comm) ctx->c.comm = std::make_shared<Comm>();
+            ctx->c.comm->emulate = (int)value;
+        }
         else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
         else if (key == "pivot_growth_warn") ctx->c.pivot_growth_warn = value;
         else if (key == "pivot_growth_fail") ctx->c.pivot_growth_fail = value;
@@ -669,6 +677,20 @@ int dre_adi_state(const dre_adi_solver* s, int64_t* iters, double* res_norm, dou
     if (abstol) *abstol = at;
     return DRE_OK;
 }
+int dre_adi_shifts(const dre_adi_solver* s, int64_t from, int64_t* count, double* re, double* im) {
+    auto v = adi_shifts_since(*s->run, (int)from);
+    if (count) *count = (int64_t)v.size();
+    for (size_t i = 0; i < v.size(); ++i) { if (re) re[i] = v[i].real(); if (im) im[i] = v[i].imag(); }
+    return DRE_OK;
+}
+int dre_adi_snapshot(dre_ctx* ctx, dre_adi_solver* s, dre_ldlt** X, dre_ldlt** residual) {
+    return guarded(ctx, [&] {
+        LDLtP x, r;
+        adi_snapshot(*s->run, X ? &x : nullptr, residual ? &r : nullptr);
+        if (X) { auto* h = new dre_ldlt(); h->x = x; h->pen = s->pen; *X = h; }
+        if (residual) { auto* h = new dre_ldlt(); h->x = r; h->pen = s->pen; *residual = h; }
+    });
+}
 int dre_adi_finish(dre_ctx* ctx, dre_adi_solver* s, dre_adi_result** out) {
     return guarded(ctx, [&] {
         auto* r = new dre_adi_result();
@@ -762,6 +784,37 @@ int dre_adi_result_take_residual(dre_adi_result* r, dre_ldlt** R) {
     auto* h = new dre_ldlt(); h->x = r->r.residual; h->pen = r->pen; *R = h; return DRE_OK;
 }
 int dre_adi_result_free(dre_adi_result* r) { delete r; return DRE_OK; }
+
+// ---- communicator (RCCL over xGMI, comm.hip) ----------------------------------------------------
+int dre_comm_unique_id(dre_ctx* ctx, void* id128) { return guarded(ctx, [&] { DRE_REQUIRE(id128, "null id buffer"); comm_unique_id(id128); }); }
+int dre_comm_init(dre_ctx* ctx, int nranks, int rank, const void* id128) {
+    return guarded(ctx, [&] {
+        const int emu = ctx->c.comm ? ctx->c.comm->emulate : 0;
+        ctx->c.comm = comm_init(&ctx->c, nranks, rank, id128);
+        ctx->c.comm->emulate = emu;
+    });
+}
+int dre_comm_free(dre_ctx* ctx) {
+    return guarded(ctx, [&] { if (ctx->c.comm) { DRE_HIP(hipStreamSynchronize(ctx->c.stream)); ctx->c.comm.reset(); } });
+}
+int dre_comm_info(dre_ctx* ctx, int64_t* info) {
+    const Comm* c = ctx->c.comm.get();
+    info[0] = c ? c->nranks : 1; info[1] = c ? c->rank : 0; info[2] = c ? (int64_t)c->ncalls : 0;
+    info[3] = c ? (int64_t)c->bytes_gathered : 0; info[4] = c ? (int64_t)c->bytes_reduced : 0; info[5] = c ? c->emulate : 0;
+    return DRE_OK;
+}
+int dre_comm_allgather(dre_ctx* ctx, const void* send_dev, void* recv_dev, size_t count) {
+    return guarded(ctx, [&] {
+        DRE_REQUIRE(ctx->c.comm, "dre_comm_allgather: no communicator (dre_comm_init)");
+        comm_allgather(&ctx->c, *ctx->c.comm, (const double*)send_dev, (double*)recv_dev, count);
+    });
+}
+int dre_comm_allreduce_sum(dre_ctx* ctx, void* buf_dev, size_t count) {
+    return guarded(ctx, [&] {
+        DRE_REQUIRE(ctx->c.comm, "dre_comm_allreduce_sum: no communicator (dre_comm_init)");
+        comm_allreduce_sum(&ctx->c, *ctx->c.comm, (double*)buf_dev, count);
+    });
+}
 
 // ---- GDRE --------------------------------------------------------------------------------------
 int dre_gdre_solve(dre_ctx* ctx, const dre_pencil* p, const dre_dense* B, const dre_dense* C, dre_ldlt* X0, double t0, double tf,

@@ -1,0 +1,106 @@
+// RCCL collectives on the library's stream (comm.hpp).  librccl is resolved at run time: the same soname PyTorch-ROCm ships
+// ("librccl.so.1"), so a process that already uses torch.distributed's nccl backend shares that copy instead of loading a second one.
+#include "comm.hpp"
+
+#include <dlfcn.h>
+
+#include <mutex>
+
+namespace dre {
+
+namespace {
+// the five entry points of rccl.h this library uses (ncclUniqueId is passed BY VALUE: a 128-byte struct)
+struct UniqueId { char internal[128]; };
+using fn_get_id = int (*)(UniqueId*);
+using fn_init = int (*)(void**, int, UniqueId, int);
+using fn_destroy = int (*)(void*);
+using fn_allgather = int (*)(const void*, void*, size_t, int, void*, hipStream_t);
+using fn_allreduce = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+using fn_errstr = const char* (*)(int);
+constexpr int NCCL_FLOAT64 = 8, NCCL_SUM = 0;      // rccl.h: ncclFloat64 = 8, ncclSum = 0
+
+struct Rccl {
+    void* h = nullptr;
+    fn_get_id get_id = nullptr; fn_init init = nullptr; fn_destroy destroy = nullptr;
+    fn_allgather allgather = nullptr; fn_allreduce allreduce = nullptr; fn_errstr errstr = nullptr;
+    std::string err;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {std::getenv("DRE_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            if (!nm) continue;
+            r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+            r.err = dlerror() ? dlerror() : "dlopen failed";
+        }
+        if (!r.h) return;
+        r.get_id = (fn_get_id)dlsym(r.h, "ncclGetUniqueId");
+        r.init = (fn_init)dlsym(r.h, "ncclCommInitRank");
+        r.destroy = (fn_destroy)dlsym(r.h, "ncclCommDestroy");
+        r.allgather = (fn_allgather)dlsym(r.h, "ncclAllGather");
+        r.allreduce = (fn_allreduce)dlsym(r.h, "ncclAllReduce");
+        r.errstr = (fn_errstr)dlsym(r.h, "ncclGetErrorString");
+        if (!(r.get_id && r.init && r.destroy && r.allgather && r.allreduce)) { r.err = "librccl lacks an expected symbol"; r.h = nullptr; }
+    });
+    return r;
+}
+void need_rccl() {
+    if (!rccl().h) throw Error(ERR_INTERNAL, "RCCL is not available: " + rccl().err);
+}
+void chk(int rc, const char* what) {
+    if (rc == 0) return;
+    const char* s = rccl().errstr ? rccl().errstr(rc) : "?";
+    throw Error(ERR_INTERNAL, std::string(what) + ": RCCL error " + std::to_string(rc) + " (" + s + ")");
+}
+}  // namespace
+
+Comm::~Comm() {
+    if (nccl && rccl().destroy) (void)rccl().destroy(nccl);
+}
+
+void comm_unique_id(void* out128) {
+    need_rccl();
+    UniqueId id;
+    std::memset(&id, 0, sizeof(id));
+    chk(rccl().get_id(&id), "ncclGetUniqueId");
+    std::memcpy(out128, &id, sizeof(id));
+}
+
+std::shared_ptr<Comm> comm_init(Ctx* ctx, int nranks, int rank, const void* id128) {
+    DRE_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "dre_comm_init: rank outside [0, nranks)");
+    auto c = std::make_shared<Comm>();
+    c->nranks = nranks; c->rank = rank;
+    if (nranks == 1 && !id128) return c;                 // a single rank without an id: no RCCL object at all
+    need_rccl();
+    DRE_REQUIRE(id128 != nullptr, "dre_comm_init: the unique id of rank 0 is required for more than one rank");
+    UniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    DRE_HIP(hipSetDevice(ctx->device));
+    chk(rccl().init(&c->nccl, nranks, id, rank), "ncclCommInitRank");
+    return c;
+}
+
+void comm_allgather(Ctx* ctx, Comm& c, const double* send, double* recv, size_t count) {
+    c.ncalls++;
+    if (c.nranks == 1 || !c.nccl) {
+        if (send != recv + (size_t)c.rank * count && count)
+            DRE_HIP(hipMemcpyAsync(recv + (size_t)c.rank * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return;
+    }
+    c.bytes_gathered += count * sizeof(double) * (size_t)(c.nranks - 1);
+    chk(rccl().allgather(send, recv, count, NCCL_FLOAT64, c.nccl, ctx->stream), "ncclAllGather");
+}
+void comm_allgather_inplace(Ctx* ctx, Comm& c, double* buf, size_t count) {
+    comm_allgather(ctx, c, buf + (size_t)c.rank * count, buf, count);
+}
+void comm_allreduce_sum(Ctx* ctx, Comm& c, double* buf, size_t count) {
+    c.ncalls++;
+    if (c.nranks == 1 || !c.nccl) return;
+    c.bytes_reduced += count * sizeof(double);
+    chk(rccl().allreduce(buf, buf, count, NCCL_FLOAT64, NCCL_SUM, c.nccl, ctx->stream), "ncclAllReduce");
+}
+
+}  // namespace dre

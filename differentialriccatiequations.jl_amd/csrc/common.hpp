@@ -98,6 +98,7 @@ class DevicePool {
 };
 
 struct KernelTimer;  // profiling.hpp
+struct Comm;         // comm.hpp
 
 struct Ctx {
     int device = 0;
@@ -178,6 +179,12 @@ struct Ctx {
     // compression bookkeeping of this context (diagnostics only)
     struct CompressCounters { long calls = 0, cols_in = 0, order = 0, tri_steps = 0, rank_out = 0; } cstats;
     bool prof_side = false;     // timing was switched on before the side context existed: it is created with its timer enabled
+    // multi-GPU (comm.hpp, dre_comm_init): with a communicator of more than one rank the shifted solves of the generic ADI path are
+    // column-sharded (engine.hip, adi_advance) — every rank solves its 16-column tiles of the residual block and ONE in-place all-gather per
+    // ADI step, enqueued on this stream, gives every rank the full V; everything else is replicated and stays bit-identical on all ranks.
+    // Residual blocks narrower than shard_min_cols are solved replicated (a rank cannot do less than one 16-column tile).
+    std::shared_ptr<Comm> comm;
+    int shard_min_cols = 32;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

@@ -3,6 +3,7 @@
 #include <exception>
 // Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
 #include "engine.hpp"
+#include "comm.hpp"
 #include <functional>
 
 #include <algorithm>
@@ -1560,6 +1561,51 @@ void adi_advance(AdiRun& run, int budget) {
                                                n, 0, k, Wst.p, Wst.ld, (const double*)nullptr, 0,
                                                V1.p, V1.ld, R.p, R.ld, 2.0 * mu.real(), dst);
                     }
+                } else if (!user_inner && ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1 && k >= ctx->shard_min_cols) {
+                    // ---- column-sharded step: V = (F' + mu E')^-1 R acts column by column (adi.jl:158-159), so rank g
+                    // solves its 16-column tiles of R only (multifrontal sweeps + SMW, both column local), writes them into its block of the
+                    // gathered panel and ONE in-place all-gather (RCCL, on this stream) completes V on every rank.  The m columns M^-1 Vt of
+                    // the SMW correction are computed by every rank that owns columns (replicated: m = 7 against k/P).
+                    Comm& cm = *ctx->comm;
+                    const int Pn = std::max(cm.nranks, cm.emulate);
+                    const ColBlocks cb(k, Pn);
+                    Mat Vg(ctx, n, cb.padded());
+                    auto local = [&](int g) {
+                        const int c0 = cb.c0(g), kc = cb.c1(g) - c0;
+                        if (kc <= 0) return;
+                        auto scl = smw_cache.find(key);
+                        const bool havel = op.has_lr && scl != smw_cache.end();
+                        const int extra = (op.has_lr && !havel) ? m : 0;
+                        Mat Vloc = Vg.colsview(c0, kc);
+                        if (!op.has_lr) {
+                            mf_solve_from(ctx, P, fe->f, R.p + (size_t)c0 * R.ld, R.ld, kc, Vloc.p, Vloc.ld, kc, dst);
+                            return;
+                        }
+                        Mat W(ctx, n, kc + extra);
+                        if (extra) { Mat d = W.colsview(kc, m); copy_mat(ctx, op.Vt, d, 1.0, dst); }
+                        mf_solve_from(ctx, P, fe->f, R.p + (size_t)c0 * R.ld, R.ld, kc, W.p, W.ld, kc + extra, dst);
+                        Mat small(ctx, m, kc + extra);
+                        gemm(ctx, true, false, 1.0, op.U, W, 0.0, small, dst, "smw_small");
+                        if (!havel) {
+                            SmwCacheEntry en;
+                            en.keep = W.buf; en.WU = W.p + (size_t)kc * W.ld; en.ldwu = W.ld;
+                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)kc * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr);
+                            scl = smw_cache.emplace(key, en).first;
+                        }
+                        TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * kc + m), 2.0 * n * kc * m);
+                        hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(kc, SMW_CB)), dim3(256), 0, ctx->stream,
+                                           n, m, kc, W.p, W.ld, (const double*)scl->second.WU, scl->second.ldwu, (const double*)scl->second.sinv->p,
+                                           small.p, small.ld, Vloc.p, Vloc.ld, (double*)nullptr, 0, 0.0, dst);
+                    };
+                    if (cm.emulate > 1) { for (int g = 0; g < Pn; ++g) local(g); }
+                    else {
+                        local(cm.rank);
+                        TimedScope ts(ctx, "comm_allgather_v", 8.0 * n * (double)cb.padded(), 0.0);
+                        comm_allgather_inplace(ctx, cm, Vg.p, (size_t)n * cb.width());
+                    }
+                    V1 = Vg.colsview(0, k);
+                    spmm(ctx, P, P.valEt.p, V1, R, -2.0 * mu.real(), 1.0, dst);          // R <- R - 2 mu E' V   (adi.jl:171), replicated
                 } else {
                     Mat W(ctx, n, ncols);
                     if (user_inner) { Mat d = W.colsview(0, k); copy_mat(ctx, R, d, 1.0, dst); }
@@ -1747,6 +1793,29 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
     auto run = adi_begin(ctx, op, C, initial_guess, opt_in, cache);
     while (!run->finished) adi_advance(*run, 1 << 30);
     return adi_finish(*run);
+}
+// The iterate and the residual object of a running solve as the reference's observer sees them at adi.jl:119 (Callbacks.jl:97-107):
+// X shares its factors with the solver (increments are never modified; a later compression replaces the list, not the buffers), the
+// residual factor is updated in place by the iteration and is therefore copied.
+void adi_snapshot(AdiRun& run, LDLtP* X, LDLtP* resid) {
+    Ctx* ctx = run.ctx;
+    if (X) *X = std::make_shared<LDLt>(*run.Xw);
+    if (resid) {
+        auto r = std::make_shared<LDLt>();
+        r->n = run.n;
+        if (run.k > 0 && run.resid && !run.resid->blocks.empty()) {
+            Mat Rc(ctx, run.n, run.k);
+            copy_mat(ctx, run.R, Rc);
+            r->blocks.push_back({Rc, run.Tm, run.alpha_res, run.tdiag, false});
+        }
+        *resid = r;
+    }
+}
+std::vector<std::complex<double>> adi_shifts_since(const AdiRun& run, int from) {
+    std::vector<std::complex<double>> out;
+    const int upto = std::min<int>(run.res.iters, (int)run.all_shifts.size());
+    for (int i = std::max(from, 0); i < upto; ++i) out.push_back(run.all_shifts[(size_t)i]);
+    return out;
 }
 bool adi_isdone(const AdiRun& run) { return run.finished; }
 void adi_peek(const AdiRun& run, int* iters, double* res_norm, double* abstol) { *iters = run.res.iters; *res_norm = run.res.res_norm; *abstol = run.abstol; }

@@ -139,6 +139,8 @@ AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& init
 struct AdiRun;
 std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt, FactorCache* cache);
 void adi_advance(AdiRun& run, int budget);
+void adi_snapshot(AdiRun& run, LDLtP* X, LDLtP* resid);     // observer payload of adi.jl:119 at the current iteration
+std::vector<std::complex<double>> adi_shifts_since(const AdiRun& run, int from);   // shifts consumed by the accepted iterations from..iters
 bool adi_isdone(const AdiRun& run);
 void adi_peek(const AdiRun& run, int* iters, double* res_norm, double* abstol);
 AdiResult adi_finish(AdiRun& run);

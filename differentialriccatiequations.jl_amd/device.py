@@ -43,6 +43,33 @@ class Context:
         self.lib.dre_ctx_info(self.ptr, a)
         return {"cus": a[0], "pool_bytes": a[1]}
 
+    # --- multi-GPU: RCCL inside the library (dre_comm_*, include/dre_hip.h) -------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self.chk(self.lib.dre_comm_unique_id(self.ptr, buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, unique_id: bytes | None = None):
+        """Attach a communicator to this context: from here on the solves entered through this context run column-sharded over the ranks
+        (every rank must make the same calls with the same inputs).  `unique_id`: the 128 bytes rank 0 got from `comm_unique_id`."""
+        idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
+        self.chk(self.lib.dre_comm_init(self.ptr, int(nranks), int(rank), idbuf))
+
+    def comm_free(self):
+        self.chk(self.lib.dre_comm_free(self.ptr))
+
+    def comm_info(self):
+        a = (C.c_int64 * 6)()
+        self.lib.dre_comm_info(self.ptr, a)
+        return dict(nranks=a[0], rank=a[1], calls=a[2], bytes_gathered=a[3], bytes_reduced=a[4], emulate=a[5])
+
+    def comm_allgather(self, send_ptr: int, recv_ptr: int, count: int):
+        """all-gather of `count` doubles per rank between device buffers, enqueued on the library stream"""
+        self.chk(self.lib.dre_comm_allgather(self.ptr, C.c_void_p(send_ptr), C.c_void_p(recv_ptr), int(count)))
+
+    def comm_allreduce_sum(self, buf_ptr: int, count: int):
+        self.chk(self.lib.dre_comm_allreduce_sum(self.ptr, C.c_void_p(buf_ptr), int(count)))
+
     # --- profiling -------------------------------------------------------------------------
     def set_option(self, name, value):
         """Engine tunables (dre_ctx_set_option), e.g. ``dense_inverse_max_n``."""

@@ -1,17 +1,41 @@
-"""Multi-GPU layer of the path: one process per GPU, independent replicas (the Rosenbrock time steps of ONE problem
-are sequentially dependent — /root/reference/src/riccati/lowrank_ros1.jl:35-57 — so the time axis does not shard), with
-the K(t) feedback trajectories gathered over RCCL/xGMI (`backend="nccl"` on ROCm) or gloo in CPU tests."""
+"""Multi-GPU plumbing of the path: one process per GPU, the communicator INSIDE the library (RCCL over xGMI, `dre_comm_*`).
+
+The Rosenbrock time steps of ONE problem are sequentially dependent (/root/reference/src/riccati/lowrank_ros1.jl:35-57), so the time axis
+does not shard.  Two modes use the same communicator (csrc/comm.hip):
+
+* replicas (weak scaling, `bench.py --gpus N`): every rank solves an independent problem; the K(t) feedback trajectories are gathered
+  with `dre_comm_allgather` on the library stream (46 * 7 * n * 8 bytes per rank);
+* column-sharded (strong scaling, `bench.py --mode strong`): every rank runs the SAME device-resident time loop and the shifted solves of
+  each ADI step are split by 16-column tiles, one in-place all-gather per step (engine.hip, adi_advance).
+
+`torch.distributed` (any backend; gloo in the CPU tests) is only the out-of-band channel that hands rank 0's 128-byte unique id to the
+other ranks and reduces the timing scalars — never the data path."""
 import torch
 import torch.distributed as dist
 
 
-def gather_trajectories(K_local: torch.Tensor, world: int):
-    """all_gather of the (nt, n, m) trajectory block of every replica; returns the list indexed by rank."""
+def attach_communicator(ctx, rank: int, world: int):
+    """dre_comm_init on every rank: rank 0 creates the RCCL unique id, the process group broadcasts it."""
     if world == 1:
-        return [K_local]
-    out = [torch.empty_like(K_local) for _ in range(world)]
-    dist.all_gather(out, K_local)
-    return out
+        ctx.comm_init(1, 0, None)
+        return
+    box = [ctx.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init(world, rank, box[0])
+
+
+def gather_trajectories(ctx, K_local: torch.Tensor, K_all: torch.Tensor, world: int):
+    """K(t) of every replica into `K_all` ((world, nt, n, m), rank-major).  With a context: through the library's communicator,
+    asynchronous on the library stream (the caller's barrier synchronises it).  ctx = None: the same gather over `torch.distributed`
+    (the CPU tests' gloo group, or `bench.py --gather torch`)."""
+    assert K_all.is_contiguous() and K_local.is_contiguous() and K_all.numel() == world * K_local.numel()
+    if ctx is not None:
+        ctx.comm_allgather(K_local.data_ptr(), K_all.data_ptr(), K_local.numel())
+    elif world == 1:
+        K_all.view(-1).copy_(K_local.view(-1))
+    else:
+        dist.all_gather_into_tensor(K_all.view(-1), K_local.view(-1)) if K_all.is_cuda else dist.all_gather(list(K_all.view(world, -1).unbind(0)), K_local.view(-1))
+    return K_all
 
 
 def reduce_timing(elapsed: float, iters: float, device, world: int):

@@ -1,23 +1,27 @@
-"""One Lyapunov solve on several GPUs: column-sharded low-rank ADI.
+"""Host-driven model of the multi-GPU scheme: column-sharded low-rank ADI, row-sharded compression and the Rosenbrock-1 time loop over
+them.
+
+PRODUCTION PATH: the same column sharding lives INSIDE the library (csrc/engine.hip adi_advance + csrc/comm.hip: RCCL all-gather on the
+library stream, device-resident time loop, no host round trip per ADI step) and is switched on by attaching a communicator to the context
+(`Context.comm_init`, `dre_comm_init`).  This module is the executable specification of that scheme — backend agnostic, so that the
+world-size-2 gloo tests can run it on CPU against the single-rank engine and the oracle — and the host-driven variant for experiments
+(row-sharded compression is not in the library yet).
 
 The time steps of a Rosenbrock run and the ADI iterations of one Lyapunov solve are sequential recursions
 (/root/reference/src/riccati/lowrank_ros1.jl:35-57, src/lyapunov/adi.jl:152-171), but inside one ADI step the shifted solve
 `V = (F' + mu E')^-1 R` (adi.jl:158-159) and the residual update `R <- R - 2 mu E'V` (adi.jl:171) act column by column.  Rank g
-therefore owns the columns `R[:, g k/P : (g+1) k/P]`, solves only those (the dominant cost: triangular sweeps over the whole
-factor per column block), and ONE collective per ADI step — an all_gather of the freshly solved column blocks, n k 8 bytes in total,
-each xGMI link carrying 1/P of it — gives every rank the full `V`; the cheap sparse residual update, the increment bookkeeping and
-the shift sequence are replicated.  The Gram matrix of the residual norm (src/LDLt.jl:77-89 in Gram form) is ROW sharded: every rank
-reduces its row block, a k x k all_reduce (tiny) completes it.  Sparse factorisations are replicated (they are opaque device
-objects behind the C ABI; a farm that factors shift j on rank j mod P and ships the factor is future work).
+therefore owns a contiguous block of columns of R (whole 16-column tiles in the library and in `solve_gdre_ros1`), solves only those
+(the dominant cost: triangular sweeps over the whole factor per column block), and ONE collective per ADI step — an all_gather of the
+freshly solved column blocks, n k 8 bytes in total, each xGMI link carrying 1/P of it — gives every rank the full `V`; the cheap sparse
+residual update, the increment bookkeeping and the shift sequence are replicated.  The Gram matrix of the residual norm
+(src/LDLt.jl:77-89 in Gram form) is ROW sharded here (replicated in the library: k x k is tiny).  Sparse factorisations are replicated.
 
 `RowShardedCompress` is SURVEY.md §8e item 3: `compress!` (src/LDLt.jl:204-225) of the replicated increment slab with the ROWS of the factor
 sharded, in the randomized form the single-GPU engine uses for wide factors (engine.hip, sketch_compress): two all_reduces of c x s
 matrices (L'Om and Q'L), one all_gather of the s x s triangles of a TSQR and two scalar reductions; the n x c factor itself never moves.
 
-Layering: `ColumnShardedADI` is backend agnostic — the per-rank operator work goes through an `ops` object (HipOps: the C ABI of
-libdre_hip on this rank's GPU; NumpyOps: SciPy stand-in used by the world-size-2 gloo test on CPU), the exchange through
-`torch.distributed` (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" on CPU).  With world size 1 the collectives are no-ops.
-No scaling curve of this mode has been measured on hardware yet (the build box has one GPU); bench.py --mode strong runs it.
+Backends: `HipOps` (the C ABI of libdre_hip on this rank's GPU); the CPU stand-in used by the gloo tests lives in tests/_numpy_ops.py —
+the product package has no CPU compute path.  Exchange: `torch.distributed` (gloo on CPU; "nccl" = RCCL on the GPUs).
 """
 from __future__ import annotations
 
@@ -37,6 +41,14 @@ def row_range(n: int, rank: int, world: int):
     return col_range(n, rank, world)
 
 
+def tile_col_range(k: int, rank: int, world: int, tile: int = 16):
+    """Column block of `rank` in whole `tile`-column tiles — csrc/comm.hpp ColBlocks: the multifrontal sweeps work on 16-column tiles, a
+    narrower block would cost a full tile anyway.  All blocks but the last non-empty one have the same width."""
+    tiles = -(-k // tile)
+    w = -(-tiles // world) * tile
+    return min(rank * w, k), min((rank + 1) * w, k)
+
+
 class Comm:
     """The two collectives of the scheme (no-ops for a single rank)."""
 
@@ -46,13 +58,14 @@ class Comm:
         self.world = (dist.get_world_size() if self.on else 1) if world is None else world
         self.bytes_gathered = 0
 
-    def all_gather_cols(self, V_loc: torch.Tensor, k: int) -> torch.Tensor:
+    def all_gather_cols(self, V_loc: torch.Tensor, k: int, split=None) -> torch.Tensor:
         """V (n x k, column-major) from the column blocks of all ranks.  Column-major storage makes a column block one contiguous
         chunk, so the gather is a plain concatenation of the ranks' buffers (variable block widths are padded to the widest)."""
         n = V_loc.shape[0]
         if self.world == 1:
             return V_loc
-        wmax = max(col_range(k, r, self.world)[1] - col_range(k, r, self.world)[0] for r in range(self.world))
+        split = split or col_range
+        wmax = max(split(k, r, self.world)[1] - split(k, r, self.world)[0] for r in range(self.world))
         send = torch.zeros((wmax, n), dtype=V_loc.dtype, device=V_loc.device)          # (cols, n) row-major == n x cols column-major
         send[: V_loc.shape[1]] = V_loc.t()
         recv = [torch.empty_like(send) for _ in range(self.world)]
@@ -60,7 +73,7 @@ class Comm:
         self.bytes_gathered += send.numel() * send.element_size() * (self.world - 1)
         parts = []
         for r in range(self.world):
-            c0, c1 = col_range(k, r, self.world)
+            c0, c1 = split(k, r, self.world)
             parts.append(recv[r][: c1 - c0])
         return torch.cat(parts, dim=0).t()
 
@@ -82,57 +95,6 @@ class Comm:
         return torch.cat(recv, dim=0)
 
 
-class NumpyOps:
-    """CPU stand-in of the per-rank operator work (SciPy SuperLU): F = A + inv(alpha) U V with sparse A.  Used by the gloo tests."""
-
-    def __init__(self, E, A, U=None, V=None, alpha=1.0):
-        import scipy.sparse as sp
-        self.E, self.A = sp.csc_matrix(E), sp.csc_matrix(A)
-        self.U, self.V, self.alpha = U, V, alpha
-        self.n = self.E.shape[0]
-        self.device = torch.device("cpu")
-        self._lu = {}
-        self.nfactor = 0
-
-    def solve(self, mu: float, Rc: torch.Tensor) -> torch.Tensor:
-        import scipy.sparse.linalg as spla
-        if Rc.shape[1] == 0:
-            return Rc.clone()
-        if mu not in self._lu:
-            self._lu[mu] = spla.splu((self.A.T + mu * self.E.T).tocsc())
-            self.nfactor += 1
-        lu = self._lu[mu]
-        B = Rc.numpy()
-        if self.U is None:
-            return torch.from_numpy(np.ascontiguousarray(lu.solve(B)))
-        # (M + inv(alpha) V' U') X = B, M = A' + mu E'   (sherman-morrison-woodbury.jl:10-45 for the transposed LowRankUpdate)
-        Vt, Ut = self.V.T, self.U.T
-        W = lu.solve(np.hstack([B, Vt]))
-        WB, WV = W[:, : B.shape[1]], W[:, B.shape[1]:]
-        S = self.alpha * np.eye(Vt.shape[1]) + Ut @ WV
-        return torch.from_numpy(np.ascontiguousarray(WB - WV @ np.linalg.solve(S, Ut @ WB)))
-
-    def apply_Et(self, V: torch.Tensor) -> torch.Tensor:
-        return torch.from_numpy(np.ascontiguousarray(self.E.T @ V.numpy()))
-
-    def gram_rows(self, R: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
-        Rb = R[r0:r1].numpy()
-        return torch.from_numpy(Rb.T @ Rb)
-
-    # dense pieces of the row-sharded compression (plain NumPy on this stand-in)
-    def mm(self, A: torch.Tensor, B: torch.Tensor, tA=False, tB=False) -> torch.Tensor:
-        a, b = A.numpy(), B.numpy()
-        return torch.from_numpy(np.ascontiguousarray((a.T if tA else a) @ (b.T if tB else b)))
-
-    def qr(self, A: torch.Tensor):
-        q, r = np.linalg.qr(A.numpy())
-        return torch.from_numpy(np.ascontiguousarray(q)), torch.from_numpy(np.ascontiguousarray(r))
-
-    def eigh(self, S: torch.Tensor):
-        w, v = np.linalg.eigh(S.numpy())
-        return w, torch.from_numpy(np.ascontiguousarray(v))
-
-
 class HipOps:
     """The same per-rank work on this rank's GPU through the C ABI (libdre_hip): multifrontal LU + Sherman-Morrison-Woodbury for the
     solve, CSR SpMM for E'V, the MFMA GEMM for the Gram block.  torch tensors are only the exchange buffers handed to RCCL; data
@@ -147,6 +109,31 @@ class HipOps:
         self.Vtd = ctx.upload(np.asarray(V).T) if V is not None else None
         self._f = {}
         self.nfactor = 0
+
+    def set_operator(self, cA, cE, U=None, V=None, alpha=1.0):
+        """F = cA*A + cE*E + inv(alpha) U V on the same pencil (factors are cached by (cA, cE, mu))"""
+        self.cA, self.cE, self.alpha = float(cA), float(cE), float(alpha)
+        self.Ud = self.ctx.upload(U) if U is not None else None
+        self.Vtd = self.ctx.upload(np.asarray(V).T) if V is not None else None
+
+    def apply_Ft(self, L: torch.Tensor) -> torch.Tensor:
+        """F'L = cA A'L + cE E'L + inv(alpha) V'(U'L)  (LowRankUpdate.jl:51-54,82-85)"""
+        Ld, keep = self._to_lib(L)
+        Y = self.pencil.spmm(1, Ld, alpha=self.cA, beta=0.0)
+        if self.cE != 0.0:
+            Y = self.pencil.spmm(0, Ld, alpha=self.cE, beta=1.0, Y=Y)
+        out = self._from_lib(Y, self.n, L.shape[1])
+        if self.Ud is not None:
+            UtL = self.ctx.gemm(True, False, 1.0, self.Ud, Ld)
+            out = out + self._from_lib(self.ctx.gemm(False, False, 1.0 / self.alpha, self.Vtd, UtL), self.n, L.shape[1])
+        return out
+
+    def compress_factor(self, L: np.ndarray, D: np.ndarray):
+        """compress!(lowrank(L, D)) (LDLt.jl:204-225), replicated: (L, D) with orthonormal L, diagonal D"""
+        from . import api
+        X = api.compress_(api.lowrank(L, D))
+        a, Ln, Dn = X.alphas[0], X.Ls[0], X.Ds[0]
+        return np.asarray(Ln), a * np.asarray(Dn)
 
     def _to_lib(self, T: torch.Tensor):
         """column-major library matrix from an (n x c) torch tensor view with unit row stride (device-to-device copy)"""
@@ -163,10 +150,11 @@ class HipOps:
     def solve(self, mu: float, Rc: torch.Tensor) -> torch.Tensor:
         if Rc.shape[1] == 0:
             return Rc.clone()
-        if mu not in self._f:
-            self._f[mu] = self.pencil.factor(self.cA, complex(self.cE + mu))
+        key = (self.cA, self.cE, mu)
+        if key not in self._f:
+            self._f[key] = self.pencil.factor(self.cA, complex(self.cE + mu))
             self.nfactor += 1
-        f = self._f[mu]
+        f = self._f[key]
         Bd, keep = self._to_lib(Rc)
         X = f.solve_device(Bd) if self.Ud is None else f.solve_smw_device(self.alpha, self.Ud, self.Vtd, Bd)
         return self._from_lib(X, self.n, Rc.shape[1])
@@ -221,10 +209,11 @@ class ColumnShardedADI:
     (adi.jl:97-179 with perform_single_step!), column-sharded as described in the module docstring.
     Returns the increments (V_j, -2 mu_j) with X = sum_j (-2 mu_j) V_j S V_j', the residual norms and the iteration count."""
 
-    def __init__(self, ops, comm: Comm, shifts, maxiters=100, reltol=None, abstol=None):
+    def __init__(self, ops, comm: Comm, shifts, maxiters=100, reltol=None, abstol=None, split=None):
         self.ops, self.comm = ops, comm
         self.shifts = [float(np.real(s)) for s in shifts]
         self.maxiters, self.reltol, self.abstol = maxiters, reltol, abstol
+        self.split = split or col_range          # tile_col_range: the library's 16-column tiles
 
     def _norm(self, R: torch.Tensor, S: torch.Tensor) -> float:
         r0, r1 = row_range(R.shape[0], self.comm.rank, self.comm.world)
@@ -232,22 +221,26 @@ class ColumnShardedADI:
         M = S.to(G.device) @ G                  # ||R S R'||_F^2 = tr((S G)^2) = sum_ij M_ij M_ji, any width
         return float(torch.sqrt(torch.clamp(torch.sum(M * M.T), min=0.0)).item())
 
-    def solve(self, G: np.ndarray, S: np.ndarray):
+    def solve(self, G: np.ndarray, S: np.ndarray, abstol=None):
+        """(G, S): the residual factor the iteration starts from — the right-hand side itself for a zero initial guess (abstol = reltol x its
+        norm, adi.jl:61-62), or the warm-start residual of lyapunov/residual.jl:3-31 with `abstol` given by the caller (it refers to the
+        right-hand side's norm, "same tolerance as if initial_guess=zero", adi.jl:62)."""
         ops, comm = self.ops, self.comm
         n, k = G.shape
         dev = ops.device
         R = torch.from_numpy(np.ascontiguousarray(G)).to(dev)
         St = torch.from_numpy(np.ascontiguousarray(S))
-        c0, c1 = col_range(k, comm.rank, comm.world)
+        c0, c1 = self.split(k, comm.rank, comm.world)
         reltol = self.reltol if self.reltol is not None else n * np.finfo(float).eps
         norm0 = self._norm(R, St)
-        abstol = self.abstol if self.abstol is not None else reltol * norm0          # adi.jl:61-62 (zero initial guess: the residual is C)
+        if abstol is None:
+            abstol = self.abstol if self.abstol is not None else reltol * norm0      # adi.jl:61-62 (zero initial guess: the residual is C)
         norms, incs = [norm0], []
         it = 0
         while norms[-1] > abstol and it < self.maxiters:
             mu = self.shifts[it % len(self.shifts)]
             V_loc = ops.solve(mu, R[:, c0:c1])                  # the sharded part: only this rank's columns are solved
-            V = comm.all_gather_cols(V_loc, k)                  # the ONE exchange of the step
+            V = comm.all_gather_cols(V_loc, k, self.split)      # the ONE exchange of the step
             R = R - 2.0 * mu * ops.apply_Et(V)                  # replicated (cheap, sparse)
             incs.append((V, -2.0 * mu))
             it += 1
@@ -332,6 +325,66 @@ class RowShardedCompress:
             a, b = row_range(n, r, comm.world)
             parts.append(allr[r * hmax: r * hmax + (b - a)])
         return torch.cat(parts, dim=0)
+
+
+def solve_gdre_ros1(ops, comm: Comm, E, A, B, C, L0, D0, tspan, dt, shifts, maxiters=100, sketch=160):
+    """The low-rank Rosenbrock-1 time loop (src/riccati/lowrank_ros1.jl:19-63) over the sharded pieces: per time step the warm-started
+    Lyapunov solve is a `ColumnShardedADI` (one all_gather of V per ADI step, 16-column tiles like the library), the compression of
+    X + increments (adi.jl:78-80) a `RowShardedCompress` (the slab never moves; its new factor is re-replicated with `gather_rows`),
+    right-hand side, warm-start residual (lyapunov/residual.jl:11-30) and feedback K = B'XE are replicated.  `ops.set_operator` switches the
+    operator F = A - E/(2 tau) - B K per step on one pencil.  Returns (K trajectory, ADI iterations per step, final (L, D))."""
+    n, q = E.shape[0], C.shape[0]
+    eps = np.finfo(float).eps
+    nsteps = int(np.floor((tspan[1] - tspan[0]) / dt + 1e-9))
+    t = tspan[0] + dt * np.arange(nsteps + 1)
+    dev = ops.device
+    comp = RowShardedCompress(ops, comm)
+    r0, r1 = row_range(n, comm.rank, comm.world)
+    L, Dm = np.asarray(L0, float), np.asarray(D0, float)
+
+    def feedback(L, Dm):
+        BtLD = (B.T @ L) @ Dm
+        EtL = np.asarray(E.T @ L)
+        return BtLD, EtL, BtLD @ EtL.T                                   # lowrank_ros1.jl:25-28
+
+    BtLD, EtL, K = feedback(L, Dm)
+    Ks, its = [K], []
+    for i in range(1, nsteps + 1):
+        tau = t[i - 1] - t[i]
+        ops.set_operator(1.0, -1.0 / (2.0 * tau), B, K, -1.0)            # F = A - E/(2 tau) - B K   (lowrank_ros1.jl:39)
+        G = np.hstack([C.T, EtL])
+        S = np.zeros((G.shape[1],) * 2)
+        S[:q, :q] = np.eye(q)
+        S[q:, q:] = BtLD.T @ BtLD + Dm / tau                             # :42-43
+        Gc, Sc = ops.compress_factor(G, S)                               # :44
+        abstol = n * eps * float(np.linalg.norm(Sc))                     # adi.jl:61-62: ||rhs||_F of the compressed form (orthonormal factor)
+        # warm-start residual  [G, E'L, F'L] blk(S; 0 D; D 0)            (lyapunov/residual.jl:11-30)
+        Lt = torch.from_numpy(np.ascontiguousarray(L)).to(dev)
+        FtL = ops.apply_Ft(Lt).cpu().numpy()
+        r = L.shape[1]
+        R0 = np.hstack([Gc, EtL, FtL])
+        kg = Gc.shape[1]
+        T0 = np.zeros((kg + 2 * r,) * 2)
+        T0[:kg, :kg] = Sc
+        T0[kg:kg + r, kg + r:] = Dm
+        T0[kg + r:, kg:kg + r] = Dm
+        Rc, Tc = ops.compress_factor(R0, T0)
+        adi = ColumnShardedADI(ops, comm, shifts, maxiters=maxiters, split=tile_col_range)
+        res = adi.solve(Rc, Tc, abstol=abstol)
+        its.append(res["iters"])
+        # X <- compress(X + sum_j c_j V_j T V_j')  row sharded; the sketch grows until the acceptance tests pass
+        blocks = [(Lt[r0:r1].contiguous(), Dm, 1.0)] + [(V[r0:r1].contiguous(), np.asarray(res["T"]), cj) for V, cj in res["increments"]]
+        s = sketch
+        while True:
+            out = comp.compress(blocks, n, min(s, n - 16 - (n - 16) % 16))
+            if out["accepted"] or s >= n - 16:
+                break
+            s *= 2
+        L = comp.gather_rows(out["L_rows"], n).cpu().numpy()
+        Dm = np.diag(out["eigenvalues"])
+        BtLD, EtL, K = feedback(L, Dm)
+        Ks.append(K)
+    return dict(K=Ks, iters=its, L=L, D=Dm, t=t)
 
 
 def dense_solution(res) -> np.ndarray:

@@ -236,6 +236,13 @@ int dre_adi_step(dre_ctx* ctx, dre_adi_solver* s);
 int dre_adi_solve(dre_ctx* ctx, dre_adi_solver* s);
 int dre_adi_isdone(const dre_adi_solver* s, int* done);
 int dre_adi_state(const dre_adi_solver* s, int64_t* iters, double* res_norm, double* abstol);     /* shifts consumed, last residual norm, abstol */
+/* observe_gale_step!(observer, i, X, residual, residual_norm) (src/lyapunov/adi.jl:119, src/Callbacks.jl:97-107): the iterate X and the
+ * residual object of the solver's CURRENT iteration as LDLᵀ handles (either pointer may be NULL).  X shares its factors with the solver
+ * (lazy list of increments, LDLt.jl:131-148); the residual factor is a copy (the iteration updates it in place, adi.jl:171). */
+int dre_adi_snapshot(dre_ctx* ctx, dre_adi_solver* s, dre_ldlt** X, dre_ldlt** residual);
+/* observe_gale_metadata!(observer, "ADI shifts", mu) (adi.jl:103,192) while stepping: the shifts of the accepted iterations from `from`
+ * (0-based) on; re/im may be NULL to ask for the count only (they must hold *count doubles otherwise). */
+int dre_adi_shifts(const dre_adi_solver* s, int64_t from, int64_t* count, double* re, double* im);
 int dre_adi_finish(dre_ctx* ctx, dre_adi_solver* s, dre_adi_result** out);
 int dre_adi_free(dre_adi_solver* s);
 /* Penzl's heuristic, device part (src/shifts/heuristic.jl:39-66,103-130): Ritz values of E^-1 F (kplus Arnoldi steps) and of F^-1 E
@@ -261,6 +268,27 @@ int dre_adi_result_history(const dre_adi_result* r, double* norms, int32_t* norm
 int dre_adi_result_take_x(dre_adi_result* r, dre_ldlt** X);            /* observe_gale_done!(…, X, …) */
 int dre_adi_result_take_residual(dre_adi_result* r, dre_ldlt** R);
 int dre_adi_result_free(dre_adi_result* r);
+
+/* ---- multi-GPU: RCCL over xGMI inside the library (SURVEY.md section 8b `dre_comm_init`, 8e) ----
+ * One process per GPU, one context per process.  Rank 0 makes the 128-byte unique id (ncclGetUniqueId), the host program hands it to
+ * the other ranks (torch.distributed / MPI / a file), every rank calls dre_comm_init(ctx, nranks, rank, id): the communicator belongs
+ * to the context and its collectives are enqueued on the context's stream (no host synchronisation, no staging copies).
+ * With a communicator of more than one rank attached, every solve entered through this ABI (dre_gdre_solve, dre_gale_solve,
+ * dre_adi_*) runs the SAME device-resident loop on every rank with the shifted solves of the generic ADI step
+ * (perform_single_step!, src/lyapunov/adi.jl:149-179; the multifrontal sweeps + SMW of src/blocklinear) column-sharded:
+ * rank g solves its 16-column tiles of the residual block and ONE in-place all-gather per ADI step completes V on every rank;
+ * residual update, norm, compression, shifts and the feedback K(t) are replicated and bit-identical on all ranks (the reference has
+ * no multi-device path; test/cuda.jl runs one GPU).  librccl is loaded lazily by the first dre_comm_* call.
+ * option "shard_min_cols" (default 32): narrower residual blocks are solved replicated; option "shard_emulate" = P: one process plays
+ * P ranks one after the other (tests). */
+int dre_comm_unique_id(dre_ctx* ctx, void* id128);
+int dre_comm_init(dre_ctx* ctx, int nranks, int rank, const void* id128);      /* id128 may be NULL for nranks == 1 (no RCCL object) */
+int dre_comm_free(dre_ctx* ctx);
+/* info: [0]=nranks [1]=rank [2]=collective calls [3]=bytes received by all-gathers [4]=bytes reduced [5]=emulated ranks */
+int dre_comm_info(dre_ctx* ctx, int64_t* info);
+/* generic collectives on device buffers of doubles (the K(t) gather of independent replicas uses them: recv holds nranks blocks of count) */
+int dre_comm_allgather(dre_ctx* ctx, const void* send_dev, void* recv_dev, size_t count);
+int dre_comm_allreduce_sum(dre_ctx* ctx, void* buf_dev, size_t count);
 
 /* ---- GDRE (src/riccati/lowrank_ros1.jl:3-66, lowrank_ros2.jl:3-89) ---------------------------- */
 /* solve(GDREProblem(E, A, B, C, X0, (t0, tf)), Ros<order>(ADI(opt)); dt, save_state).  B is n x m, C is q x n. */

@@ -10,7 +10,9 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from dre_amd.sharded import ColumnShardedADI, Comm, NumpyOps, col_range, dense_solution   # noqa: E402
+from dre_amd.sharded import ColumnShardedADI, Comm, col_range, dense_solution   # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _numpy_ops import NumpyOps   # noqa: E402
 import dre_oracle as o   # noqa: E402
 
 dist.init_process_group(backend="gloo")

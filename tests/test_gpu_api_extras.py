@@ -280,7 +280,8 @@ def test_column_sharded_adi_device_ops_single_rank(ctx):
     """dre_amd.sharded.HipOps (the per-rank work of the multi-GPU ADI through the C ABI + device-to-device exchange buffers) against the
     SciPy stand-in the gloo test uses, world size 1: same iterates, and the sharded bookkeeping (column / row ranges) covers everything."""
     import torch
-    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, NumpyOps, col_range, dense_solution
+    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, col_range, dense_solution
+    from _numpy_ops import NumpyOps
     d = D.steel_profile(371)
     L, Dm = D.initial_value(d)
     tau = 100.0
@@ -305,7 +306,8 @@ def test_row_sharded_compression_device_ops_single_rank(ctx):
     device-to-device exchange buffers) at world size 1: the increments of a device ADI run compress to the same X as the SciPy stand-in
     and as the dense sum (the world-size-2 exchange pattern is covered by the gloo test on CPU)."""
     import torch
-    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, NumpyOps, RowShardedCompress
+    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, RowShardedCompress
+    from _numpy_ops import NumpyOps
     d = D.steel_profile(371)
     L, Dm = D.initial_value(d)
     tau = 100.0
