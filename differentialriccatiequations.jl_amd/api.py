@@ -220,7 +220,7 @@ class LowRankUpdate:
 
 def lr_update(A, alpha, U, V):
     """lr_update (LowRankUpdate.jl:38-39): dense -> Matrix, sparse -> lazy."""
-    if sp.issparse(A):
+    if sp.issparse(A) or isinstance(A, ScaledPencil):
         return LowRankUpdate(A, alpha, np.asarray(U, float), np.asarray(V, float))
     return np.asarray(A) + (1.0 / alpha) * (np.asarray(U) @ np.asarray(V))
 

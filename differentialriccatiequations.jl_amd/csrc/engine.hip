@@ -1483,7 +1483,9 @@ void adi_advance(AdiRun& run, int budget) {
             res.iters = h.iters;
             res.res_norm = h.res_norm;
             if (h.done || acc_it < nit) finished = true;
-            else if (opt.compression && last_compression >= opt.compression_interval) {
+            // (literal mode: the interval compression also runs after the LAST step, before the observer looks — adi.jl:111-119; it is the
+            // compression adi.jl:78-80 would do anyway)
+            if (opt.compression && last_compression >= opt.compression_interval && (!finished || cex)) {
                 const long rk = Xw->rank();
                 const bool defer = !cex && (n <= 512 ? rk <= 16L * n : (n <= ctx->compress_direct_max_n && rk <= 16L * n));
                 if (!defer) { ldlt_compress(ctx, *Xw, ctf, cex); last_compression = 0; }
@@ -1725,9 +1727,8 @@ void adi_advance(AdiRun& run, int budget) {
         res.iters = h.iters;
         res.res_norm = h.res_norm;
         if (h.smw_singular) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
-        if (h.done || recs.empty()) {
-            finished = true;
-        } else if (opt.compression && last_compression >= opt.compression_interval) {
+        if (h.done || recs.empty()) finished = true;
+        if (opt.compression && last_compression >= opt.compression_interval && (!finished || cex)) {
             // Small n: the compression works on the n x n matrix L D L' whatever the number of columns, and the increments
             // never depend on X, so the intermediate compressions of adi.jl:72-76 are deferred to the final one
             // (adi.jl:78-80) as long as the uncompressed factor stays small.

@@ -72,7 +72,9 @@ def test_sharded_step_covers_save_state_and_ros2_at_1357():
     prob, alg = _problem(1357, 3)
     ctx.set_option("dense_inverse_max_n", 0)            # force the multifrontal step (the dense-inverse step is not sharded)
     try:
-        for order_alg in (alg, D.Ros2(alg.inner_alg)):
+        gt = (1.0 + 1.0 / np.sqrt(2.0)) * 100.0                 # the Ros2 Lyapunov operator is gamma tau A - E/2 (lowrank_ros2.jl:41): map the shifts
+        ros2 = D.Ros2(D.ADI(shifts=D.Shifts.Cyclic([gt * float(np.real(p)) - 0.5 for p in alg.inner_alg.shifts.inner]), maxiters=200))
+        for order_alg in (alg, ros2):
             ref, st0 = D.solve_gdre(prob, order_alg, dt=-100.0, ctx=ctx, save_state=True, return_stats=True)
             ctx.set_option("shard_emulate", 4)
             sol, st = D.solve_gdre(prob, order_alg, dt=-100.0, ctx=ctx, save_state=True, return_stats=True)

