@@ -27,7 +27,7 @@ import numpy as np
 KERNEL_SYMBOL = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band": "k_gemm", "gemm_qr": "k_gemm", "gemm_compress": "k_gemm",
                  "gemm_gram": "k_gemm", "gemm_dinv": "k_gemm", "dense_step": "k_dense_step", "band_w": "k_band_w", "mf_solve_real": "k_mf_",
                  "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
-                 "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_", "adi_fast_iter": "k_adi_fast",
+                 "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_", "adi_fast_iter": "k_adi_fast", "adi_group_iter": "k_adi_group",
                  "adi_fast_flush": "k_adi_fast", "band_z": "k_band_z", "band_upd": "k_band_upd", "adi_eff_stack": "k_eff_stack",
                  "gemm_xupdate": "k_gemm"}
 

@@ -147,6 +147,10 @@ struct Ctx {
     // residual factors wider than this leave the dense-X loop for the factored path (0: the fast chain's own limit ADI_FAST_MAX_K); also the
     // switch the tests use to force that fallback in the middle of a run
     int dense_x_max_k = 0;
+    // group chain of the dense-X loop (dense.hip k_adi_group, engine.hip group_ops_prepare): g ADI iterations per launch.  1 = auto (largest
+    // divisor of the cycle length up to 5), 0 = off (one launch per iteration), g >= 2 = that group size if it divides the cycle length
+    int adi_group = 1;
+    int adi_group_max_n = 768;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;

@@ -1596,6 +1596,179 @@ void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
     DRE_HIP(hipGetLastError());
 }
 
+
+// =============================================================================================
+// Group ADI chain (round 3): g consecutive ADI iterations in ONE launch.
+//   R_i = Pi_i R_0,  V_i = Om_i R_0   with  Pi_i = P_{p+i-1} ... P_p,  P_s = I - 2 mu_s E' A_s,  Om_i = A_{p+i} Pi_i,  A_s = (F' + mu_s E')^-1
+// (perform_single_step!, adi.jl:149-179, applied g times: same iterates, the operator products are formed once per time step on the side
+// stream — engine.hip, group_ops_prepare).  The launch-per-iteration chain at n = 371 is bound by the dependent kernel boundary and the
+// memory round trips of a 6-us kernel, not by its 32 MFLOP; the group stack [Om_0 .. Om_{g-1}; Pi_1 .. Pi_g] (2 g blocks of n x n, packed in
+// the MFMA A-operand order like the single-iteration stack) turns g of those launches into one with 2 g times the tile workgroups.
+// Riders: the Gram matrices of the g residuals the PREVIOUS launch produced, and the norms + decisions (adi.jl:115-123, taken in iteration
+// order by the last norm workgroup to arrive) for the g residuals of the launch before that.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_pack_blocks(int n, int nblk, int nstrip, int kst, const double* __restrict__ src, int lds_, double* __restrict__ out) {
+    // out[((b * nstrip + s) * kst + t) * 64 + lane] = src[b n + 16 s + (lane & 15), 4 t + (lane >> 4)]   (zero padded)
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int hs = blockIdx.y;                                     // b * nstrip + s
+    if (t >= kst) return;
+    const int b = hs / nstrip, sidx = hs - b * nstrip;
+    const int row = 16 * sidx + (lane & 15), col = 4 * t + (lane >> 4);
+    out[((size_t)hs * kst + t) * 64 + lane] = (row < n && col < n) ? src[(size_t)b * n + row + (size_t)col * lds_] : 0.0;
+}
+void adi_group_pack(Ctx* ctx, int n, int nblk, const double* src, int lds_, double* out) {
+    const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+    TimedScope ts(ctx, "adi_group_pack", 16.0 * nblk * n * (double)n, 0.0);
+    hipLaunchKernelGGL(k_pack_blocks, dim3(ceil_div(kst, 4), nblk * nstrip), dim3(256), 0, ctx->stream, n, nblk, nstrip, kst, src, lds_, out);
+    DRE_HIP(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
+    if (a.st->done) return;
+    __shared__ double partbuf[4 * 4 * 64];
+    double (*part)[4][64] = reinterpret_cast<double (*)[4][64]>(partbuf);
+    __shared__ double nred[17];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4;
+    const int k = a.k, ct = (k + 15) >> 4, n = a.n, g = a.g;
+    const int ngrp = (ct + 3) >> 2;
+    const int nnorm = a.n_prev2 * ct * ngrp, ngram = a.n_prev * ct * ct;
+    const int hstride = (2 * g * a.nstrip + 7) & ~7;
+    const int nsw = a.do_strips ? hstride * ct : 0;
+    int b = blockIdx.x;
+    const int nrider = nnorm + ngram;
+    b = (b >= nrider) ? b - nrider : b + nsw;                     // riders first in the grid, strips occupy [0, nsw) of the logical index
+    if (b < nsw) {
+        const int tc = b / hstride, hs = b - tc * hstride;
+        if (hs >= 2 * g * a.nstrip) return;
+        const int blk = hs / a.nstrip, s = hs - blk * a.nstrip;    // blk < g: V of iteration blk;  blk >= g: residual after iteration blk - g + 1
+        const int col = tc * 16 + (lane & 15);
+        const bool colok = col < k;
+        const int erow = s * 16 + (lane >> 4) + 4 * wave;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
+        const v4d acc = adi_fast_tile<true>(a.Gpack + (size_t)hs * a.kst * 64 + lane, a.Rpc + (size_t)tc * 64 + lane, colok, lk, n, t0, t1, (size_t)ct * 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+        __syncthreads();
+        const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+        const bool ok = colok && erow < n;
+        if (blk < g) {
+            if (ok) a.V[(size_t)blk * k * a.ldv + erow + (size_t)col * a.ldv] = v;
+        } else {
+            const int i = blk - g;
+            if (ok) a.Rring[(size_t)i * k * a.ldr + erow + (size_t)col * a.ldr] = v;
+            a.Rpk[(size_t)i * a.rpd + ((size_t)(4 * s + wave) * ct + tc) * 64 + lane] = ok ? v : 0.0;
+        }
+        return;
+    }
+    b -= nsw;
+    if (b < ngram) {
+        // Gram tile (ta, tb) of residual i of the previous launch
+        const int i = b / (ct * ct), bb = b - i * ct * ct;
+        const int ta = bb % ct, tb = bb / ct;
+        if (ta > tb) return;
+        const double* __restrict__ Rp = a.Rp_prev + (size_t)i * a.rpd;
+        const bool aok = ta * 16 + (lane & 15) < k, bok = tb * 16 + (lane & 15) < k;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int tb0 = t0; tb0 < t1; tb0 += ADI_FAST_KB) {
+            double av[ADI_FAST_KB], bv[ADI_FAST_KB];
+#pragma unroll
+            for (int u = 0; u < ADI_FAST_KB; ++u) {
+                const int t = min(tb0 + u, t1 - 1);
+                av[u] = Rp[((size_t)t * ct + ta) * 64 + lane];
+                bv[u] = Rp[((size_t)t * ct + tb) * 64 + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < ADI_FAST_KB; ++u) {
+                const bool ok = (tb0 + u < t1) && 4 * (tb0 + u) + lk < n;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && aok) ? av[u] : 0.0, (ok && bok) ? bv[u] : 0.0, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+        __syncthreads();
+        const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+        const int gr = ta * 16 + (lane >> 4) + 4 * wave, gc = tb * 16 + (lane & 15);
+        double* __restrict__ G = a.G_prev + (size_t)i * k * k;
+        if (gr < k && gc < k) {
+            G[gr + (size_t)gc * k] = v;
+            if (ta != tb) G[gc + (size_t)gr * k] = v;
+        }
+        return;
+    }
+    b -= ngram;
+    if (b >= nnorm) return;
+    // norm workgroup (residual i of the launch before the previous one, tile row I, four tile columns): tr((T G)^2) partial sums
+    const int per_it = ct * ngrp;
+    const int i = b / per_it, bb = b - i * per_it;
+    const int I = bb / ngrp, J0 = (bb - I * ngrp) * 4;
+    double sloc = 0.0;
+    const double* __restrict__ G = a.G_prev2 + (size_t)i * k * k; const double* __restrict__ T = a.T;
+    const int lr = lane & 15;
+    for (int J = J0 + wave; J < min(ct, J0 + 4); J += 4) {
+        v4d mm = (v4d){0.0, 0.0, 0.0, 0.0}, nn = (v4d){0.0, 0.0, 0.0, 0.0};
+        const int ri = I * 16 + lr, rj = J * 16 + lr;
+        const bool iok = ri < k, jok = rj < k;
+        const int ric = iok ? ri : 0, rjc = jok ? rj : 0;
+        for (int kk0 = 0; kk0 < ct * 4; kk0 += 16) {
+            double ta[16], gb[16], ga[16], tb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = min((kk0 + u) * 4 + lk, k - 1);
+                ta[u] = T[ric + (size_t)c * a.ldt]; gb[u] = G[rjc + (size_t)c * k];
+                ga[u] = G[ric + (size_t)c * k];     tb[u] = T[rjc + (size_t)c * a.ldt];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const bool cok = (kk0 + u) < ct * 4 && (kk0 + u) * 4 + lk < k;
+                mm = __builtin_amdgcn_mfma_f64_16x16x4f64((cok && iok) ? ta[u] : 0.0, (cok && jok) ? gb[u] : 0.0, mm, 0, 0, 0);
+                nn = __builtin_amdgcn_mfma_f64_16x16x4f64((cok && iok) ? ga[u] : 0.0, (cok && jok) ? tb[u] : 0.0, nn, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sloc += mm[r] * nn[r];
+    }
+    sloc = block_sum(sloc, nred);
+    if (tid == 0) {
+        __hip_atomic_store(a.nws + b, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.nws + ADI_FAST_NWS - 1);
+        const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tk == (unsigned)(nnorm - 1)) {
+            // the last norm workgroup of the launch: the decisions of adi.jl:115-123 in ITERATION order — the first residual at or below
+            // abstol (or at maxiters) ends the solve; the norms of later, speculatively computed iterations are not recorded
+            AdiState* st = a.st;
+            for (int it = 0; it < a.n_prev2; ++it) {
+                double tot = 0.0;
+                for (int q = 0; q < per_it; ++q) tot += __hip_atomic_load(a.nws + it * per_it + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double nrm = fabs(a.alpha) * sqrt(fmax(tot, 0.0));
+                const int iters_after = a.it0_prev2 + it;
+                st->res_norm = nrm;
+                st->iters = iters_after;
+                if (iters_after < 512) st->norms[iters_after] = nrm;
+                if (nrm <= st->abstol || iters_after >= st->maxiters) { st->done = 1; break; }
+            }
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+        }
+    }
+}
+void adi_group_cost(const AdiGroupArgs& a, double* bytes, double* flops) {
+    *flops = (a.do_strips ? 2.0 * (2.0 * a.g) * a.n * (double)a.n * a.k : 0.0) + 2.0 * a.n_prev * a.n * (double)a.k * a.k;
+    *bytes = a.do_strips ? 8.0 * (2.0 * a.g * a.nstrip * 16.0 * a.kst * 4.0 + (1.0 + 3.0 * a.g) * a.n * a.k) : 8.0 * (double)a.n_prev * a.n * a.k;
+}
+void adi_group_iter(Ctx* ctx, const AdiGroupArgs& a) {
+    DRE_REQUIRE(a.k >= 1 && a.k <= ADI_GROUP_MAX_K && a.g >= 2 && a.g <= ADI_GROUP_MAX_G, "adi_group_iter: residual too wide or bad group size");
+    const int ct = (a.k + 15) >> 4, ngrp = (ct + 3) >> 2;
+    DRE_REQUIRE(a.g * ct * ngrp <= ADI_FAST_NWS - 1, "adi_group_iter: norm meeting point too small");
+    const int nsw = a.do_strips ? ((2 * a.g * a.nstrip + 7) & ~7) * ct : 0;
+    const int grid = nsw + a.n_prev * ct * ct + a.n_prev2 * ct * ngrp;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(k_adi_group, dim3(grid), dim3(256), 0, ctx->stream, a);
+    DRE_HIP(hipGetLastError());
+}
+
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
     if (k > 96) {

@@ -104,7 +104,7 @@ void dense_norm_flush(Ctx* ctx, int k, const Mat& T, bool tdiag, double alpha, A
 // Fast ADI chain (dense.hip): SMW-folded stacked inverse in MFMA-operand order, one launch per ADI iteration, residual norm
 // pipelined over the next two launches.
 #define ADI_FAST_MAX_K 512
-#define ADI_FAST_NWS 264          // doubles of the norm meeting point: (MAX_K/16) * (MAX_K/64) partial sums + the ticket word in the last slot
+#define ADI_FAST_NWS 1032         // doubles of the norm meeting point: (MAX_K/16) * (MAX_K/64) partial sums + the ticket word in the last slot
 inline int adi_fast_nstrip(int n) { return (n + 15) / 16; }
 inline int adi_fast_kst(int n) { return (n + 3) / 4; }
 inline size_t adi_fast_pack_doubles(int n) { return (size_t)2 * adi_fast_nstrip(n) * adi_fast_kst(n) * 64; }
@@ -151,6 +151,27 @@ inline void adi_fast_pick(int n, int k, int* mode, int* nt) {
     }
 }
 void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a);
+// Group chain (dense.hip, k_adi_group): g ADI iterations per launch on the group stack [Om_0 .. Om_{g-1}; Pi_1 .. Pi_g]
+#define ADI_GROUP_MAX_K 256
+#define ADI_GROUP_MAX_G 6
+struct AdiGroupArgs {
+    int n, k, nstrip, kst, g;
+    const double* Gpack;        // packed group stack of this launch's start position: [2 g][nstrip][kst][64]
+    const double* Rpc;          // the group's input residual R_0, packed (B-operand lane order)
+    double* Rring; int ldr;     // column-major residuals R_1 .. R_g: R_i at Rring + (i - 1) k ldr
+    double* Rpk; size_t rpd;    // the same, packed: R_i at Rpk + (i - 1) rpd
+    double* V; int ldv;         // V_0 .. V_{g-1}: V_i at V + i k ldv
+    const double* Rp_prev; int n_prev;      // packed residuals the previous launch produced (Gram matrices now) ...
+    double* G_prev;                         // ... into n_prev matrices of k x k
+    const double* G_prev2; int n_prev2;     // Gram matrices the previous launch produced: norms + decisions now
+    int it0_prev2;                          // shifts consumed after the first of those residuals
+    const double* T; int ldt; double alpha;
+    AdiState* st; double* nws;
+    int do_strips;                          // 0: flush launch (riders only)
+};
+void adi_group_iter(Ctx* ctx, const AdiGroupArgs& a);
+void adi_group_cost(const AdiGroupArgs& a, double* bytes, double* flops);
+void adi_group_pack(Ctx* ctx, int n, int nblk, const double* src, int lds_, double* out);   // nblk row blocks of n x n (column-major, leading dimension lds_) -> packed
 inline size_t adi_fast_rpack_doubles(int n, int k) { return (size_t)4 * adi_fast_nstrip(n) * ((k + 15) / 16) * 64; }
 void adi_fast_pack_r(Ctx* ctx, int n, int k, const double* R, int ldr, double* Rp, const AdiState* st);      // column-major -> packed
 void adi_fast_cost(const AdiFastArgs& a, double* bytes, double* flops);     // algorithmic bytes / flops of one launch

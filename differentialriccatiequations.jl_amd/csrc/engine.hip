@@ -2080,10 +2080,65 @@ __global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __r
     }
 }
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+// 16-row strip of  W = Apk X  (X: n x ncols <= 32, column-major), K split over the four waves; returns this thread's element (row lk + 4 wave,
+// column 16 j + lr) of both column tiles in v0 / v1
+__device__ __forceinline__ void group_thin_tile(const double* __restrict__ Apk_strip, const double* __restrict__ X, int ldx, int n, int ncols,
+                                                double (*part)[2][4][64], double& v0, double& v1) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int kst = (n + 3) >> 2, per = (kst + 3) >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int t0 = wv * per, t1 = min(kst, t0 + per);
+    const bool c0ok = lr < ncols, c1ok = 16 + lr < ncols;
+    const double* __restrict__ ap = Apk_strip + lane;
+    const double* __restrict__ x0 = X + (size_t)(c0ok ? lr : 0) * ldx;
+    const double* __restrict__ x1 = X + (size_t)(c1ok ? 16 + lr : 0) * ldx;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], b0[24], b1[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int t = min(tb + u, t1 - 1);
+            const int c = min(4 * t + lk, n - 1);
+            av[u] = ap[(size_t)t * 64]; b0[u] = x0[c]; b1[u] = x1[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < n;
+            const double a = kok ? av[u] : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kok && c0ok) ? b0[u] : 0.0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kok && c1ok) ? b1[u] : 0.0, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[wave][0][r][lane] = acc0[r]; part[wave][1][r][lane] = acc1[r]; }
+    __syncthreads();
+    v0 = ((part[0][0][wave][lane] + part[1][0][wave][lane]) + part[2][0][wave][lane]) + part[3][0][wave][lane];
+    v1 = ((part[0][1][wave][lane] + part[1][1][wave][lane]) + part[2][1][wave][lane]) + part[3][1][wave][lane];
+}
+// W_s = stack_s X for every shift s of the cycle in one launch (X: n x ncols <= 32, the same for all): the SMW products N K', E'N K', B'N K'
+struct StackThinBatch { const double* Apk[16]; double* W[16]; };
+__global__ __launch_bounds__(256) void k_stack_thin(int M, int n, int ncols, const double* __restrict__ X, int ldx, int ldw, StackThinBatch bt) {
+    __shared__ double part[4][2][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int kst = (n + 3) >> 2;
+    double v0, v1;
+    group_thin_tile(bt.Apk[blockIdx.y] + (size_t)blockIdx.x * kst * 64, X, ldx, n, ncols, part, v0, v1);
+    const int orow = blockIdx.x * 16 + lk + 4 * wave;
+    if (orow >= M) return;
+    double* __restrict__ W = bt.W[blockIdx.y];
+    if (lr < ncols) W[orow + (size_t)lr * ldw] = v0;
+    if (16 + lr < ncols) W[orow + (size_t)(16 + lr) * ldw] = v1;
+}
 // SMW products of every shift of a real Cyclic list for the low-rank factor (U, Vt) of `op`, and the SMW-folded packed stacks of the
 // fast chain (dense.hip).  Factors, dense inverses and stacked inverses come from the cache (built on first use).  false: some shift
 // cannot take the dense-inverse path (complex, or its inverse was rejected by the condition estimate).
 struct CycleOps {
+    std::vector<const double*> wks_pos; // per position of the cycle: [N K' Sinv; E'N K' Sinv] (2n x m, leading dimension 2n) of its shift, or null (no low-rank part)
+    std::vector<const double*> gpack;   // group chain: packed group stack per start position (index = start / g), empty = not available
+    int group_g = 0;
+    bool single_built = true;           // the single-iteration packed stacks (k_adi_fast) exist; false: build_single makes them on demand
+    std::function<void(Ctx*)> build_single;
     std::vector<double*> pack;          // per position of the cycle
     std::vector<std::shared_ptr<FactorEntry<double>>> fe;
     std::vector<Mat> keep;
@@ -2101,11 +2156,15 @@ static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& 
     if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe.dinv, 0.0, bot, nullptr, "gemm_dinv"); }
     fe.stack = stk; fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
 }
-static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache, CycleOps& co) {
+static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache, CycleOps& co,
+                              std::vector<Mat>* wks_store = nullptr /* persistent 2n x m buffers per position of the cycle (group chain) */,
+                              const std::vector<Mat>* spack = nullptr /* packed stacks per position (group chain): thin products without k_gemm */,
+                              bool defer_single = false /* the single-iteration packs are only needed by a fallback chunk: build on demand */) {
     const Pencil& P = *op.P;
     const int n = P.n, m = op.has_lr ? op.U.cols : 0;
     if (m > 32) return false;
     std::map<double, double*> by_mu;
+    std::map<double, const double*> wks_by_mu;
     std::vector<GemmBatchDesc> descs;
     std::vector<SmwBatch> hb;
     std::vector<const double*> stacks, wks; std::vector<double*> outs;
@@ -2154,7 +2213,9 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
         }
         finalize_dense(ctx, dd);
     }
+    size_t pos_idx = 0;
     for (auto& mu : values) {
+        const size_t pos = pos_idx++;
         auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, true);
         if (!fe->dense) return false;
         ensure_stack(ctx, op, *fe);
@@ -2165,7 +2226,8 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
             co.keep.push_back(pk);
             const double* wksp = nullptr;
             if (m) {
-                Mat WK(ctx, 2 * n + m, m), WKS(ctx, 2 * n, m);
+                Mat WK(ctx, 2 * n + m, m);
+                Mat WKS = (wks_store && pos < wks_store->size()) ? (*wks_store)[pos] : Mat(ctx, 2 * n, m);
                 auto sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
                 co.keep.push_back(WK); co.keep.push_back(WKS); co.keepb.push_back(sinv);
                 descs.push_back({fe->stack.p, op.Vt.p, WK.p, nullptr, 1.0, 2 * n + m, m, n, fe->stack.ld, op.Vt.ld, WK.ld, 0});
@@ -2174,15 +2236,24 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
             }
             stacks.push_back(fe->stack.p); wks.push_back(wksp); outs.push_back(pk.p);
             bm = by_mu.emplace(mu.real(), pk.p).first;
+            wks_by_mu[mu.real()] = wksp;
         }
         co.pack.push_back(bm->second);
+        co.wks_pos.push_back(wks_by_mu[mu.real()]);
     }
     if (m) {
         co.serr8 = DevArr<long long>(ctx, 1);
         co.serr = DevArr<int>();
         co.serr.buf = co.serr8.buf; co.serr.p = (int*)co.serr8.p; co.serr.n = 2;     // the kernels write the low word
         DRE_HIP(hipMemsetAsync(co.serr8.p, 0, sizeof(long long), ctx->stream));
-        gemm_batched(ctx, descs, "gemm_dinv");
+        if (spack && spack->size() == values.size() && m <= 32 && descs.size() <= 16 && descs.size() == values.size()) {
+            // WK_s = stack_s K' for every shift in one launch on the packed stacks (the general batched GEMM spends 31 us on these 749 x 371 x 7 products)
+            StackThinBatch tb;
+            for (size_t i = 0; i < 16; ++i) { const size_t j = i < descs.size() ? i : 0; tb.Apk[i] = (*spack)[j].p; tb.W[i] = descs[j].C; }
+            TimedScope ts(ctx, "gemm_dinv", 8.0 * descs.size() * (2.0 * n + m) * n, 2.0 * descs.size() * (2.0 * n + m) * n * (double)m);
+            hipLaunchKernelGGL(k_stack_thin, dim3(ceil_div(2 * n + m, 16), (unsigned)descs.size()), dim3(256), 0, ctx->stream, 2 * n + m, n, m, (const double*)op.Vt.p,
+                               op.Vt.ld, 2 * n + m, tb);
+        } else gemm_batched(ctx, descs, "gemm_dinv");
         for (size_t b0 = 0; b0 < hb.size(); b0 += 16) {
             SmwBatchArgs ba;
             const unsigned nb = (unsigned)std::min<size_t>(16, hb.size() - b0);
@@ -2192,8 +2263,287 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
             hipLaunchKernelGGL(k_fold_sinv_batched_args, dim3(ceil_div(2 * n * m, 256), nb), dim3(256), 0, ctx->stream, 2 * n, m, 2 * n + m, ba);
         }
     }
-    adi_fast_build(ctx, n, m, stacks, 2 * n + m, wks, 2 * n, outs);
+    if (defer_single) {
+        co.single_built = false;
+        co.build_single = [n, m, stacks, wks, outs](Ctx* c) { adi_fast_build(c, n, m, stacks, 2 * n + m, wks, 2 * n, outs); };
+    } else adi_fast_build(ctx, n, m, stacks, 2 * n + m, wks, 2 * n, outs);
     return true;
+}
+
+// ---- group chain (dense.hip, k_adi_group): operator products of g consecutive ADI iterations --------------------------------------
+// With N_s = (A' + (mu_s - 1/(2 tau)) E')^-1 (K independent, kept per shift as stack_s = [N_s; E'N_s; B'N_s]) the shifted operator of a time
+// step is a rank-m correction (Sherman-Morrison-Woodbury, smw.jl:20-43):  A_s = N_s + a_s b_s',  P_s = I - 2 mu_s E'A_s = P0_s + c_s b_s'
+// with a_s = -(N_s K' Sinv_s), c_s = 2 mu_s (E'N_s K' Sinv_s), b_s' = B'N_s.  For the g shifts s_0 .. s_{g-1} of a group (index i for s_i):
+//   Pi_i = P_{i-1} ... P_0 = Pi0_i + X_i Y_i',      Om_i = A_i Pi_i = Om0_i + [N_i X_i, a_i] Y_{i+1}',
+//   X_i  block j (j < i)  = Phi(j+1, i) c_j,        Phi(a, b) = P0_{b-1} ... P0_a   (K independent; Pi0_i = Phi(0, i), Om0_i = N_i Phi(0, i)),
+//   Y_{i+1} = [Y_i, y_i],  y_i = Pi_i' b_i = D_i' + sum_{j<i} y_j M(j, i),   D_i = b_i' Phi(0, i),   M(j, i) = c_j' Psi(j, i),   Psi(j, i) = Phi(j+1, i)' b_i.
+// Everything K independent (Phi, N Phi, Psi, D: GroupBase) is formed ONCE per run — one stacked product stack_b Phi(a, b) delivers
+// N_b Phi(a, b), the next Phi(a, b+1) and Psi(a-1, b)' at once — and a time step costs three launches on the side stream: the left-factor
+// blocks (independent thin products, no recursion), the rows of Y, and the fold + packing of the effective group stack.
+struct GroupLeftDesc { const double* Mtx; int ldm; const double* v; int ldv; double* out; int ldo; double scale; int kind; int pad; };   // kind 0: out = scale Mtx v (null Mtx: copy), 1: M = scale v' PsiT'
+struct GroupBase {
+    int g = 0, n = 0, m = 0;
+    uint64_t tag = 0;
+    std::vector<double> mus;            // the cycle this base was built for
+    std::vector<int> starts;            // start positions (multiples of g)
+    std::vector<Mat> G0;                // per start: (2 g n) x n  rows [i n, (i+1) n) = Om0_i, rows [(g + i) n, ...) = Pi0_{i+1}
+    std::vector<Mat> D;                 // per start: (g m) x n    rows [i m, (i+1) m) = D_i
+    std::vector<Mat> spack;             // per position of the cycle: stack_s = [N_s; E'N_s; B'N_s] in the MFMA A-operand order
+    std::vector<Mat> wks;               // persistent [N K' Sinv; E'N K' Sinv] per position of the cycle (2n x m): the descriptors point into them
+    std::vector<Mat> XL, Yt, Mb;        // per start: left factors (2 g n) x (m g), Y' (m g) x n, the M(j, i) blocks (m x m each, g*g slots)
+    std::vector<Mat> pack;              // packed effective group stacks
+    DevArr<GroupLeftDesc> table;        // descriptors of the left-factor launch (built once per run)
+    int ndesc = 0;
+};
+// out(16-row strip) = scale * Mtx(strip, :) v   (v: n x m, m <= 16), K split over the four waves;  kind 1: the m x m matrix scale * v' P' with P = Mtx (m x n)
+__global__ __launch_bounds__(256) void k_group_left(int n, int m, const GroupLeftDesc* __restrict__ table) {
+    __shared__ double part[4][4][64];
+    const GroupLeftDesc d = table[blockIdx.y];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    if (d.kind == 1) {
+        if (blockIdx.x > 0) return;
+        // M[u, v] = scale * sum_r vv[r, u] * PsiT[v, r]
+        for (int e = tid; e < m * m; e += 256) {
+            const int u = e % m, vv = e / m;
+            double sacc = 0.0;
+            for (int r = 0; r < n; ++r) sacc += d.v[r + (size_t)u * d.ldv] * d.Mtx[vv + (size_t)r * d.ldm];
+            d.out[u + (size_t)vv * d.ldo] = d.scale * sacc;
+        }
+        return;
+    }
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= n) return;
+    if (!d.Mtx) {
+        for (int e = tid; e < 16 * m; e += 256) {
+            const int r = row0 + (e & 15), c = e >> 4;
+            if (r < n) d.out[r + (size_t)c * d.ldo] = d.scale * d.v[r + (size_t)c * d.ldv];
+        }
+        return;
+    }
+    const int row = row0 + lr;
+    const bool rok = row < n, cok = lr < m;
+    const int kst = (n + 3) >> 2, per = (kst + 3) >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int t0 = wv * per, t1 = min(kst, t0 + per);
+    const double* __restrict__ ap = d.Mtx + (rok ? row : 0);
+    const double* __restrict__ xp = d.v + (size_t)(cok ? lr : 0) * d.ldv;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], bv[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int c = min(4 * min(tb + u, t1 - 1) + lk, n - 1);
+            av[u] = ap[(size_t)c * d.ldm]; bv[u] = xp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < n;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok) ? av[u] : 0.0, (kok && cok) ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    const double vsum = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    const int orow = row0 + lk + 4 * wave;
+    if (orow < n && lr < m) d.out[orow + (size_t)lr * d.ldo] = d.scale * vsum;
+}
+// rows of Y' = [y_0 .. y_{g-1}]':  y_i = D_i' + sum_{j<i} y_j M(j, i).  One thread per (row, component v); the g levels are sequential, the
+// row's earlier y_j go through LDS (32 rows per workgroup, 8 component slots per row).
+struct GroupYOne { const double* D; const double* Mb; double* Yt; };
+struct GroupYBatch { GroupYOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_y(int n, int m, int g, int ldd, GroupYBatch bt) {
+    __shared__ double ysh[32][ADI_GROUP_MAX_G][8];
+    __shared__ double msh[ADI_GROUP_MAX_G * ADI_GROUP_MAX_G][8][8];
+    const GroupYOne& o = bt.s[blockIdx.y];
+    const int rl = threadIdx.x >> 3, v = threadIdx.x & 7;
+    const int rr = blockIdx.x * 32 + rl;
+    const int r = m * g;
+    for (int e = threadIdx.x; e < g * g * 64; e += 256) {
+        const int ji = e >> 6, u = (e >> 3) & 7, vv = e & 7;
+        msh[ji][u][vv] = (u < m && vv < m) ? o.Mb[(size_t)ji * m * m + u + (size_t)vv * m] : 0.0;
+    }
+    __syncthreads();
+    const bool ok = rr < n && v < m;
+    for (int i = 0; i < g; ++i) {
+        double acc = ok ? o.D[(size_t)i * m + v + (size_t)rr * ldd] : 0.0;
+        for (int j = 0; j < i; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += ysh[rl][j][u] * msh[j * g + i][u][v];
+        ysh[rl][i][v] = ok ? acc : 0.0;
+        if (ok) o.Yt[(size_t)i * m + v + (size_t)rr * r] = acc;
+        __syncthreads();
+    }
+}
+// Packed effective group stack in one pass:  out = pack(G0 + XL Yt).  The rank-r product of a 16 x 16 tile is computed TRANSPOSED, so that the
+// accumulator layout is the packed layout (acc[q] = K-step 4 tt + q, position lane) — the trick of k_eff_stack_mfma (dense.hip).
+struct GroupFoldOne { const double* G0; const double* XL; const double* Yt; double* out; };
+struct GroupFoldBatch { GroupFoldOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_fold(int n, int nblk, int nstrip, int kst, int r, int ldg, int ldx, GroupFoldBatch bt) {
+    const GroupFoldOne& o = bt.s[blockIdx.z];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
+    const int tt = blockIdx.x * 4 + wave;                          // column tile: K-steps 4 tt .. 4 tt + 3
+    const int ntile = (kst + 3) >> 2;
+    if (tt >= ntile) return;
+    const int hs = blockIdx.y, b = hs / nstrip, s = hs - b * nstrip;
+    const int rowl = 16 * s + lr;                                  // row within the block (B-operand column index j = lr)
+    const bool rok = rowl < n;
+    const size_t grow = (size_t)b * n + (rok ? rowl : 0);
+    const int colA = 16 * tt + lr;                                 // A operand: A[i = lr][k] = Yt[k, 16 tt + lr]
+    const bool cok = colA < n;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int ksteps = (r + 3) >> 2;
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int q = 4 * kk + lk;
+        const bool qok = q < r;
+        const double ya = (qok && cok) ? o.Yt[q + (size_t)colA * r] : 0.0;
+        const double xb = (qok && rok) ? o.XL[grow + (size_t)q * ldx] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, xb, acc, 0, 0, 0);
+    }
+    // acc[q] = (XL Yt)[row = rowl, col = 16 tt + 4 q + lk]   (transposed tile: D'[i = lk + 4 q][j = lr])
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = 4 * tt + q, col = 4 * t + lk;
+        if (t < kst) {
+            const double base = (rok && col < n) ? o.G0[grow + (size_t)col * ldg] : 0.0;
+            o.out[((size_t)hs * kst + t) * 64 + lane] = (rok && col < n) ? base + acc[q] : 0.0;
+        }
+    }
+}
+// next = prev - two_mu * W_mid  (n x n);  prev = null: identity
+__global__ __launch_bounds__(256) void k_group_next_phi(int n, double two_mu, const double* __restrict__ prev, int ldp, const double* __restrict__ Wmid, int ldw,
+                                                       double* __restrict__ next, int ldn) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int r = idx % n, c = idx / n;
+    const double p = prev ? prev[r + (size_t)c * ldp] : (r == c ? 1.0 : 0.0);
+    next[r + (size_t)c * ldn] = p - two_mu * Wmid[r + (size_t)c * ldw];
+}
+static int group_size_for(Ctx* ctx, int ncycle, int n, int m) {
+    if (ctx->adi_group == 0 || n > ctx->adi_group_max_n || m < 1 || m > 8) return 0;
+    if (ctx->adi_group > 1) return (ncycle % ctx->adi_group == 0 && ctx->adi_group <= ADI_GROUP_MAX_G && m * (ctx->adi_group - 1) <= 32) ? ctx->adi_group : 0;
+    for (int g = std::min(5, ADI_GROUP_MAX_G); g >= 2; --g) if (ncycle % g == 0 && m * (g - 1) <= 32) return g;      // auto: the largest divisor of the cycle length up to 5
+    return 0;
+}
+// (2n + m) x n stack -> A-operand order: strip of 16 rows x K-step of 4 columns = 64 consecutive doubles (one coalesced 512-byte fragment load)
+__global__ __launch_bounds__(256) void k_pack_rows(int M, int n, int kst, const double* __restrict__ src, int lds_, double* __restrict__ out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= kst) return;
+    const int row = 16 * blockIdx.y + (lane & 15), col = 4 * t + (lane >> 4);
+    out[((size_t)blockIdx.y * kst + t) * 64 + lane] = (row < M && col < n) ? src[row + (size_t)col * lds_] : 0.0;
+}
+// Level i of the thin recursion, one launch for all start positions:  W = stack_{s_i} X_i  (X_i: n x m i, the left factor of Pi_i, in XL block
+// row g + i - 1), one workgroup per 16-row strip of the packed stack, K split over the four waves, two column tiles; the epilogue writes the
+// three row ranges of W where they are needed:  top -> XV_i (XL block row i),  mid -> X_{i+1} = X_i - 2 mu W_mid (XL block row g + i),
+// bottom (b_i' X_i, m x m i) -> the blocks M(j, i) of the Y recursion.
+struct GroupLevelOne { const double* Apk; double* XL; double* Mb; double two_mu; };
+struct GroupLevelBatch { GroupLevelOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_level_gemm(int n, int m, int g, int i, int ldx, GroupLevelBatch bt) {
+    __shared__ double part[4][2][4][64];
+    const GroupLevelOne& o = bt.s[blockIdx.y];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int M = 2 * n + m, ncols = m * i, kst = (n + 3) >> 2;
+    const double* __restrict__ Xi = o.XL + (size_t)(g + i - 1) * n;
+    double vv2[2];
+    group_thin_tile(o.Apk + (size_t)blockIdx.x * kst * 64, Xi, ldx, n, ncols, part, vv2[0], vv2[1]);
+    const int orow = blockIdx.x * 16 + lk + 4 * wave;
+    if (orow >= M) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double v = vv2[j];
+        const int col = 16 * j + lr;
+        if (col >= ncols) continue;
+        if (orow < n) o.XL[(size_t)i * n + orow + (size_t)col * ldx] = v;                                            // XV_i
+        else if (orow < 2 * n) {
+            const int r = orow - n;
+            o.XL[(size_t)(g + i) * n + r + (size_t)col * ldx] = Xi[r + (size_t)col * ldx] - o.two_mu * v;           // X_{i+1}
+        } else {
+            const int vv = orow - 2 * n, jj = col / m, u = col - jj * m;
+            o.Mb[(size_t)(jj * g + i) * m * m + u + (size_t)vv * m] = v;                                               // M(jj, i)[u, vv]
+        }
+    }
+}
+// K-independent part, once per run (every shift of the cycle has its stacked inverse)
+static void group_base_build(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, const CycleOps& co, GroupBase& gb, int g) {
+    const int n = op.P->n, m = op.U.cols, c = (int)values.size();
+    gb = GroupBase();
+    gb.g = g; gb.n = n; gb.m = m; gb.tag = op.tag;
+    for (auto& v : values) gb.mus.push_back(v.real());
+    const int r = m * g, M = 2 * n + m, kst = adi_fast_kst(n), nstripM = ceil_div(M, 16);
+    std::vector<GroupLeftDesc> tab;
+    const unsigned nn_blocks = (unsigned)(((size_t)n * n + 255) / 256);
+    for (int pos = 0; pos < c; ++pos) {
+        gb.wks.push_back(Mat(ctx, 2 * n, m));
+        const FactorEntry<double>& fe = *co.fe[(size_t)pos];
+        Mat pk(ctx, nstripM * kst, 64);
+        hipLaunchKernelGGL(k_pack_rows, dim3(ceil_div(kst, 4), nstripM), dim3(256), 0, ctx->stream, M, n, kst, (const double*)fe.stack.p, fe.stack.ld, pk.p);
+        gb.spack.push_back(pk);
+    }
+    for (int p = 0; p < c; p += g) {
+        gb.starts.push_back(p);
+        Mat G0(ctx, 2 * g * n, n), D(ctx, g * m, n), XL(ctx, 2 * g * n, r), Yt(ctx, r, n), Mb(ctx, m * m, g * g);
+        fill_mat(ctx, XL, 0.0); fill_mat(ctx, Yt, 0.0); fill_mat(ctx, Mb, 0.0);
+        Mat W(ctx, M, n);
+        for (int b = 0; b < g; ++b) {       // Phi(0, b) = Pi0_b:  stack_b Pi0_b = [Om0_b; E'N_b Pi0_b; D_b],  Pi0_{b+1} = Pi0_b - 2 mu_b (mid)
+            const FactorEntry<double>& fe = *co.fe[(size_t)(p + b)];
+            const double two_mu = 2.0 * values[(size_t)(p + b)].real();
+            Mat top, mid, bot, prev;
+            if (b == 0) { top = fe.stack.view(0, 0, n, n); mid = fe.stack.view(n, 0, n, n); bot = fe.stack.view(2 * n, 0, m, n); }
+            else {
+                prev = G0.view((g + b - 1) * n, 0, n, n);
+                gemm(ctx, false, false, 1.0, fe.stack, prev, 0.0, W, nullptr, "gemm_group_base");
+                top = W.view(0, 0, n, n); mid = W.view(n, 0, n, n); bot = W.view(2 * n, 0, m, n);
+            }
+            Mat nxt = G0.view((g + b) * n, 0, n, n);
+            hipLaunchKernelGGL(k_group_next_phi, dim3(nn_blocks), dim3(256), 0, ctx->stream, n, two_mu, b == 0 ? (const double*)nullptr : (const double*)prev.p,
+                               b == 0 ? 0 : prev.ld, (const double*)mid.p, mid.ld, nxt.p, nxt.ld);
+            Mat om = G0.view(b * n, 0, n, n); copy_mat(ctx, top, om);
+            Mat dd = D.view(b * m, 0, m, n); copy_mat(ctx, bot, dd);
+        }
+        // the K-dependent blocks that are plain copies:  XV_i block i = a_i = -(N K' Sinv)_i,  X_{i+1} block i = c_i = 2 mu_i (E'N K' Sinv)_i
+        for (int i = 0; i < g; ++i) {
+            const Mat& w = gb.wks[(size_t)(p + i)];
+            tab.push_back({nullptr, 0, w.p, w.ld, XL.p + (size_t)i * n + (size_t)(i * m) * XL.ld, XL.ld, -1.0, 0, 0});
+            tab.push_back({nullptr, 0, w.p + n, w.ld, XL.p + (size_t)(g + i) * n + (size_t)(i * m) * XL.ld, XL.ld, 2.0 * values[(size_t)(p + i)].real(), 0, 0});
+        }
+        gb.G0.push_back(G0); gb.D.push_back(D); gb.XL.push_back(XL); gb.Yt.push_back(Yt); gb.Mb.push_back(Mb);
+        gb.pack.push_back(Mat(ctx, (int)((size_t)g * adi_fast_pack_doubles(n) / 64), 64));
+    }
+    gb.ndesc = (int)tab.size();
+    gb.table = DevArr<GroupLeftDesc>(ctx, tab.size());
+    DRE_HIP(hipMemcpyAsync(gb.table.p, tab.data(), tab.size() * sizeof(GroupLeftDesc), hipMemcpyHostToDevice, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));          // (once per run; the host table goes out of scope)
+}
+// K-dependent part, once per time step (side stream): copies, g - 1 thin levels, the rows of Y, fold + packing
+static void group_ops_prepare(Ctx* ctx, const std::vector<std::complex<double>>& values, CycleOps& co, GroupBase& gb) {
+    const int n = gb.n, m = gb.m, g = gb.g, r = m * g;
+    const int ns = (int)gb.starts.size();
+    TimedScope tsall(ctx, "group_prepare", 8.0 * ns * ((g - 1) * (2.0 * n + m) * n + 4.0 * g * n * (double)n), 2.0 * ns * 2.0 * g * n * (double)n * r, g + 2);
+    hipLaunchKernelGGL(k_group_left, dim3(ceil_div(n, 16), gb.ndesc), dim3(256), 0, ctx->stream, n, m, (const GroupLeftDesc*)gb.table.p);
+    for (int i = 1; i < g; ++i) {
+        GroupLevelBatch lb;
+        for (int q = 0; q < 8; ++q) {
+            const int qq = q < ns ? q : 0, pos = gb.starts[(size_t)qq] + i;
+            lb.s[q] = {gb.spack[(size_t)pos].p, gb.XL[(size_t)qq].p, gb.Mb[(size_t)qq].p, 2.0 * values[(size_t)pos].real()};
+        }
+        hipLaunchKernelGGL(k_group_level_gemm, dim3(ceil_div(2 * n + m, 16), ns), dim3(256), 0, ctx->stream, n, m, g, i, gb.XL[0].ld, lb);
+    }
+    {
+        GroupYBatch yb;
+        for (int q = 0; q < 8; ++q) { const int qq = q < ns ? q : 0; yb.s[q] = {gb.D[(size_t)qq].p, gb.Mb[(size_t)qq].p, gb.Yt[(size_t)qq].p}; }
+        hipLaunchKernelGGL(k_group_y, dim3(ceil_div(n, 32), ns), dim3(256), 0, ctx->stream, n, m, g, gb.D[0].ld, yb);
+    }
+    co.gpack.clear();
+    {
+        const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+        GroupFoldBatch ft;
+        for (int q = 0; q < 8; ++q) { const int qq = q < ns ? q : 0; ft.s[q] = {gb.G0[(size_t)qq].p, gb.XL[(size_t)qq].p, gb.Yt[(size_t)qq].p, gb.pack[(size_t)qq].p}; }
+        hipLaunchKernelGGL(k_group_fold, dim3(ceil_div((kst + 3) / 4, 4), 2 * g * nstrip, ns), dim3(256), 0, ctx->stream, n, 2 * g, nstrip, kst, r,
+                           gb.G0[0].ld, gb.XL[0].ld, ft);
+        for (int q = 0; q < ns; ++q) co.gpack.push_back(gb.pack[(size_t)q].p);
+    }
+    co.group_g = g;
+    DRE_HIP(hipGetLastError());
 }
 
 struct DenseXState {
@@ -2201,6 +2551,7 @@ struct DenseXState {
     Mat P1;       // E' X
     Mat Kt;       // K' = E' X B  (n x m)
     int hint = 0; // ADI iterations of the previous step
+    GroupBase gb; // K-independent operator products of the group chain (built at the first dense step)
     // pinned host landing zone: control block, tolerances and the SMW breakdown flag come back with ONE synchronisation per chunk
     struct Landing { AdiState st; double tols[4]; int serr; };
     Landing* land = nullptr;
@@ -2244,6 +2595,42 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
     if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));          // K of the previous step is ready here
     sx.mark(ctx, 0);
+    // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
+    // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
+    CycleOps co;
+    bool co_ok = true;
+    auto side_setup = [&]() {
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+        // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
+        // every step land in the persistent buffers the left-factor descriptors point into
+        const int gwant = group_size_for(ctx, (int)adi.shifts.values.size(), n, m);       // (the MAIN context's options)
+        bool gb_ok = gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8 && sx.gb.g == gwant && sx.gb.tag == op.tag && sx.gb.m == m &&
+                     sx.gb.mus.size() == adi.shifts.values.size();
+        for (size_t i = 0; gb_ok && i < sx.gb.mus.size(); ++i) gb_ok = sx.gb.mus[i] == adi.shifts.values[i].real();
+        co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co, gb_ok ? &sx.gb.wks : nullptr, gb_ok ? &sx.gb.spack : nullptr, gb_ok);
+        if (co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8) {
+            bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
+            for (size_t i = 0; i < adi.shifts.values.size(); ++i)
+                for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
+            if (distinct) {
+                group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
+                for (size_t pos = 0; pos < co.wks_pos.size(); ++pos) {
+                    Mat src = sx.gb.wks[pos];         // same shape: view the step's temporary product through a Mat header
+                    src.p = const_cast<double*>(co.wks_pos[pos]); src.ld = 2 * n;
+                    copy_mat(wctx, src, sx.gb.wks[pos]);
+                }
+                gb_ok = true;
+            }
+        }
+        if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
+        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+    };
+    // DRE_SIDE_EARLY=1: enqueue the side stream's work (SMW products, thin recursion, fold) before the assembly instead of inside the band
+    // reduction's first read-back.  Measured at n = 371 with the group chain: 21.7 ms per solve early against 21.2 ms in the read-back slot (the
+    // host calls delay the main stream's first kernels by more than the earlier start gains) — off by default.
+    static const int side_early_env = std::getenv("DRE_SIDE_EARLY") ? std::atoi(std::getenv("DRE_SIDE_EARLY")) : -1;
+    const bool side_early = wctx != ctx && side_early_env > 0;
+    if (side_early) side_setup();
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
     // The main stream's kernels are enqueued BEFORE the side stream is set up: the host calls for the side stream (event wait, six
     // launches) would otherwise sit in front of them while the main stream idles.
@@ -2257,21 +2644,12 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
     hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
     sx.mark(ctx, 1);
-    // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
-    // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
-    CycleOps co;
-    bool co_ok = true;
-    auto side_setup = [&]() {
-        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
-        co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co);
-        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
-    };
     // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
     BandSpec spec;
     static const bool side_in_fetch = !(std::getenv("DRE_SIDE_IN_FETCH") && std::atoi(std::getenv("DRE_SIDE_IN_FETCH")) == 0);
-    const bool defer_side = wctx != ctx && side_in_fetch;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
+    const bool defer_side = wctx != ctx && side_in_fetch && !side_early;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
     if (defer_side) spec.extra = side_setup;
-    else side_setup();
+    else if (!side_early) side_setup();
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     if (defer_side && !spec.ran) side_setup();
     // Leaving early (refusal or exception) after the side stream was set up: the caller falls back to the generic ADI on the MAIN stream
@@ -2292,6 +2670,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     ar.rhs_cols = k;
     if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return false;
     std::vector<Mat> keepV;
+    std::vector<BufP> keepRpk;
     Mat Vall, Wall;
     int acc_total = 0;
     std::vector<double> coef;
@@ -2317,11 +2696,14 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         size_t cyc = 0;
         bool finished = false;
         const int cap = std::max(1, adi.maxiters);
-        Vall = Mat(ctx, n, k * std::min(cap, std::max(adi.compression_interval, sx.hint + 1) + 64));
+        const int ctk = (k + 15) / 16;
+        const int gsz = co.group_g;
+        const bool grp = gsz >= 2 && use_pk && k <= ADI_GROUP_MAX_K && gsz * ctk * ((ctk + 3) / 4) <= ADI_FAST_NWS - 1 && !co.gpack.empty();
+        Vall = Mat(ctx, n, k * (std::min(cap, std::max(adi.compression_interval, sx.hint + 1) + 64) + (grp ? gsz : 0)));
         int vcols_used = 0;
         // specx: every chunk's update of X is enqueued during its read-back (the batched product takes its descriptors as kernel arguments,
         // 48 at most; chunks never grow within a solve)
-        const bool specx = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters) <= 48;
+        const bool specx = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters) + (grp ? gsz : 0) <= 48;
         bool any_plain = false;
         while (!finished) {
             const int base_it = iters_host;
@@ -2329,8 +2711,59 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             int nit = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters - iters_host);
             nit = std::min(nit, (Vall.cols - vcols_used) / k);
             if (nit <= 0) break;
+            // group chain (first chunk of a solve: it starts at position 0 of the cycle): whole groups of gsz iterations per launch; the
+            // iteration count of the previous time step (counts fall from step to step) rounded up to a multiple of gsz is enqueued
+            const bool grp_now = grp && base_it == 0 && cyc == 0;
+            if (grp_now) {
+                const int want = std::min(std::max(sx.hint, 1), adi.maxiters);
+                nit = ((want + gsz - 1) / gsz) * gsz;
+                nit = std::min(nit, ((Vall.cols - vcols_used) / k / gsz) * gsz);
+            }
             Mat Rring(ctx, n, k * nit);
             keepV.push_back(Rring);
+            if (grp_now && nit >= gsz) {
+                const int NG = nit / gsz, ncyc = (int)adi.shifts.values.size();
+                DevArr<double> Rpk(ctx, rpd * (size_t)(nit + 1));
+                Mat Gg(ctx, k * k, 2 * gsz);
+                AdiGroupArgs ga;
+                std::memset(&ga, 0, sizeof(ga));
+                ga.n = n; ga.k = k; ga.nstrip = nstrip; ga.kst = kst; ga.g = gsz;
+                ga.ldr = Rring.ld; ga.rpd = rpd; ga.ldv = Vall.ld;
+                ga.T = Tm.p; ga.ldt = Tm.ld; ga.alpha = 1.0; ga.st = st.p; ga.nws = nws.p;
+                double by1 = 0.0, fl1 = 0.0;
+                ga.do_strips = 1; ga.n_prev = gsz;
+                adi_group_cost(ga, &by1, &fl1);
+                {
+                    TimedScope chain_ts(ctx, "adi_group_iter", by1 * NG, fl1 * NG, NG + 2);
+                    for (int L = 0; L <= NG + 1; ++L) {
+                        ga.do_strips = L < NG ? 1 : 0;
+                        if (L < NG) {
+                            ga.Gpack = co.gpack[(size_t)(((L * gsz) % ncyc) / gsz)];
+                            ga.Rpc = L == 0 ? Rp0.p : Rpk.p + (size_t)(L * gsz) * rpd;
+                            ga.Rring = Rring.p + (size_t)(L * gsz) * k * Rring.ld;
+                            ga.Rpk = Rpk.p + (size_t)(L * gsz + 1) * rpd;
+                            ga.V = Vall.p + (size_t)(vcols_used + L * gsz * k) * Vall.ld;
+                        }
+                        // Gram matrices of the residuals launch L - 1 produced; norms + decisions for those of launch L - 2
+                        ga.n_prev = (L >= 1 && L <= NG) ? gsz : 0;
+                        ga.Rp_prev = ga.n_prev ? Rpk.p + (size_t)((L - 1) * gsz + 1) * rpd : nullptr;
+                        ga.G_prev = Gg.p + (size_t)(L & 1) * gsz * k * k;
+                        ga.n_prev2 = L >= 2 ? gsz : 0;
+                        ga.G_prev2 = Gg.p + (size_t)((L - 1) & 1) * gsz * k * k;
+                        ga.it0_prev2 = base_it + (L - 2) * gsz + 1;
+                        adi_group_iter(ctx, ga);
+                    }
+                }
+                for (int j = 0; j < nit; ++j) {
+                    const std::complex<double> mu = adi.shifts.values[cyc % adi.shifts.values.size()];
+                    ar.shifts.push_back(mu);
+                    coef.push_back(-2.0 * mu.real());
+                    ++cyc; ++iters_host;
+                }
+                keepRpk.push_back(Rpk.buf);
+                sx.mark(ctx, 4);
+            } else {
+            if (!co.single_built) { co.build_single(ctx); co.single_built = true; }
             AdiFastArgs a;
             std::memset(&a, 0, sizeof(a));
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
@@ -2377,6 +2810,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             }
             chain_ts.reset();
             sx.mark(ctx, 4);
+            }
             {
                 // control block (header + the norms of this chunk), tolerances and the SMW breakdown flag in ONE read-back.  The update
                 //   X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated: one batched product + one GEMM)
