@@ -97,6 +97,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_X_SIDE_STREAM")) ctx->c.x_side_stream = std::atoi(e);
         if (const char* e = std::getenv("DRE_DENSE_X_MAX_N")) ctx->c.dense_x_max_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_ADI_GROUP")) ctx->c.adi_group = std::atoi(e);
+        if (const char* e = std::getenv("DRE_ADI_GROUP_MAX_N")) ctx->c.adi_group_max_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_X_COMPRESS_EVERY")) ctx->c.x_compress_every = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
