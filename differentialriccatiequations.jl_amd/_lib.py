@@ -86,6 +86,7 @@ PROTOTYPES = {
     "dre_shift_solve": (C.c_int, [_vp, _vp, _vp, _pvp, _pvp]),
     "dre_shift_solve_smw": (C.c_int, [_vp, _vp, C.c_double, _vp, _vp, _vp, _pvp, _pvp]),
     "dre_factor_growth": (C.c_int, [_vp, _vp, _pd]),
+    "dre_factor_perturbed": (C.c_int, [_vp, _vp, _pi64]),
     "dre_factor_free": (C.c_int, [_vp, _vp]),
     "dre_ldlt_create": (C.c_int, [_vp, _vp, _vp, _vp, C.c_double, _pvp]),
     "dre_ldlt_zero": (C.c_int, [_vp, _vp, C.c_int, _pvp]),

@@ -185,6 +185,8 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
         else if (key == "pivot_growth_warn") ctx->c.pivot_growth_warn = value;
         else if (key == "pivot_growth_fail") ctx->c.pivot_growth_fail = value;
+        else if (key == "pivot_static") ctx->c.pivot_static = value;
+        else if (key == "pivot_refine_steps") ctx->c.pivot_refine_steps = (int)value;
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
     });
 }
@@ -513,6 +515,12 @@ int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const d
 }
 int dre_factor_growth(dre_ctx* ctx, const dre_factor* f, double* growth) {
     return guarded(ctx, [&] { *growth = f->is_cplx ? mf_check(&ctx->c, f->fc) : mf_check(&ctx->c, f->fr); });
+}
+int dre_factor_perturbed(dre_ctx* ctx, const dre_factor* f, int64_t* count) {
+    return guarded(ctx, [&] {
+        if (f->is_cplx) { if (f->fc.nperturbed < 0) mf_check(&ctx->c, f->fc); *count = f->fc.nperturbed; }
+        else { if (f->fr.nperturbed < 0) mf_check(&ctx->c, f->fr); *count = f->fr.nperturbed; }
+    });
 }
 int dre_factor_free(dre_ctx*, dre_factor* f) { delete f; return DRE_OK; }
 

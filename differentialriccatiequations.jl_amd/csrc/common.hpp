@@ -154,6 +154,10 @@ struct Ctx {
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;
+    // static pivoting of the multifrontal LU (sparse.hpp, Factor): relative floor for the pivots (sqrt(eps) like SuperLU_DIST; 0 = off: plain
+    // pivot-free LU with growth detection only) and the number of refinement steps of a solve with a perturbed factor
+    double pivot_static = 1.4901161193847656e-08;
+    int pivot_refine_steps = 3;
     int x_side_stream = 1;
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)

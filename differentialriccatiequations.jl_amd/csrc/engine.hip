@@ -1045,7 +1045,10 @@ static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
     ctx_fetch(ctx, dd.norms.p, (size_t)2 * cnt * sizeof(double), h.data());
     for (int i = 0; i < cnt; ++i) {
         const double cond_est = std::sqrt(h[2 * i]) * std::sqrt(h[2 * i + 1]);
-        if (cond_est == cond_est && cond_est < 1e7) { dd.items[i].fe->dinv = dd.items[i].W; dd.items[i].fe->dense = true; }
+        auto& fe = *dd.items[i].fe;
+        if (!fe.checked) { fe.growth = mf_check(ctx, fe.f); fe.checked = true; }       // also reads the static-pivot count (sparse.hpp)
+        // (a factor with replaced pivots belongs to a perturbed matrix: its explicit inverse is not the operator's — sweeps + refinement instead)
+        if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) { fe.dinv = dd.items[i].W; fe.dense = true; }
     }
     dd.items.clear();
 }
@@ -1061,10 +1064,14 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     auto fe = std::make_shared<FactorEntry<T>>();
     mf_factor<T>(ctx, *op.P, op.valFt.p, op.P->valEt.p, make_scalar<T>(1.0, 0.0), make_scalar<T>(mu.real(), mu.imag()), fe->f);
     cache->nfactor++;
+    // static pivoting: whether pivots were replaced decides how this factor may be used (refinement, no explicit inverse), so the count is
+    // read back here — one synchronisation per NEW factorisation (ten per run with a Cyclic list); the deferred set-up of a whole cycle
+    // reads it with its acceptance norms instead (finalize_dense)
+    if (ctx->pivot_static > 0.0 && !defer) { fe->growth = mf_check(ctx, fe->f); fe->checked = true; }
     if constexpr (sizeof(T) == sizeof(double)) {
         const int n = op.P->n;
         fe->f.allow_topinv = cache->enabled;     // a factor that keeps being reused gets the dense top-level inverse (sparse.hip)
-        if (want_dense && n <= ctx->dense_inv_max_n) {      // only for shifts that will be reused (Cyclic): the inverse costs n solves
+        if (want_dense && n <= ctx->dense_inv_max_n && fe->f.nperturbed <= 0) {      // only for shifts that will be reused (Cyclic): the inverse costs n solves
             // explicit inverse through n unit right-hand sides; kept only if the operator is well conditioned enough
             // that inverse-times-vector is as accurate as the triangular solves for the ADI recurrences
             Mat W(ctx, n, n);

@@ -308,8 +308,35 @@ __device__ __forceinline__ void growth_commit(double g, unsigned long long* out)
     for (int o = 32; o > 0; o >>= 1) g = fmax(g, __shfl_xor(g, o, 64));
     if ((threadIdx.x & 63) == 0 && g > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(g));
 }
+// static pivoting: a pivot below the floor is replaced by the floor with the pivot's direction (sign for real, phase for complex)
+__device__ __forceinline__ double static_pivot(double piv, double fl) { return piv >= 0.0 ? fl : -fl; }
+__device__ __forceinline__ cplx static_pivot(cplx piv, double fl) {
+    const double a = sqrt(piv.re * piv.re + piv.im * piv.im);
+    if (a == 0.0) return cplx{fl, 0.0};
+    return cplx{piv.re / a * fl, piv.im / a * fl};
+}
+__global__ void k_pivot_floor(int nnz, const double* __restrict__ valF, const double* __restrict__ valE, double cFr, double cFi, double cEr, double cEi,
+                              double rel, double* __restrict__ out /* [0] floor, [1] max |entry| */) {
+    __shared__ double red[4];
+    double m = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nnz; i += gridDim.x * 256) {
+        const double re = cFr * valF[i] + cEr * valE[i], im = cFi * valF[i] + cEi * valE[i];
+        m = fmax(m, fabs(re) + fabs(im));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        // max over the workgroups: non-negative doubles order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)__double_as_longlong(m));
+    }
+}
+__global__ void k_pivot_floor_finish(double rel, double* __restrict__ out) { out[0] = rel * out[1]; }
+
 template <typename T>
-__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err, unsigned long long* __restrict__ growth) {
+__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err, unsigned long long* __restrict__ growth,
+                               const double* __restrict__ pivfloor, int* __restrict__ npert) {
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -328,8 +355,15 @@ __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, 
     double gmax = 0.0;
     for (int k = 0; k < s; ++k) {
         __syncthreads();
-        const T piv = F[k + (size_t)k * f];
-        if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) { if (tid == 0) *err = 1; return; }
+        T piv = F[k + (size_t)k * f];
+        if (!(abs1(piv) == abs1(piv))) { if (tid == 0) *err = 1; return; }
+        const double fl = pivfloor ? pivfloor[0] : 0.0;
+        if (abs1(piv) < fl) {                       // (every thread takes the same branch)
+            piv = static_pivot(piv, fl);
+            __syncthreads();
+            if (tid == 0) { F[k + (size_t)k * f] = piv; atomicAdd(npert, 1); }
+        }
+        if (abs1(piv) == 0.0) { if (tid == 0) *err = 1; return; }
         const T rp = recip(piv);
         for (int i = k + 1 + tid; i < f; i += nt) { const T l = F[i + (size_t)k * f] * rp; F[i + (size_t)k * f] = l; gmax = fmax(gmax, abs1(l)); }
         __syncthreads();
@@ -380,7 +414,8 @@ template <> __device__ __forceinline__ cplx group16_sum<cplx>(cplx v) {
 #define FF_NB 16
 template <typename T>
 __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv,
-                                                               int* __restrict__ err, int inv_lds, unsigned long long* __restrict__ growth) {
+                                                               int* __restrict__ err, int inv_lds, unsigned long long* __restrict__ growth,
+                                                               const double* __restrict__ pivfloor, int* __restrict__ npert) {
     extern __shared__ double ffraw[];
     double gmax = 0.0;
     T* sm = reinterpret_cast<T*>(ffraw);
@@ -411,10 +446,14 @@ __global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl
         __syncthreads();
         // unblocked LU of the column panel
         for (int c = 0; c < jb; ++c) {
-            const T piv = Pn[c + c * rows];
-            if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) bad = 1;      // every thread sees the same value
+            T piv = Pn[c + c * rows];
+            const double fl = pivfloor ? pivfloor[0] : 0.0;
+            const bool small = abs1(piv) < fl;       // every thread sees the same value
+            if (small) piv = static_pivot(piv, fl);
+            if (abs1(piv) == 0.0 || !(abs1(piv) == abs1(piv))) bad = 1;
             const T rp = recip(piv);
             __syncthreads();
+            if (small && tid == 0) { Pn[c + c * rows] = piv; atomicAdd(npert, 1); }
             for (int r = c + 1 + tid; r < rows; r += nt) { const T l = Pn[r + c * rows] * rp; Pn[r + c * rows] = l; gmax = fmax(gmax, abs1(l)); }
             __syncthreads();
             const int nr = rows - c - 1, ncc = jb - c - 1;
@@ -537,6 +576,21 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
     DRE_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
     DRE_HIP(hipMemsetAsync(out.growth.p, 0, sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p);
+    if (!out.pivfloor.p) out.pivfloor = DevArr<double>(ctx, 2);
+    if (!out.npert.p) out.npert = DevArr<int>(ctx, 1);
+    out.nperturbed = -1;
+    out.ref_valF = valF; out.ref_valE = valE; out.ref_cF = cF; out.ref_cE = cE;
+    DRE_HIP(hipMemsetAsync(out.pivfloor.p, 0, 2 * sizeof(double), ctx->stream));
+    DRE_HIP(hipMemsetAsync(out.npert.p, 0, sizeof(int), ctx->stream));
+    const double* pf = nullptr;
+    if (ctx->pivot_static > 0.0) {
+        double cfr, cfi, cer, cei;
+        if constexpr (sizeof(T) == sizeof(double)) { cfr = cF; cfi = 0.0; cer = cE; cei = 0.0; }
+        else { cfr = cF.re; cfi = cF.im; cer = cE.re; cei = cE.im; }
+        hipLaunchKernelGGL(k_pivot_floor, dim3(std::min(64, ceil_div(P.nnz, 256))), dim3(256), 0, ctx->stream, P.nnz, valF, valE, cfr, cfi, cer, cei, ctx->pivot_static, out.pivfloor.p);
+        hipLaunchKernelGGL(k_pivot_floor_finish, dim3(1), dim3(1), 0, ctx->stream, ctx->pivot_static, out.pivfloor.p);
+        pf = out.pivfloor.p;
+    }
     MfArgs a = mf_args(P);
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
@@ -548,9 +602,9 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
             const int inv_lds = inv_b <= lim ? 1 : 0;
             const size_t shm = std::max(panel_b, inv_lds ? inv_b : (size_t)0);
             lds_attr(ctx, (const void*)k_front_factor_blocked<double>, 150 * 1024); lds_attr(ctx, (const void*)k_front_factor_blocked<cplx>, 150 * 1024);
-            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds, out.growth.p);
+            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds, out.growth.p, pf, out.npert.p);
         } else {
-            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, out.growth.p);
+            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, out.growth.p, pf, out.npert.p);
         }
     }
     DRE_HIP(hipGetLastError());
@@ -562,7 +616,10 @@ double mf_check(Ctx* ctx, const Factor<T>& F) {
     unsigned long long hg = 0;
     DRE_HIP(hipMemcpyAsync(&herr, F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if (F.growth.p) DRE_HIP(hipMemcpyAsync(&hg, F.growth.p, sizeof(hg), hipMemcpyDeviceToHost, ctx->stream));
+    int hnp = 0;
+    if (F.npert.p) DRE_HIP(hipMemcpyAsync(&hnp, F.npert.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipStreamSynchronize(ctx->stream));
+    F.nperturbed = hnp;
     if (herr) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
     double g;
     std::memcpy(&g, &hg, sizeof(g));
@@ -1660,7 +1717,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
 void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs, const AdiState* st) {
     if (nrhs <= 0) return;
     DRE_REQUIRE(nin >= 0 && nin <= nrhs && Win != W, "mf_solve_from: bad column split");
-    if (P.use_mfma_sweeps) {
+    if (P.use_mfma_sweeps && Fc.nperturbed <= 0) {
         MfIn in; in.p = Win; in.ld = ldwin; in.n = nin;
         mf_solve_mfma(ctx, P, Fc, W, ldw, nrhs, st, &in);
         return;
@@ -1669,7 +1726,42 @@ void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, const do
     mf_solve<double>(ctx, P, Fc, W, ldw, nrhs, st);
 }
 template <typename T>
+static void mf_solve_once(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st);
+__global__ void k_refine_axpy(int n, int nrhs, const double* __restrict__ d, int ldd, double* __restrict__ x, int ldx, const AdiState* st) {
+    if (st && st->done) return;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * nrhs) return;
+    const int r = id % n, c = id / n;
+    x[r + (size_t)c * ldx] += d[r + (size_t)c * ldd];
+}
+template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st) {
+    if (nrhs <= 0) return;
+    if (Fc.nperturbed > 0) {
+        // the factor belongs to a perturbed matrix (static pivoting): fixed-point refinement against the true operator M = cF F' + cE E'
+        if constexpr (sizeof(T) == sizeof(double)) {
+            const int n = P.n;
+            Mat B0(ctx, n, nrhs), Rr(ctx, n, nrhs), X(ctx, 0, 0);
+            Mat Wm; Wm.p = W; Wm.rows = n; Wm.cols = nrhs; Wm.ld = ldw;       // header over the caller's panel
+            copy_mat(ctx, Wm, B0, 1.0, st);
+            mf_solve_once<T>(ctx, P, Fc, W, ldw, nrhs, st);
+            for (int it = 0; it < ctx->pivot_refine_steps; ++it) {
+                copy_mat(ctx, B0, Rr, 1.0, st);
+                spmm(ctx, P, Fc.ref_valF, Wm, Rr, -Fc.ref_cF, 1.0, st);         // r = b - M x
+                spmm(ctx, P, Fc.ref_valE, Wm, Rr, -Fc.ref_cE, 1.0, st);
+                mf_solve_once<T>(ctx, P, Fc, Rr.p, Rr.ld, nrhs, st);
+                hipLaunchKernelGGL(k_refine_axpy, dim3((unsigned)(((size_t)n * nrhs + 255) / 256)), dim3(256), 0, ctx->stream, n, nrhs, (const double*)Rr.p, Rr.ld, W, ldw, st);
+            }
+            return;
+        } else {
+            throw Error(ERR_SINGULAR, "mf_solve: the complex shifted operator needed static pivots; refinement is implemented for real shifts only — "
+                                      "use a user block solver (dre_adi_options.inner_solve) for this pencil");
+        }
+    }
+    mf_solve_once<T>(ctx, P, Fc, W, ldw, nrhs, st);
+}
+template <typename T>
+static void mf_solve_once(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st) {
     if (nrhs <= 0) return;
     if constexpr (sizeof(T) == sizeof(double)) {
         if (P.use_mfma_sweeps) { mf_solve_mfma(ctx, P, Fc, W, ldw, nrhs, st); return; }

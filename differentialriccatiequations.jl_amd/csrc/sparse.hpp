@@ -117,6 +117,15 @@ struct Factor {
     bool allow_topinv = false;
     mutable int uses = 0;
     mutable Mat topinv;
+    // Static pivoting (round 3; the reference factorises with partial pivoting, UMFPACK / CHOLMOD, blocklinear/backslash.jl:13): a pivot smaller
+    // than pivot_static x max|entry of the shifted operator| is replaced by that value with the pivot's sign (SuperLU_DIST's GESP), so the
+    // multipliers stay below 1 / pivot_static and what is factorised is a slightly perturbed matrix; solves with such a factor run fixed-point
+    // refinement x += F^-1 (b - M x) against the TRUE operator (values kept below).  npert counts the replaced pivots (device), nperturbed is
+    // the host copy mf_check fills in (-1 = not read back yet).
+    DevArr<double> pivfloor;            // [0] the floor, [1] max |entry|
+    DevArr<int> npert;
+    mutable int nperturbed = -1;
+    const double* ref_valF = nullptr; const double* ref_valE = nullptr; T ref_cF{}, ref_cE{};
 };
 
 // Numeric multifrontal LU (no pivoting) of  M = cF * F' + cE * E'  where valF/valE live on the pencil's pattern.

@@ -264,6 +264,13 @@ class Factor:
         ctx.chk(ctx.lib.dre_factor_growth(ctx.ptr, self.ptr, C.byref(g)))
         return g.value
 
+    def perturbed(self) -> int:
+        """Number of pivots the static pivoting replaced (dre_factor_perturbed); solves with such a factor are refined against the true operator."""
+        c = C.c_int64()
+        ctx = self.pencil.ctx
+        ctx.chk(ctx.lib.dre_factor_perturbed(ctx.ptr, self.ptr, C.byref(c)))
+        return c.value
+
     def solve_smw(self, alpha, U, Vt, B):
         """(M + inv(alpha) Vt U') \\ B through Sherman-Morrison-Woodbury (dre_shift_solve_smw; blocklinear/sherman-morrison-woodbury.jl:10-45)."""
         ctx = self.pencil.ctx

@@ -153,7 +153,13 @@ int dre_shift_solve(dre_ctx* ctx, const dre_factor* f, const dre_dense* B, dre_d
  * U and Vt are n x m (m <= DRE_SMW_MAX_RANK); complex iff the factor is. */
 int dre_shift_solve_smw(dre_ctx* ctx, const dre_factor* f, double alpha, const dre_dense* U, const dre_dense* Vt, const dre_dense* B,
                         dre_dense** X_re, dre_dense** X_im);
-int dre_factor_growth(dre_ctx* ctx, const dre_factor* f, double* growth);   /* largest multiplier met by the pivot-free LU */
+int dre_factor_growth(dre_ctx* ctx, const dre_factor* f, double* growth);   /* largest multiplier met by the LU */
+/* Static pivoting (the reference's factorize pivots: UMFPACK / CHOLMOD, src/blocklinear/backslash.jl:13): pivots below
+ * pivot_static * max|entry| (option "pivot_static", default sqrt(eps); 0 = plain pivot-free LU) are replaced by that value, which bounds
+ * the multipliers by 1 / pivot_static; solves with a factor that has replaced pivots run "pivot_refine_steps" (default 3) steps of
+ * fixed-point refinement against the true operator (real shifts; a complex factor with replaced pivots is refused: user block solver).
+ * count = number of replaced pivots of this factor. */
+int dre_factor_perturbed(dre_ctx* ctx, const dre_factor* f, int64_t* count);
 int dre_factor_free(dre_ctx* ctx, dre_factor* f);
 
 /* ---- LDLᵀ objects (src/LDLt.jl) ------------------------------------------------------------ */
