@@ -1,5 +1,7 @@
 #include <chrono>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <exception>
 // Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
 #include "engine.hpp"
@@ -2911,6 +2913,41 @@ static LDLtP dense_to_ldlt(Ctx* ctx, int n, const Mat& Xd, double ctf) {
     return X;
 }
 
+// One parked host thread per GDRE solve for work that is DRIVEN beside the main loop (the side-stream compression of X has host read-backs of
+// its own, so it cannot simply be enqueued): jobs are handed over through a condition variable — no thread is spawned per time step.
+class SideWorker {
+  public:
+    ~SideWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+    void submit(std::function<void()> job) {
+        if (!th_.joinable()) th_ = std::thread([this] { run(); });
+        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; }
+        cv_.notify_all();
+    }
+    bool pending() { std::lock_guard<std::mutex> lk(m_); return busy_; }
+    void wait() {       // returns when the submitted job is finished; rethrows what it threw
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return !busy_; });
+        if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; job = std::move(job_); job_ = nullptr; }
+            std::exception_ptr e;
+            try { job(); } catch (...) { e = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(m_); busy_ = false; err_ = e; }
+            done_.notify_all();
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void()> job_;
+    std::exception_ptr err_;
+    bool busy_ = false, quit_ = false;
+};
+
 GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {
     DRE_REQUIRE(order == 1 || order == 2, "only Ros1 and Ros2 have a low-rank formulation");
     DRE_REQUIRE(dt != 0.0, "dt must be nonzero");
@@ -2960,6 +2997,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                   n <= ctx->dense_x_max_n && n <= ctx->dense_inv_max_n && m <= 32 && !adi.shifts.values.empty();
     for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
     DenseXState sx;
+    SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
     bool sx_init = false, x_is_dense = false;
 
     const bool wall_on = std::getenv("DRE_PHASE_TIMING") != nullptr;
@@ -3038,28 +3076,25 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             static const bool fold_e = !(std::getenv("DRE_FOLD_E") && std::atoi(std::getenv("DRE_FOLD_E")) == 0);
             if (fold_e) { a2.rhs_lead_blocks = 2; a2.rhs_e_coeff = 1.0 / tau; }     // rhs = [C'C, K'K] + E'XE / tau
             // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
-            std::thread worker;
             LDLtP Xc;
-            std::exception_ptr werr;
             const size_t nb_prev = X->blocks.size();
+            bool side_job = false;
             if (xside && nb_prev > 1) {
                 DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
                 Xc = std::make_shared<LDLt>(*X);               // shallow: shares the summands, which stay alive in X until the join
-                worker = std::thread([&, Xc]() {
-                    try {
-                        DRE_HIP(hipSetDevice(side->device));
-                        DRE_HIP(hipStreamWaitEvent(side->stream, ctx->side_e1, 0));
-                        ldlt_compress(side, *Xc, ctf, false);
-                        DRE_HIP(hipEventRecord(ctx->side_e2, side->stream));
-                    } catch (...) { werr = std::current_exception(); }
+                side_worker.submit([&, Xc]() {
+                    DRE_HIP(hipSetDevice(side->device));
+                    DRE_HIP(hipStreamWaitEvent(side->stream, ctx->side_e1, 0));
+                    ldlt_compress(side, *Xc, ctf, false);
+                    DRE_HIP(hipEventRecord(ctx->side_e2, side->stream));
                 });
+                side_job = true;
             }
             AdiResult ar;
             try { ar = adi_solve(ctx, op, *rhs, X, a2, &cache); }
-            catch (...) { if (worker.joinable()) worker.join(); throw; }
-            if (worker.joinable()) {
-                worker.join();
-                if (werr) std::rethrow_exception(werr);
+            catch (...) { if (side_job) { try { side_worker.wait(); } catch (...) {} } throw; }
+            if (side_job) {
+                side_worker.wait();
                 DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
                 // X_i = compress(X_{i-1}) + increments_i  (unless the ADI loop had to compress in between: then its X stands)
                 bool intact = ar.X->blocks.size() >= nb_prev;
