@@ -4,9 +4,16 @@
 One "step" = one complete low-rank Rosenbrock-1 solve of the generalized differential Riccati equation on the
 SteelProfile(n) surrogate: tspan = (4500, 0), dt = -100 (45 time steps), X0 = L(0.01 I)L', ADI with
 Cyclic real shifts (real parts of Heuristic(10,20,20), tests/golden/heuristic_shifts_<n>.npy), all inputs
-resident in HBM before the timed region starts.  N > 1: one process per GPU (torchrun), every rank solves an
-independent replica (time steps are sequentially dependent) and the K(t) feedback
-trajectories are gathered over RCCL/xGMI inside the timed region (weak scaling).
+resident in HBM before the timed region starts.
+
+N > 1: one process per GPU (torchrun).  Default mode `replicas` (weak scaling): every rank solves an independent replica (time steps are
+sequentially dependent) and the K(t) feedback trajectories are gathered inside the timed region by the LIBRARY's
+communicator (RCCL over xGMI, dre_comm_allgather on the library stream).  `--mode strong`: ONE solve, the same device-resident time loop on
+every rank, the shifted solves of every ADI step column-sharded inside the library (meant for --n 5177 / 20209).
+
+Legs after the timed region (rank 0): `roofline` (one profiled solve, HIP events per kernel class on the library's streams), `parity` (K(t)
+of the timed solve against the oracle's committed full-length fixture; the run FAILS on a mismatch), `general_path` (N = 1, n = 371 only: the
+sparse multifrontal path at SteelProfile(5177), 12 steps, with its own roofline and parity), `cpu_baseline` (the NumPy/SciPy oracle, N = 1).
 
 Prints ONE JSON line (rank 0).
 """
@@ -85,6 +92,39 @@ def roofline_record(stats, n, m, pencil, its_solve, kw, wall):
     roof.update(avg_launch_us=avg_s * 1e6, launches=s["launches"], share_of_device_time=s["ms"] / max(total_ms, 1e-12),
                 measured_on="one extra profiled solve after the timed region (HIP events on the library's streams, main + side context merged)")
     roof["by_kernel_ms"] = {k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+    top_share = dict(roof)          # the class with the largest share of device time, whatever it is (kept for transparency)
+    # the ADI iteration kernel itself (the hot op the metric counts), whatever class leads the device time: group chain (g iterations per
+    # launch, n <= 768), single-iteration chain, or the multifrontal sweeps of the general path
+    for cls in ("adi_group_iter", "adi_fast_iter", "mf_solve_real"):
+        c = stats.get(cls)
+        if c and c["launches"] > 0 and c["ms"] > 0:
+            t = c["ms"] * 1e-3 / c["launches"]
+            mf = c["flops"] > 0 and c["bytes"] > 0 and c["flops"] / c["bytes"] > 12.0
+            ach = c["flops"] / c["launches"] / t / 1e12 if mf else c["bytes"] / c["launches"] / t / 1e9
+            # SURVEY 8(d) defines the roofline figure per ADI ITERATION, so the record's headline entry is the ADI iteration kernel; when another
+            # class leads the device time (n = 371: the Householder panel of the per-time-step residual compression) it is reported next to it
+            if cls != name:
+                roof.update(kernel=cls, bound="mfma" if mf else "hbm", achieved=ach, peak=78.6 if mf else 8000.0, unit="TFLOP/s" if mf else "GB/s",
+                            frac=ach / (78.6 if mf else 8000.0), avg_launch_us=t * 1e6, launches=c["launches"], traffic=None,
+                            algorithmic_flops_per_launch=c["flops"] / c["launches"], algorithmic_bytes_per_launch=c["bytes"] / c["launches"],
+                            share_of_device_time=c["ms"] / max(total_ms, 1e-12))
+                roof.pop("traffic_source", None)
+                roof["largest_share_kernel"] = {k: top_share[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches",
+                                                                          "share_of_device_time", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch") if k in top_share}
+                for rnd in ("r03", "r02"):
+                    try:
+                        pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{rnd}_n{n}.json")))
+                        sym = KERNEL_SYMBOL.get(cls)
+                        hits = [v for k, v in pmc["kernels"].items() if sym and sym in k]
+                        if hits:
+                            tot_l = sum(h["launches"] for h in hits)
+                            roof["traffic"] = sum(h["fabric_bytes_per_launch"] * h["launches"] for h in hits) / max(tot_l, 1)
+                            roof["traffic_source"] = (f"profiles/pmc_traffic_{rnd}_n{n}.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and WRITE_SIZE in separate passes; "
+                                                      "L2-fabric bytes, Infinity-Cache hits included, not pure HBM bytes")
+                            break
+                    except Exception:
+                        pass
+            break
     # whole solve against the HBM roofline: SURVEY.md 8(d) B_iter per ADI iteration, summed with the measured residual widths
     pinfo = pencil.info()
     z, nnzF = float(pinfo["nnz"]), float(pinfo["factor_nnz"])

@@ -317,6 +317,23 @@ function CommonSolve.init(prob::GALEProblem, alg::ADI; initial_guess=nothing, ob
     finalizer(x -> (ccall((:dre_adi_free, LIB), Cint, (Ptr{Cvoid},), x.ptr); free_operands(x.ctx, x.keep[1]); release!(x.ctx)), s)
 end
 isdone(s::ADISolver) = (d = Ref{Cint}(0); ccall((:dre_adi_isdone, LIB), Cint, (Ptr{Cvoid}, Ref{Cint}), s.ptr, d); d[] != 0)
+"(X, residual) of the solver's current iteration — the payload of observe_gale_step! (src/lyapunov/adi.jl:119, src/Callbacks.jl:97-107); dre_adi_snapshot"
+function snapshot(s::ADISolver)
+    xh, rh = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL)
+    chk(s.ctx, ccall((:dre_adi_snapshot, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}), s.ctx.ptr, s.ptr, xh, rh))
+    X, R = from_device(s.ctx, xh[]), from_device(s.ctx, rh[])
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, xh[])
+    ccall((:dre_ldlt_free, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, rh[])
+    X, R
+end
+
+# ---- multi-GPU: the communicator lives inside the library (RCCL over xGMI; include/dre_hip.h dre_comm_*) ---------------------------
+"128-byte RCCL unique id (rank 0 creates it; hand it to the other ranks with MPI / Distributed)"
+comm_unique_id(ctx::Context) = (id = zeros(UInt8, 128); chk(ctx, ccall((:dre_comm_unique_id, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}), ctx.ptr, id)); id)
+"attach a communicator: from here on the solves entered through `ctx` run column-sharded over the ranks (same calls, same inputs on every rank)"
+comm_init!(ctx::Context, nranks::Integer, rank::Integer, id::Vector{UInt8}) =
+    chk(ctx, ccall((:dre_comm_init, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}), ctx.ptr, nranks, rank, id))
+comm_free!(ctx::Context) = chk(ctx, ccall((:dre_comm_free, LIB), Cint, (Ptr{Cvoid},), ctx.ptr))
 CommonSolve.step!(s::ADISolver) = (chk(s.ctx, ccall((:dre_adi_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), s.ctx.ptr, s.ptr)); s)
 Base.iterate(s::ADISolver, _=nothing) = isdone(s) ? nothing : (CommonSolve.step!(s), nothing)
 function CommonSolve.solve!(s::ADISolver)
