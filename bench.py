@@ -266,9 +266,24 @@ def main():
     # strong: it carries the one all-gather of V per ADI step of the column-sharded solve.  torch.distributed only hands the unique id around.
     from dre_amd.replicas import attach_communicator
     use_lib_comm = strong or (world > 1 and args.gather == "lib")
+    comm_note = None
     if use_lib_comm:
-        attach_communicator(ctx, rank, world)
-        if not strong:
+        try:
+            attach_communicator(ctx, rank, world)
+        except Exception as e:          # replicas: the gather of K(t) is auxiliary — fall back to torch.distributed and SAY so; strong mode has no fallback
+            if strong:
+                raise
+            comm_note = f"library communicator failed on rank {rank} ({e}); K(t) gathered by torch.distributed"
+            print(f"[bench] {comm_note}", file=sys.stderr, flush=True)
+            use_lib_comm = False
+        if world > 1 and not strong:
+            # every rank must take the same path: if any rank fell back, all do
+            flag = torch.tensor([1.0 if use_lib_comm else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0 and use_lib_comm:
+                ctx.comm_free(); use_lib_comm = False
+                comm_note = "another rank's library communicator failed; K(t) gathered by torch.distributed"
+        if use_lib_comm and not strong:
             ctx.set_option("shard_min_cols", 1 << 30)        # replicas: the communicator only gathers K(t), every rank solves its own problem
     # replicas: rank r starts from a slightly different X0 (0.01 * (1 + r/8) * L L'); strong: the SAME problem on every rank
     Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
@@ -407,7 +422,7 @@ def main():
                        "parallelism": (f"ONE solve, ADI solves column-sharded x{world} inside the library (RCCL all-gather of V per ADI step)" if strong else
                                        f"replicas x{world}" + ((" + K(t) gathered by " + ("dre_comm_allgather (RCCL inside the library)" if use_lib_comm
                                                                                           else "torch.distributed all_gather")) if world > 1 else "")),
-                       "comm": ctx.comm_info() if use_lib_comm else None},
+                       "comm": ctx.comm_info() if use_lib_comm else comm_note},
             "roofline": roof,
             "cpu_baseline": cpu,
             "general_path": general,

@@ -1560,6 +1560,43 @@ __global__ void k_top_scatter(int ntop, int nrhs, const int* __restrict__ topidx
     const int p = idx % ntop; const size_t c = idx / ntop;
     W[topidx[p] + c * ldw] = x[p + c * ldx];
 }
+// x = Sinv g with the result SCATTERED into the panel:  W[topidx[p], c] = sum_q Sinv[p, q] g[q, c]  — the dense top of the elimination tree as ONE
+// launch behind the gather (was: split-K GEMM + reduction of the slabs + scatter).  Tile workgroups (16 rows x 16 columns), the four waves
+// split K = ntop and meet through LDS (the k_adi_fast tile scheme); A fragments are 128-byte row segments of the column-major inverse.
+__global__ __launch_bounds__(256) void k_top_apply(int ntop, int nrhs, const double* __restrict__ Sinv, int lds_, const double* __restrict__ g, int ldg,
+                                                   const int* __restrict__ topidx, double* __restrict__ W, int ldw, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double part[4][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int p0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
+    const int kst = (ntop + 3) >> 2, per = (kst + 3) >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int t0 = wv * per, t1 = min(kst, t0 + per);
+    const int row = p0 + lr, col = c0 + lr;
+    const bool rok = row < ntop, cok = col < nrhs;
+    const double* __restrict__ ap = Sinv + (rok ? row : 0);
+    const double* __restrict__ bp = g + (size_t)(cok ? col : 0) * ldg;
+    mf_v4d acc = (mf_v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], bv[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int q = min(4 * min(tb + u, t1 - 1) + lk, ntop - 1);
+            av[u] = ap[(size_t)q * lds_]; bv[u] = bp[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < ntop;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok) ? av[u] : 0.0, (kok && cok) ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    const int orow = p0 + lk + 4 * wave;          // thread (wave = r, lane) finishes element (row lk + 4 r, column lr)
+    if (orow < ntop && cok) W[topidx[orow] + (size_t)col * ldw] = v;
+}
 __global__ void k_top_unit_rows(int nrhs, int c0, const int* __restrict__ topidx, double* __restrict__ W, int ldw) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nrhs) W[topidx[c0 + j] + (size_t)j * ldw] = 1.0;
@@ -1701,12 +1738,25 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n);
         }
+        // DRE_TOP_FUSED=1: one K-split tile kernel (k_top_apply) instead of split-K GEMM + slab reduction + scatter.  Measured (round 3,
+        // tools/ab_general.sh): 21.5 us against 17.5 + 3.8 us per solve at n = 5177 — the same wall-clock (109.9 against 109.6 ms); off by default.
+        static const bool fused_top = std::getenv("DRE_TOP_FUSED") && std::atoi(std::getenv("DRE_TOP_FUSED")) != 0;
+        if (fused_top) {
+            {
+                TimedScope ts(ctx, "gemm_mf_top", 8.0 * ((double)ntop * ntop + 2.0 * ntop * nrhs), 2.0 * ntop * (double)ntop * nrhs);
+                hipLaunchKernelGGL(k_top_apply, dim3(ceil_div(ntop, 16), ceil_div(nrhs, 16)), dim3(256), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
+                                   (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
+            }
+            TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
+            backward_from(T);
+        } else {
         gemm(ctx, false, false, 1.0, Fc.topinv, g, 0.0, x, st, "gemm_mf_top");
         {
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
             hipLaunchKernelGGL(k_top_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const double*)x.p, x.ld, W, ldw, st);
             backward_from(T);
+        }
         }
     }
     DRE_HIP(hipGetLastError());
