@@ -154,3 +154,30 @@ def test_dense_x_loop_falls_back_mid_run_with_the_side_stream_on(ctx, rail371):
     assert [x["iters"] for x in st["gales"]] == [int(v) for v in g["iters"][:10]]
     for i in range(1, 11):
         assert D.delta(sol.K[i], g["K"][i]) < 1e-7
+
+
+@pytest.mark.parametrize("nshifts,maxiters", [(10, 100), (10, 12), (6, 100), (7, 100), (4, 100)])
+def test_group_adi_chain_is_equivalent_to_one_launch_per_iteration(ctx, rail371, nshifts, maxiters):
+    """g ADI iterations per launch on the products of the shifted operators.  Whatever the group size (option `adi_group`: 0 = one
+    launch per iteration, 1 = auto, g = that size) the Lyapunov solves take the same number of iterations and K(t) agrees to rounding — for cycle
+    lengths with divisors 5 / 3 / 2 / none (7 shifts: the chain stays ungrouped), and when `maxiters` cuts the solves short (warning bit, same
+    counts: a group never runs past maxiters in the record)."""
+    d, L, Dm = rail371
+    pick = {10: range(10), 6: (0, 2, 4, 5, 7, 9), 7: (0, 1, 3, 4, 6, 8, 9), 4: (0, 3, 6, 9)}[nshifts]      # sub-lists that still span the spectrum
+    p = [_shifts(371)[i] for i in pick]
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 3900.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(list(p)), maxiters=maxiters))
+    runs = {}
+    try:
+        for g in (0, 1, 2):
+            ctx.set_option("adi_group", g)
+            sol, st = _quiet(D.solve_gdre, prob, alg, dt=-100.0, return_stats=True)
+            runs[g] = (sol, [x["iters"] for x in st["gales"]], [x["warnings"] & 1 for x in st["gales"]])
+    finally:
+        ctx.set_option("adi_group", 1)
+    for g in (1, 2):
+        assert runs[g][1] == runs[0][1] and runs[g][2] == runs[0][2], (g, runs[g][1], runs[0][1])
+        for a, b in zip(runs[g][0].K, runs[0][0].K):
+            assert D.delta(a, b) < 1e-10 or np.linalg.norm(a - b) == 0.0
+    if maxiters == 12:
+        assert max(runs[1][1]) <= 13 and any(runs[1][2])
