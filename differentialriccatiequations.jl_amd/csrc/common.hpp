@@ -97,6 +97,7 @@ class DevicePool {
     size_t total_ = 0;
 };
 
+#define DRE_ADI_MAX_ITERS_LIMIT 100000     // = DRE_ADI_MAX_ITERS of include/dre_hip.h
 struct KernelTimer;  // profiling.hpp
 struct Comm;         // comm.hpp
 

@@ -838,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_ldlt_norm(int k, const double* __restr
         if (st) {
             st->res_norm = nrm;
             st->iters = iters_after;
-            if (iters_after < 512) st->norms[iters_after] = nrm;
+            st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
             if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
         }
     }
@@ -858,7 +858,7 @@ __global__ __launch_bounds__(1024) void k_trace_sq(int k, const double* __restri
         if (st) {
             st->res_norm = nrm;
             st->iters = iters_after;
-            if (iters_after < 512) st->norms[iters_after] = nrm;
+            st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
             if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
         }
     }
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(64) void k_trace_finish(int nparts, const double* _
         if (st) {
             st->res_norm = nrm;
             st->iters = iters_after;
-            if (iters_after < 512) st->norms[iters_after] = nrm;
+            st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
             if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
         }
     }
@@ -1003,7 +1003,7 @@ __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* 
         const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
         st->res_norm = nrm;
         st->iters = iters_after;
-        if (iters_after < 512) st->norms[iters_after] = nrm;
+        st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
         if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
     }
 }
@@ -1365,7 +1365,7 @@ __device__ __forceinline__ void gram_norm_global(int k, const double* __restrict
         const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
         st->res_norm = nrm;
         st->iters = iters_after;
-        if (iters_after < 512) st->norms[iters_after] = nrm;
+        st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
         if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
     }
 }
@@ -1710,7 +1710,7 @@ __global__ __launch_bounds__(256) void k_adi_fast(AdiFastArgs a) {
             AdiState* st = a.st;
             st->res_norm = nrm;
             st->iters = a.it_prev2;
-            if (a.it_prev2 < 512) st->norms[a.it_prev2] = nrm;
+            st->norms[a.it_prev2 & 511] = nrm;
             if (nrm <= st->abstol || a.it_prev2 >= st->maxiters) st->done = 1;
         }
     }
@@ -1901,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
                 const int iters_after = a.it0_prev2 + it;
                 st->res_norm = nrm;
                 st->iters = iters_after;
-                if (iters_after < 512) st->norms[iters_after] = nrm;
+                st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
                 if (nrm <= st->abstol || iters_after >= st->maxiters) { st->done = 1; break; }
             }
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch

@@ -1273,7 +1273,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     res.residual = resid;
     res.X = X;
     res.res_norm = norm0;
-    DRE_REQUIRE(opt.maxiters < 500, "ADI: maxiters must be below 500 (dre_hip.h, DRE_ADI_MAX_ITERS)");
+    DRE_REQUIRE(opt.maxiters >= 0 && opt.maxiters <= DRE_ADI_MAX_ITERS_LIMIT, "ADI: maxiters out of range (dre_hip.h, DRE_ADI_MAX_ITERS)");
     run.X = X; run.resid = resid; run.alpha_res = alpha_res; run.abstol = abstol; run.ctf = ctf; run.cex = cex; run.tdiag = tdiag;
     run.n = n; run.k = k; run.m = op.has_lr ? op.U.cols : 0;
     run.Xw = std::make_shared<LDLt>(*X);        // the iterate: never mutate the caller's initial guess (adi.jl:174 builds a new list)
@@ -1408,7 +1408,7 @@ void adi_advance(AdiRun& run, int budget) {
     auto& used_real = run.used_real; auto& used_cplx = run.used_cplx;
     auto& npend = run.npend;
     auto& resid = run.resid;
-    const int chunk_limit = std::max(1, std::min(run.chunk_limit, budget));
+    const int chunk_limit = std::max(1, std::min(std::min(run.chunk_limit, budget), 480));     // (< 512: ring of the norm history)
     auto check_used = [&]() { run.check_used(); };
     static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
     (void)P; (void)opt_in; (void)serr; (void)lazy_norm;
@@ -1427,7 +1427,7 @@ void adi_advance(AdiRun& run, int budget) {
             const int base_it = iters_host;
             // one more iteration than the previous solve needed; the two flush launches deliver the decisions of the last two
             const int fast_chunk = cache->iters_hint > 0 ? std::max(opt.compression_interval, cache->iters_hint + 1) : run.chunk_limit;
-            const int nit = std::min(std::min(std::max(1, fast_chunk), std::max(1, budget)), opt.maxiters - iters_host);
+            const int nit = std::min(std::min(std::min(std::max(1, fast_chunk), std::max(1, budget)), opt.maxiters - iters_host), 480);
             if (nit <= 0) { finished = true; resid->blocks[0].L = R; return; }
             Mat Rring(ctx, n, k * nit), Vall(ctx, n, k * nit);
             const size_t blocks_before = Xw->blocks.size();
@@ -1481,7 +1481,7 @@ void adi_advance(AdiRun& run, int budget) {
             DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
             DRE_HIP(hipStreamSynchronize(ctx->stream));
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);          // accepted iterations of this chunk
-            for (int j = 1; j <= acc_it; ++j) { res.norms.push_back(h.norms[base_it + j]); res.norm_iters.push_back(base_it + j); }
+            for (int j = 1; j <= acc_it; ++j) { res.norms.push_back(h.norms[(base_it + j) & 511]); res.norm_iters.push_back(base_it + j); }
             Xw->blocks.resize(blocks_before + acc_it);
             check_used();
             if (acc_it > 0) R = Rring.colsview((acc_it - 1) * k, k);
@@ -1726,7 +1726,7 @@ void adi_advance(AdiRun& run, int budget) {
         for (auto& r : recs) {
             if (r.iters_after <= h.iters) {
                 nblocks = r.nblocks; lc += r.nshifts;
-                res.norms.push_back(h.norms[r.iters_after]);
+                res.norms.push_back(h.norms[r.iters_after & 511]);
                 res.norm_iters.push_back(r.iters_after);
             }
         }
@@ -2680,6 +2680,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return false;
     std::vector<Mat> keepV;
     std::vector<BufP> keepRpk;
+    double init_norm = 0.0;
     Mat Vall, Wall;
     int acc_total = 0;
     std::vector<double> coef;
@@ -2718,13 +2719,13 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             const int base_it = iters_host;
             const size_t cyc0 = cyc;
             int nit = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters - iters_host);
-            nit = std::min(nit, (Vall.cols - vcols_used) / k);
+            nit = std::min(std::min(nit, 480), (Vall.cols - vcols_used) / k);        // (< 512: the device keeps the norm history as a ring)
             if (nit <= 0) break;
             // group chain (first chunk of a solve: it starts at position 0 of the cycle): whole groups of gsz iterations per launch; the
             // iteration count of the previous time step (counts fall from step to step) rounded up to a multiple of gsz is enqueued
             const bool grp_now = grp && base_it == 0 && cyc == 0;
             if (grp_now) {
-                const int want = std::min(std::max(sx.hint, 1), adi.maxiters);
+                const int want = std::min(std::min(std::max(sx.hint, 1), adi.maxiters), 480);
                 nit = ((want + gsz - 1) / gsz) * gsz;
                 nit = std::min(nit, ((Vall.cols - vcols_used) / k / gsz) * gsz);
             }
@@ -2825,7 +2826,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                 //   X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated: one batched product + one GEMM)
                 // of this chunk is enqueued right behind the read-back kernel: how many of the speculatively enqueued iterations count is
                 // read from the control block ON THE DEVICE (DevCount), so the device works on X while the host waits for the words.
-                const size_t stb = sizeof(int) * 4 + sizeof(double) * (2 + (size_t)std::min(511, base_it + nit + 1));
+                const size_t stb = sizeof(int) * 4 + sizeof(double) * (2 + (size_t)std::min(512, base_it + nit + 1 + 8));
                 long long serr8 = 0;
                 std::function<void()> between;
                 if (specx) between = [&]() {
@@ -2847,7 +2848,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             }
             h = sx.land->st;
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
-            for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[base_it + j]); ar.norm_iters.push_back(base_it + j); }
+            for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[(base_it + j) & 511]); ar.norm_iters.push_back(base_it + j); }
+            if (base_it == 0) init_norm = h.norms[0];
             if (!specx && acc_it > 0) any_plain = true;
             iters_host = base_it + acc_it;
             vcols_used += acc_it * k;
@@ -2879,8 +2881,8 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     }
     ar.abstol = sx.land->tols[0];
     ar.iters = acc_total;
-    ar.initial_norm = k > 0 ? h.norms[0] : 0.0;
-    ar.res_norm = k > 0 ? (acc_total > 0 ? h.res_norm : h.norms[0]) : 0.0;
+    ar.initial_norm = k > 0 ? init_norm : 0.0;
+    ar.res_norm = k > 0 ? (acc_total > 0 ? h.res_norm : init_norm) : 0.0;
     ar.norms.insert(ar.norms.begin(), ar.initial_norm); ar.norm_iters.insert(ar.norm_iters.begin(), 0);
     ar.converged = ar.res_norm <= ar.abstol;
     if (!ar.converged) ar.warnings |= 1;

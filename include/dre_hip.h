@@ -35,7 +35,7 @@ extern "C" {
 #define DRE_ERR_NODEVICE (-6)
 
 /* hard limits of the engine */
-#define DRE_ADI_MAX_ITERS 499         /* dre_adi_options.maxiters must stay below 500 (size of the device-resident norm history) */
+#define DRE_ADI_MAX_ITERS 100000      /* largest dre_adi_options.maxiters (the device keeps the norm history as a ring that the host empties per chunk) */
 #define DRE_SMW_MAX_RANK 32           /* columns of the low-rank factors U, V of F = cA*A + cE*E + inv(alpha)*U*V */
 
 /* warning bits reported by ADI (AdiResult.warnings) */

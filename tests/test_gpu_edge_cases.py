@@ -90,3 +90,27 @@ def test_two_contexts_on_two_host_threads_give_identical_results(rail371):
         assert s is not None and len(s.K) == len(ref.K)
         for a, b in zip(s.K, ref.K):
             assert np.array_equal(a, b)
+
+
+def test_maxiters_beyond_the_old_history_limit(ctx):
+    """Round 3: the device keeps the residual-norm history as a ring that the host empties per chunk, so `maxiters` is no longer capped at 499
+    (DRE_ADI_MAX_ITERS).  A slowly converging Lyapunov solve (one poor shift) runs 700 iterations: every norm is recorded, in order, and the
+    stepwise protocol sees the same count."""
+    rng = np.random.default_rng(5)
+    n = 60
+    A = (-sp.identity(n) * 1.0 - sp.diags(np.linspace(0.0, 40.0, n))).tocsc()
+    E = sp.identity(n, format="csc")
+    Cl = D.lowrank(rng.standard_normal((n, 2)), np.eye(2))
+    prob = D.GALEProblem(E, A, Cl)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic([-0.05]), maxiters=700, reltol=1e-300), return_info=True)
+    assert info["iters"] == 700 and not info["converged"]
+    assert list(info["norm_iters"]) == list(range(701))
+    nr = np.asarray(info["norms"])
+    assert np.all(np.isfinite(nr)) and np.all(nr[1:] <= nr[:-1] * (1 + 1e-9))       # the ADI residual of a stable pencil never grows with a real shift
+    Xd = X.dense()
+    Ad, Ed = A.toarray(), E.toarray()
+    res = Ad.T @ Xd @ Ed + Ed.T @ Xd @ Ad + Cl.dense()
+    assert abs(np.linalg.norm(res) - nr[-1]) <= 1e-8 * max(nr[-1], 1e-300) + 1e-12 * np.linalg.norm(Cl.dense())
