@@ -1045,10 +1045,18 @@ static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
     if (!cnt) return;
     std::vector<double> h((size_t)2 * cnt);
     ctx_fetch(ctx, dd.norms.p, (size_t)2 * cnt * sizeof(double), h.data());
+    {   // breakdown flag, pivot growth and static-pivot count of all factors of the cycle with one synchronisation (sparse.hpp)
+        std::vector<const Factor<double>*> fs;
+        std::vector<int> who;
+        for (int i = 0; i < cnt; ++i) if (!dd.items[i].fe->checked) { fs.push_back(&dd.items[i].fe->f); who.push_back(i); }
+        if (!fs.empty()) {
+            const std::vector<double> gr = mf_check_batch(ctx, fs);
+            for (size_t j = 0; j < who.size(); ++j) { dd.items[who[j]].fe->growth = gr[j]; dd.items[who[j]].fe->checked = true; }
+        }
+    }
     for (int i = 0; i < cnt; ++i) {
         const double cond_est = std::sqrt(h[2 * i]) * std::sqrt(h[2 * i + 1]);
         auto& fe = *dd.items[i].fe;
-        if (!fe.checked) { fe.growth = mf_check(ctx, fe.f); fe.checked = true; }       // also reads the static-pivot count (sparse.hpp)
         // (a factor with replaced pivots belongs to a perturbed matrix: its explicit inverse is not the operator's — sweeps + refinement instead)
         if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) { fe.dinv = dd.items[i].W; fe.dense = true; }
     }
@@ -2302,6 +2310,7 @@ struct GroupBase {
     std::vector<Mat> XL, Yt, Mb;        // per start: left factors (2 g n) x (m g), Y' (m g) x n, the M(j, i) blocks (m x m each, g*g slots)
     std::vector<Mat> pack;              // packed effective group stacks
     DevArr<GroupLeftDesc> table;        // descriptors of the left-factor launch (built once per run)
+    std::vector<GroupLeftDesc> host_table;
     int ndesc = 0;
 };
 // out(16-row strip) = scale * Mtx(strip, :) v   (v: n x m, m <= 16), K split over the four waves;  kind 1: the m x m matrix scale * v' P' with P = Mtx (m x n)
@@ -2520,8 +2529,8 @@ static void group_base_build(Ctx* ctx, const GaleOperator& op, const std::vector
     }
     gb.ndesc = (int)tab.size();
     gb.table = DevArr<GroupLeftDesc>(ctx, tab.size());
-    DRE_HIP(hipMemcpyAsync(gb.table.p, tab.data(), tab.size() * sizeof(GroupLeftDesc), hipMemcpyHostToDevice, ctx->stream));
-    DRE_HIP(hipStreamSynchronize(ctx->stream));          // (once per run; the host table goes out of scope)
+    gb.host_table = std::move(tab);                      // stays alive with the base: the upload is asynchronous
+    DRE_HIP(hipMemcpyAsync(gb.table.p, gb.host_table.data(), gb.host_table.size() * sizeof(GroupLeftDesc), hipMemcpyHostToDevice, ctx->stream));
 }
 // K-dependent part, once per time step (side stream): copies, g - 1 thin levels, the rows of Y, fold + packing
 static void group_ops_prepare(Ctx* ctx, const std::vector<std::complex<double>>& values, CycleOps& co, GroupBase& gb) {
@@ -2607,7 +2616,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
     // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
     CycleOps co;
-    bool co_ok = true;
+    bool co_ok = true, build_group_base = false;
     auto side_setup = [&]() {
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
         // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
@@ -2617,22 +2626,17 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                      sx.gb.mus.size() == adi.shifts.values.size();
         for (size_t i = 0; gb_ok && i < sx.gb.mus.size(); ++i) gb_ok = sx.gb.mus[i] == adi.shifts.values[i].real();
         co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co, gb_ok ? &sx.gb.wks : nullptr, gb_ok ? &sx.gb.spack : nullptr, gb_ok);
-        if (co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8) {
+        if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
+        build_group_base = co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8;
+        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+        if (build_group_base) {
+            // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
+            // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
             bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
             for (size_t i = 0; i < adi.shifts.values.size(); ++i)
                 for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
-            if (distinct) {
-                group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
-                for (size_t pos = 0; pos < co.wks_pos.size(); ++pos) {
-                    Mat src = sx.gb.wks[pos];         // same shape: view the step's temporary product through a Mat header
-                    src.p = const_cast<double*>(co.wks_pos[pos]); src.ld = 2 * n;
-                    copy_mat(wctx, src, sx.gb.wks[pos]);
-                }
-                gb_ok = true;
-            }
+            if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
         }
-        if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
-        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
     };
     // DRE_SIDE_EARLY=1: enqueue the side stream's work (SMW products, thin recursion, fold) before the assembly instead of inside the band
     // reduction's first read-back.  Measured at n = 371 with the group chain: 21.7 ms per solve early against 21.2 ms in the read-back slot (the

@@ -628,6 +628,32 @@ double mf_check(Ctx* ctx, const Factor<T>& F) {
                                   "needs pivoting; use a user block solver (dre_adi_options.inner_solve) for this pencil");
     return g;
 }
+// the same for several factors with ONE synchronisation (set-up of a whole Cyclic list); returns the growth of each
+std::vector<double> mf_check_batch(Ctx* ctx, const std::vector<const Factor<double>*>& fs) {
+    const size_t nf = fs.size();
+    std::vector<int> herr(nf, 0), hnp(nf, 0);
+    std::vector<unsigned long long> hg(nf, 0);
+    for (size_t i = 0; i < nf; ++i) {
+        const Factor<double>& F = *fs[i];
+        if (!F.err.p) continue;
+        DRE_HIP(hipMemcpyAsync(&herr[i], F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (F.growth.p) DRE_HIP(hipMemcpyAsync(&hg[i], F.growth.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        if (F.npert.p) DRE_HIP(hipMemcpyAsync(&hnp[i], F.npert.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<double> out(nf, 0.0);
+    for (size_t i = 0; i < nf; ++i) {
+        if (!fs[i]->err.p) continue;
+        if (herr[i]) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
+        double g;
+        std::memcpy(&g, &hg[i], sizeof(g));
+        if (!(g == g) || g > ctx->pivot_growth_fail)
+            throw Error(ERR_SINGULAR, "mf_factor: pivot growth " + std::to_string(g) + " of the LU exceeds the limit (pivot_growth_fail)");
+        fs[i]->nperturbed = hnp[i];
+        out[i] = g;
+    }
+    return out;
+}
 template double mf_check<double>(Ctx*, const Factor<double>&);
 template double mf_check<cplx>(Ctx*, const Factor<cplx>&);
 template void mf_factor<double>(Ctx*, const Pencil&, const double*, const double*, double, double, Factor<double>&);

@@ -135,6 +135,7 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
 // Also returns the pivot growth (largest multiplier); throws ERR_SINGULAR beyond ctx->pivot_growth_fail.
 template <typename T>
 double mf_check(Ctx* ctx, const Factor<T>& F);
+std::vector<double> mf_check_batch(Ctx* ctx, const std::vector<const Factor<double>*>& fs);     // several factors, one synchronisation
 // In-place solve  M * X = W  for the n x nrhs panel W (column-major, leading dimension ldw), solver ordering.
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& F, T* W, int ldw, int nrhs, const AdiState* st = nullptr);
