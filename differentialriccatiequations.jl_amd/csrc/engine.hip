@@ -730,6 +730,8 @@ struct ShiftOracle {
     virtual ~ShiftOracle() {}
     virtual std::complex<double> take(int* warn) = 0;
     virtual void update(const Mat& R, const std::vector<Mat>& Vs) {}
+    // the shifts that take() will return next, as far as they are already known (never triggers a computation)
+    virtual std::vector<std::complex<double>> peek(size_t) const { return {}; }
 };
 struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
     std::vector<std::complex<double>> v;
@@ -784,17 +786,84 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         std::vector<double> Us, sv;
         static const bool trace = std::getenv("DRE_TRACE_PROJ") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
-        host_svd_left(kq, w, hR, Us, sv);      // R = Us diag(sv) W'
+        // orth(N) keeps the left singular vectors with sigma > n eps (Stuff.jl:13-19).  With N = Q R and R square, every sigma(R) > n eps means
+        // span(N) = span(Q): the Ritz values of the projected pencil do not depend on WHICH orthonormal basis of that subspace is used, so the
+        // SVD of R (one-sided Jacobi on the host: 59 % of the wall-clock of a default-ADI run at n = 371, measured with DRE_TRACE_PROJ) is
+        // only run when R may be rank deficient: sigma_min is estimated by four steps of inverse iteration on R'R (triangular solves) and
+        // compared with 100 n eps.
+        bool full_rank = false;
+        static const bool skip_svd = !(std::getenv("DRE_PROJ_SKIP_SVD") && std::atoi(std::getenv("DRE_PROJ_SKIP_SVD")) == 0);
+        if (skip_svd && kq == w && w >= 1) {
+            double dmin = 1e300;
+            for (int i = 0; i < w; ++i) dmin = std::min(dmin, std::fabs(hR[i + (size_t)i * kq]));
+            if (dmin > 100.0 * P.n * EPS) {
+                std::vector<double> x((size_t)w, 1.0 / std::sqrt((double)w)), y((size_t)w);
+                double zn = 0.0;
+                for (int it = 0; it < 4; ++it) {
+                    for (int i = 0; i < w; ++i) {                  // R' y = x  (forward substitution, R upper triangular column-major)
+                        double acc = x[(size_t)i];
+                        for (int j = 0; j < i; ++j) acc -= hR[j + (size_t)i * kq] * y[(size_t)j];
+                        y[(size_t)i] = acc / hR[i + (size_t)i * kq];
+                    }
+                    for (int i = w - 1; i >= 0; --i) {             // R z = y  (back substitution; z overwrites x)
+                        double acc = y[(size_t)i];
+                        for (int j = i + 1; j < w; ++j) acc -= hR[i + (size_t)j * kq] * x[(size_t)j];
+                        x[(size_t)i] = acc / hR[i + (size_t)i * kq];
+                    }
+                    zn = 0.0;
+                    for (int i = 0; i < w; ++i) zn += x[(size_t)i] * x[(size_t)i];
+                    zn = std::sqrt(zn);
+                    if (!(zn > 0.0) || !std::isfinite(zn)) break;
+                    for (int i = 0; i < w; ++i) x[(size_t)i] /= zn;
+                }
+                const double smin_est = (zn > 0.0 && std::isfinite(zn)) ? 1.0 / std::sqrt(zn) : 0.0;      // ||(R'R)^-1 x|| -> 1 / sigma_min^2
+                full_rank = smin_est > 100.0 * P.n * EPS;
+            }
+        }
+        if (full_rank) {
+            Us.assign((size_t)kq * kq, 0.0);
+            for (int i = 0; i < kq; ++i) Us[i + (size_t)i * kq] = 1.0;
+            sv.assign((size_t)kq, 1.0);
+        }
+        // A TINY rank-deficient R (the last two increments of a converging solve: ||R|| ~ 1e-12, a handful of singular values above n eps) took
+        // 55 ms of host Jacobi per batch.  Its left singular vectors are the eigenvectors of R R' and the eigenvalues sigma^2 are resolved to
+        // eps sigma_max^2, i.e. sigma to ~1.5e-8 sigma_max: exact enough for the absolute cut n eps whenever 3e-8 ||R||_F < n eps — then the
+        // device eigensolver (early-terminating tridiagonalisation + QL, dense.hip) does it in ~2 ms and the basis never leaves the device.
+        Mat Qdev;
+        int r = 0;
+        double fro = 0.0;
+        for (double v : hR) fro += v * v;
+        fro = std::sqrt(fro);
+        if (!full_rank && skip_svd && fro * 3e-8 < P.n * EPS && fro > 0.0) {
+            Mat G(ctx, kq, kq);
+            gemm(ctx, false, true, 1.0, qr.R, qr.R, 0.0, G, nullptr, "gemm_proj");
+            symmetrize(ctx, G);
+            SymEig e = sym_eig(ctx, G, 4.0, true);
+            std::vector<int> ids;
+            const double thr2 = (P.n * EPS) * (P.n * EPS);
+            for (int i = 0; i < e.j; ++i) if (e.w[(size_t)i] > thr2) ids.push_back(i);
+            r = (int)ids.size();
+            DRE_REQUIRE(r > 0, "Projection shifts: residual factor is numerically zero");
+            Mat B = sym_eig_backtransform(ctx, e, ids);          // kq x r, orthonormal columns
+            Qdev = Mat(ctx, P.n, r);
+            fill_mat(ctx, Qdev, 0.0);
+            Mat top = Qdev.view(0, 0, kq, r);
+            copy_mat(ctx, B, top);
+        } else if (!full_rank && skip_svd) host_rrqr_svd_left(kq, w, hR, P.n * EPS, Us, sv);      // steeply graded history block: pivoted QR + small SVD
+        else if (!full_rank) host_svd_left(kq, w, hR, Us, sv);      // R = Us diag(sv) W'
         auto t1 = std::chrono::steady_clock::now();
-        std::vector<int> keep;
-        for (int i = 0; i < (int)sv.size(); ++i) if (std::fabs(sv[i]) > P.n * EPS) keep.push_back(i);
-        const int r = (int)keep.size();
-        DRE_REQUIRE(r > 0, "Projection shifts: residual factor is numerically zero");
-        std::vector<double> hB((size_t)P.n * r, 0.0);
-        for (int c = 0; c < r; ++c) for (int i = 0; i < kq; ++i) hB[i + (size_t)c * P.n] = Us[i + (size_t)keep[c] * kq];
-        Mat Q(ctx, P.n, r);
-        DRE_HIP(hipMemcpyAsync(Q.p, hB.data(), hB.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (Qdev.empty()) {
+            std::vector<int> keep;
+            for (int i = 0; i < (int)sv.size(); ++i) if (std::fabs(sv[i]) > P.n * EPS) keep.push_back(i);
+            r = (int)keep.size();
+            DRE_REQUIRE(r > 0, "Projection shifts: residual factor is numerically zero");
+            std::vector<double> hB((size_t)P.n * r, 0.0);
+            for (int c = 0; c < r; ++c) for (int i = 0; i < kq; ++i) hB[i + (size_t)c * P.n] = Us[i + (size_t)keep[c] * kq];
+            Qdev = Mat(ctx, P.n, r);
+            DRE_HIP(hipMemcpyAsync(Qdev.p, hB.data(), hB.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        Mat Q = Qdev;
         qr_apply_q(ctx, qr, Q, false);
         // restrictions: Q'EQ = (Q'E'Q)',  Q'FQ = (Q'F'Q)'
         Mat EQ(ctx, P.n, r), FQ(ctx, P.n, r), Et(ctx, r, r), Ft(ctx, r, r);
@@ -812,7 +881,9 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         if (trace) {
             auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[projection] w=%d kq=%d r=%d  svd %.1f ms  device %.1f ms  eig %.1f ms\n", w, kq, r, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+            double svmax = 0.0; for (double v : sv) svmax = std::max(svmax, std::fabs(v));
+            std::fprintf(stderr, "[projection] w=%d kq=%d r=%d  svd %.1f ms  device %.1f ms  eig %.1f ms  ||R||_F %.2e sv_max %.2e full_rank %d\n", w, kq, r, ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                         fro, svmax, (int)full_rank);
         }
         // stabilize_ritz_values! + safe_sort!  (helpers.jl:122-140)
         int nun = 0;
@@ -835,6 +906,11 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
     std::complex<double> take(int* warn) override {
         if (pos >= buffer.size()) take_many(warn);
         return buffer[pos++];
+    }
+    std::vector<std::complex<double>> peek(size_t count) const override {
+        std::vector<std::complex<double>> out;
+        for (size_t i = pos; i < buffer.size() && out.size() < count; ++i) out.push_back(buffer[i]);
+        return out;
     }
 };
 
@@ -1065,7 +1141,7 @@ static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
 template <typename T>
 static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& op, FactorCache* cache,
                                                   std::map<std::tuple<uint64_t, double, double>, std::shared_ptr<FactorEntry<T>>>& store,
-                                                  std::complex<double> mu, bool want_dense = true, DeferredDense* defer = nullptr) {
+                                                  std::complex<double> mu, bool want_dense = true, DeferredDense* defer = nullptr, bool check_now = true) {
     auto key = std::make_tuple(op.tag, mu.real(), mu.imag());
     if (cache->enabled) {
         auto it = store.find(key);
@@ -1077,7 +1153,9 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
     // static pivoting: whether pivots were replaced decides how this factor may be used (refinement, no explicit inverse), so the count is
     // read back here — one synchronisation per NEW factorisation (ten per run with a Cyclic list); the deferred set-up of a whole cycle
     // reads it with its acceptance norms instead (finalize_dense)
-    if (ctx->pivot_static > 0.0 && !defer) { fe->growth = mf_check(ctx, fe->f); fe->checked = true; }
+    // Single-use factors (self-generated shifts: one new factorisation per ADI iteration) are checked with their chunk instead (AdiRun::check_used):
+    // a read-back per iteration would undo the speculative enqueue; a late-detected replaced pivot is handled like a growth warning there.
+    if (ctx->pivot_static > 0.0 && !defer && check_now) { fe->growth = mf_check(ctx, fe->f); fe->checked = true; }
     if constexpr (sizeof(T) == sizeof(double)) {
         const int n = op.P->n;
         fe->f.allow_topinv = cache->enabled;     // a factor that keeps being reused gets the dense top-level inverse (sparse.hip)
@@ -1227,11 +1305,25 @@ struct AdiRun {
     // factorisation kernels only); the handles are dropped then, so single-use factors are freed chunk by chunk
     double max_growth = 0.0;         // largest pivot growth among the factorisations this solve used
     LDLt Crhs;                       // the right-hand side (shallow copy) for the true-residual verification after a growth warning
+    // single-use factors (Projection / per-solve Heuristic shifts): factorised AHEAD on the helper streams while the current iteration solves
+    // (all shifts of a batch are known at once and their factorisations are independent), checked lazily with their chunk
+    std::map<std::pair<double, double>, hipEvent_t> prefetch_ev;      // factor of this shift is being made on a helper stream: wait for the event before use
+    std::vector<hipEvent_t> ev_pool;
+    bool check_now = false;           // a lazily checked factor turned out to have replaced pivots: from now on every new factor is checked at once
+    size_t prefetch_rr = 0;
+    bool helpers_ready = false;
     void check_used() {
-        for (auto& f : used_real) { if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; } max_growth = std::max(max_growth, f->growth); }
-        for (auto& f : used_cplx) { if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; } max_growth = std::max(max_growth, f->growth); }
+        for (auto& f : used_real) {
+            if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; if (f->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); } }
+            max_growth = std::max(max_growth, f->growth);
+        }
+        for (auto& f : used_cplx) {
+            if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; if (f->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); } }
+            max_growth = std::max(max_growth, f->growth);
+        }
         used_real.clear(); used_cplx.clear();
     }
+    ~AdiRun() { for (auto& kv : prefetch_ev) (void)hipEventDestroy(kv.second); for (auto e : ev_pool) (void)hipEventDestroy(e); }
 };
 
 std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
@@ -1516,11 +1608,68 @@ void adi_advance(AdiRun& run, int budget) {
         const size_t blocks_before = Xw->blocks.size();
         const int lc_before = last_compression;
         int since_sync = 0, chunk_shifts = 0;
+        const bool single_use = opt_in.shifts.kind != ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled;
+        // the shift about to be used may have been factorised ahead on a helper stream: the main stream waits for that factorisation's event
+        auto wait_prefetched = [&](std::complex<double> mu) {
+            auto it = run.prefetch_ev.find({mu.real(), mu.imag()});
+            if (it == run.prefetch_ev.end()) return;
+            DRE_HIP(hipStreamWaitEvent(ctx->stream, it->second, 0));
+            run.ev_pool.push_back(it->second);
+            run.prefetch_ev.erase(it);
+        };
+        // factorise the next few shifts of the batch on the helper streams (one workgroup per front: a factorisation uses a handful of CUs
+        // for ~200 us at n = 371 — 45 % of the kernel time of a default-ADI run when it sits on the main stream)
+        auto prefetch_ahead = [&]() {
+            static const int depth_env = std::getenv("DRE_PREFETCH_FACTORS") ? std::atoi(std::getenv("DRE_PREFETCH_FACTORS")) : -1;
+            const int nh = depth_env >= 0 ? std::min(depth_env, 8) : std::max(0, ctx->setup_streams);
+            if (!single_use || nh < 1) return;
+            const auto ups = oracle->peek((size_t)2 * nh + 2);
+            int scheduled = (int)run.prefetch_ev.size();
+            for (size_t i = 0; i < ups.size() && scheduled < nh; ++i) {
+                const std::complex<double> nx = ups[i];
+                const bool cx = nx.imag() != 0.0;
+                const auto ck = std::make_tuple(op.tag, nx.real(), nx.imag());
+                const bool known = cx ? cache->cplx_.count(ck) > 0 : cache->real.count(ck) > 0;
+                if (cx) ++i;                                   // the conjugate partner follows (adi.jl:190) and needs no factorisation of its own
+                if (known) continue;
+                if (!run.helpers_ready) {
+                    while ((int)ctx->helpers.size() < nh) {
+                        auto hc = std::make_unique<Ctx>();
+                        hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+                        DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+                        hc->timer = std::make_unique<KernelTimer>();
+                        hipEvent_t ev;
+                        DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                        ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+                    }
+                    if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
+                    DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));         // the operator's value arrays are ready here
+                    for (int h = 0; h < nh; ++h) {
+                        Ctx* hc = ctx->helpers[(size_t)h].get();
+                        hc->pivot_static = ctx->pivot_static; hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
+                        hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->mf_subtree = ctx->mf_subtree;
+                        hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+                        DRE_HIP(hipStreamWaitEvent(hc->stream, ctx->helper_e0, 0));
+                    }
+                    run.helpers_ready = true;
+                }
+                Ctx* hc = ctx->helpers[run.prefetch_rr++ % (size_t)nh].get();
+                if (cx) (void)get_factor<cplx>(hc, op, cache, cache->cplx_, nx, false, nullptr, run.check_now);
+                else (void)get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
+                hipEvent_t ev;
+                if (!run.ev_pool.empty()) { ev = run.ev_pool.back(); run.ev_pool.pop_back(); }
+                else DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                DRE_HIP(hipEventRecord(ev, hc->stream));
+                run.prefetch_ev[{nx.real(), nx.imag()}] = ev;
+                ++scheduled;
+            }
+        };
         while (iters_host < opt.maxiters) {
             std::complex<double> mu = oracle->take(&res.warnings);
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
             const AdiState* dst = st.p;
+            if (single_use) { wait_prefetched(mu); prefetch_ahead(); }
             Mat V1, V2;
             bool norm_done = false, rode = false;
             if (is_real) {
@@ -1528,7 +1677,7 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<double>> fe;
                 if (!user_inner) {
-                    fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC);
+                    fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC, nullptr, !single_use || run.check_now);
                     used_real.push_back(fe);
                 }
                 auto key = std::make_pair(mu.real(), 0.0);
@@ -1665,7 +1814,7 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<cplx>> fe;
                 if (!user_inner) {
-                    fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu);
+                    fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu, true, nullptr, !single_use || run.check_now);
                     used_cplx.push_back(fe);
                 }
                 auto key = std::make_pair(mu.real(), mu.imag());

@@ -49,6 +49,72 @@ inline void host_svd_left(int p, int w, const std::vector<double>& R, std::vecto
     }
 }
 
+// The same for a matrix whose singular values fall off steeply (the history block of a converging ADI solve: sigma from 1e-3 to below
+// 1e-13 within a few directions): Householder QR with column pivoting, stopped as soon as everything not yet eliminated is below
+// 0.1 * tol in the Frobenius norm (those directions cannot hold a singular value above tol), then the Jacobi SVD of the rp leading ROWS only.
+// One-sided Jacobi on the full 224 x 224 block took 55 ms per call; this takes well under a millisecond when rp is a handful.
+// On return U is p x rp (column-major, ld p), sv has rp entries.
+inline void host_rrqr_svd_left(int p, int w, const std::vector<double>& R, double tol, std::vector<double>& U, std::vector<double>& sv) {
+    std::vector<double> A(R);                              // p x w, ld p
+    std::vector<double> cn((size_t)w, 0.0);
+    std::vector<std::vector<double>> vs;                   // Householder vectors (length p, zero above their pivot row), unit scaling in betas
+    std::vector<double> betas;
+    const int kmax = p < w ? p : w;
+    int rp = 0;
+    for (int step = 0; step < kmax; ++step) {
+        double tot = 0.0; int piv = step; double best = -1.0;
+        for (int j = step; j < w; ++j) {
+            double sacc = 0.0;
+            for (int i = step; i < p; ++i) sacc += A[i + (size_t)j * p] * A[i + (size_t)j * p];
+            cn[(size_t)j] = sacc; tot += sacc;
+            if (sacc > best) { best = sacc; piv = j; }
+        }
+        if (tot <= (0.1 * tol) * (0.1 * tol)) break;
+        if (piv != step) for (int i = 0; i < p; ++i) { const double t = A[i + (size_t)step * p]; A[i + (size_t)step * p] = A[i + (size_t)piv * p]; A[i + (size_t)piv * p] = t; }
+        // Householder reflector for A[step:, step]
+        double alpha = A[step + (size_t)step * p], sig = 0.0;
+        for (int i = step + 1; i < p; ++i) sig += A[i + (size_t)step * p] * A[i + (size_t)step * p];
+        std::vector<double> v((size_t)p, 0.0);
+        double beta = 0.0;
+        if (sig > 0.0 || alpha < 0.0) {
+            const double nrm = std::sqrt(alpha * alpha + sig);
+            const double b = alpha >= 0.0 ? -nrm : nrm;
+            v[(size_t)step] = alpha - b;
+            for (int i = step + 1; i < p; ++i) v[(size_t)i] = A[i + (size_t)step * p];
+            double vv = 0.0;
+            for (int i = step; i < p; ++i) vv += v[(size_t)i] * v[(size_t)i];
+            beta = vv > 0.0 ? 2.0 / vv : 0.0;
+            for (int j = step; j < w; ++j) {
+                double d = 0.0;
+                for (int i = step; i < p; ++i) d += v[(size_t)i] * A[i + (size_t)j * p];
+                d *= beta;
+                for (int i = step; i < p; ++i) A[i + (size_t)j * p] -= d * v[(size_t)i];
+            }
+        }
+        vs.push_back(std::move(v)); betas.push_back(beta);
+        rp = step + 1;
+    }
+    if (rp == 0) { U.clear(); sv.clear(); return; }
+    std::vector<double> B((size_t)rp * w);
+    for (int j = 0; j < w; ++j)
+        for (int i = 0; i < rp; ++i) B[i + (size_t)j * rp] = (i <= j || true) ? A[i + (size_t)j * p] : 0.0;
+    std::vector<double> Us;
+    host_svd_left(rp, w, B, Us, sv);                     // rp x rp
+    U.assign((size_t)p * rp, 0.0);
+    for (int c = 0; c < rp; ++c) for (int i = 0; i < rp; ++i) U[i + (size_t)c * p] = Us[i + (size_t)c * rp];
+    for (int step = rp - 1; step >= 0; --step) {          // U <- H_step U
+        const std::vector<double>& v = vs[(size_t)step];
+        const double beta = betas[(size_t)step];
+        if (beta == 0.0) continue;
+        for (int c = 0; c < rp; ++c) {
+            double d = 0.0;
+            for (int i = step; i < p; ++i) d += v[(size_t)i] * U[i + (size_t)c * p];
+            d *= beta;
+            for (int i = step; i < p; ++i) U[i + (size_t)c * p] -= d * v[(size_t)i];
+        }
+    }
+}
+
 // Solve E X = A for X (n x n) by LU with partial pivoting; A is overwritten by X.
 inline void host_lu_solve(int n, std::vector<double> E, std::vector<double>& A) {
     std::vector<int> piv(n);

@@ -289,9 +289,16 @@ void permute_rows(Ctx* ctx, const Mat& src, const int* map, Mat& dst) {
 // =============================================================================================
 template <typename T>
 __global__ void k_assemble(int nnz, const int64_t* __restrict__ dest, const double* __restrict__ vF,
-                           const double* __restrict__ vE, T cF, T cE, T* __restrict__ fronts) {
+                           const double* __restrict__ vE, T cF, T cE, T* __restrict__ fronts, double rel, double* __restrict__ pivfloor) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nnz) fronts[dest[p]] = cF * vF[p] + cE * vE[p];
+    double m = 0.0;
+    if (p < nnz) { const T v = cF * vF[p] + cE * vE[p]; fronts[dest[p]] = v; m = abs1(v); }
+    if (pivfloor) {
+        // static pivoting: floor = rel * max |entry| of the shifted operator (non-negative doubles order like their bit patterns), as [0] of the
+        // factor's control block; every workgroup contributes its maximum
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(reinterpret_cast<unsigned long long*>(pivfloor), (unsigned long long)__double_as_longlong(rel * m));
+    }
 }
 
 struct MfArgs {
@@ -315,25 +322,6 @@ __device__ __forceinline__ cplx static_pivot(cplx piv, double fl) {
     if (a == 0.0) return cplx{fl, 0.0};
     return cplx{piv.re / a * fl, piv.im / a * fl};
 }
-__global__ void k_pivot_floor(int nnz, const double* __restrict__ valF, const double* __restrict__ valE, double cFr, double cFi, double cEr, double cEi,
-                              double rel, double* __restrict__ out /* [0] floor, [1] max |entry| */) {
-    __shared__ double red[4];
-    double m = 0.0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nnz; i += gridDim.x * 256) {
-        const double re = cFr * valF[i] + cEr * valE[i], im = cFi * valF[i] + cEi * valE[i];
-        m = fmax(m, fabs(re) + fabs(im));
-    }
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-        // max over the workgroups: non-negative doubles order like their bit patterns
-        atomicMax(reinterpret_cast<unsigned long long*>(out + 1), (unsigned long long)__double_as_longlong(m));
-    }
-}
-__global__ void k_pivot_floor_finish(double rel, double* __restrict__ out) { out[0] = rel * out[1]; }
-
 template <typename T>
 __global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err, unsigned long long* __restrict__ growth,
                                const double* __restrict__ pivfloor, int* __restrict__ npert) {
@@ -569,28 +557,23 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
     if (!out.inv.p) out.inv = DevArr<T>(ctx, (size_t)std::max<int64_t>(S.inv_size, 1));
     TimedScope ts(ctx, sizeof(T) == 8 ? "mf_factor_real" : "mf_factor_complex", (double)sizeof(T) * 2.0 * S.fronts_size, 0);
     DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(T), ctx->stream));
-    if (!out.err.p) out.err = DevArr<int>(ctx, 1);
-    if (!out.growth.p) out.growth = DevArr<unsigned long long>(ctx, 1);
+    if (!out.err.p) {
+        // the four small control words of a factor live in ONE 64-byte block (one memset per factorisation instead of four):
+        //   [0] growth (u64)  [8] floor, max|entry| (2 doubles)  [24] err (int)  [28] npert (int)
+        auto blk = std::make_shared<Buf>(ctx, 64);
+        out.growth.buf = blk; out.growth.p = (unsigned long long*)blk->p; out.growth.n = 1;
+        out.pivfloor.buf = blk; out.pivfloor.p = (double*)((char*)blk->p + 8); out.pivfloor.n = 2;
+        out.err.buf = blk; out.err.p = (int*)((char*)blk->p + 24); out.err.n = 1;
+        out.npert.buf = blk; out.npert.p = (int*)((char*)blk->p + 28); out.npert.n = 1;
+    }
     out.topinv = Mat(); out.uses = 0;          // a new factorisation invalidates the dense top inverse
     DevArr<int>& err = out.err;
-    DRE_HIP(hipMemsetAsync(err.p, 0, sizeof(int), ctx->stream));
-    DRE_HIP(hipMemsetAsync(out.growth.p, 0, sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p);
-    if (!out.pivfloor.p) out.pivfloor = DevArr<double>(ctx, 2);
-    if (!out.npert.p) out.npert = DevArr<int>(ctx, 1);
+    DRE_HIP(hipMemsetAsync(out.growth.p, 0, 64, ctx->stream));
     out.nperturbed = -1;
     out.ref_valF = valF; out.ref_valE = valE; out.ref_cF = cF; out.ref_cE = cE;
-    DRE_HIP(hipMemsetAsync(out.pivfloor.p, 0, 2 * sizeof(double), ctx->stream));
-    DRE_HIP(hipMemsetAsync(out.npert.p, 0, sizeof(int), ctx->stream));
-    const double* pf = nullptr;
-    if (ctx->pivot_static > 0.0) {
-        double cfr, cfi, cer, cei;
-        if constexpr (sizeof(T) == sizeof(double)) { cfr = cF; cfi = 0.0; cer = cE; cei = 0.0; }
-        else { cfr = cF.re; cfi = cF.im; cer = cE.re; cei = cE.im; }
-        hipLaunchKernelGGL(k_pivot_floor, dim3(std::min(64, ceil_div(P.nnz, 256))), dim3(256), 0, ctx->stream, P.nnz, valF, valE, cfr, cfi, cer, cei, ctx->pivot_static, out.pivfloor.p);
-        hipLaunchKernelGGL(k_pivot_floor_finish, dim3(1), dim3(1), 0, ctx->stream, ctx->pivot_static, out.pivfloor.p);
-        pf = out.pivfloor.p;
-    }
+    const double* pf = ctx->pivot_static > 0.0 ? out.pivfloor.p : nullptr;
+    hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p,
+                       ctx->pivot_static, ctx->pivot_static > 0.0 ? out.pivfloor.p : (double*)nullptr);
     MfArgs a = mf_args(P);
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
