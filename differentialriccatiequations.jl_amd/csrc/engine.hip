@@ -1114,7 +1114,7 @@ Mat ldlt_feedback_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& B) {
 // Dense inverses whose acceptance test (condition estimate ||M||_F ||inv(M)||_F, two norms in device memory) is still outstanding: a run
 // over all shifts of a cycle enqueues every factorisation and inverse first and reads all norms back with ONE synchronisation
 // (finalize_dense) instead of two per shift.
-struct PendingDense { std::shared_ptr<FactorEntry<double>> fe; Mat W; };
+struct PendingDense { std::shared_ptr<FactorEntry<double>> fe; Mat W; Mat stack; const void* stack_U = nullptr; int stack_m = -1; };
 struct DeferredDense { std::vector<PendingDense> items; DevArr<double> norms; int cap = 0; };
 static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
     const int cnt = (int)dd.items.size();
@@ -1134,7 +1134,10 @@ static void finalize_dense(Ctx* ctx, DeferredDense& dd) {
         const double cond_est = std::sqrt(h[2 * i]) * std::sqrt(h[2 * i + 1]);
         auto& fe = *dd.items[i].fe;
         // (a factor with replaced pivots belongs to a perturbed matrix: its explicit inverse is not the operator's — sweeps + refinement instead)
-        if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) { fe.dinv = dd.items[i].W; fe.dense = true; }
+        if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) {
+            fe.dinv = dd.items[i].W; fe.dense = true;
+            if (!dd.items[i].stack.empty()) { fe.stack = dd.items[i].stack; fe.stack_U = dd.items[i].stack_U; fe.stack_m = dd.items[i].stack_m; }
+        }
     }
     dd.items.clear();
 }
@@ -1171,7 +1174,18 @@ static std::shared_ptr<FactorEntry<T>> get_factor(Ctx* ctx, const GaleOperator& 
                 const size_t slot = defer->items.size();
                 frob2_device(ctx, fv, defer->norms.p + 2 * slot);
                 frob2_device(ctx, W, defer->norms.p + 2 * slot + 1);
-                defer->items.push_back({fe, W});
+                PendingDense pd{fe, W};
+                {
+                    // the stacked inverse [N; E'N; B'N] of this shift in the same helper chain (it was a serial tail of four launches per shift
+                    // on the side stream: 0.5 ms of the first time step)
+                    const int mm = op.has_lr ? op.U.cols : 0;
+                    Mat stk(ctx, 2 * n + mm, n);
+                    { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, W, top); }
+                    { Mat mid = stk.view(n, 0, n, n); spmm(ctx, *op.P, op.P->valEt.p, W, mid, 1.0, 0.0, nullptr); }
+                    if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, W, 0.0, bot, nullptr, "gemm_dinv"); }
+                    pd.stack = stk; pd.stack_U = (const void*)op.U.p; pd.stack_m = mm;
+                }
+                defer->items.push_back(pd);
             } else {
                 const double cond_est = frob_norm_host(ctx, fv) * frob_norm_host(ctx, W);
                 if (cond_est == cond_est && cond_est < 1e7) { fe->dinv = W; fe->dense = true; }

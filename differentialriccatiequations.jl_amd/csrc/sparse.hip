@@ -595,45 +595,49 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
 template <typename T>
 double mf_check(Ctx* ctx, const Factor<T>& F) {
     if (!F.err.p) return 0.0;
-    int herr = 0;
-    unsigned long long hg = 0;
-    DRE_HIP(hipMemcpyAsync(&herr, F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (F.growth.p) DRE_HIP(hipMemcpyAsync(&hg, F.growth.p, sizeof(hg), hipMemcpyDeviceToHost, ctx->stream));
-    int hnp = 0;
-    if (F.npert.p) DRE_HIP(hipMemcpyAsync(&hnp, F.npert.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long w[4] = {0, 0, 0, 0};       // the factor's control block (mf_factor): growth | floor, max|entry| | err, npert — one copy
+    DRE_HIP(hipMemcpyAsync(w, F.growth.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
     DRE_HIP(hipStreamSynchronize(ctx->stream));
-    F.nperturbed = hnp;
+    const int herr = (int)(w[3] & 0xffffffffull);
+    F.nperturbed = (int)(w[3] >> 32);
     if (herr) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
     double g;
-    std::memcpy(&g, &hg, sizeof(g));
+    std::memcpy(&g, &w[0], sizeof(g));
     if (!(g == g) || g > ctx->pivot_growth_fail)
         throw Error(ERR_SINGULAR, "mf_factor: pivot growth " + std::to_string(g) + " of the pivot-free LU exceeds the limit (pivot_growth_fail): the shifted operator "
                                   "needs pivoting; use a user block solver (dre_adi_options.inner_solve) for this pencil");
     return g;
 }
-// the same for several factors with ONE synchronisation (set-up of a whole Cyclic list); returns the growth of each
+// the same for several factors with ONE synchronisation AND one copy (set-up of a whole Cyclic list): the 64-byte control blocks are
+// gathered by a tiny kernel (three separate 4/8-byte copies per factor cost ~19 us each in the first time step's critical path)
+struct MetaPtrs { const unsigned long long* p[16]; };
+__global__ void k_gather_meta(MetaPtrs m, int nf, unsigned long long* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (i < nf * 8) out[i] = m.p[i >> 3][i & 7];
+}
 std::vector<double> mf_check_batch(Ctx* ctx, const std::vector<const Factor<double>*>& fs) {
     const size_t nf = fs.size();
-    std::vector<int> herr(nf, 0), hnp(nf, 0);
-    std::vector<unsigned long long> hg(nf, 0);
-    for (size_t i = 0; i < nf; ++i) {
-        const Factor<double>& F = *fs[i];
-        if (!F.err.p) continue;
-        DRE_HIP(hipMemcpyAsync(&herr[i], F.err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        if (F.growth.p) DRE_HIP(hipMemcpyAsync(&hg[i], F.growth.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        if (F.npert.p) DRE_HIP(hipMemcpyAsync(&hnp[i], F.npert.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    }
-    DRE_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<double> out(nf, 0.0);
-    for (size_t i = 0; i < nf; ++i) {
-        if (!fs[i]->err.p) continue;
-        if (herr[i]) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
-        double g;
-        std::memcpy(&g, &hg[i], sizeof(g));
-        if (!(g == g) || g > ctx->pivot_growth_fail)
-            throw Error(ERR_SINGULAR, "mf_factor: pivot growth " + std::to_string(g) + " of the LU exceeds the limit (pivot_growth_fail)");
-        fs[i]->nperturbed = hnp[i];
-        out[i] = g;
+    for (size_t b0 = 0; b0 < nf; b0 += 16) {
+        const int nb = (int)std::min<size_t>(16, nf - b0);
+        MetaPtrs mp;
+        for (int i = 0; i < 16; ++i) mp.p[i] = fs[b0 + (size_t)(i < nb ? i : 0)]->growth.p;      // start of the control block (mf_factor)
+        DevArr<unsigned long long> g(ctx, 16 * 8);
+        hipLaunchKernelGGL(k_gather_meta, dim3(1), dim3(128), 0, ctx->stream, mp, nb, g.p);
+        unsigned long long h[16 * 8];
+        DRE_HIP(hipMemcpyAsync(h, g.p, (size_t)nb * 64, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < nb; ++i) {
+            const unsigned long long* w = h + 8 * i;       // [0] growth, [1..2] floor / max|entry|, [3] = err (low word) | npert (high word)
+            const int herr = (int)(w[3] & 0xffffffffull), hnp = (int)(w[3] >> 32);
+            if (herr) throw Error(ERR_SINGULAR, "mf_factor: zero or NaN pivot (shifted operator numerically singular)");
+            double gr;
+            std::memcpy(&gr, &w[0], sizeof(gr));
+            if (!(gr == gr) || gr > ctx->pivot_growth_fail)
+                throw Error(ERR_SINGULAR, "mf_factor: pivot growth " + std::to_string(gr) + " of the LU exceeds the limit (pivot_growth_fail)");
+            fs[b0 + (size_t)i]->nperturbed = hnp;
+            out[b0 + (size_t)i] = gr;
+        }
     }
     return out;
 }
