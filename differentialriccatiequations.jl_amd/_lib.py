@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdre_hip.so")
+LIB_PATH = os.environ.get("DRE_HIP_LIB") or os.path.join(_HERE, "libdre_hip.so")      # DRE_HIP_LIB: another build of the same library (A/B timing)
 
 
 class DREError(RuntimeError):

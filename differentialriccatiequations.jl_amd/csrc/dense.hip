@@ -469,6 +469,56 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
     DRE_HIP(hipGetLastError());
 }
 
+// Small outputs with a long inner dimension in ONE launch: one workgroup per 16 x 16 tile of C = alpha op(A) B + beta C, the four waves split K and
+// meet in LDS (fixed order) — the split-K GEMM above needs a second launch to sum its slabs, and at a few dozen tiles both are pure latency.
+template <bool TA>
+__global__ __launch_bounds__(256) void k_gemm_thin(int M, int N, int K, double alpha, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                                   double beta, double* __restrict__ C, int ldc, const AdiState* st) {
+    const int done_flag = st ? st->done : 0;
+    __shared__ double part[4][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int ai = min(i0 + lr, M - 1), bj = min(j0 + lr, N - 1);
+    const bool aok = i0 + lr < M, bok = j0 + lr < N;
+    const int kst = (K + 3) >> 2, per = (kst + 3) >> 2, t0 = wv * per, t1 = min(kst, t0 + per);
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], bv[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int t = min(tb + u, t1 - 1), kk = min(4 * t + lk, K - 1);
+            av[u] = TA ? A[kk + (size_t)ai * lda] : A[ai + (size_t)kk * lda];
+            bv[u] = B[kk + (size_t)bj * ldb];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool ok = (tb + u < t1) && 4 * (tb + u) + lk < K;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && aok) ? av[u] : 0.0, (ok && bok) ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+    if (done_flag) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    const int row = i0 + lk + 4 * wave, col = j0 + lr;
+    if (row < M && col < N) {
+        double* c = C + row + (size_t)col * ldc;
+        *c = (beta == 0.0) ? alpha * v : alpha * v + beta * (*c);
+    }
+}
+void gemm_thin(Ctx* ctx, bool tA, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
+               const AdiState* st, const char* tag) {
+    if (M <= 0 || N <= 0) return;
+    DRE_REQUIRE(K >= 1, "gemm_thin: empty inner dimension");
+    TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
+    const dim3 grid(ceil_div(M, 16), ceil_div(N, 16));
+    if (tA) hipLaunchKernelGGL((k_gemm_thin<true>), grid, dim3(256), 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+    else hipLaunchKernelGGL((k_gemm_thin<false>), grid, dim3(256), 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st);
+    DRE_HIP(hipGetLastError());
+}
+
 BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                    int* splits_out, const AdiState* st, const char* tag, DevCount dc) {
     TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
@@ -1778,7 +1828,9 @@ void adi_group_pack(Ctx* ctx, int n, int nblk, const double* src, int lds_, doub
 }
 
 __global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
-    if (a.st->done) return;
+    // the flag is REQUESTED here and looked at after the operand loads of the tile product are in flight: a dependent ~1 us round trip to L2
+    // in front of every workgroup's first load otherwise (launches enqueued past the end of the solve do their loads for nothing)
+    const int done_flag = a.st->done;
     __shared__ double partbuf[4 * 4 * 64];
     double (*part)[4][64] = reinterpret_cast<double (*)[4][64]>(partbuf);
     __shared__ double nred[17];
@@ -1801,6 +1853,7 @@ __global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int per = (a.kst + 3) >> 2, t0 = wv * per, t1 = min(a.kst, t0 + per);
         const v4d acc = adi_fast_tile<true>(a.Gpack + (size_t)hs * a.kst * 64 + lane, a.Rpc + (size_t)tc * 64 + lane, colok, lk, n, t0, t1, (size_t)ct * 64);
+        if (done_flag) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
         __syncthreads();
@@ -1840,6 +1893,7 @@ __global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && aok) ? av[u] : 0.0, (ok && bok) ? bv[u] : 0.0, acc, 0, 0, 0);
             }
         }
+        if (done_flag) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
         __syncthreads();
@@ -1884,6 +1938,7 @@ __global__ __launch_bounds__(256) void k_adi_group(AdiGroupArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sloc += mm[r] * nn[r];
     }
+    if (done_flag) return;
     sloc = block_sum(sloc, nred);
     if (tid == 0) {
         __hip_atomic_store(a.nws + b, sloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2664,8 +2719,17 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
                                                     double* __restrict__ T, int ldt, double* __restrict__ VT, int ldvt, AdiState* st,
                                                     const double* __restrict__ part, int nparts, int kpanel, double tolfac,
                                                     double* __restrict__ part_out, int zero_above) {
-    if (st && st->done) return;
+    // the flag, the panel and the partial sums of the termination test are all REQUESTED before the first of them is looked at: three dependent
+    // round trips to L2 (flag -> sums -> panel, ~1 us each) in front of the column loop otherwise.  (The barrier below keeps the compiler from
+    // sinking the panel loads behind the early exit.)
+    const int done_flag = st ? st->done : 0;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int c0 = wave * 4;
+    double x[4][NR];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int u = 0; u < NR; ++u) { const int r = lane + 64 * u; x[c][u] = r < rows ? A[r + (size_t)(c0 + c) * lda] : 0.0; }
     if (part) {
         const double resn = st->res_norm;
         double r2 = 0.0;
@@ -2675,22 +2739,17 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
         const double tol = band_tol(st, tolfac, base);
         const bool stop = r2 <= tol * tol;
         __syncthreads();
+        if (done_flag) return;
         if (tid == 0) {
             if (kpanel == 0) st->res_norm = r2;
             if (stop) { st->done = 1; st->iters = kpanel; }
         }
         if (stop) return;
-    }
+    } else if (done_flag) return;
     extern __shared__ double q16[];
     double* pv = q16;                                 // 2 x 512: the published reflector
     double* Vs = q16 + 1024;                          // rows x 17: V (explicit) for V'V and V T
     __shared__ double taus[16], Zs[4][16][17], Tsh[16][17];
-    const int c0 = wave * 4;
-    double x[4][NR];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int u = 0; u < NR; ++u) { const int r = lane + 64 * u; x[c][u] = r < rows ? A[r + (size_t)(c0 + c) * lda] : 0.0; }
     double sig = 0.0;                                 // ||column[j+1:]||^2 of the column this wave owns next (valid in its owner)
     if (wave == 0) {
 #pragma unroll
@@ -3463,7 +3522,7 @@ __global__ __launch_bounds__(256) void k_band_w_rows(int m, int splits, const do
 //             the termination test of the next panel.
 __global__ __launch_bounds__(256) void k_band_z(int m, const double* __restrict__ S22, int lds_, const double* __restrict__ VT, int ldvt,
                                                 double* __restrict__ Z, int ldz, const AdiState* st) {
-    if (st->done) return;
+    const int done_flag = st->done;          // requested now, looked at behind the product (see k_adi_group)
     __shared__ double part[4][4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -3484,6 +3543,7 @@ __global__ __launch_bounds__(256) void k_band_z(int m, const double* __restrict_
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64((ok && row < m) ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
         }
     }
+    if (done_flag) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
     __syncthreads();
@@ -3494,7 +3554,7 @@ __global__ __launch_bounds__(256) void k_band_z(int m, const double* __restrict_
 __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S22, int lds_, const double* __restrict__ V, int ldv,
                                                   const double* __restrict__ Z, int ldz, const double* __restrict__ T, int ldt,
                                                   double* __restrict__ tile_sumsq, const AdiState* st) {
-    if (st->done) return;
+    const int done_flag = st->done;          // requested now, looked at behind the first product (see k_adi_group)
     __shared__ double part[4][4][64];
     __shared__ double Msh[16][17], Nsh[16][17];
     __shared__ double Ar[64][33], Bc[64][33];
@@ -3541,6 +3601,7 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, ok ? bv[u] : 0.0, acc, 0, 0, 0);
             }
         }
+        if (done_flag) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
         __syncthreads();
@@ -3611,8 +3672,10 @@ __global__ __launch_bounds__(256) void k_band_upd(int m, double* __restrict__ S2
     }
 }
 // D(i,j) for the leading J x J block: diagonal blocks as stored, sub-diagonal blocks = upper triangle of the panel's R
-__global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd) {
+__global__ void k_extract_band(int J, int b, int kred, const double* __restrict__ S, int ld, double* __restrict__ D, int ldd, int q, double* __restrict__ B0,
+                               int ldb) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (B0 && idx < (size_t)q * J) { const int r = idx % q, c = idx / q; B0[r + (size_t)c * ldb] = r == c ? 1.0 : 0.0; }     // rider: [I; 0], q x J
     if (idx >= (size_t)J * J) return;
     int i = idx % J, j = idx / J;
     const bool swap = i < j;
@@ -3626,9 +3689,20 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
 }
 
 // control block of a reduction set up on the device (abs_tol_dev: the tolerance only exists in device memory)
-__global__ void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev, int floor_mode) {
+struct BandTolJob { const double* parts; int nparts; double reltol, abstol, frac; double* out; };
+__global__ __launch_bounds__(64) void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev, int floor_mode, BandTolJob job) {
+    double at_dev = 0.0;
+    if (job.parts) {       // tolerances of the dense time loop's Lyapunov solve (engine.hip, ros1_dense_step): adi.jl:61-62
+        double s = 0.0;
+        for (int i = threadIdx.x; i < job.nparts; i += 64) s += job.parts[i];
+        s = wave_sum(s);
+        const double nc = sqrt(s), at = job.abstol >= 0.0 ? job.abstol : job.reltol * nc;
+        at_dev = job.frac * at;
+        if (threadIdx.x == 0) { job.out[0] = at; job.out[1] = at_dev; job.out[2] = nc; }
+    }
+    if (threadIdx.x != 0) return;
     st->done = 0; st->iters = 0; st->maxiters = floor_mode ? BAND_TOL_FLOOR : 0; st->smw_singular = 0;
-    st->abstol = abs_tol_dev ? abs_tol_dev[0] : abs_tol;
+    st->abstol = job.parts ? at_dev : (abs_tol_dev ? abs_tol_dev[0] : abs_tol);
     st->res_norm = 0.0;
 }
 // debug (DRE_CLOCK_PROBE=1): shader clock while the solve runs = delta s_memtime / delta s_memrealtime x 100 MHz over ~10 us of dependent ALU work
@@ -3662,7 +3736,11 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     DevArr<double> part(ctx, (size_t)std::max(BAND_REM_BLOCKS, 1 + gemm_num_tiles(q, q)));
     int nparts = BAND_REM_BLOCKS;
     DevArr<AdiState> st(ctx, 1);
-    hipLaunchKernelGGL(k_band_init, dim3(1), dim3(1), 0, ctx->stream, st.p, abs_tol, abs_tol_dev, tol_is_floor ? 1 : 0);
+    {
+        BandTolJob job{nullptr, 0, 0.0, -1.0, 1.0, nullptr};
+        if (spec && spec->tol_parts) job = BandTolJob{spec->tol_parts, spec->tol_nparts, spec->tol_reltol, spec->tol_abstol, spec->tol_frac, spec->tols_out};
+        hipLaunchKernelGGL(k_band_init, dim3(1), dim3(64), 0, ctx->stream, st.p, abs_tol, abs_tol_dev, tol_is_floor ? 1 : 0, job);
+    }
     {
         static const bool cp = std::getenv("DRE_CLOCK_PROBE") != nullptr;
         static int cp_count = 0;
@@ -3777,8 +3855,10 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 SymBand tmp = out;
                 tmp.J = Js; tmp.npanels = nps;
                 tmp.D = Mat(ctx, Js, Js);
-                const size_t tots = (size_t)Js * Js;
-                hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tots + 255) / 256)), dim3(256), 0, ctx->stream, Js, b, nps * b, S.p, S.ld, tmp.D.p, tmp.D.ld);
+                tmp.B0 = Mat(ctx, q, Js);
+                const size_t tots = (size_t)q * Js;
+                hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tots + 255) / 256)), dim3(256), 0, ctx->stream, Js, b, nps * b, S.p, S.ld, tmp.D.p, tmp.D.ld,
+                                   q, tmp.B0.p, tmp.B0.ld);
                 spec->B = sym_band_basis(ctx, tmp);
                 spec->D = tmp.D; spec->J = Js;
                 if (spec->extra && !spec->ran) { spec->ran = true; spec->extra(); }
@@ -3799,8 +3879,10 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     if (spec && spec->J == J && J > 0) { out.D = spec->D; spec->hit = true; DRE_HIP(hipGetLastError()); return out; }
     if (spec) { spec->hit = false; spec->B = Mat(); spec->D = Mat(); }
     out.D = Mat(ctx, J, J);
-    size_t tot = (size_t)J * J;
-    if (tot) hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, J, b, np * b, S.p, S.ld, out.D.p, out.D.ld);
+    if (J > 0) out.B0 = Mat(ctx, q, J);
+    size_t tot = (size_t)q * J;
+    if (tot) hipLaunchKernelGGL(k_extract_band, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, J, b, np * b, S.p, S.ld, out.D.p, out.D.ld,
+                                q, out.B0.p, out.B0.ld);
     DRE_HIP(hipGetLastError());
     return out;
 }
@@ -4277,8 +4359,9 @@ Mat sym_band_basis(Ctx* ctx, const SymBand& sb) {
     return B;
 }
 static Mat sym_band_basis_core(Ctx* ctx, const SymBand& sb) {
-    Mat B(ctx, sb.q, sb.J);
-    set_identity(ctx, B, 1.0);
+    Mat B;
+    if (!sb.B0.empty() && !sb.B0_used && sb.B0.rows == sb.q && sb.B0.cols == sb.J) { B = sb.B0; sb.B0_used = true; }
+    else { B = Mat(ctx, sb.q, sb.J); set_identity(ctx, B, 1.0); }
     const int b = sb.nb;
     int np = sb.npanels;
     while (np > 0 && sb.q - (np - 1) * b - b < b) --np;        // panels that really hold reflectors
@@ -4289,7 +4372,8 @@ static Mat sym_band_basis_core(Ctx* ctx, const SymBand& sb) {
         Mat Vall = sb.V.view(0, 0, sb.q, nr);
         DRE_REQUIRE(b == 16, "sym_band_basis: panel width 16 expected");
         Mat G(ctx, nr, nr), M(ctx, nr, sb.J);
-        gemm(ctx, true, false, 1.0, Vall, Vall, 0.0, G, nullptr, "gemm_band");
+        if (sb.q <= 2048) gemm_thin(ctx, true, nr, nr, sb.q, 1.0, Vall.p, Vall.ld, Vall.p, Vall.ld, 0.0, G.p, G.ld, nullptr, "gemm_band");   // one launch, no slabs
+        else gemm(ctx, true, false, 1.0, Vall, Vall, 0.0, G, nullptr, "gemm_band");
         {
             TimedScope ts(ctx, "blocktri", 8.0 * (nr * (double)nr / 2 + 2.0 * nr * sb.J), (double)nr * nr * sb.J);
             const size_t shm = ((size_t)2 * nr + 48) * 17 * sizeof(double);

@@ -35,6 +35,9 @@ void gemm(Ctx* ctx, bool transA, bool transB, int M, int N, int K, double alpha,
 // tile_sumsq (optional, K <= 64 only): receives one partial sum of squares of the updated C per 64 x 64 tile
 // (gemm_num_tiles(M, N) entries) — the band reduction's termination norm comes out of the update GEMM's epilogue.
 inline int gemm_num_tiles(int M, int N) { return ((M + 63) / 64) * ((N + 63) / 64); }
+// C = alpha op(A) B + beta C for a SMALL C (a few dozen 16 x 16 tiles) and a long inner dimension, in one launch (no split-K slabs)
+void gemm_thin(Ctx* ctx, bool tA, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
+               const AdiState* st = nullptr, const char* tag = "gemm");
 inline void gemm(Ctx* ctx, bool tA, bool tB, double alpha, const Mat& A, const Mat& B, double beta, Mat& C,
                  const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma", double* tile_sumsq = nullptr) {
     int M = tA ? A.cols : A.rows, K = tA ? A.rows : A.cols, N = tB ? B.rows : B.cols;
@@ -225,6 +228,8 @@ struct SymBand {
     Mat T;      // nb x q block-reflector factors
     Mat D;      // J x J symmetric band matrix (dense storage)
     Mat V0, VT0; // optional leading reflector block Q0 = I - VT0 V0' (factor-form reduction with a warm start): Qb <- Q0 Qb
+    Mat B0;      // optional q x J identity block written by the launch that extracted D (start of sym_band_basis: saves its fill launch)
+    mutable bool B0_used = false;      // the basis is built in place: the block serves ONE call
 };
 // abs_tol > 0 replaces the relative criterion by ||remainder||_F <= abs_tol
 // spec (optional): the band matrix and the basis for the predicted result are enqueued while the control block is read back (spec->hit
@@ -235,6 +240,9 @@ struct BandSpec {
     // further host work to slot into the wait for the control block (runs once, after the speculative kernels were enqueued; ran = true)
     std::function<void()> extra;
     bool ran = false;
+    // optional job of the control-block launch (the dense time loop's tolerances; saves a launch): with nc = sqrt(sum tol_parts),
+    // at = tol_abstol >= 0 ? tol_abstol : tol_reltol nc  ->  tols_out = {at, tol_frac at, nc}; the reduction's absolute tolerance is tols_out[1]
+    const double* tol_parts = nullptr; int tol_nparts = 0; double tol_reltol = 0.0, tol_abstol = -1.0, tol_frac = 1.0; double* tols_out = nullptr;
 };
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, const double* abs_tol_dev = nullptr, BandSpec* spec = nullptr,
                         const double* ext_part = nullptr, int ext_nparts = 0, bool tol_is_floor = false);   // abs_tol_dev: the tolerance lives in device memory;

@@ -2221,16 +2221,6 @@ __global__ __launch_bounds__(256) void k_dense_residual(int n, int q, int m, con
         part[ntot + slot] = (red[4] + red[5]) + (red[6] + red[7]);      // ||Res||_F^2: the first termination norm of the band reduction
     }
 }
-// tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F
-__global__ __launch_bounds__(64) void k_dense_tols(int nparts, const double* __restrict__ part, double reltol, double abstol_given, double frac, double* __restrict__ tols) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nparts; i += 64) s += part[i];
-    s = wave_sum_t<double>(s);
-    if (threadIdx.x == 0) {
-        const double nc = sqrt(s), at = abstol_given >= 0.0 ? abstol_given : reltol * nc;
-        tols[0] = at; tols[1] = frac * at; tols[2] = nc;
-    }
-}
 // control block of the Lyapunov solve: residual = R D R' with orthonormal R, so its norm is ||D||_F
 // Workgroup 0: control block of the Lyapunov solve.  Workgroups 1..: the initial residual R (n x J) in the B-operand lane order of the fast
 // chain (dense.hpp, AdiFastArgs::Rpc; four 64-entry blocks per workgroup) — rides on this launch instead of a launch of its own.
@@ -2730,6 +2720,7 @@ static void group_ops_prepare(Ctx* ctx, const std::vector<std::complex<double>>&
 struct DenseXState {
     Mat X;        // n x n, symmetric
     Mat P1;       // E' X
+    Mat P1t;      // X E (= P1'), written by the same SpMM launch
     Mat Kt;       // K' = E' X B  (n x m)
     int hint = 0; // ADI iterations of the previous step
     GroupBase gb; // K-independent operator products of the group chain (built at the first dense step)
@@ -2810,18 +2801,21 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
     // The main stream's kernels are enqueued BEFORE the side stream is set up: the host calls for the side stream (event wait, six
     // launches) would otherwise sit in front of them while the main stream idles.
-    Mat Y(ctx, n, n), Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
-    transpose_mat(ctx, sx.P1, Y);                                               // Y = X E
+    Mat Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
+    const Mat& Y = sx.P1t;                                                      // Y = X E
     spmm_dual(ctx, P, P.valAt.p, P.valEt.p, Y, Mx, EY);       // A' X E and E' X E in one pass over X E
     const int nt = ceil_div(n, 16);
     DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 4);
     hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
                        (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
-    hipLaunchKernelGGL(k_dense_tols, dim3(1), dim3(64), 0, ctx->stream, nt * nt, (const double*)part.p, reltol, adi.abstol, adi.residual_abs_frac, tols.p);
     sx.mark(ctx, 1);
     // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
     BandSpec spec;
+    // tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F:
+    // computed by the reduction's control-block launch
+    spec.tol_parts = part.p; spec.tol_nparts = nt * nt; spec.tol_reltol = reltol; spec.tol_abstol = adi.abstol; spec.tol_frac = adi.residual_abs_frac;
+    spec.tols_out = tols.p;
     static const bool side_in_fetch = !(std::getenv("DRE_SIDE_IN_FETCH") && std::atoi(std::getenv("DRE_SIDE_IN_FETCH")) == 0);
     const bool defer_side = wctx != ctx && side_in_fetch && !side_early;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
     if (defer_side) spec.extra = side_setup;
@@ -3057,9 +3051,9 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     cache->iters_hint = acc_total;
     sx.mark(ctx, 5);
     // feedback of the new X:  P1 = E' X,  K' = P1 B      (lowrank_ros1.jl:53-56)
-    spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+    spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0, nullptr, &sx.P1t);
     Mat Kt(ctx, n, m);
-    gemm(ctx, false, false, 1.0, sx.P1, prob.B, 0.0, Kt);
+    gemm_thin(ctx, false, n, m, n, 1.0, sx.P1.p, sx.P1.ld, prob.B.p, prob.B.ld, 0.0, Kt.p, Kt.ld);
     sx.Kt = Kt;
     sx.mark(ctx, 6);
     side_guard.armed = false;          // the main stream waited for side_e2 above: nothing of the side stream is pending
@@ -3205,7 +3199,8 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                     symmetrize(ctx, sx.X);
                 } else fill_mat(ctx, sx.X, 0.0);
                 sx.P1 = Mat(ctx, n, n);
-                spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0);
+                sx.P1t = Mat(ctx, n, n);
+                spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0, nullptr, &sx.P1t);
                 sx.Kt = fb.Kt;
                 sx.hint = cache.iters_hint > 0 ? cache.iters_hint : 3 * adi.compression_interval;    // first solve: a few chunks at most
                 sx_init = true;

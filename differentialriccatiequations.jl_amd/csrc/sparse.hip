@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ ptr
 __global__ __launch_bounds__(256) void k_spmm_lds(int n, const int* __restrict__ ptr, const int* __restrict__ idx,
                                                   const double* __restrict__ val, const double* __restrict__ X, int ldx,
                                                   double* __restrict__ Y, int ldy, int ncols, double alpha, double beta,
-                                                  const AdiState* st) {
+                                                  const AdiState* st, double* __restrict__ Yt, int ldyt) {
     if (st && st->done) return;
     __shared__ double vs[SPMM_LDS_NNZ];
     __shared__ int is[SPMM_LDS_NNZ];
@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256) void k_spmm_lds(int n, const int* __restrict__
             for (int c = 0; c < SPMM_CB; ++c) acc[c] += v0 * x0[(size_t)c * ldx];
         }
 #pragma unroll
-        for (int c = 0; c < SPMM_CB; ++c) Y[i + (size_t)(c0 + c) * ldy] = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * yold[c];
+        for (int c = 0; c < SPMM_CB; ++c) {
+            const double o = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * yold[c];
+            Y[i + (size_t)(c0 + c) * ldy] = o;
+            if (Yt) Yt[(c0 + c) + (size_t)i * ldyt] = o;          // the transposed copy rides along (64 contiguous bytes per thread)
+        }
         return;
     }
     for (int p = pb; p < pe; ++p) {
@@ -179,18 +183,21 @@ __global__ __launch_bounds__(256) void k_spmm_lds(int n, const int* __restrict__
     for (int c = 0; c < SPMM_CB; ++c)
         if (c0 + c < c1) {
             double* y = Y + i + (size_t)(c0 + c) * ldy;
-            *y = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
+            const double o = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
+            *y = o;
+            if (Yt) Yt[(c0 + c) + (size_t)i * ldyt] = o;
         }
 }
 void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
-          double beta, const AdiState* st, int nnz) {
+          double beta, const AdiState* st, int nnz, Mat* Yt) {
     DRE_REQUIRE(X.rows == n && Y.rows == n && X.cols == Y.cols, "spmm: shape mismatch");
+    DRE_REQUIRE(!Yt || (Yt->rows == Y.cols && Yt->cols == n), "spmm: shape of the transposed copy");
     if (X.cols == 0) return;
     // algorithmic bytes: CSR (12 B/nnz + 4 B/row) + X read + Y read/write; nnz < 0: unknown to the caller, 7-point estimate
     const double z = nnz >= 0 ? (double)nnz : 7.0 * n;
     TimedScope ts(ctx, "spmm_csr", 12.0 * z + 4.0 * n + 8.0 * n * X.cols * (beta == 0.0 ? 2.0 : 3.0), 2.0 * z * X.cols);
     hipLaunchKernelGGL(k_spmm_lds, dim3(ceil_div(n, 256), ceil_div(X.cols, SPMM_CB)), dim3(256), 0, ctx->stream, n, ptr, idx, val,
-                       X.p, X.ld, Y.p, Y.ld, X.cols, alpha, beta, st);
+                       X.p, X.ld, Y.p, Y.ld, X.cols, alpha, beta, st, Yt ? Yt->p : (double*)nullptr, Yt ? Yt->ld : 0);
     DRE_HIP(hipGetLastError());
 }
 // Two operators on the SAME pattern applied to the same panel in one pass (the pencil keeps E' and A' on one union pattern):

@@ -93,11 +93,12 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
 
 // Y = alpha * M * X + beta * Y with M given by CSR (ptr, idx, val) of order n; X, Y are n x ncols.
 void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, const Mat& X, Mat& Y, double alpha,
-          double beta, const AdiState* st = nullptr, int nnz = -1);
+          double beta, const AdiState* st = nullptr, int nnz = -1, Mat* Yt = nullptr);      // Yt (optional): Y' written by the same launch
 // the same on the pencil's pattern (val = one of its value arrays): the CSR segment of each 256-row workgroup is staged through LDS
 // with coalesced loads, and the byte count of the timers uses the real number of nonzeros
-inline void spmm(Ctx* ctx, const Pencil& P, const double* val, const Mat& X, Mat& Y, double alpha, double beta, const AdiState* st = nullptr) {
-    spmm(ctx, P.n, P.ptr.p, P.idx.p, val, X, Y, alpha, beta, st, P.nnz);
+inline void spmm(Ctx* ctx, const Pencil& P, const double* val, const Mat& X, Mat& Y, double alpha, double beta, const AdiState* st = nullptr,
+                 Mat* Yt = nullptr) {
+    spmm(ctx, P.n, P.ptr.p, P.idx.p, val, X, Y, alpha, beta, st, P.nnz, Yt);
 }
 // Y1 = M1 X and Y2 = M2 X for two value arrays on the pencil's pattern in one pass over X
 void spmm_dual(Ctx* ctx, const Pencil& P, const double* val1, const double* val2, const Mat& X, Mat& Y1, Mat& Y2);
