@@ -347,6 +347,9 @@ def main():
         one_solve(gather=False)      # collectives stay matched across ranks: the profiled solve does not gather
         stats = ctx.prof_stats()
         ctx.prof_enable(False)
+        if os.environ.get("DRE_BENCH_CLASSES"):        # builder's view: every kernel class of the profiled solve (stderr; the JSON line is unchanged)
+            for k_, v_ in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"[class] {k_:24s} launches {v_['launches']:6d}  ms {v_['ms']:9.3f}  avg_us {v_['ms'] * 1e3 / max(v_['launches'], 1):8.2f}", file=sys.stderr)
         roof = roofline_record(stats, n, m, pencil, total_iters / (args.steps * (1 if strong else world)), width["kw"], elapsed / args.steps)
         # ---- parity leg (after the timed region): the K(t) trajectory of the last timed solve of rank 0 against the committed oracle fixture
         parity = parity_check(n, args.nsteps, Kdev.cpu().numpy(), its_last)

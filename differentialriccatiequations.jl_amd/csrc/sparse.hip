@@ -1583,13 +1583,14 @@ __global__ void k_top_scatter(int ntop, int nrhs, const int* __restrict__ topidx
 // x = Sinv g with the result SCATTERED into the panel:  W[topidx[p], c] = sum_q Sinv[p, q] g[q, c]  — the dense top of the elimination tree as ONE
 // launch behind the gather (was: split-K GEMM + reduction of the slabs + scatter).  Tile workgroups (16 rows x 16 columns), the four waves
 // split K = ntop and meet through LDS (the k_adi_fast tile scheme); A fragments are 128-byte row segments of the column-major inverse.
-__global__ __launch_bounds__(256) void k_top_apply(int ntop, int nrhs, const double* __restrict__ Sinv, int lds_, const double* __restrict__ g, int ldg,
-                                                   const int* __restrict__ topidx, double* __restrict__ W, int ldw, const AdiState* st) {
-    if (st && st->done) return;
-    __shared__ double part[4][4][64];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_top_apply(int ntop, int nrhs, const double* __restrict__ Sinv, int lds_, const double* __restrict__ g, int ldg,
+                                                       const int* __restrict__ topidx, double* __restrict__ W, int ldw, const AdiState* st) {
+    const int done_flag = st ? st->done : 0;
+    __shared__ double part[NW][4][64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
     const int p0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
-    const int kst = (ntop + 3) >> 2, per = (kst + 3) >> 2;
+    const int kst = (ntop + 3) >> 2, per = (kst + NW - 1) / NW;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int t0 = wv * per, t1 = min(kst, t0 + per);
     const int row = p0 + lr, col = c0 + lr;
@@ -1610,10 +1611,14 @@ __global__ __launch_bounds__(256) void k_top_apply(int ntop, int nrhs, const dou
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok) ? av[u] : 0.0, (kok && cok) ? bv[u] : 0.0, acc, 0, 0, 0);
         }
     }
+    if (done_flag) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
     __syncthreads();
-    const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    if (wave >= 4) return;
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += part[w][wave][lane];      // fixed order
     const int orow = p0 + lk + 4 * wave;          // thread (wave = r, lane) finishes element (row lk + 4 r, column lr)
     if (orow < ntop && cok) W[topidx[orow] + (size_t)col * ldw] = v;
 }
@@ -1758,14 +1763,21 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n);
         }
-        // DRE_TOP_FUSED=1: one K-split tile kernel (k_top_apply) instead of split-K GEMM + slab reduction + scatter.  Measured (round 3,
-        // tools/ab_general.sh): 21.5 us against 17.5 + 3.8 us per solve at n = 5177 — the same wall-clock (109.9 against 109.6 ms); off by default.
-        static const bool fused_top = std::getenv("DRE_TOP_FUSED") && std::atoi(std::getenv("DRE_TOP_FUSED")) != 0;
+        // DRE_TOP_FUSED=4|8|16: one K-split tile kernel (k_top_apply, that many waves) instead of split-K GEMM + slab reduction + scatter.  Measured
+        // (round 3, tools/ab_general.sh): 22-24 us per launch whatever the wave count against 17.5 + 3.8 us at n = 5177 — the same wall-clock.  The
+        // product streams the 18.9 MB inverse from HBM (40 shifts x 18.9 MB are not MALL resident): a variant with one workgroup per 16-row strip and
+        // all column tiles (inverse read once, 96 workgroups) took 34 us — too few bytes in flight; the 504-workgroup split-K GEMM stays the default.
+        static const int fused_top = std::getenv("DRE_TOP_FUSED") ? std::atoi(std::getenv("DRE_TOP_FUSED")) : 0;
         if (fused_top) {
             {
                 TimedScope ts(ctx, "gemm_mf_top", 8.0 * ((double)ntop * ntop + 2.0 * ntop * nrhs), 2.0 * ntop * (double)ntop * nrhs);
-                hipLaunchKernelGGL(k_top_apply, dim3(ceil_div(ntop, 16), ceil_div(nrhs, 16)), dim3(256), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
-                                   (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
+                const dim3 grid(ceil_div(ntop, 16), ceil_div(nrhs, 16));
+                if (fused_top >= 16) hipLaunchKernelGGL((k_top_apply<16>), grid, dim3(1024), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
+                                                        (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
+                else if (fused_top >= 8) hipLaunchKernelGGL((k_top_apply<8>), grid, dim3(512), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
+                                                            (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
+                else hipLaunchKernelGGL((k_top_apply<4>), grid, dim3(256), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
+                                        (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
             }
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
             backward_from(T);
