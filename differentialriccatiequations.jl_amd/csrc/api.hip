@@ -98,6 +98,8 @@ int dre_ctx_create(int device, dre_ctx** out) {
         if (const char* e = std::getenv("DRE_DENSE_X_MAX_N")) ctx->c.dense_x_max_n = std::atoi(e);
         if (const char* e = std::getenv("DRE_ADI_GROUP")) ctx->c.adi_group = std::atoi(e);
         if (const char* e = std::getenv("DRE_ADI_GROUP_MAX_N")) ctx->c.adi_group_max_n = std::atoi(e);
+        if (const char* e = std::getenv("DRE_ADI_FAN")) ctx->c.adi_fan = std::atoi(e);
+        if (const char* e = std::getenv("DRE_ADI_FAN_MAX_COEF")) ctx->c.adi_fan_max_coef = std::atof(e);
         if (const char* e = std::getenv("DRE_X_COMPRESS_EVERY")) ctx->c.x_compress_every = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
@@ -176,6 +178,8 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "dense_x_max_k") ctx->c.dense_x_max_k = (int)value;
         else if (key == "adi_group") ctx->c.adi_group = (int)value;
         else if (key == "adi_group_max_n") ctx->c.adi_group_max_n = (int)value;
+        else if (key == "adi_fan") ctx->c.adi_fan = (int)value;
+        else if (key == "adi_fan_max_coef") ctx->c.adi_fan_max_coef = value;
         else if (key == "shard_min_cols") ctx->c.shard_min_cols = (int)value;
         else if (key == "shard_emulate") {
             // ONE process plays `value` ranks of the column-sharded ADI step one after the other (tests of the blocking logic on one GPU)

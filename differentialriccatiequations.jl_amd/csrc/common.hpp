@@ -7,8 +7,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -52,8 +54,9 @@ enum : int {
 // ---------------------------------------------------------------------------------------------
 class DevicePool {
   public:
-    ~DevicePool() { trim(); }
+    ~DevicePool() { trim_locked(); }
     void* alloc(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu_);       // (buffers are handed out by the thread that drives the pool's stream, but released by whoever drops the last handle)
         size_t sz = round_up(bytes);
         auto it = free_.lower_bound(sz);
         if (it != free_.end() && it->first <= sz * 2) {
@@ -65,7 +68,7 @@ class DevicePool {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
-            trim();
+            trim_locked();
             e = hipMalloc(&p, sz);
             if (e != hipSuccess) throw Error(ERR_ALLOC, "hipMalloc failed for " + std::to_string(sz) + " bytes");
         }
@@ -75,18 +78,21 @@ class DevicePool {
     }
     void release(void* p) {
         if (!p) return;
+        std::lock_guard<std::mutex> lk(mu_);
         auto it = live_.find(p);
         if (it == live_.end()) return;
         free_.emplace(it->second, p);
         live_.erase(it);
     }
-    void trim() {
-        for (auto& kv : free_) { (void)hipFree(kv.second); total_ -= kv.first; }
-        free_.clear();
-    }
+    void trim() { std::lock_guard<std::mutex> lk(mu_); trim_locked(); }
     size_t total_bytes() const { return total_; }
 
   private:
+    void trim_locked() {
+        for (auto& kv : free_) { (void)hipFree(kv.second); total_ -= kv.first; }
+        free_.clear();
+    }
+    std::mutex mu_;
     static size_t round_up(size_t b) {
         if (b < 256) b = 256;
         size_t g = b < (1u << 20) ? 4096 : (1u << 20);
@@ -152,6 +158,10 @@ struct Ctx {
     // divisor of the cycle length up to 5), 0 = off (one launch per iteration), g >= 2 = that group size if it divides the cycle length
     int adi_group = 1;
     int adi_group_max_n = 768;
+    // fan groups of the general path (engine.hip, k_fan_mix): up to adi_fan consecutive real-shift iterations from independent solves that run
+    // side by side on the helper streams (0 / 1 = off, at most 4); a group is cut where the partial-fraction coefficients exceed adi_fan_max_coef
+    int adi_fan = 3;
+    double adi_fan_max_coef = 64.0;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;

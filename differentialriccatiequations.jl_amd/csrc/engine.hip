@@ -737,6 +737,11 @@ struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
     std::vector<std::complex<double>> v;
     size_t i = 0;
     std::complex<double> take(int*) override { auto x = v[i % v.size()]; ++i; return x; }
+    std::vector<std::complex<double>> peek(size_t count) const override {
+        std::vector<std::complex<double>> out;
+        for (size_t j = 0; j < count && !v.empty(); ++j) out.push_back(v[(i + j) % v.size()]);
+        return out;
+    }
 };
 
 static void apply_Ft(Ctx* ctx, const GaleOperator& op, const Mat& L, Mat& out) {
@@ -1283,7 +1288,86 @@ std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOpe
 // The solver object of one Lyapunov solve (the reference's ADICache, adi.jl:5-21): adi_begin = init (adi.jl:29-69), adi_advance = step!
 // / solve! (adi.jl:71-128; one call enqueues up to `budget` shifts speculatively and synchronises once), adi_finish = the tail of solve!
 // (final compression adi.jl:78-80, result).  adi_solve runs the three in sequence.
-struct StepRec { int iters_after; size_t nblocks; int nshifts; };
+// =============================================================================================
+// Fan groups (round 3, general path): g consecutive real-shift ADI iterations from g INDEPENDENT solves with the same right-hand side.
+// With Z_s = (A' + mu_s E')^-1 (low-rank term included) the resolvent identity  Z_a - Z_b = (mu_b - mu_a) Z_b E' Z_a  turns the iterates of
+// adi.jl:158-171,   V_j = Z_j R_{j-1},  R_j = R_{j-1} - 2 mu_j E' V_j   (j = 1..g, from R_0),   into partial fractions of  W_s = Z_s R_0:
+//     V_j = sum_{s<=j} c_js W_s,     c_js = prod_{i<j} (-mu_s - mu_i) / prod_{i<=j, i!=s} (mu_i - mu_s),
+//     R_j = R_0 - E' Y_j,            Y_j = 2 sum_{i<=j} mu_i V_i = sum_{s<=j} d_js W_s,   d_js = 2 sum_{i=s..j} mu_i c_is.
+// The g multifrontal solves (+ SMW corrections) are latency bound and use a fraction of the chip each: they run side by side on the helper
+// streams; one mixing launch forms all V_j and Y_j, ONE SpMM over the g k columns all residuals, and the norms/decisions follow in iteration
+// order.  The coefficients grow when shifts of a group are close (~ mu / delta mu per pair): groups are cut so that max_j sum_s |c_js| stays
+// below fan_max_coef (the products W_s are accurate to ~eps cond, the combination amplifies that by the coefficient sum).
+// =============================================================================================
+struct FanCoef { double c[4][4], d[4][4]; };
+static double fan_coefficients(const double* mu, int g, FanCoef* out) {
+    long double c[4][4] = {{0}}, d[4][4] = {{0}};
+    double worst = 0.0;
+    for (int j = 0; j < g; ++j) {
+        long double sum = 0.0L;
+        for (int s = 0; s <= j; ++s) {
+            long double num = 1.0L, den = 1.0L;
+            for (int i = 0; i < j; ++i) num *= -(long double)mu[s] - (long double)mu[i];
+            for (int i = 0; i <= j; ++i) if (i != s) den *= (long double)mu[i] - (long double)mu[s];
+            c[j][s] = num / den;
+            sum += fabsl(c[j][s]);
+        }
+        worst = std::max(worst, (double)sum);
+    }
+    for (int j = 0; j < g; ++j)
+        for (int s = 0; s <= j; ++s) {
+            long double acc = 0.0L;
+            for (int i = s; i <= j; ++i) acc += 2.0L * (long double)mu[i] * c[i][s];
+            d[j][s] = acc;
+        }
+    for (int j = 0; j < 4; ++j) for (int s = 0; s < 4; ++s) { out->c[j][s] = (double)c[j][s]; out->d[j][s] = (double)d[j][s]; }
+    return worst;
+}
+// W: n x (g k) = [W_1 .. W_g];  V_j, Y_j as above;  Rcat_j = R_0 (the SpMM that follows subtracts E' Y_j in place)
+__global__ __launch_bounds__(256) void k_fan_mix(int n, int k, int g, const double* __restrict__ W, int ldw, const double* __restrict__ R0, int ldr,
+                                                 double* __restrict__ V, int ldv, double* __restrict__ Y, int ldy, double* __restrict__ Rcat, int ldrc,
+                                                 FanCoef co, const AdiState* st) {
+    if (st && st->done) return;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * k) return;
+    const int i = idx % n, c = idx / n;
+    double w[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = s < g ? W[i + (size_t)(s * k + c) * ldw] : 0.0;
+    const double r0 = R0[i + (size_t)c * ldr];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j >= g) break;
+        double v = 0.0, y = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) if (s <= j) { v += co.c[j][s] * w[s]; y += co.d[j][s] * w[s]; }
+        V[i + (size_t)(j * k + c) * ldv] = v;
+        Y[i + (size_t)(j * k + c) * ldy] = y;
+        Rcat[i + (size_t)(j * k + c) * ldrc] = r0;
+    }
+}
+// helper contexts (own stream and pool each) of a context; the first use makes the streams wait for everything the main stream holds so far
+static void ensure_helpers(Ctx* ctx, int nh) {
+    while ((int)ctx->helpers.size() < nh) {
+        auto hc = std::make_unique<Ctx>();
+        hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+        DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+        hc->timer = std::make_unique<KernelTimer>();
+        hipEvent_t ev;
+        DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+    }
+    if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
+    for (int h = 0; h < nh; ++h) {
+        Ctx* hc = ctx->helpers[(size_t)h].get();
+        hc->pivot_static = ctx->pivot_static; hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
+        hc->pivot_refine_steps = ctx->pivot_refine_steps;
+        hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->mf_subtree = ctx->mf_subtree;
+        hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+    }
+}
+
+struct StepRec { int iters_after; size_t nblocks; int nshifts; Mat Rafter; };      // Rafter: the residual factor after this iteration where it is NOT updated in place (fan groups)
 struct AdiRun {
     Ctx* ctx = nullptr;
     GaleOperator op;
@@ -1326,6 +1410,7 @@ struct AdiRun {
     bool check_now = false;           // a lazily checked factor turned out to have replaced pivots: from now on every new factor is checked at once
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
+    std::vector<BufP> fan_keep;       // work panels of the fan groups of the current chunk (written on helper streams)
     void check_used() {
         for (auto& f : used_real) {
             if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; if (f->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); } }
@@ -1621,6 +1706,9 @@ void adi_advance(AdiRun& run, int budget) {
         std::vector<StepRec> recs;
         const size_t blocks_before = Xw->blocks.size();
         const int lc_before = last_compression;
+        const Mat R_chunk_start = R;
+        static const int chunk_timing = std::getenv("DRE_CHUNK_TIMING") ? std::atoi(std::getenv("DRE_CHUNK_TIMING")) : 0;
+        const auto ct0 = std::chrono::steady_clock::now();
         int since_sync = 0, chunk_shifts = 0;
         const bool single_use = opt_in.shifts.kind != ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled;
         // the shift about to be used may have been factorised ahead on a helper stream: the main stream waits for that factorisation's event
@@ -1678,7 +1766,131 @@ void adi_advance(AdiRun& run, int budget) {
                 ++scheduled;
             }
         };
+        const bool sharded_now = ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1 && k >= ctx->shard_min_cols;
+        const int fan_max = (opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && !sharded_now && cache->enabled && n > ctx->dense_inv_max_n)
+                                ? std::min(ctx->adi_fan, 4) : 0;
         while (iters_host < opt.maxiters) {
+            // ---- fan group: the next g real shifts of the cycle at once (independent solves side by side, see k_fan_mix) ----------------
+            if (fan_max >= 2) {
+                const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), chunk_limit - chunk_shifts);
+                const auto ups = room >= 2 ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
+                int g = 0;
+                double mus[4];
+                while (g < (int)ups.size() && g < room && ups[(size_t)g].imag() == 0.0) {
+                    bool dup = false;
+                    for (int i = 0; i < g; ++i) dup = dup || mus[i] == ups[(size_t)g].real();
+                    if (dup) break;
+                    mus[g] = ups[(size_t)g].real(); ++g;
+                }
+                FanCoef co;
+                while (g >= 2 && fan_coefficients(mus, g, &co) > ctx->adi_fan_max_coef) --g;
+                std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+                for (int s_ = 0; s_ < g && g >= 2; ++s_) {
+                    auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, true);
+                    if (fe->dense) { g = 0; break; }              // the dense-inverse step has its own fused kernels
+                    fes.push_back(fe);
+                }
+                if (g >= 2) {
+                    const AdiState* dst = st.p;
+                    static const bool fan_timing = std::getenv("DRE_FAN_TIMING") != nullptr;
+                    const auto h_t0 = std::chrono::steady_clock::now();
+                    hipEvent_t ft0 = nullptr, ft1 = nullptr;
+                    if (fan_timing) { (void)hipEventCreate(&ft0); (void)hipEventCreate(&ft1); (void)hipEventRecord(ft0, ctx->stream); }
+                    dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
+                    ensure_helpers(ctx, g - 1);
+                    Mat Wcat(ctx, n, g * k), Vcat(ctx, n, g * k), Ycat(ctx, n, g * k), Rcat(ctx, n, g * k);
+                    // host-side bookkeeping (SMW cache, buffers from the main pool) first; a job only enqueues on its stream
+                    std::vector<std::function<void()>> jobs;
+                    for (int s_ = 0; s_ < g; ++s_) {
+                        Ctx* c = s_ < g - 1 ? ctx->helpers[(size_t)s_].get() : ctx;
+                        const auto fe = fes[(size_t)s_];
+                        const double mur = mus[s_];
+                        Mat Vout = Wcat.colsview(s_ * k, k);
+                        const Mat Rin = R;
+                        hipEvent_t e0 = ctx->helper_e0, ev = c != ctx ? ctx->helper_ev[(size_t)s_] : nullptr;
+                        Ctx* const mainc = ctx;
+                        used_real.push_back(fe);
+                        if (!op.has_lr) {
+                            jobs.push_back([=, &P]() {
+                                if (c != mainc) DRE_HIP(hipStreamWaitEvent(c->stream, e0, 0));
+                                mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Vout.p, Vout.ld, k, dst);
+                                if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
+                            });
+                            continue;
+                        }
+                        auto key = std::make_pair(mur, 0.0);
+                        auto sc = smw_cache.find(key);
+                        const bool have = sc != smw_cache.end();
+                        const int ncols = k + (have ? 0 : m);
+                        Mat W(ctx, n, ncols), small(ctx, m, ncols);
+                        if (!have) {
+                            SmwCacheEntry en;
+                            en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
+                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                            sc = smw_cache.emplace(key, en).first;
+                        }
+                        const double* WU = (const double*)sc->second.WU; const int ldwu = sc->second.ldwu;
+                        double* sinv = (double*)sc->second.sinv->p;
+                        run.fan_keep.push_back(W.buf); run.fan_keep.push_back(small.buf);
+                        const GaleOperator* opp = &op;
+                        int* const serr_ = serr;
+                        jobs.push_back([=, &P]() {
+                            if (c != mainc) DRE_HIP(hipStreamWaitEvent(c->stream, e0, 0));
+                            Mat Wl = W, sm = small;
+                            if (!have) { Mat d = Wl.colsview(k, m); copy_mat(c, opp->Vt, d, 1.0, dst); }
+                            mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Wl.p, Wl.ld, ncols, dst);
+                            gemm(c, true, false, 1.0, opp->U, Wl, 0.0, sm, dst, "smw_small");
+                            if (!have)
+                                hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, c->stream, m, sm.p + (size_t)k * sm.ld, sm.ld, opp->alpha, sinv, dst, serr_);
+                            {
+                                TimedScope ts(c, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
+                                hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, c->stream,
+                                                   n, m, k, (const double*)Wl.p, Wl.ld, WU, ldwu, (const double*)sinv, (const double*)sm.p, sm.ld, Vout.p, Vout.ld,
+                                                   (double*)nullptr, 0, 0.0, dst);
+                            }
+                            if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
+                        });
+                    }
+                    DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));              // R_0 (and everything before it) is ready here
+                    // (Feeding every helper stream from a host thread of its own was tried: host enqueue 97 -> 83 us per iteration at g = 4, wall-clock
+                    // unchanged — the device is the bound: the sweep kernels take a whole CU's LDS per workgroup, so two solves interleave kernel by
+                    // kernel rather than overlap; only their latency-bound small kernels run side by side.)
+                    for (auto& jb : jobs) jb();
+                    for (int s_ = 0; s_ < g - 1; ++s_) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->helper_ev[(size_t)s_], 0));
+                    {
+                        TimedScope ts(ctx, "fan_mix", 8.0 * n * k * (4.0 * g + 1.0), 2.0 * n * k * (double)g * (g + 1));
+                        const size_t tot = (size_t)n * k;
+                        hipLaunchKernelGGL(k_fan_mix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, g, (const double*)Wcat.p, Wcat.ld,
+                                           (const double*)R.p, R.ld, Vcat.p, Vcat.ld, Ycat.p, Ycat.ld, Rcat.p, Rcat.ld, co, dst);
+                    }
+                    spmm(ctx, P, P.valEt.p, Ycat, Rcat, -1.0, 1.0, dst);              // R_j = R_0 - E' Y_j, all j in one pass
+                    for (int j = 0; j < g; ++j) {
+                        const std::complex<double> muj = oracle->take(&res.warnings);
+                        all_shifts.push_back(muj);
+                        Mat Vj = Vcat.colsview(j * k, k), Rj = Rcat.colsview(j * k, k);
+                        Xw->blocks.push_back({Vj, Tm, -2.0 * muj.real() * alpha_res, tdiag});
+                        iters_host += 1; last_compression += 1;
+                        oracle->update(Rj, {Vj});
+                        residual_norm_step(ctx, Rj, Tm, tdiag, alpha_res, st.p, iters_host);
+                        recs.push_back({iters_host, Xw->blocks.size(), 1, Rj});
+                        ++since_sync; ++chunk_shifts;
+                    }
+                    R = Rcat.colsview((g - 1) * k, k);
+                    run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(Ycat.buf);
+                    if (fan_timing) {
+                        (void)hipEventRecord(ft1, ctx->stream);
+                        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h_t0).count();
+                        (void)hipEventSynchronize(ft1);
+                        float ms = 0; (void)hipEventElapsedTime(&ms, ft0, ft1);
+                        static int cnt = 0;
+                        if (++cnt % 16 == 8) std::fprintf(stderr, "[fan timing] g=%d  host enqueue %.1f us  device %.1f us\n", g, host_us, ms * 1e3);
+                        (void)hipEventDestroy(ft0); (void)hipEventDestroy(ft1);
+                    }
+                    if (opt.compression && chunk_shifts >= chunk_limit) break;
+                    if (!opt.compression && since_sync >= std::min(10, chunk_limit)) break;
+                    continue;
+                }
+            }
             std::complex<double> mu = oracle->take(&res.warnings);
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
@@ -1882,7 +2094,7 @@ void adi_advance(AdiRun& run, int budget) {
             // residual norm through the Gram matrix, convergence decision on the device
             if (!rode) dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);     // a step of another kind: norms stay in order
             if (!norm_done) residual_norm_step(ctx, R, Tm, tdiag, alpha_res, st.p, iters_host);
-            recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2});
+            recs.push_back({iters_host, Xw->blocks.size(), is_real ? 1 : 2, R});
             ++since_sync; chunk_shifts += is_real ? 1 : 2;
             if (opt.compression && chunk_shifts >= chunk_limit) break;
             if (!opt.compression && since_sync >= std::min(10, chunk_limit)) break;
@@ -1890,13 +2102,25 @@ void adi_advance(AdiRun& run, int budget) {
         // synchronise once per chunk and find out how far the device really got
         dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
         AdiState h;
+        const auto ct1 = std::chrono::steady_clock::now();
         DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (chunk_timing) {
+            static double enq = 0.0, wait = 0.0; static long nch = 0, nit_ = 0;
+            const auto ct2 = std::chrono::steady_clock::now();
+            enq += std::chrono::duration<double, std::micro>(ct1 - ct0).count(); wait += std::chrono::duration<double, std::micro>(ct2 - ct1).count();
+            nit_ += (long)recs.size();
+            if (++nch % 64 == 0) std::fprintf(stderr, "[chunk timing] %ld chunks, %ld iterations: host enqueue %.1f us / iteration, wait at the synchronisation %.1f us / iteration\n",
+                                              nch, nit_, enq / nit_, wait / nit_);
+        }
         size_t nblocks = blocks_before;
         int lc = lc_before;
+        R = R_chunk_start;
+        run.fan_keep.clear();
         for (auto& r : recs) {
             if (r.iters_after <= h.iters) {
                 nblocks = r.nblocks; lc += r.nshifts;
+                R = r.Rafter;                                  // (fan groups leave every residual in a buffer of its own)
                 res.norms.push_back(h.norms[r.iters_after & 511]);
                 res.norm_iters.push_back(r.iters_after);
             }
@@ -1925,6 +2149,7 @@ void adi_advance(AdiRun& run, int budget) {
                 last_compression = 0;
             }
         }
+        if (resid && !resid->blocks.empty()) resid->blocks[0].L = R;      // (the factor may have moved to a fan group's buffer)
     }
 }
 

@@ -2,7 +2,7 @@
 # A/B of environment switches on one configuration (GPU box): usage tools/ab_env.sh "<bench args>" "ENV=.. ENV=.." ...   (interleaved, 2 rounds)
 cd "$GRAFT_REPO_ROOT"
 bargs=$1; shift
-for round in 1 2; do
+for round in $(seq ${AB_ROUNDS:-2}); do
 for cfg in "$@"; do
     env $cfg python bench.py $bargs --no-cpu-baseline --no-general-path > gpurun_out/ab_env.json 2> gpurun_out/ab_env.err || { tail -5 gpurun_out/ab_env.err; continue; }
     python - "$cfg" <<'PY'
