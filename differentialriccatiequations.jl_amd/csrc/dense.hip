@@ -256,6 +256,32 @@ void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char*
     DRE_HIP(hipGetLastError());
 }
 
+// fixed-order sum of split-K slabs written to C[rowmap[row], col] (the scatter of a gathered sub-system rides on the reduction)
+__global__ void k_gemm_reduce_rows(int M, int N, int splits, const double* __restrict__ partial, const int* __restrict__ rowmap, double* __restrict__ C, int ldc,
+                                   const AdiState* st) {
+    if (st && st->done) return;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    const size_t slab = (size_t)M * N;
+    double s = 0.0;
+    int z = 0;
+    for (; z + 7 < splits; z += 8) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = partial[(z + u) * slab + idx];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += q[u];
+    }
+    for (; z < splits; ++z) s += partial[z * slab + idx];
+    const int row = idx % M, col = idx / M;
+    C[rowmap[row] + (size_t)col * ldc] = s;
+}
+void gemm_reduce_rows(Ctx* ctx, int M, int N, int splits, const double* partial, const int* rowmap, double* C, int ldc, const AdiState* st) {
+    const size_t tot = (size_t)M * N;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_gemm_reduce_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, M, N, splits, partial, rowmap, C, ldc, st);
+    DRE_HIP(hipGetLastError());
+}
 __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const double* __restrict__ partial,
                               double beta, double* __restrict__ C, int ldc, const AdiState* st) {
     if (st && st->done) return;

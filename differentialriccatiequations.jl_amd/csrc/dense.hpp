@@ -55,6 +55,8 @@ struct GemmBatchDesc {
     int M, N, K, lda, ldb, ldc, ldcopy;
 };
 void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char* tag = "gemm_batched", DevCount dc = DevCount{});
+// sum of the split-K slabs of gemm_partials (M x N each, fixed order) written to C[rowmap[row], col]
+void gemm_reduce_rows(Ctx* ctx, int M, int N, int splits, const double* partial, const int* rowmap, double* C, int ldc, const AdiState* st = nullptr);
 BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                    int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma", DevCount dc = DevCount{});
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src

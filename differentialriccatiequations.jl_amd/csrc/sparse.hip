@@ -1755,7 +1755,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     } else {
         const TopPlan& tp = P.top;
         const int ntop = tp.ntop, T = tp.T;
-        Mat g(ctx, ntop, nrhs), x(ctx, ntop, nrhs);
+        Mat g(ctx, ntop, nrhs);
         const size_t tot = (size_t)ntop * nrhs;
         {
             TimedScope ts(ctx, "mf_solve_real", bytes, flops);
@@ -1782,11 +1782,12 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
             backward_from(T);
         } else {
-        gemm(ctx, false, false, 1.0, Fc.topinv, g, 0.0, x, st, "gemm_mf_top");
+        // x_top = inv(S) g as split-K slabs; their fixed-order sum lands directly in the rows of the panel (no x, no scatter launch)
+        int zs = 1;
+        BufP xpart = gemm_partials(ctx, false, false, ntop, nrhs, ntop, Fc.topinv.p, Fc.topinv.ld, g.p, g.ld, &zs, st, "gemm_mf_top");
         {
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
-            hipLaunchKernelGGL(k_top_scatter, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
-                               (const double*)x.p, x.ld, W, ldw, st);
+            gemm_reduce_rows(ctx, ntop, nrhs, zs, (const double*)xpart->p, (const int*)tp.topidx.p, W, ldw, st);
             backward_from(T);
         }
         }
