@@ -1007,8 +1007,9 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 // same lane layout, so tr(M M) = sum_ij M_ij N_ij needs no transposition; only blocks bi <= bj are computed.
 template <bool COHERENT>
 __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* part, const double* __restrict__ T, int ldt,
-                                               int tdiag, double alpha, AdiState* st, int iters_after, double* gsm, double* red) {
+                                               int tdiag, double alpha, AdiState* st, int iters_after, double* gsm, double* red, int ldp = 0, size_t slab = 0) {
     const int kp = (k + 31) & ~31, ld = kp;
+    if (ldp == 0) { ldp = k; slab = (size_t)k * k; }       // default: dense k x k slabs
     double* G = gsm;                        // kp x kp
     double* Ts = gsm + (size_t)kp * kp;     // kp x kp (or k diagonal entries)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
@@ -1018,8 +1019,8 @@ __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* 
         double s = 0.0;
         if (in) {
             // fixed summation order; up to four slab loads in flight
-            const double* q = part + r + (size_t)c * k;
-            const size_t sl = (size_t)k * k;
+            const double* q = part + r + (size_t)c * ldp;
+            const size_t sl = slab;
             int z = 0;
             if (!COHERENT)
                 for (; z + 3 < splits; z += 4) {
@@ -1089,6 +1090,23 @@ __global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const dou
     extern __shared__ double gsm[];
     __shared__ double red[17];
     gram_norm_body<false>(k, splits, part, T, ldt, tdiag, alpha, st, iters_after, gsm, red);
+}
+
+// The norms and decisions of g consecutive iterations in ONE launch (fan groups, engine.hip): Gall is the (g k) x (g k) Gram matrix of
+// [R_1 .. R_g]; its diagonal blocks are taken in iteration order, and the first residual at or below abstol ends the loop (adi.jl:115-123).
+__global__ __launch_bounds__(1024) void k_gram_norm_multi(int k, int g, const double* __restrict__ Gall, int ldg, const double* __restrict__ T, int ldt,
+                                                          int tdiag, double alpha, AdiState* st, int iters0) {
+    if (st->done) return;
+    extern __shared__ double gsm[];
+    __shared__ double red[17];
+    __shared__ int stop;
+    for (int j = 0; j < g; ++j) {
+        gram_norm_body<false>(k, 1, Gall + (size_t)j * k + (size_t)j * k * ldg, T, ldt, tdiag, alpha, st, iters0 + j + 1, gsm, red, ldg, 0);
+        if (threadIdx.x == 0) stop = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (stop) return;
+        __syncthreads();
+    }
 }
 
 // Dense-inverse ADI step for a real shift: everything after the stacked GEMM except the final norm reduction (k <= 96):
@@ -2004,6 +2022,22 @@ void adi_group_iter(Ctx* ctx, const AdiGroupArgs& a) {
     DRE_HIP(hipGetLastError());
 }
 
+// norms + decisions for the g residuals Rcat = [R_1 .. R_g] (n x g k) of a fan group, iterations iters0 + 1 .. iters0 + g: one Gram product
+// (cross blocks included: the product is latency bound, the extra tiles ride along), its slab reduction and one decision launch
+void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0) {
+    if (k > 96 || g * k > 512) {
+        for (int j = 0; j < g; ++j) { Mat Rj = Rcat.colsview(j * k, k); residual_norm_step(ctx, Rj, T, tdiag, alpha, st, iters0 + j + 1); }
+        return;
+    }
+    Mat Gall(ctx, g * k, g * k);
+    gemm(ctx, true, false, 1.0, Rcat, Rcat, 0.0, Gall, st, "gemm_gram");
+    TimedScope ts(ctx, "ldlt_norm", 8.0 * g * k * k, 4.0 * g * (double)k * k * k);
+    const int kp = (k + 31) & ~31;
+    const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
+    lds_attr(ctx, (const void*)k_gram_norm_multi, 150 * 1024);
+    hipLaunchKernelGGL(k_gram_norm_multi, dim3(1), dim3(1024), shm, ctx->stream, k, g, (const double*)Gall.p, Gall.ld, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters0);
+    DRE_HIP(hipGetLastError());
+}
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
     if (k <= 96 && tsmm_enabled() && R.rows >= 2048) {

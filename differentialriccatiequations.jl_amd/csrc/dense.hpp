@@ -97,6 +97,7 @@ bool is_diagonal_host(Ctx* ctx, const Mat& D);               // synchronising (s
 void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 // The whole residual-norm step  G = R'R,  nrm = |alpha| sqrt(tr((T G)^2)),  convergence decision  in two launches:
 // the split-K Gram GEMM and one workgroup that reduces the partial slabs, forms T G in LDS and decides (k <= 88).
+void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0);   // g residuals at once
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 // fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
 // The norm kernel of iteration i can ride on the step kernel of iteration i + 1 (one more workgroup) instead of being a launch of

@@ -1924,10 +1924,10 @@ void adi_advance(AdiRun& run, int budget) {
                         Xw->blocks.push_back({Vj, Tm, -2.0 * muj.real() * alpha_res, tdiag});
                         iters_host += 1; last_compression += 1;
                         oracle->update(Rj, {Vj});
-                        residual_norm_step(ctx, Rj, Tm, tdiag, alpha_res, st.p, iters_host);
                         recs.push_back({iters_host, Xw->blocks.size(), 1, Rj});
                         ++since_sync; ++chunk_shifts;
                     }
+                    residual_norm_group(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
                     run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(Ycat.buf);
                     if (fan_timing) {
