@@ -66,6 +66,7 @@ class DevicePool {
             return p;
         }
         void* p = nullptr;
+        ++misses_;
         hipError_t e = hipMalloc(&p, sz);
         if (e != hipSuccess) {
             trim_locked();
@@ -86,6 +87,7 @@ class DevicePool {
     }
     void trim() { std::lock_guard<std::mutex> lk(mu_); trim_locked(); }
     size_t total_bytes() const { return total_; }
+    long misses() const { return misses_; }          // allocations that went to hipMalloc
 
   private:
     void trim_locked() {
@@ -93,6 +95,7 @@ class DevicePool {
         free_.clear();
     }
     std::mutex mu_;
+    long misses_ = 0;
     static size_t round_up(size_t b) {
         if (b < 256) b = 256;
         size_t g = b < (1u << 20) ? 4096 : (1u << 20);

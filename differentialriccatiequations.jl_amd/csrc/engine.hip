@@ -1849,6 +1849,7 @@ void adi_advance(AdiRun& run, int budget) {
                     hipEvent_t ft0 = nullptr, ft1 = nullptr;
                     if (fan_timing) { (void)hipEventCreate(&ft0); (void)hipEventCreate(&ft1); (void)hipEventRecord(ft0, ctx->stream); }
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
+                    const auto hp0 = std::chrono::steady_clock::now();
                     ensure_helpers(ctx, g - 1);
                     Mat Wcat(ctx, n, g * k), Vcat(ctx, n, g * k), Ycat(ctx, n, g * k), Rcat(ctx, n, g * k);
                     // host-side bookkeeping (SMW cache, buffers from the main pool) first; a job only enqueues on its stream
@@ -1908,7 +1909,9 @@ void adi_advance(AdiRun& run, int budget) {
                     // (Feeding every helper stream from a host thread of its own was tried: host enqueue 97 -> 83 us per iteration at g = 4, wall-clock
                     // unchanged — the device is the bound: the sweep kernels take a whole CU's LDS per workgroup, so two solves interleave kernel by
                     // kernel rather than overlap; only their latency-bound small kernels run side by side.)
+                    const auto hp1 = std::chrono::steady_clock::now();
                     for (auto& jb : jobs) jb();
+                    const auto hp2 = std::chrono::steady_clock::now();
                     for (int s_ = 0; s_ < g - 1; ++s_) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->helper_ev[(size_t)s_], 0));
                     {
                         TimedScope ts(ctx, "fan_mix", 8.0 * n * k * (4.0 * g + 1.0), 2.0 * n * k * (double)g * (g + 1));
@@ -1930,6 +1933,13 @@ void adi_advance(AdiRun& run, int budget) {
                     residual_norm_group(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
                     run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(Ycat.buf);
+                    if (chunk_timing) {
+                        static double tp = 0, tj = 0, tt = 0; static long ng = 0;
+                        const auto hp3 = std::chrono::steady_clock::now();
+                        tp += std::chrono::duration<double, std::micro>(hp1 - hp0).count(); tj += std::chrono::duration<double, std::micro>(hp2 - hp1).count();
+                        tt += std::chrono::duration<double, std::micro>(hp3 - hp2).count();
+                        if (++ng % 256 == 0) std::fprintf(stderr, "[fan host] per group: prep %.1f us, solve jobs %.1f us, tail %.1f us\n", tp / ng, tj / ng, tt / ng);
+                    }
                     if (fan_timing) {
                         (void)hipEventRecord(ft1, ctx->stream);
                         const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h_t0).count();
