@@ -76,7 +76,7 @@ int dre_ctx_create(int device, dre_ctx** out) {
     int rc = guarded(ctx, [&] {
         DRE_HIP(hipSetDevice(device));
         ctx->c.device = device;
-        DRE_HIP(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
+        ctx->c.stream = create_stream(0);
         hipDeviceProp_t prop;
         DRE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -255,6 +256,27 @@ struct Mat {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // raise the dynamic shared memory limit of a kernel once per context (device)
+// Streams of a library context by role.  HIP maps streams onto a handful of hardware queues round-robin PER PRIORITY LEVEL; with everything at
+// the default priority the fifth, sixth ... stream of a process lands on the queue of the main stream and its kernels are serialised with the
+// critical path.  DRE_STREAM_PRIORITIES=1 gives the main stream the highest priority (a queue of its own), the side stream the middle one and
+// the helper streams the lowest.  Measured (round 3, default-ADI runs with the factorisations on helper streams): no gain at depth 5 and a
+// LOSS at depth 8 (n = 1357 Ros2: 2 830 against 3 250 it/s — low-priority factorisations are starved by the main stream's kernels and arrive
+// late), so equal priorities stay the default.   role: 0 main, 1 side, 2 helper.
+inline hipStream_t create_stream(int role) {
+    static const bool on = std::getenv("DRE_STREAM_PRIORITIES") && std::atoi(std::getenv("DRE_STREAM_PRIORITIES")) != 0;
+    hipStream_t st = nullptr;
+    int least = 0, greatest = 0;
+    if (on && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+        // numerically lower = higher priority
+        const int mid = (least + greatest) / 2;
+        const int prio = role == 0 ? greatest : (role == 1 ? mid : least);
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) == hipSuccess) return st;
+        (void)hipGetLastError();
+    }
+    DRE_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
+}
+
 inline void lds_attr(Ctx* ctx, const void* func, int bytes) {
     auto it = ctx->lds_attr_done.find(func);
     if (it != ctx->lds_attr_done.end() && it->second >= bytes) return;

@@ -1403,7 +1403,7 @@ static void ensure_helpers(Ctx* ctx, int nh) {
     while ((int)ctx->helpers.size() < nh) {
         auto hc = std::make_unique<Ctx>();
         hc->device = ctx->device; hc->num_cus = ctx->num_cus;
-        DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+        hc->stream = create_stream(2);
         hc->timer = std::make_unique<KernelTimer>();
         hipEvent_t ev;
         DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1457,7 +1457,8 @@ struct AdiRun {
     LDLt Crhs;                       // the right-hand side (shallow copy) for the true-residual verification after a growth warning
     // single-use factors (Projection / per-solve Heuristic shifts): factorised AHEAD on the helper streams while the current iteration solves
     // (all shifts of a batch are known at once and their factorisations are independent), checked lazily with their chunk
-    std::map<std::pair<double, double>, hipEvent_t> prefetch_ev;      // factor of this shift is being made on a helper stream: wait for the event before use
+    struct Prefetched { hipEvent_t ev; long ticket; };
+    std::map<std::pair<double, double>, Prefetched> prefetch_ev;     // factor of this shift is being made on a helper stream: wait for the event before use
     std::vector<hipEvent_t> ev_pool;
     bool check_now = false;           // a lazily checked factor turned out to have replaced pivots: from now on every new factor is checked at once
     size_t prefetch_rr = 0;
@@ -1474,7 +1475,7 @@ struct AdiRun {
         }
         used_real.clear(); used_cplx.clear();
     }
-    ~AdiRun() { for (auto& kv : prefetch_ev) (void)hipEventDestroy(kv.second); for (auto e : ev_pool) (void)hipEventDestroy(e); }
+    ~AdiRun() { for (auto& kv : prefetch_ev) (void)hipEventDestroy(kv.second.ev); for (auto e : ev_pool) (void)hipEventDestroy(e); }
 };
 
 std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
@@ -1767,18 +1768,38 @@ void adi_advance(AdiRun& run, int budget) {
         auto wait_prefetched = [&](std::complex<double> mu) {
             auto it = run.prefetch_ev.find({mu.real(), mu.imag()});
             if (it == run.prefetch_ev.end()) return;
-            DRE_HIP(hipStreamWaitEvent(ctx->stream, it->second, 0));
-            run.ev_pool.push_back(it->second);
+            DRE_HIP(hipStreamWaitEvent(ctx->stream, it->second.ev, 0));
+            run.ev_pool.push_back(it->second.ev);
             run.prefetch_ev.erase(it);
         };
         // factorise the next few shifts of the batch on the helper streams (one workgroup per front: a factorisation uses a handful of CUs
         // for ~200 us at n = 371 — 45 % of the kernel time of a default-ADI run when it sits on the main stream)
-        auto prefetch_ahead = [&]() {
+        auto prefetch_ahead = [&](std::complex<double> cur) {
             static const int depth_env = std::getenv("DRE_PREFETCH_FACTORS") ? std::atoi(std::getenv("DRE_PREFETCH_FACTORS")) : -1;
-            const int nh = depth_env >= 0 ? std::min(depth_env, 8) : std::max(0, ctx->setup_streams);
+            const int nh = depth_env >= 0 ? std::min(depth_env, 16) : (ctx->setup_streams >= 1 ? std::max(8, ctx->setup_streams) : 0);
             if (!single_use || nh < 1) return;
-            const auto ups = oracle->peek((size_t)2 * nh + 2);
+            auto ups = oracle->peek((size_t)2 * nh + 3);
+            // `cur` was just taken; when it opens a conjugate pair its partner is still the FIRST upcoming shift (the double step takes it later,
+            // adi.jl:190) and must not be read as the start of a new pair — that shifted every later pair by one: the partners were factorised
+            // ahead (never used, their slots never freed) and the shifts really needed were factorised inline (round 3 finding: 88 % of the
+            // complex factorisations of a default-ADI run sat on the main stream).
+            if (cur.imag() != 0.0 && !ups.empty() && ups[0] == std::conj(cur)) ups.erase(ups.begin());
+            // slots whose shift is no longer ahead (never the case when the pairs are read correctly; cheap insurance against a leak)
+            for (auto it = run.prefetch_ev.begin(); it != run.prefetch_ev.end();) {
+                bool ahead = false;
+                for (auto& u : ups) ahead = ahead || (u.real() == it->first.first && u.imag() == it->first.second);
+                if (ahead) { ++it; continue; }
+                run.ev_pool.push_back(it->second.ev);
+                it = run.prefetch_ev.erase(it);
+            }
             int scheduled = (int)run.prefetch_ev.size();
+            static const bool trace_pf = std::getenv("DRE_TRACE_PREFETCH") != nullptr;
+            if (trace_pf) {
+                static long calls = 0, nups = 0, pend = 0;
+                ++calls; nups += (long)ups.size(); pend += scheduled;
+                if (calls % 500 == 0) std::fprintf(stderr, "[prefetch] %ld calls: %.2f upcoming shifts known per call, %.2f factorisations already in flight per call (depth %d)\n",
+                                                   calls, (double)nups / calls, (double)pend / calls, nh);
+            }
             for (size_t i = 0; i < ups.size() && scheduled < nh; ++i) {
                 const std::complex<double> nx = ups[i];
                 const bool cx = nx.imag() != 0.0;
@@ -1790,7 +1811,7 @@ void adi_advance(AdiRun& run, int budget) {
                     while ((int)ctx->helpers.size() < nh) {
                         auto hc = std::make_unique<Ctx>();
                         hc->device = ctx->device; hc->num_cus = ctx->num_cus;
-                        DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+                        hc->stream = create_stream(2);
                         hc->timer = std::make_unique<KernelTimer>();
                         hipEvent_t ev;
                         DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -1808,13 +1829,16 @@ void adi_advance(AdiRun& run, int budget) {
                     run.helpers_ready = true;
                 }
                 Ctx* hc = ctx->helpers[run.prefetch_rr++ % (size_t)nh].get();
-                if (cx) (void)get_factor<cplx>(hc, op, cache, cache->cplx_, nx, false, nullptr, run.check_now);
-                else (void)get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
                 hipEvent_t ev;
                 if (!run.ev_pool.empty()) { ev = run.ev_pool.back(); run.ev_pool.pop_back(); }
                 else DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                // (Issuing these factorisations from a host thread of their own was tried — the loop spends ~250 us of host time per iteration on
+                // launch calls: no gain, 3 230 against 3 250 it/s at n = 1357 Ros2; launches from two threads serialise inside the HIP runtime.)
+                if (cx) (void)get_factor<cplx>(hc, op, cache, cache->cplx_, nx, false, nullptr, run.check_now);
+                else (void)get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
                 DRE_HIP(hipEventRecord(ev, hc->stream));
-                run.prefetch_ev[{nx.real(), nx.imag()}] = ev;
+                const long ticket = 0;
+                run.prefetch_ev[{nx.real(), nx.imag()}] = AdiRun::Prefetched{ev, ticket};
                 ++scheduled;
             }
         };
@@ -1958,7 +1982,7 @@ void adi_advance(AdiRun& run, int budget) {
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
             const AdiState* dst = st.p;
-            if (single_use) { wait_prefetched(mu); prefetch_ahead(); }
+            if (single_use) { wait_prefetched(mu); prefetch_ahead(mu); }
             Mat V1, V2;
             bool norm_done = false, rode = false;
             if (is_real) {
@@ -1966,6 +1990,11 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<double>> fe;
                 if (!user_inner) {
+                    if (single_use && std::getenv("DRE_TRACE_PREFETCH")) {
+                        static long hit = 0, miss = 0;
+                        (cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) ? hit : miss)++;
+                        if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] real shifts: %ld found ready, %ld factorised inline\n", hit, miss);
+                    }
                     fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC, nullptr, !single_use || run.check_now);
                     used_real.push_back(fe);
                 }
@@ -2104,6 +2133,11 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<cplx>> fe;
                 if (!user_inner) {
+                    if (single_use && std::getenv("DRE_TRACE_PREFETCH")) {
+                        static long hit = 0, miss = 0;
+                        (cache->cplx_.count(std::make_tuple(op.tag, mu.real(), mu.imag())) ? hit : miss)++;
+                        if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] complex pairs: %ld found ready, %ld factorised inline\n", hit, miss);
+                    }
                     fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu, true, nullptr, !single_use || run.check_now);
                     used_cplx.push_back(fe);
                 }
@@ -2642,7 +2676,7 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
             while ((int)ctx->helpers.size() < nh) {
                 auto hc = std::make_unique<Ctx>();
                 hc->device = ctx->device; hc->num_cus = ctx->num_cus;
-                DRE_HIP(hipStreamCreateWithFlags(&hc->stream, hipStreamNonBlocking));
+                hc->stream = create_stream(2);
                 hc->timer = std::make_unique<KernelTimer>();
                 hipEvent_t ev;
                 DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -3429,7 +3463,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     if (xside_env && !ctx->side) {
         auto sc = std::make_unique<Ctx>();
         sc->device = ctx->device; sc->num_cus = ctx->num_cus;
-        DRE_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+        sc->stream = create_stream(1);
         DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
         DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
         sc->timer = std::make_unique<KernelTimer>();

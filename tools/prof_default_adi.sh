@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_d
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_d -- python tools/time_default_adi.py ${1:-371} ${2:-10} > gpurun_out/prof_d.json 2> gpurun_out/prof_d.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_d -- python tools/time_default_adi.py ${1:-371} ${2:-10} ${3:-1} > gpurun_out/prof_d.json 2> gpurun_out/prof_d.err
 f=$(find gpurun_out/prof_d -name "*kernel_stats.csv" | head -1)
 python - "$f" <<'PY'
 import csv,sys

@@ -4,7 +4,11 @@
 frac=$1; len=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_t
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-general-path "$@" > /dev/null 2> gpurun_out/prof_t.err
+if [ -n "$WT_SCRIPT" ]; then      # another driver script instead of bench.py (e.g. WT_SCRIPT=tools/time_default_adi.py with its own arguments)
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_t -- python $WT_SCRIPT "$@" > /dev/null 2> gpurun_out/prof_t.err
+else
+  timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_t -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-general-path "$@" > /dev/null 2> gpurun_out/prof_t.err
+fi
 f=$(find gpurun_out/prof_t -name "*kernel_trace.csv" | head -1)
 python - "$f" $frac $len <<'PY'
 import csv,sys
@@ -24,6 +28,13 @@ print("last solve span ms", (t1-t0)/1e6, "kernels", len(seg))
 busy=defaultdict(float)
 for r in seg: busy[r["Queue_Id"]]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
 print("busy ms per queue", {k:round(v,2) for k,v in busy.items()})
+import os
+if os.environ.get("WT_QUEUE_KERNELS"):
+    cnt=defaultdict(lambda: defaultdict(lambda:[0,0.0]))
+    for r in seg:
+        c=cnt[r["Queue_Id"]][r["Kernel_Name"].split('(')[0].replace('void ','')[:44]]; c[0]+=1; c[1]+=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3
+    for q,d in cnt.items():
+        print("queue",q, sorted(((k,v[0],round(v[1])) for k,v in d.items()), key=lambda t:-t[2])[:6])
 w0=t0+frac*(t1-t0); w1=w0+ln
 for r in seg:
     s=int(r["Start_Timestamp"]); e=int(r["End_Timestamp"])
