@@ -181,3 +181,50 @@ def test_norm_is_accurate_when_terms_cancel(ctx):
         ref = np.linalg.norm(X.dense() - Lp @ Dd @ Lp.T)
         assert abs(D.norm(Y) - ref) < 1e-2 * ref + 1e-14 * np.linalg.norm(X.dense())
     assert D.norm(X - X) < 1e-14 * D.norm(X)
+
+
+def test_fan_groups_on_a_gale_with_low_rank_update(ctx):
+    """Fan groups (engine.hip, k_fan_mix) at the GALE level: Cyclic real shifts on a low-rank-updated operator through the multifrontal solves
+    (`dense_inverse_max_n` = 0).  Group sizes 2..4 give the iterates of the sequential recurrence (adi.jl:158-171): same iteration count, X to
+    rounding; a `maxiters` that ends the solve INSIDE a group records exactly `maxiters` iterations; the stepwise protocol (one shift per step:
+    no groups) ends at the same X."""
+    rng = np.random.default_rng(77)
+    n, g = 120, 5
+    E, A = _rand_pencil(rng, n, True, False)
+    Cl = (-2) * D.lowrank(rng.random((n, g)), -np.eye(g))
+    U = rng.random((n, 2)); V = rng.random((2, n))
+    prob = D.GALEProblem(E, D.lr_update(A, -1.0 * n, U, V), Cl)
+    shifts = [-0.3, -0.9, -2.5, -7.0, -20.0, -0.5, -1.5]
+    res = {}
+    try:
+        ctx.set_option("dense_inverse_max_n", 0)
+        for fan in (0, 2, 3, 4):
+            ctx.set_option("adi_fan", fan)
+            for mi in (200, 7):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=mi), return_info=True)
+                res[(fan, mi)] = (X, info)
+        ctx.set_option("adi_fan", 3)
+        s = D.init(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=200))
+        while not D.isdone(s):
+            D.step_(s)
+        Xs = s.X
+    finally:
+        ctx.set_option("dense_inverse_max_n", 1536); ctx.set_option("adi_fan", 3)
+    X0, i0 = res[(0, 200)]
+    assert i0["converged"]
+    def dense(X):
+        a, L, Dm = X
+        return a * (L @ Dm @ L.T)
+    ref = dense(X0)
+    for fan in (2, 3, 4):
+        X, info = res[(fan, 200)]
+        assert info["iters"] == i0["iters"] and info["converged"]
+        assert np.linalg.norm(dense(X) - ref) <= 1e-10 * np.linalg.norm(ref)
+        assert np.allclose(info["norms"], i0["norms"], rtol=1e-6, atol=1e-12 * i0["norms"][0])
+        assert not np.array_equal(dense(X), ref)        # (re-associated arithmetic: the group path really ran)
+        Xc, ic = res[(fan, 7)]
+        assert ic["iters"] == 7 == res[(0, 7)][1]["iters"] and not ic["converged"]
+        assert np.linalg.norm(dense(Xc) - dense(res[(0, 7)][0])) <= 1e-10 * np.linalg.norm(ref)
+    assert np.linalg.norm(dense(Xs) - ref) <= 1e-10 * np.linalg.norm(ref)
