@@ -10,10 +10,12 @@ rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # solves start with k_assemble bursts after a long gap; find last big gap (> 2 ms) = start of last (profiled) solve
 starts=[int(r["Start_Timestamp"]) for r in rows]; ends=[int(r["End_Timestamp"]) for r in rows]
-cut=0
+segs=[[rows[0]]]; hi=ends[0]
 for i in range(1,len(rows)):
-    if starts[i]-max(ends[:i][-50:])>1_000_000: cut=i
-sel=rows[cut:]
+    if starts[i]-hi>1_000_000: segs.append([])
+    segs[-1].append(rows[i]); hi=max(hi,ends[i])
+big=[g for g in segs if sum(1 for r in g if "k_dense_residual" in r["Kernel_Name"])>=2]
+sel=big[-1] if big else max(segs,key=len)
 t0=int(sel[0]["Start_Timestamp"])
 # end of first step: the second k_dense_residual launch
 cnt=0; tend=None
