@@ -1764,6 +1764,13 @@ void adi_advance(AdiRun& run, int budget) {
         const auto ct0 = std::chrono::steady_clock::now();
         int since_sync = 0, chunk_shifts = 0;
         const bool single_use = opt_in.shifts.kind != ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled;
+        // Cyclic lists on the multifrontal path: the factorisations of the FIRST pass through the cycle (one workgroup per front: ~0.5 ms each at
+        // n = 5177, 1.4 ms at n = 20209, a handful of CUs busy) also run ahead on the helper streams instead of one after the other in front of
+        // their first use; from the second pass on every factor is cached and the look-ahead finds nothing to do.
+        static const bool cyc_ahead_env = !(std::getenv("DRE_CYCLIC_LOOKAHEAD") && std::atoi(std::getenv("DRE_CYCLIC_LOOKAHEAD")) == 0);
+        const bool sharded_la = ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1;
+        const bool cyc_ahead = cyc_ahead_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n && !sharded_la;
+        const bool lookahead = single_use || cyc_ahead;
         // the shift about to be used may have been factorised ahead on a helper stream: the main stream waits for that factorisation's event
         auto wait_prefetched = [&](std::complex<double> mu) {
             auto it = run.prefetch_ev.find({mu.real(), mu.imag()});
@@ -1777,7 +1784,7 @@ void adi_advance(AdiRun& run, int budget) {
         auto prefetch_ahead = [&](std::complex<double> cur) {
             static const int depth_env = std::getenv("DRE_PREFETCH_FACTORS") ? std::atoi(std::getenv("DRE_PREFETCH_FACTORS")) : -1;
             const int nh = depth_env >= 0 ? std::min(depth_env, 16) : (ctx->setup_streams >= 1 ? std::max(8, ctx->setup_streams) : 0);
-            if (!single_use || nh < 1) return;
+            if (!lookahead || nh < 1) return;
             auto ups = oracle->peek((size_t)2 * nh + 3);
             // `cur` was just taken; when it opens a conjugate pair its partner is still the FIRST upcoming shift (the double step takes it later,
             // adi.jl:190) and must not be read as the start of a new pair — that shifted every later pair by one: the partners were factorised
@@ -1861,8 +1868,10 @@ void adi_advance(AdiRun& run, int budget) {
                 FanCoef co;
                 while (g >= 2 && fan_coefficients(mus, g, &co) > ctx->adi_fan_max_coef) --g;
                 std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+                if (lookahead && g >= 2) prefetch_ahead(std::complex<double>(0.0, 0.0));      // (first pass through the cycle: this group's and the next groups' factors)
                 for (int s_ = 0; s_ < g && g >= 2; ++s_) {
-                    auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, true);
+                    if (lookahead) wait_prefetched(std::complex<double>(mus[s_], 0.0));
+                    auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, !lookahead || run.check_now);
                     if (fe->dense) { g = 0; break; }              // the dense-inverse step has its own fused kernels
                     fes.push_back(fe);
                 }
@@ -1982,7 +1991,7 @@ void adi_advance(AdiRun& run, int budget) {
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
             const AdiState* dst = st.p;
-            if (single_use) { wait_prefetched(mu); prefetch_ahead(mu); }
+            if (lookahead) { wait_prefetched(mu); prefetch_ahead(mu); }
             Mat V1, V2;
             bool norm_done = false, rode = false;
             if (is_real) {
@@ -1995,7 +2004,7 @@ void adi_advance(AdiRun& run, int budget) {
                         (cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] real shifts: %ld found ready, %ld factorised inline\n", hit, miss);
                     }
-                    fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC, nullptr, !single_use || run.check_now);
+                    fe = get_factor<double>(ctx, op, cache, cache->real, mu, opt_in.shifts.kind == ShiftSpec::CYCLIC, nullptr, !lookahead || run.check_now);
                     used_real.push_back(fe);
                 }
                 auto key = std::make_pair(mu.real(), 0.0);
@@ -2138,7 +2147,7 @@ void adi_advance(AdiRun& run, int budget) {
                         (cache->cplx_.count(std::make_tuple(op.tag, mu.real(), mu.imag())) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] complex pairs: %ld found ready, %ld factorised inline\n", hit, miss);
                     }
-                    fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu, true, nullptr, !single_use || run.check_now);
+                    fe = get_factor<cplx>(ctx, op, cache, cache->cplx_, mu, true, nullptr, !lookahead || run.check_now);
                     used_cplx.push_back(fe);
                 }
                 auto key = std::make_pair(mu.real(), mu.imag());
