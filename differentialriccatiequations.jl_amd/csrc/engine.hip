@@ -1842,7 +1842,13 @@ void adi_advance(AdiRun& run, int budget) {
                 // (Issuing these factorisations from a host thread of their own was tried — the loop spends ~250 us of host time per iteration on
                 // launch calls: no gain, 3 230 against 3 250 it/s at n = 1357 Ros2; launches from two threads serialise inside the HIP runtime.)
                 if (cx) (void)get_factor<cplx>(hc, op, cache, cache->cplx_, nx, false, nullptr, run.check_now);
-                else (void)get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
+                else {
+                    auto fnew = get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
+                    // a Cyclic factor will be used in every time step: its dense top-of-tree inverse is built right behind the factorisation, on
+                    // the helper stream (mf_solve would build it inside the third solve that uses the factor, on the critical path)
+                    static const bool top_ahead = !(std::getenv("DRE_TOPINV_AHEAD") && std::atoi(std::getenv("DRE_TOPINV_AHEAD")) == 0);
+                    if (cyc_ahead && top_ahead) mf_prepare_topinv(hc, *op.P, fnew->f);
+                }
                 DRE_HIP(hipEventRecord(ev, hc->stream));
                 const long ticket = 0;
                 run.prefetch_ev[{nx.real(), nx.imag()}] = AdiRun::Prefetched{ev, ticket};

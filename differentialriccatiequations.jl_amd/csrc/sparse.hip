@@ -1795,6 +1795,13 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     DRE_HIP(hipGetLastError());
 }
 
+void mf_prepare_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc) {
+    if (!P.use_mfma_sweeps || !Fc.allow_topinv || ctx->top_inverse_max_rows <= 0 || !Fc.topinv.empty()) return;
+    if (!P.top.built) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
+    if (!P.sub.built) sub_plan_build(ctx, P, P.top.T);
+    if (P.top.T >= 2) mf_build_topinv(ctx, P, Fc);
+    Fc.uses = 3;
+}
 // W = F^-1 [Win(:, 0:nin) | W(:, nin:nrhs)]: the leading right-hand sides are read where they are (no copy into the panel) when the
 // matrix-core sweeps run; otherwise they are copied in and the in-place solve follows.
 void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs, const AdiState* st) {

@@ -140,6 +140,9 @@ std::vector<double> mf_check_batch(Ctx* ctx, const std::vector<const Factor<doub
 // In-place solve  M * X = W  for the n x nrhs panel W (column-major, leading dimension ldw), solver ordering.
 template <typename T>
 void mf_solve(Ctx* ctx, const Pencil& P, const Factor<T>& F, T* W, int ldw, int nrhs, const AdiState* st = nullptr);
+// Builds the dense inverse of the top of the elimination tree NOW (mf_solve builds it lazily at the third multi-column solve of a reusable
+// factor): for factors that are known to be reused many times (Cyclic shift lists), on whatever stream the caller runs them on.
+void mf_prepare_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& F);
 // W = F^-1 [Win(:, 0:nin) | W(:, nin:nrhs)] — the leading right-hand sides are read in place (no copy into the work panel)
 void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& F, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs,
                    const AdiState* st = nullptr);
