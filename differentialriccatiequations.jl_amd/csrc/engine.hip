@@ -1781,7 +1781,7 @@ void adi_advance(AdiRun& run, int budget) {
         };
         // factorise the next few shifts of the batch on the helper streams (one workgroup per front: a factorisation uses a handful of CUs
         // for ~200 us at n = 371 — 45 % of the kernel time of a default-ADI run when it sits on the main stream)
-        auto prefetch_ahead = [&](std::complex<double> cur) {
+        auto prefetch_ahead = [&](std::complex<double> cur, bool fan_call = false) {
             static const int depth_env = std::getenv("DRE_PREFETCH_FACTORS") ? std::atoi(std::getenv("DRE_PREFETCH_FACTORS")) : -1;
             const int nh = depth_env >= 0 ? std::min(depth_env, 16) : (ctx->setup_streams >= 1 ? std::max(8, ctx->setup_streams) : 0);
             if (!lookahead || nh < 1) return;
@@ -1814,6 +1814,10 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool known = cx ? cache->cplx_.count(ck) > 0 : cache->real.count(ck) > 0;
                 if (cx) ++i;                                   // the conjugate partner follows (adi.jl:190) and needs no factorisation of its own
                 if (known) continue;
+                // the shift the caller is about to use RIGHT NOW comes round again inside the horizon when the cycle is shorter than it: the
+                // caller factorises it inline on its own stream — handing it to a helper here would put an unfinished factor into the cache that
+                // the caller picks up without an event to wait for
+                if (nx == cur && !fan_call) continue;
                 if (!run.helpers_ready) {
                     while ((int)ctx->helpers.size() < nh) {
                         auto hc = std::make_unique<Ctx>();
@@ -1861,7 +1865,10 @@ void adi_advance(AdiRun& run, int budget) {
         while (iters_host < opt.maxiters) {
             // ---- fan group: the next g real shifts of the cycle at once (independent solves side by side, see k_fan_mix) ----------------
             if (fan_max >= 2) {
-                const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), chunk_limit - chunk_shifts);
+                // (a group may cross the chunk limit — 3, 3, 3, 3 instead of 3, 3, 3, 1 iterations per chunk of 10 — unless the caller steps
+                // with a budget or the literal mode compresses at exact intervals)
+                const bool strict = cex || budget < (1 << 29);
+                const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), strict ? chunk_limit - chunk_shifts : fan_max);
                 const auto ups = room >= 2 ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
                 int g = 0;
                 double mus[4];
@@ -1874,7 +1881,7 @@ void adi_advance(AdiRun& run, int budget) {
                 FanCoef co;
                 while (g >= 2 && fan_coefficients(mus, g, &co) > ctx->adi_fan_max_coef) --g;
                 std::vector<std::shared_ptr<FactorEntry<double>>> fes;
-                if (lookahead && g >= 2) prefetch_ahead(std::complex<double>(0.0, 0.0));      // (first pass through the cycle: this group's and the next groups' factors)
+                if (lookahead && g >= 2) prefetch_ahead(std::complex<double>(0.0, 0.0), true);      // (first pass through the cycle: this group's and the next groups' factors; all waited for below)
                 for (int s_ = 0; s_ < g && g >= 2; ++s_) {
                     if (lookahead) wait_prefetched(std::complex<double>(mus[s_], 0.0));
                     auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, !lookahead || run.check_now);
@@ -2277,6 +2284,9 @@ AdiResult adi_finish(AdiRun& run) {
     auto& Xw = run.Xw;
     int& last_compression = run.last_compression;
     auto& all_shifts = run.all_shifts;
+    // look-ahead factorisations the solve did not get to use stay in a persistent cache (Cyclic lists): whatever runs on the main stream from
+    // here on — the next Lyapunov solve finds them "known" — is ordered behind them
+    for (auto& kv : run.prefetch_ev) (void)hipStreamWaitEvent(ctx->stream, kv.second.ev, 0);
     if (run.finalized || run.res.rhs_cols == 0 || (run.iters_host == 0 && run.res.converged)) { run.finalized = true; return res; }
     run.finalized = true;
     auto check_used = [&]() { run.check_used(); };
