@@ -1475,7 +1475,10 @@ struct AdiRun {
         }
         used_real.clear(); used_cplx.clear();
     }
-    ~AdiRun() { for (auto& kv : prefetch_ev) (void)hipEventDestroy(kv.second.ev); for (auto e : ev_pool) (void)hipEventDestroy(e); }
+    ~AdiRun() {
+        for (auto& kv : prefetch_ev) { if (ctx) (void)hipStreamWaitEvent(ctx->stream, kv.second.ev, 0); (void)hipEventDestroy(kv.second.ev); }
+        for (auto e : ev_pool) (void)hipEventDestroy(e);
+    }
 };
 
 std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
