@@ -939,6 +939,34 @@ __global__ __launch_bounds__(1024) void k_trace_sq(int k, const double* __restri
         }
     }
 }
+// g matrices M_j = T G_jj (k x k each, stored side by side: M_j at columns j k of TGall) in iteration order, with the decisions of adi.jl:115-123:
+// the first residual at or below abstol ends the loop (fan groups, residual wider than 96 columns)
+__global__ __launch_bounds__(1024) void k_trace_sq_multi(int k, int g, const double* __restrict__ TGall, int ldm, double alpha, AdiState* st, int iters0) {
+    __shared__ double red[17];
+    __shared__ int stop;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    for (int j = 0; j < g; ++j) {
+        const double* __restrict__ M = TGall + (size_t)j * k * ldm;
+        double s = 0.0;
+        for (int c = wave; c < k; c += nw)
+            for (int r = lane; r < k; r += 64) s += M[r + (size_t)c * ldm] * M[c + (size_t)r * ldm];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) {
+            const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+            const int iters_after = iters0 + j + 1;
+            st->res_norm = nrm;
+            st->iters = iters_after;
+            st->norms[iters_after & 511] = nrm;
+            const int d = (nrm <= st->abstol || iters_after >= st->maxiters) ? 1 : 0;
+            if (d) st->done = 1;
+            stop = d;
+        }
+        __syncthreads();
+        if (stop) return;
+        __syncthreads();
+    }
+}
 // The same for large k in two launches: 32 x 32 tile pairs (bi <= bj) through LDS, so that both M_ij and M_ji are read coalesced,
 // one partial sum per pair; then the fixed-order sum and the decision.
 __global__ __launch_bounds__(256) void k_trace_sq_tiles(int k, const double* __restrict__ M, int ldm, double* __restrict__ part, const AdiState* st) {
@@ -2025,6 +2053,19 @@ void adi_group_iter(Ctx* ctx, const AdiGroupArgs& a) {
 // norms + decisions for the g residuals Rcat = [R_1 .. R_g] (n x g k) of a fan group, iterations iters0 + 1 .. iters0 + g: one Gram product
 // (cross blocks included: the product is latency bound, the extra tiles ride along), its slab reduction and one decision launch
 void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0) {
+    if (k > 96 && k <= 256 && !tdiag && g * k <= 1024) {
+        // wide residual: one Gram product for the group, one batched product T G_jj, one decision launch (4 launches instead of 4 g)
+        Mat Gall(ctx, g * k, g * k), TGall(ctx, k, g * k);
+        gemm(ctx, true, false, 1.0, Rcat, Rcat, 0.0, Gall, st, "gemm_gram");
+        std::vector<GemmBatchDesc> descs;
+        for (int j = 0; j < g; ++j)
+            descs.push_back({T.p, Gall.p + (size_t)j * k + (size_t)j * k * Gall.ld, TGall.p + (size_t)j * k * TGall.ld, nullptr, 1.0, k, k, k, T.ld, Gall.ld, TGall.ld, 0});
+        gemm_batched(ctx, descs, "gemm_norm");
+        TimedScope ts(ctx, "ldlt_norm", 16.0 * g * k * k, 4.0 * g * k * k);
+        hipLaunchKernelGGL(k_trace_sq_multi, dim3(1), dim3(1024), 0, ctx->stream, k, g, (const double*)TGall.p, TGall.ld, alpha, st, iters0);
+        DRE_HIP(hipGetLastError());
+        return;
+    }
     if (k > 96 || g * k > 512) {
         for (int j = 0; j < g; ++j) { Mat Rj = Rcat.colsview(j * k, k); residual_norm_step(ctx, Rj, T, tdiag, alpha, st, iters0 + j + 1); }
         return;

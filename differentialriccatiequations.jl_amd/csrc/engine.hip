@@ -669,58 +669,6 @@ __global__ __launch_bounds__(256) void k_smw_apply(int n, int m, int k, const T*
     }
 }
 
-// The same (real shift, low-rank term) with small = U' W still in split-K slabs (gemm_partials): every workgroup sums the m x kc entries it needs
-// itself (fixed order: four interleaved partial sums per entry, combined in a fixed order) — the slab-reduction launch of the SMW product is gone.
-__global__ __launch_bounds__(256) void k_smw_apply_slabs(int n, int m, int k, const double* __restrict__ W, int ldw, const double* __restrict__ WU, int ldwu,
-                                                         const double* __restrict__ Sinv, const double* __restrict__ part, int nslab, size_t slab, int ldp,
-                                                         double* __restrict__ V1, int ldv1, const AdiState* st) {
-    if (st && st->done) return;
-    __shared__ double sred[SMW_CB * 32], y[SMW_CB * 32];
-    const int c0 = blockIdx.y * SMW_CB, kc = min(SMW_CB, k - c0);
-    const int tid = threadIdx.x, q = tid & 3;
-    for (int e = tid >> 2; e < kc * m; e += 64) {
-        const int l = e % m, c = e / m;
-        const double* p = part + l + (size_t)(c0 + c) * ldp;
-        double acc = 0.0;
-        for (int z = q; z < nslab; z += 4) acc += p[(size_t)z * slab];
-        const double a1 = __shfl_xor(acc, 1), b = acc + a1;
-        const double a2 = __shfl_xor(b, 2);
-        if (q == 0) sred[l + c * 32] = b + a2;
-    }
-    __syncthreads();
-    for (int id = tid; id < kc * m; id += 256) {
-        const int j = id % m, c = id / m;
-        double acc = 0.0;
-        for (int l = 0; l < m; ++l) acc += Sinv[j + (size_t)l * m] * sred[l + c * 32];
-        y[j + c * 32] = acc;
-    }
-    __syncthreads();
-    const int i = blockIdx.x * 256 + tid;
-    if (i >= n) return;
-    for (int c = 0; c < kc; ++c) {
-        double v = W[i + (size_t)(c0 + c) * ldw];
-        for (int j = 0; j < m; ++j) v -= WU[i + (size_t)j * ldwu] * y[j + c * 32];
-        V1[i + (size_t)(c0 + c) * ldv1] = v;
-    }
-}
-// capacitance matrix from the slabs: S = sum of the m x m blocks at column col0, then the inversion of k_sinv
-__global__ __launch_bounds__(64) void k_sinv_slabs(int m, const double* __restrict__ part, int nslab, size_t slab, int ldp, int col0, double alpha,
-                                                   double* __restrict__ Sinv, const AdiState* st, int* err) {
-    if (st && st->done) return;
-    __shared__ double S[32 * 32];
-    for (int e = threadIdx.x; e < m * m; e += 64) {
-        const int i = e % m, j = e / m;
-        const double* p = part + i + (size_t)(col0 + j) * ldp;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int z = 0;
-        for (; z + 3 < nslab; z += 4) { a0 += p[(size_t)z * slab]; a1 += p[(size_t)(z + 1) * slab]; a2 += p[(size_t)(z + 2) * slab]; a3 += p[(size_t)(z + 3) * slab]; }
-        for (; z < nslab; ++z) a0 += p[(size_t)z * slab];
-        S[i + j * m] = (a0 + a1) + (a2 + a3);
-    }
-    __syncthreads();
-    sinv_body<double>(m, S, m, alpha, Sinv, err);
-}
-
 // Dense-inverse ADI step (real shift).  Wst = [inv; E' inv; U' inv] * R holds W (n rows), EW = E' W (n rows) and
 // small = U' W (m rows);  WKst the same products for the low-rank factor Vt.  With y = Sinv * small:
 //   V = W - WK y,      R <- R - 2 mu E' V = R - 2 mu (EW - EWK y)          (adi.jl:166-171 with LowRankUpdate.jl:29-39)
@@ -1941,15 +1889,15 @@ void adi_advance(AdiRun& run, int budget) {
                             Mat Wl = W;
                             if (!have) { Mat d = Wl.colsview(k, m); copy_mat(c, opp->Vt, d, 1.0, dst); }
                             mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Wl.p, Wl.ld, ncols, dst);
-                            int zs = 1;
-                            BufP spart = gemm_partials(c, true, false, m, ncols, n, opp->U.p, opp->U.ld, Wl.p, Wl.ld, &zs, dst, "smw_small");
+                            Mat sm(c, m, ncols);
+                            gemm(c, true, false, 1.0, opp->U, Wl, 0.0, sm, dst, "smw_small");
                             if (!have)
-                                hipLaunchKernelGGL(k_sinv_slabs, dim3(1), dim3(64), 0, c->stream, m, (const double*)spart->p, zs, (size_t)m * ncols, m, k, opp->alpha, sinv, dst, serr_);
+                                hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, c->stream, m, sm.p + (size_t)k * sm.ld, sm.ld, opp->alpha, sinv, dst, serr_);
                             {
                                 TimedScope ts(c, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
-                                hipLaunchKernelGGL(k_smw_apply_slabs, dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, c->stream,
-                                                   n, m, k, (const double*)Wl.p, Wl.ld, WU, ldwu, (const double*)sinv, (const double*)spart->p, zs, (size_t)m * ncols, m,
-                                                   Vout.p, Vout.ld, dst);
+                                hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, c->stream,
+                                                   n, m, k, (const double*)Wl.p, Wl.ld, WU, ldwu, (const double*)sinv, (const double*)sm.p, sm.ld, Vout.p, Vout.ld,
+                                                   (double*)nullptr, 0, 0.0, dst);
                             }
                             if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
                         });
@@ -2125,21 +2073,22 @@ void adi_advance(AdiRun& run, int budget) {
                     else mf_solve_from(ctx, P, fe->f, R.p, R.ld, k, W.p, W.ld, ncols, dst);     // the residual block is read where it is
                     if (op.has_lr) {
                         V1 = Mat(ctx, n, k);
-                        // small = U' W: a skinny split-K MFMA GEMM whose slabs are summed by the kernels that consume them
-                        int zs = 1;
-                        BufP spart = gemm_partials(ctx, true, false, m, ncols, n, op.U.p, op.U.ld, W.p, W.ld, &zs, dst, "smw_small");
+                        // small = U' W: a skinny split-K MFMA GEMM (the one-workgroup-per-column kernel is latency bound at large n).  (Letting the
+                        // SMW kernels sum the slabs themselves saves the reduction launch and is neutral at n = 5177, but every one of the 1264
+                        // workgroups of the apply kernel then sums its 56 entries over 80 slabs at n = 20209: 59 us against 20 + 10 — reverted.)
+                        Mat small(ctx, m, ncols);
+                        gemm(ctx, true, false, 1.0, op.U, W, 0.0, small, dst, "smw_small");
                         if (!have) {
                             SmwCacheEntry en;
                             en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
                             en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                            hipLaunchKernelGGL(k_sinv_slabs, dim3(1), dim3(64), 0, ctx->stream, m, (const double*)spart->p, zs, (size_t)m * ncols, m, k, op.alpha,
-                                               (double*)en.sinv->p, dst, serr);
+                            hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, ctx->stream, m, small.p + (size_t)k * small.ld, small.ld, op.alpha, (double*)en.sinv->p, dst, serr);
                             sc = smw_cache.emplace(key, en).first;
                         }
                         TimedScope ts(ctx, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
-                        hipLaunchKernelGGL(k_smw_apply_slabs, dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
-                                           n, m, k, (const double*)W.p, W.ld, (const double*)sc->second.WU, sc->second.ldwu, (const double*)sc->second.sinv->p,
-                                           (const double*)spart->p, zs, (size_t)m * ncols, m, V1.p, V1.ld, dst);
+                        hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, ctx->stream,
+                                           n, m, k, W.p, W.ld, (const double*)sc->second.WU, sc->second.ldwu, (const double*)sc->second.sinv->p,
+                                           small.p, small.ld, V1.p, V1.ld, (double*)nullptr, 0, 0.0, dst);
                     } else {
                         V1 = W;
                     }
