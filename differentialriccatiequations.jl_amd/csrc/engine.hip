@@ -1323,27 +1323,26 @@ static double fan_coefficients(const double* mu, int g, FanCoef* out) {
     for (int j = 0; j < 4; ++j) for (int s = 0; s < 4; ++s) { out->c[j][s] = (double)c[j][s]; out->d[j][s] = (double)d[j][s]; }
     return worst;
 }
-// W: n x (g k) = [W_1 .. W_g];  V_j, Y_j as above;  Rcat_j = R_0 (the SpMM that follows subtracts E' Y_j in place)
-__global__ __launch_bounds__(256) void k_fan_mix(int n, int k, int g, const double* __restrict__ W, int ldw, const double* __restrict__ R0, int ldr,
-                                                 double* __restrict__ V, int ldv, double* __restrict__ Y, int ldy, double* __restrict__ Rcat, int ldrc,
+// W: n x (g k) = [W_1 .. W_g],  EW = E' W (formed by each solve's own stream):   V_j = sum_s c_js W_s,   R_j = R_0 - sum_s d_js (E' W_s)
+__global__ __launch_bounds__(256) void k_fan_mix(int n, int k, int g, const double* __restrict__ W, int ldw, const double* __restrict__ EW, int ldew,
+                                                 const double* __restrict__ R0, int ldr, double* __restrict__ V, int ldv, double* __restrict__ Rcat, int ldrc,
                                                  FanCoef co, const AdiState* st) {
     if (st && st->done) return;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)n * k) return;
     const int i = idx % n, c = idx / n;
-    double w[4];
+    double w[4], ew[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w[s] = s < g ? W[i + (size_t)(s * k + c) * ldw] : 0.0;
+    for (int s = 0; s < 4; ++s) { w[s] = s < g ? W[i + (size_t)(s * k + c) * ldw] : 0.0; ew[s] = s < g ? EW[i + (size_t)(s * k + c) * ldew] : 0.0; }
     const double r0 = R0[i + (size_t)c * ldr];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (j >= g) break;
         double v = 0.0, y = 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) if (s <= j) { v += co.c[j][s] * w[s]; y += co.d[j][s] * w[s]; }
+        for (int s = 0; s < 4; ++s) if (s <= j) { v += co.c[j][s] * w[s]; y += co.d[j][s] * ew[s]; }
         V[i + (size_t)(j * k + c) * ldv] = v;
-        Y[i + (size_t)(j * k + c) * ldy] = y;
-        Rcat[i + (size_t)(j * k + c) * ldrc] = r0;
+        Rcat[i + (size_t)(j * k + c) * ldrc] = r0 - y;
     }
 }
 // helper contexts (own stream and pool each) of a context; the first use makes the streams wait for everything the main stream holds so far
@@ -1848,7 +1847,7 @@ void adi_advance(AdiRun& run, int budget) {
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
                     const auto hp0 = std::chrono::steady_clock::now();
                     ensure_helpers(ctx, g - 1);
-                    Mat Wcat(ctx, n, g * k), Vcat(ctx, n, g * k), Ycat(ctx, n, g * k), Rcat(ctx, n, g * k);
+                    Mat Wcat(ctx, n, g * k), Vcat(ctx, n, g * k), EWcat(ctx, n, g * k), Rcat(ctx, n, g * k);
                     // host-side bookkeeping (SMW cache, buffers from the main pool) first; a job only enqueues on its stream
                     std::vector<std::function<void()>> jobs;
                     for (int s_ = 0; s_ < g; ++s_) {
@@ -1856,6 +1855,7 @@ void adi_advance(AdiRun& run, int budget) {
                         const auto fe = fes[(size_t)s_];
                         const double mur = mus[s_];
                         Mat Vout = Wcat.colsview(s_ * k, k);
+                        Mat EWout = EWcat.colsview(s_ * k, k);
                         const Mat Rin = R;
                         hipEvent_t e0 = ctx->helper_e0, ev = c != ctx ? ctx->helper_ev[(size_t)s_] : nullptr;
                         Ctx* const mainc = ctx;
@@ -1864,6 +1864,7 @@ void adi_advance(AdiRun& run, int budget) {
                             jobs.push_back([=, &P]() {
                                 if (c != mainc) DRE_HIP(hipStreamWaitEvent(c->stream, e0, 0));
                                 mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Vout.p, Vout.ld, k, dst);
+                                { Mat Vo = Vout, Eo = EWout; spmm(c, P, P.valEt.p, Vo, Eo, 1.0, 0.0, dst); }
                                 if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
                             });
                             continue;
@@ -1899,6 +1900,7 @@ void adi_advance(AdiRun& run, int budget) {
                                                    n, m, k, (const double*)Wl.p, Wl.ld, WU, ldwu, (const double*)sinv, (const double*)sm.p, sm.ld, Vout.p, Vout.ld,
                                                    (double*)nullptr, 0, 0.0, dst);
                             }
+                            { Mat Vo = Vout, Eo = EWout; spmm(c, P, P.valEt.p, Vo, Eo, 1.0, 0.0, dst); }       // E' W_s on the solve's own stream (all g side by side)
                             if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
                         });
                     }
@@ -1914,9 +1916,8 @@ void adi_advance(AdiRun& run, int budget) {
                         TimedScope ts(ctx, "fan_mix", 8.0 * n * k * (4.0 * g + 1.0), 2.0 * n * k * (double)g * (g + 1));
                         const size_t tot = (size_t)n * k;
                         hipLaunchKernelGGL(k_fan_mix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, g, (const double*)Wcat.p, Wcat.ld,
-                                           (const double*)R.p, R.ld, Vcat.p, Vcat.ld, Ycat.p, Ycat.ld, Rcat.p, Rcat.ld, co, dst);
+                                           (const double*)EWcat.p, EWcat.ld, (const double*)R.p, R.ld, Vcat.p, Vcat.ld, Rcat.p, Rcat.ld, co, dst);
                     }
-                    spmm(ctx, P, P.valEt.p, Ycat, Rcat, -1.0, 1.0, dst);              // R_j = R_0 - E' Y_j, all j in one pass
                     for (int j = 0; j < g; ++j) {
                         const std::complex<double> muj = oracle->take(&res.warnings);
                         all_shifts.push_back(muj);
@@ -1929,7 +1930,7 @@ void adi_advance(AdiRun& run, int budget) {
                     }
                     residual_norm_group(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
-                    run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(Ycat.buf);
+                    run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(EWcat.buf);
                     if (chunk_timing) {
                         static double tp = 0, tj = 0, tt = 0; static long ng = 0;
                         const auto hp3 = std::chrono::steady_clock::now();
