@@ -1294,9 +1294,9 @@ std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOpe
 // adi.jl:158-171,   V_j = Z_j R_{j-1},  R_j = R_{j-1} - 2 mu_j E' V_j   (j = 1..g, from R_0),   into partial fractions of  W_s = Z_s R_0:
 //     V_j = sum_{s<=j} c_js W_s,     c_js = prod_{i<j} (-mu_s - mu_i) / prod_{i<=j, i!=s} (mu_i - mu_s),
 //     R_j = R_0 - E' Y_j,            Y_j = 2 sum_{i<=j} mu_i V_i = sum_{s<=j} d_js W_s,   d_js = 2 sum_{i=s..j} mu_i c_is.
-// The g multifrontal solves (+ SMW corrections) are latency bound and use a fraction of the chip each: they run side by side on the helper
-// streams; one mixing launch forms all V_j and Y_j, ONE SpMM over the g k columns all residuals, and the norms/decisions follow in iteration
-// order.  The coefficients grow when shifts of a group are close (~ mu / delta mu per pair): groups are cut so that max_j sum_s |c_js| stays
+// The g multifrontal solves (+ SMW corrections + the products E' W_s) are latency bound and use a fraction of the chip each: they run side by
+// side on the helper streams; one mixing launch forms all V_j and all residuals R_j = R_0 - sum_s d_js E' W_s, and the norms/decisions follow
+// in iteration order (one Gram product + one decision launch for the group).  The coefficients grow when shifts of a group are close (~ mu / delta mu per pair): groups are cut so that max_j sum_s |c_js| stays
 // below fan_max_coef (the products W_s are accurate to ~eps cond, the combination amplifies that by the coefficient sum).
 // =============================================================================================
 struct FanCoef { double c[4][4], d[4][4]; };
