@@ -4050,17 +4050,18 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
     // first-pass bound of 1e-13 struck there and sent every later sketch of the run to Householder panels: 27 % of a 45-step run.)
     const double thr = (mode == 2 ? 0.25 : 1e-15) * dmax_s;
     bool bad = false;
-    double minratio = 1.0;                           // smallest live pivot / largest diagonal entry (trace only)
+    double minpiv = dmax_s;                          // smallest live pivot (trace only; divided by the largest diagonal entry once, at the end)
     // step k (one barrier): with l_ik = A_ik / pivot,   A_ij -= l_ik A_jk  (k < j <= i: the Schur complement)   and
     //                                                   Y_ij -= l_ik Y_kj  (j <= k: rows of inv(L), unscaled; Y_kk = 1)
     // on a 16 x 16 thread grid; the first version inverted L afterwards with one thread per column (b^3/6 dependent steps: 100 of its 107 us)
+    // Only ONE division sits in the dependent chain of a step (1 / pivot); the square roots of the scaling are taken after the loop, all at once.
     for (int k = 0; k < b; ++k) {
         const double piv = A[k][k];
         const bool live = piv > floor_abs;           // (NaN: not live)
         if (live && !(piv > thr)) bad = true;
-        if (live) minratio = fmin(minratio, piv / dmax_s);
-        const double rd = live ? 1.0 / sqrt(piv) : 0.0, rp = rd * rd;
-        if (tid == 0) { rds[k] = rd; if (nullmask) nullmask[k] = live ? 0 : 1; }
+        if (live) minpiv = fmin(minpiv, piv);
+        const double rp = live ? 1.0 / piv : 0.0;
+        if (tid == 0) { rds[k] = live ? piv : 0.0; if (nullmask) nullmask[k] = live ? 0 : 1; }
         for (int i = k + 1 + ty; i < b; i += 16) {
             const double lik = A[i][k] * rp;
             for (int j = tx; j <= i; j += 16) {
@@ -4070,13 +4071,15 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
         }
         __syncthreads();
     }
+    if (tid < 64) rds[tid] = (tid < b && rds[tid] > 0.0) ? 1.0 / sqrt(rds[tid]) : 0.0;        // rd_k = 1 / sqrt(pivot_k), null column: 0
+    __syncthreads();
     // Rinv = inv(L)':  Rinv(r, c) = rd_c Y(c, r) for r <= c  (a null column c: rd_c = 0)
     for (int id = tid; id < 64 * 64; id += 256) {
         const int r = id & 63, c = id >> 6;
         if (r < b && c < b) Rinv[r + (size_t)c * ldr] = (r <= c) ? Y[c][r] * rds[c] : 0.0;
     }
     if (bad && tid == 0) atomicOr(flag, 1);
-    if (dbg && tid == 0) *dbg = minratio;
+    if (dbg && tid == 0) *dbg = minpiv / dmax_s;
 }
 // Unit-scale Gaussian entries (variance 1/n) into the columns of T that mask marks
 __global__ void k_fill_gauss_masked(int n, int cols, unsigned long long seed, double* __restrict__ out, int ld, const int* __restrict__ mask, double scale) {
