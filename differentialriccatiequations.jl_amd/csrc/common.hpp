@@ -162,9 +162,9 @@ struct Ctx {
     // divisor of the cycle length up to 5), 0 = off (one launch per iteration), g >= 2 = that group size if it divides the cycle length
     int adi_group = 1;
     int adi_group_max_n = 768;
-    // fan groups of the general path (engine.hip, k_fan_mix): up to adi_fan consecutive real-shift iterations from independent solves that run
-    // side by side on the helper streams (0 / 1 = off, at most 4); a group is cut where the partial-fraction coefficients exceed adi_fan_max_coef
-    int adi_fan = 3;
+    // fan groups of the general path (engine.hip): up to adi_fan consecutive real-shift iterations from independent solves that share every
+    // launch (0 / 1 = off, at most 8); a group is cut where the partial-fraction coefficients exceed adi_fan_max_coef
+    int adi_fan = 5;
     double adi_fan_max_coef = 64.0;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)

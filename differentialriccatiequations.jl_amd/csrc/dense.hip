@@ -569,6 +569,69 @@ BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double
     return pb;
 }
 
+// ---------------------------------------------------------------------------------------------
+// z-batched split-K products (round 4): nz products C_z = op(A_z) op(B_z) of one shape in ONE launch — the g solves of a fan group
+// (engine.hip) share every launch instead of running side by side on g streams.  Slab (z, split) lies at partial + (z * splits + split) M N.
+// ---------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void k_gemm_z(int M, int N, int K, GemmZ zb, int lda, int ldb, int kchunk, int splits, double* __restrict__ partial,
+                                                const AdiState* st) {
+    if (st && st->done) return;
+    const int z = blockIdx.z / splits, sp = blockIdx.z - z * splits;
+    const int kbeg = sp * kchunk;
+    gemm_tile<TA, TB>(M, N, K, 1.0, zb.A[z], lda, zb.B[z], ldb, 0.0, nullptr, 0, blockIdx.x * GB_M, blockIdx.y * GB_N, kbeg, min(K, kbeg + kchunk),
+                      partial + (size_t)blockIdx.z * M * N);
+}
+BufP gemm_partials_z(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const GemmZ& zb, int nz, int lda, int ldb, int* splits_out, const AdiState* st,
+                     const char* tag) {
+    DRE_REQUIRE(nz >= 1 && nz <= MF_ZMAX, "gemm_partials_z: batch size");
+    TimedScope ts(ctx, tag, 8.0 * nz * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * nz * M * N * (double)K);
+    const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
+    int splits = 1;
+    if (K > 2 * GB_K) {
+        int want = ceil_div(2 * ctx->num_cus, tm * tn * nz);
+        splits = std::max(1, std::min(want, K / (2 * GB_K)));
+    }
+    int kchunk = K > 0 ? ceil_div(ceil_div(K, splits), GB_K) * GB_K : GB_K;
+    splits = K > 0 ? ceil_div(K, kchunk) : 1;
+    dim3 grid(tm, tn, splits * nz), block(256);
+    auto pb = std::make_shared<Buf>(ctx, (size_t)splits * nz * M * N * sizeof(double));
+    double* partial = (double*)pb->p;
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm_z<false, false>), grid, block, 0, ctx->stream, M, N, K, zb, lda, ldb, kchunk, splits, partial, st);
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm_z<true, false>), grid, block, 0, ctx->stream, M, N, K, zb, lda, ldb, kchunk, splits, partial, st);
+    else DRE_REQUIRE(false, "gemm_partials_z: only NN and TN products");
+    DRE_HIP(hipGetLastError());
+    *splits_out = splits;
+    return pb;
+}
+// fixed-order sums of the slabs of gemm_partials_z: C_z[rowmap ? rowmap[row] : row, col] = sum_split slab(z, split)[row, col],  C_z = C + z cz
+__global__ void k_gemm_reduce_z(int M, int N, int splits, const double* __restrict__ partial, const int* __restrict__ rowmap, double* __restrict__ C, int ldc,
+                                long cz, const AdiState* st) {
+    if (st && st->done) return;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * N) return;
+    const size_t slab = (size_t)M * N;
+    const double* __restrict__ p = partial + (size_t)blockIdx.y * splits * slab + idx;
+    double s = 0.0;
+    int z = 0;
+    for (; z + 7 < splits; z += 8) {
+        double q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = p[(z + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += q[u];
+    }
+    for (; z < splits; ++z) s += p[z * slab];
+    const int row = idx % M, col = idx / M;
+    C[(size_t)blockIdx.y * cz + (rowmap ? rowmap[row] : row) + (size_t)col * ldc] = s;
+}
+void gemm_reduce_z(Ctx* ctx, int M, int N, int splits, int nz, const double* partial, const int* rowmap, double* C, int ldc, long cz, const AdiState* st) {
+    const size_t tot = (size_t)M * N;
+    if (!tot) return;
+    hipLaunchKernelGGL(k_gemm_reduce_z, dim3((unsigned)((tot + 255) / 256), nz), dim3(256), 0, ctx->stream, M, N, splits, partial, rowmap, C, ldc, cz, st);
+    DRE_HIP(hipGetLastError());
+}
+
 // =============================================================================================
 // small helpers
 // =============================================================================================
@@ -1035,7 +1098,8 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 // same lane layout, so tr(M M) = sum_ij M_ij N_ij needs no transposition; only blocks bi <= bj are computed.
 template <bool COHERENT>
 __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* part, const double* __restrict__ T, int ldt,
-                                               int tdiag, double alpha, AdiState* st, int iters_after, double* gsm, double* red, int ldp = 0, size_t slab = 0) {
+                                               int tdiag, double alpha, AdiState* st, int iters_after, double* gsm, double* red, int ldp = 0, size_t slab = 0,
+                                               double* nrm_out = nullptr) {
     const int kp = (k + 31) & ~31, ld = kp;
     if (ldp == 0) { ldp = k; slab = (size_t)k * k; }       // default: dense k x k slabs
     double* G = gsm;                        // kp x kp
@@ -1106,10 +1170,35 @@ __device__ __forceinline__ void gram_norm_body(int k, int splits, const double* 
     s = block_sum(s, red);
     if (tid == 0) {
         const double nrm = fabs(alpha) * sqrt(fmax(s, 0.0));
+        if (nrm_out) { *nrm_out = nrm; return; }          // (the caller decides: fan groups take their g norms in iteration order)
         st->res_norm = nrm;
         st->iters = iters_after;
         st->norms[iters_after & 511] = nrm;          // ring: the host reads every chunk (< 512 iterations) before it wraps
         if (nrm <= st->abstol || iters_after >= st->maxiters) st->done = 1;
+    }
+}
+// Fan groups, round 4: the norms of the g residuals of a group from their g Gram blocks Gd = [G_11 .. G_gg] (k x g k) in g workgroups side by side;
+// the LAST one to arrive (ticket in the control block) takes the decisions of adi.jl:115-123 in iteration order — the first residual at or
+// below abstol ends the loop.  (Round 3: one workgroup, the g norms one after the other: 42 us at g = 5, k = 64.)
+__global__ __launch_bounds__(1024) void k_gram_norm_z(int k, int g, const double* __restrict__ Gd, const double* __restrict__ T, int ldt, int tdiag, double alpha,
+                                                      AdiState* st, int iters0) {
+    if (st->done) return;
+    extern __shared__ double gsm[];
+    __shared__ double red[17];
+    const int j = blockIdx.x;
+    gram_norm_body<false>(k, 1, Gd + (size_t)j * k * k, T, ldt, tdiag, alpha, st, 0, gsm, red, k, 0, &st->gnorm[j]);
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&st->ticket, 1) != g - 1) return;
+    __threadfence();
+    st->ticket = 0;
+    for (int i = 0; i < g; ++i) {
+        const double nrm = __hip_atomic_load(&st->gnorm[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int iters_after = iters0 + i + 1;
+        st->res_norm = nrm;
+        st->iters = iters_after;
+        st->norms[iters_after & 511] = nrm;
+        if (nrm <= st->abstol || iters_after >= st->maxiters) { st->done = 1; break; }
     }
 }
 __global__ __launch_bounds__(1024) void k_gram_norm(int k, int splits, const double* __restrict__ part, const double* __restrict__ T, int ldt,
@@ -2087,6 +2176,37 @@ void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, 
     const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
     lds_attr(ctx, (const void*)k_gram_norm_multi, 150 * 1024);
     hipLaunchKernelGGL(k_gram_norm_multi, dim3(1), dim3(1024), shm, ctx->stream, k, g, (const double*)Gall.p, Gall.ld, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters0);
+    DRE_HIP(hipGetLastError());
+}
+void residual_norm_group_diag(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0) {
+    DRE_REQUIRE(g >= 1 && g <= 16 && Rcat.cols == g * k, "residual_norm_group_diag: shapes");
+    // G_jj = R_j' R_j for the g residuals: one z-batched split-K product + one reduction of its slabs
+    GemmZ gz; std::memset(&gz, 0, sizeof(gz));
+    for (int j = 0; j < g; ++j) gz.A[j] = gz.B[j] = Rcat.p + (size_t)j * k * Rcat.ld;
+    int zs = 1;
+    BufP part = gemm_partials_z(ctx, true, false, k, k, Rcat.rows, gz, g, Rcat.ld, Rcat.ld, &zs, st, "gemm_gram");
+    Mat Gd(ctx, k, g * k);
+    gemm_reduce_z(ctx, k, k, zs, g, (const double*)part->p, nullptr, Gd.p, Gd.ld, (long)k * k, st);
+    if (k <= 96) {
+        TimedScope ts(ctx, "ldlt_norm", 8.0 * g * k * k, 4.0 * g * (double)k * k * k);
+        const int kp = (k + 31) & ~31;
+        const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
+        lds_attr(ctx, (const void*)k_gram_norm_z, 150 * 1024);
+        hipLaunchKernelGGL(k_gram_norm_z, dim3(g), dim3(1024), shm, ctx->stream, k, g, (const double*)Gd.p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters0);
+        DRE_HIP(hipGetLastError());
+        return;
+    }
+    if (tdiag) {
+        for (int j = 0; j < g; ++j) { Mat Gj = Gd.colsview(j * k, k); ldlt_norm_update_state(ctx, Gj, T, true, alpha, st, iters0 + j + 1); }
+        return;
+    }
+    // wide residual: one batched product T G_jj, one decision launch
+    Mat TGall(ctx, k, g * k);
+    std::vector<GemmBatchDesc> descs;
+    for (int j = 0; j < g; ++j) descs.push_back({T.p, Gd.p + (size_t)j * k * Gd.ld, TGall.p + (size_t)j * k * TGall.ld, nullptr, 1.0, k, k, k, T.ld, Gd.ld, TGall.ld, 0});
+    gemm_batched(ctx, descs, "gemm_norm");
+    TimedScope ts(ctx, "ldlt_norm", 16.0 * g * k * k, 4.0 * g * k * k);
+    hipLaunchKernelGGL(k_trace_sq_multi, dim3(1), dim3(1024), 0, ctx->stream, k, g, (const double*)TGall.p, TGall.ld, alpha, st, iters0);
     DRE_HIP(hipGetLastError());
 }
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {

@@ -18,6 +18,9 @@ struct AdiState {
     double abstol;
     double res_norm;
     double norms[512];   // residual norm after iteration i (index = shifts consumed)
+    // meeting point of the g norm workgroups of a fan group (dense.hip, k_gram_norm_z): zeroed with the control block, reset by the last arrival
+    int ticket, pad_;
+    double gnorm[16];
 };
 
 // A count that only exists in device memory when the consumer is enqueued: the number of ADI iterations of a speculatively enqueued
@@ -59,6 +62,13 @@ void gemm_batched(Ctx* ctx, const std::vector<GemmBatchDesc>& descs, const char*
 void gemm_reduce_rows(Ctx* ctx, int M, int N, int splits, const double* partial, const int* rowmap, double* C, int ldc, const AdiState* st = nullptr);
 BufP gemm_partials(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const double* A, int lda, const double* B, int ldb,
                    int* splits_out, const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma", DevCount dc = DevCount{});
+// z-batched split-K products of one shape in one launch (fan groups of the general path): slab (z, split) at (z * splits + split) * M * N
+#define MF_ZMAX 16
+struct GemmZ { const double* A[MF_ZMAX]; const double* B[MF_ZMAX]; };
+BufP gemm_partials_z(Ctx* ctx, bool transA, bool transB, int M, int N, int K, const GemmZ& zb, int nz, int lda, int ldb, int* splits_out,
+                     const AdiState* st = nullptr, const char* tag = "gemm_f64_mfma");
+// C_z[rowmap ? rowmap[row] : row, col] = fixed-order sum of the slabs of product z;  C_z = C + z * cz
+void gemm_reduce_z(Ctx* ctx, int M, int N, int splits, int nz, const double* partial, const int* rowmap, double* C, int ldc, long cz, const AdiState* st = nullptr);
 void copy_mat(Ctx* ctx, const Mat& src, Mat& dst, double scale = 1.0, const AdiState* st = nullptr);  // dst = scale*src
 struct CopyDesc { const double* src; double* dst; int rows, cols, lds, ldd; };
 void copy_batched(Ctx* ctx, const std::vector<CopyDesc>& descs);                      // all blocks in one launch per 32
@@ -98,6 +108,8 @@ void ldlt_norm_update_state(Ctx* ctx, const Mat& G, const Mat& T, bool tdiag, do
 // The whole residual-norm step  G = R'R,  nrm = |alpha| sqrt(tr((T G)^2)),  convergence decision  in two launches:
 // the split-K Gram GEMM and one workgroup that reduces the partial slabs, forms T G in LDS and decides (k <= 88).
 void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0);   // g residuals at once
+// the same from the g DIAGONAL blocks of the Gram matrix only (one z-batched product), the g norms in parallel workgroups, decisions in order
+void residual_norm_group_diag(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0);
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
 // fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
 // The norm kernel of iteration i can ride on the step kernel of iteration i + 1 (one more workgroup) instead of being a launch of

@@ -1294,14 +1294,14 @@ std::vector<std::complex<double>> heuristic_shift_values(Ctx* ctx, const GaleOpe
 // adi.jl:158-171,   V_j = Z_j R_{j-1},  R_j = R_{j-1} - 2 mu_j E' V_j   (j = 1..g, from R_0),   into partial fractions of  W_s = Z_s R_0:
 //     V_j = sum_{s<=j} c_js W_s,     c_js = prod_{i<j} (-mu_s - mu_i) / prod_{i<=j, i!=s} (mu_i - mu_s),
 //     R_j = R_0 - E' Y_j,            Y_j = 2 sum_{i<=j} mu_i V_i = sum_{s<=j} d_js W_s,   d_js = 2 sum_{i=s..j} mu_i c_is.
-// The g multifrontal solves (+ SMW corrections + the products E' W_s) are latency bound and use a fraction of the chip each: they run side by
-// side on the helper streams; one mixing launch forms all V_j and all residuals R_j = R_0 - sum_s d_js E' W_s, and the norms/decisions follow
-// in iteration order (one Gram product + one decision launch for the group).  The coefficients grow when shifts of a group are close (~ mu / delta mu per pair): groups are cut so that max_j sum_s |c_js| stays
+// The g multifrontal solves (+ SMW corrections) are latency bound and use a fraction of the chip each: they SHARE every launch (round 4:
+// blockIdx.z = shift, sparse.hip mf_solve_batch; round 3 ran them side by side on g streams, 13 launches each); one pass over E' forms all V_j and
+// all residuals R_j = R_0 - sum_s d_js E' W_s (sparse.hip, k_fan_spmm_mix), and the norms/decisions follow in iteration order (one batched Gram
+// product + one decision launch for the group).  The coefficients grow when shifts of a group are close (~ mu / delta mu per pair): groups are cut so that max_j sum_s |c_js| stays
 // below fan_max_coef (the products W_s are accurate to ~eps cond, the combination amplifies that by the coefficient sum).
 // =============================================================================================
-struct FanCoef { double c[4][4], d[4][4]; };
 static double fan_coefficients(const double* mu, int g, FanCoef* out) {
-    long double c[4][4] = {{0}}, d[4][4] = {{0}};
+    long double c[FAN_GMAX][FAN_GMAX] = {{0}}, d[FAN_GMAX][FAN_GMAX] = {{0}};
     double worst = 0.0;
     for (int j = 0; j < g; ++j) {
         long double sum = 0.0L;
@@ -1320,52 +1320,49 @@ static double fan_coefficients(const double* mu, int g, FanCoef* out) {
             for (int i = s; i <= j; ++i) acc += 2.0L * (long double)mu[i] * c[i][s];
             d[j][s] = acc;
         }
-    for (int j = 0; j < 4; ++j) for (int s = 0; s < 4; ++s) { out->c[j][s] = (double)c[j][s]; out->d[j][s] = (double)d[j][s]; }
+    for (int j = 0; j < FAN_GMAX; ++j) for (int s = 0; s < FAN_GMAX; ++s) { out->c[j][s] = (double)c[j][s]; out->d[j][s] = (double)d[j][s]; }
     return worst;
 }
-// W: n x (g k) = [W_1 .. W_g],  EW = E' W (formed by each solve's own stream):   V_j = sum_s c_js W_s,   R_j = R_0 - sum_s d_js (E' W_s)
-__global__ __launch_bounds__(256) void k_fan_mix(int n, int k, int g, const double* __restrict__ W, int ldw, const double* __restrict__ EW, int ldew,
-                                                 const double* __restrict__ R0, int ldr, double* __restrict__ V, int ldv, double* __restrict__ Rcat, int ldrc,
-                                                 FanCoef co, const AdiState* st) {
+// SMW of the g solves of a fan group in one launch (blockIdx.z = solve): W_z <- W_z - W_U,z (Sinv_z small_z) in place;  W_z / small_z = columns
+// z k .. of the n x (g k) panel / of small = U' W  (smw.jl:36-43)
+struct SmwZ { const double* WU[MF_ZMAX]; const double* Sinv[MF_ZMAX]; int ldwu[MF_ZMAX]; };
+__global__ __launch_bounds__(256) void k_smw_apply_z(int n, int m, int k, double* __restrict__ W, int ldw, SmwZ sz, const double* __restrict__ small, int lds_,
+                                                     const AdiState* st) {
     if (st && st->done) return;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)n * k) return;
-    const int i = idx % n, c = idx / n;
-    double w[4], ew[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { w[s] = s < g ? W[i + (size_t)(s * k + c) * ldw] : 0.0; ew[s] = s < g ? EW[i + (size_t)(s * k + c) * ldew] : 0.0; }
-    const double r0 = R0[i + (size_t)c * ldr];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j >= g) break;
-        double v = 0.0, y = 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) if (s <= j) { v += co.c[j][s] * w[s]; y += co.d[j][s] * ew[s]; }
-        V[i + (size_t)(j * k + c) * ldv] = v;
-        Rcat[i + (size_t)(j * k + c) * ldrc] = r0 - y;
+    __shared__ double y[SMW_CB * 32];
+    const int z = blockIdx.z;
+    const int c0 = blockIdx.y * SMW_CB, kc = min(SMW_CB, k - c0);
+    const int tid = threadIdx.x;
+    const double* __restrict__ Sinv = sz.Sinv[z];
+    const double* __restrict__ WU = sz.WU[z];
+    const int ldwu = sz.ldwu[z];
+    for (int id = tid; id < kc * m; id += 256) {
+        const int j = id % m, c = id / m;
+        double acc = 0.0;
+        for (int l = 0; l < m; ++l) acc += Sinv[j + (size_t)l * m] * small[l + (size_t)(z * k + c0 + c) * lds_];
+        y[j + c * 32] = acc;
     }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= n) return;
+    double* __restrict__ w = W + i + (size_t)(z * k + c0) * ldw;
+    double v[SMW_CB];
+#pragma unroll
+    for (int c = 0; c < SMW_CB; ++c) v[c] = w[(size_t)min(c, kc - 1) * ldw];
+    for (int j = 0; j < m; ++j) {
+        const double wuj = WU[i + (size_t)j * ldwu];
+#pragma unroll
+        for (int c = 0; c < SMW_CB; ++c) v[c] -= wuj * y[j + c * 32];
+    }
+#pragma unroll
+    for (int c = 0; c < SMW_CB; ++c) if (c < kc) w[(size_t)c * ldw] = v[c];
 }
-// helper contexts (own stream and pool each) of a context; the first use makes the streams wait for everything the main stream holds so far
-static void ensure_helpers(Ctx* ctx, int nh) {
-    while ((int)ctx->helpers.size() < nh) {
-        auto hc = std::make_unique<Ctx>();
-        hc->device = ctx->device; hc->num_cus = ctx->num_cus;
-        hc->stream = create_stream(2);
-        hc->timer = std::make_unique<KernelTimer>();
-        hipEvent_t ev;
-        DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
-    }
-    if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
-    for (int h = 0; h < nh; ++h) {
-        Ctx* hc = ctx->helpers[(size_t)h].get();
-        hc->pivot_static = ctx->pivot_static; hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
-        hc->pivot_refine_steps = ctx->pivot_refine_steps;
-        hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->mf_subtree = ctx->mf_subtree;
-        hc->timer->enabled = ctx->timer && ctx->timer->enabled;
-    }
+// the capacitance matrices of several shifts inverted in one launch (blockIdx.x = shift): Sinv_z = inv(alpha I + small[:, z m .. (z+1) m))
+struct SinvZ { double* out[MF_ZMAX]; };
+__global__ __launch_bounds__(64) void k_sinv_z(int m, const double* __restrict__ small, int lds_, double alpha, SinvZ iz, const AdiState* st, int* err) {
+    if (st && st->done) return;
+    sinv_body<double>(m, small + (size_t)blockIdx.x * m * lds_, lds_, alpha, iz.out[blockIdx.x], err);
 }
-
 struct StepRec { int iters_after; size_t nblocks; int nshifts; Mat Rafter; };      // Rafter: the residual factor after this iteration where it is NOT updated in place (fan groups)
 struct AdiRun {
     Ctx* ctx = nullptr;
@@ -1410,7 +1407,8 @@ struct AdiRun {
     bool check_now = false;           // a lazily checked factor turned out to have replaced pivots: from now on every new factor is checked at once
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
-    std::vector<BufP> fan_keep;       // work panels of the fan groups of the current chunk (written on helper streams)
+    bool fan_off = false;             // the batched fan form does not apply to this solve's factors (sparse.hip, mf_solve_batch): one iteration at a time
+    bool fan_smw_all = false;         // the SMW products of every cached shift of the cycle were formed with the first group's
     void check_used() {
         for (auto& f : used_real) {
             if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; if (f->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); } }
@@ -1502,7 +1500,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     AdiState& h0 = run.h0;           // stays alive with the solver object (source of an asynchronous upload)
     std::memset(&h0, 0, sizeof(h0));
     h0.maxiters = opt.maxiters; h0.abstol = abstol; h0.res_norm = norm0; h0.norms[0] = norm0;
-    DRE_HIP(hipMemcpyAsync(st.p, &h0, sizeof(int) * 4 + sizeof(double) * 3, hipMemcpyHostToDevice, ctx->stream));
+    DRE_HIP(hipMemcpyAsync(st.p, &h0, sizeof(AdiState), hipMemcpyHostToDevice, ctx->stream));      // (whole block: the ticket of the fan groups' norm launch starts at 0)
     const int m = op.has_lr ? op.U.cols : 0;
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported (dre_hip.h, DRE_SMW_MAX_RANK)");
     auto& smw_cache = run.smw_cache;
@@ -1548,6 +1546,14 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     // previous solve (+2), so that a whole Lyapunov solve is enqueued before the first host synchronisation
     run.chunk_limit = (!cex && n <= xblocks_max_n() && cache->iters_hint > 0) ? std::max(opt.compression_interval, cache->iters_hint + 2)
                                                                           : opt.compression_interval;
+    // The same on the multifrontal path with a Cyclic list (fan groups): the intermediate compressions are deferred there as long as the factor
+    // fits the factor form (adi_advance), so a whole solve of the previous length is enqueued before the first synchronisation — provided the
+    // uncompressed iterate still fits afterwards with a further compression interval to spare.
+    if (!cex && opt.compression && opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && cache->iters_hint > 0 &&
+        n > ctx->dense_inv_max_n && n >= ctx->compress_factor_min_n && k > 0) {
+        const long room = ((long)n - 64 - X->rank()) / k - 2L * opt.compression_interval - FAN_GMAX;
+        run.chunk_limit = (int)std::max<long>(opt.compression_interval, std::min<long>(cache->iters_hint + 2, room));
+    }
     // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
     // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
     static const bool fast_env = !(std::getenv("DRE_ADI_FAST") && std::atoi(std::getenv("DRE_ADI_FAST")) == 0);
@@ -1811,7 +1817,7 @@ void adi_advance(AdiRun& run, int budget) {
         };
         const bool sharded_now = ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1 && k >= ctx->shard_min_cols;
         const int fan_max = (opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && !sharded_now && cache->enabled && n > ctx->dense_inv_max_n)
-                                ? std::min(ctx->adi_fan, 4) : 0;
+                                ? std::min(ctx->adi_fan, FAN_GMAX) : 0;
         while (iters_host < opt.maxiters) {
             // ---- fan group: the next g real shifts of the cycle at once (independent solves side by side, see k_fan_mix) ----------------
             if (fan_max >= 2) {
@@ -1821,7 +1827,7 @@ void adi_advance(AdiRun& run, int budget) {
                 const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), strict ? chunk_limit - chunk_shifts : fan_max);
                 const auto ups = room >= 2 ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
                 int g = 0;
-                double mus[4];
+                double mus[FAN_GMAX];
                 while (g < (int)ups.size() && g < room && ups[(size_t)g].imag() == 0.0) {
                     bool dup = false;
                     for (int i = 0; i < g; ++i) dup = dup || mus[i] == ups[(size_t)g].real();
@@ -1838,86 +1844,74 @@ void adi_advance(AdiRun& run, int budget) {
                     if (fe->dense) { g = 0; break; }              // the dense-inverse step has its own fused kernels
                     fes.push_back(fe);
                 }
-                if (g >= 2) {
+                if (g >= 2 && !run.fan_off) {
+                    // ---- batched fan group (round 4): the g solves share every launch (sparse.hip, mf_solve_batch: blockIdx.z = shift) instead of
+                    // running side by side on g streams — ~15 launches per GROUP where the stream form needed 13 per solve + 4 -----------------
                     const AdiState* dst = st.p;
-                    static const bool fan_timing = std::getenv("DRE_FAN_TIMING") != nullptr;
-                    const auto h_t0 = std::chrono::steady_clock::now();
-                    hipEvent_t ft0 = nullptr, ft1 = nullptr;
-                    if (fan_timing) { (void)hipEventCreate(&ft0); (void)hipEventCreate(&ft1); (void)hipEventRecord(ft0, ctx->stream); }
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
-                    const auto hp0 = std::chrono::steady_clock::now();
-                    ensure_helpers(ctx, g - 1);
-                    Mat Wcat(ctx, n, g * k), Vcat(ctx, n, g * k), EWcat(ctx, n, g * k), Rcat(ctx, n, g * k);
-                    // host-side bookkeeping (SMW cache, buffers from the main pool) first; a job only enqueues on its stream
-                    std::vector<std::function<void()>> jobs;
-                    for (int s_ = 0; s_ < g; ++s_) {
-                        Ctx* c = s_ < g - 1 ? ctx->helpers[(size_t)s_].get() : ctx;
-                        const auto fe = fes[(size_t)s_];
-                        const double mur = mus[s_];
-                        Mat Vout = Wcat.colsview(s_ * k, k);
-                        Mat EWout = EWcat.colsview(s_ * k, k);
-                        const Mat Rin = R;
-                        hipEvent_t e0 = ctx->helper_e0, ev = c != ctx ? ctx->helper_ev[(size_t)s_] : nullptr;
-                        Ctx* const mainc = ctx;
-                        used_real.push_back(fe);
-                        if (!op.has_lr) {
-                            jobs.push_back([=, &P]() {
-                                if (c != mainc) DRE_HIP(hipStreamWaitEvent(c->stream, e0, 0));
-                                mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Vout.p, Vout.ld, k, dst);
-                                { Mat Vo = Vout, Eo = EWout; spmm(c, P, P.valEt.p, Vo, Eo, 1.0, 0.0, dst); }
-                                if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
-                            });
-                            continue;
-                        }
-                        auto key = std::make_pair(mur, 0.0);
-                        auto sc = smw_cache.find(key);
-                        const bool have = sc != smw_cache.end();
-                        const int ncols = k + (have ? 0 : m);
-                        Mat W(ctx, n, ncols);
-                        if (!have) {
-                            SmwCacheEntry en;
-                            en.keep = W.buf; en.WU = W.p + (size_t)k * W.ld; en.ldwu = W.ld;
-                            en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
-                            sc = smw_cache.emplace(key, en).first;
-                        }
-                        const double* WU = (const double*)sc->second.WU; const int ldwu = sc->second.ldwu;
-                        double* sinv = (double*)sc->second.sinv->p;
-                        run.fan_keep.push_back(W.buf);
-                        const GaleOperator* opp = &op;
-                        int* const serr_ = serr;
-                        jobs.push_back([=, &P]() {
-                            if (c != mainc) DRE_HIP(hipStreamWaitEvent(c->stream, e0, 0));
-                            Mat Wl = W;
-                            if (!have) { Mat d = Wl.colsview(k, m); copy_mat(c, opp->Vt, d, 1.0, dst); }
-                            mf_solve_from(c, P, fe->f, Rin.p, Rin.ld, k, Wl.p, Wl.ld, ncols, dst);
-                            Mat sm(c, m, ncols);
-                            gemm(c, true, false, 1.0, opp->U, Wl, 0.0, sm, dst, "smw_small");
-                            if (!have)
-                                hipLaunchKernelGGL((k_sinv<double>), dim3(1), dim3(64), 0, c->stream, m, sm.p + (size_t)k * sm.ld, sm.ld, opp->alpha, sinv, dst, serr_);
-                            {
-                                TimedScope ts(c, "smw_apply", 8.0 * n * (2.0 * k + m), 2.0 * n * k * m);
-                                hipLaunchKernelGGL((k_smw_apply<double, true>), dim3(ceil_div(n, 256), ceil_div(k, SMW_CB)), dim3(256), 0, c->stream,
-                                                   n, m, k, (const double*)Wl.p, Wl.ld, WU, ldwu, (const double*)sinv, (const double*)sm.p, sm.ld, Vout.p, Vout.ld,
-                                                   (double*)nullptr, 0, 0.0, dst);
+                    const Factor<double>* Fs[MF_ZMAX];
+                    for (int s_ = 0; s_ < g; ++s_) Fs[s_] = &fes[(size_t)s_]->f;
+                    bool ok = true;
+                    SmwZ sz; std::memset(&sz, 0, sizeof(sz));
+                    if (op.has_lr) {
+                        // SMW products of the group's shifts that this solve has not formed yet: W_U = M_s^-1 Vt for all of them in one batched
+                        // solve, the capacitance matrices inverted in one launch (smw.jl:19-28); at the first group of a solve every other shift of
+                        // the cycle whose factor exists rides along, so that a time step pays this chain once
+                        std::vector<std::pair<double, std::shared_ptr<FactorEntry<double>>>> need;
+                        for (int s_ = 0; s_ < g; ++s_) if (!smw_cache.count({mus[s_], 0.0})) need.push_back({mus[s_], fes[(size_t)s_]});
+                        if (!need.empty() && !run.fan_smw_all) {
+                            run.fan_smw_all = true;
+                            for (auto& mv : opt.shifts.values) {
+                                if (mv.imag() != 0.0 || (int)need.size() >= MF_ZMAX) continue;
+                                bool dup = smw_cache.count({mv.real(), 0.0}) > 0;
+                                for (auto& nd : need) dup = dup || nd.first == mv.real();
+                                if (dup) continue;
+                                auto itf = cache->real.find(std::make_tuple(op.tag, mv.real(), 0.0));
+                                if (itf == cache->real.end() || itf->second->dense || run.prefetch_ev.count({mv.real(), 0.0})) continue;
+                                need.push_back({mv.real(), itf->second});
                             }
-                            { Mat Vo = Vout, Eo = EWout; spmm(c, P, P.valEt.p, Vo, Eo, 1.0, 0.0, dst); }       // E' W_s on the solve's own stream (all g side by side)
-                            if (c != mainc) DRE_HIP(hipEventRecord(ev, c->stream));
-                        });
+                        }
+                        if (!need.empty()) {
+                            const int np = (int)need.size();
+                            const Factor<double>* Fp[MF_ZMAX];
+                            for (int z = 0; z < np; ++z) Fp[z] = &need[(size_t)z].second->f;
+                            Mat WUcat(ctx, n, np * m);
+                            ok = mf_solve_batch(ctx, P, Fp, np, op.Vt.p, op.Vt.ld, m, WUcat.p, WUcat.ld, m, dst);
+                            if (ok) {
+                                Mat smu(ctx, m, np * m);
+                                gemm(ctx, true, false, 1.0, op.U, WUcat, 0.0, smu, dst, "smw_small");
+                                SinvZ iz; std::memset(&iz, 0, sizeof(iz));
+                                for (int z = 0; z < np; ++z) {
+                                    SmwCacheEntry en;
+                                    en.keep = WUcat.buf; en.WU = WUcat.p + (size_t)z * m * WUcat.ld; en.ldwu = WUcat.ld;
+                                    en.sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                                    iz.out[z] = (double*)en.sinv->p;
+                                    smw_cache.emplace(std::make_pair(need[(size_t)z].first, 0.0), en);
+                                    used_real.push_back(need[(size_t)z].second);
+                                }
+                                hipLaunchKernelGGL(k_sinv_z, dim3(np), dim3(64), 0, ctx->stream, m, (const double*)smu.p, smu.ld, op.alpha, iz, dst, serr);
+                            }
+                        }
+                        for (int s_ = 0; s_ < g && ok; ++s_) {
+                            const auto& en = smw_cache.find({mus[s_], 0.0})->second;
+                            sz.WU[s_] = (const double*)en.WU; sz.ldwu[s_] = en.ldwu; sz.Sinv[s_] = (const double*)en.sinv->p;
+                        }
                     }
-                    DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));              // R_0 (and everything before it) is ready here
-                    // (Feeding every helper stream from a host thread of its own was tried: host enqueue 97 -> 83 us per iteration at g = 4, wall-clock
-                    // unchanged — the device is the bound: the sweep kernels take a whole CU's LDS per workgroup, so two solves interleave kernel by
-                    // kernel rather than overlap; only their latency-bound small kernels run side by side.)
-                    const auto hp1 = std::chrono::steady_clock::now();
-                    for (auto& jb : jobs) jb();
-                    const auto hp2 = std::chrono::steady_clock::now();
-                    for (int s_ = 0; s_ < g - 1; ++s_) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->helper_ev[(size_t)s_], 0));
-                    {
-                        TimedScope ts(ctx, "fan_mix", 8.0 * n * k * (4.0 * g + 1.0), 2.0 * n * k * (double)g * (g + 1));
-                        const size_t tot = (size_t)n * k;
-                        hipLaunchKernelGGL(k_fan_mix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, g, (const double*)Wcat.p, Wcat.ld,
-                                           (const double*)EWcat.p, EWcat.ld, (const double*)R.p, R.ld, Vcat.p, Vcat.ld, Rcat.p, Rcat.ld, co, dst);
+                    Mat Wcat(ctx, n, g * k);
+                    if (ok) ok = mf_solve_batch(ctx, P, Fs, g, R.p, R.ld, k, Wcat.p, Wcat.ld, k, dst);
+                    if (!ok) { run.fan_off = true; continue; }        // (nothing was enqueued: this solve goes on one iteration at a time)
+                    for (int s_ = 0; s_ < g; ++s_) used_real.push_back(fes[(size_t)s_]);
+                    if (op.has_lr) {
+                        // W_s <- W_s - W_U,s (S_s^-1 (U' W_s))  for the g solves: one product U' [W_1 .. W_g], one apply launch (in place)
+                        Mat sm(ctx, m, g * k);
+                        gemm(ctx, true, false, 1.0, op.U, Wcat, 0.0, sm, dst, "smw_small");
+                        TimedScope ts(ctx, "smw_apply", 8.0 * n * g * (2.0 * k + m), 2.0 * n * g * (double)k * m, g);
+                        hipLaunchKernelGGL(k_smw_apply_z, dim3(ceil_div(n, 256), ceil_div(k, SMW_CB), g), dim3(256), 0, ctx->stream, n, m, k, Wcat.p, Wcat.ld, sz,
+                                           (const double*)sm.p, sm.ld, dst);
                     }
+                    // V_j = sum_s c_js W_s,  R_j = R_0 - sum_s d_js E' W_s  for the g iterations: one pass over E' and the panels
+                    Mat Vcat(ctx, n, g * k), Rcat(ctx, n, g * k);
+                    fan_spmm_mix(ctx, P, Wcat, R, Vcat, Rcat, g, k, co, dst);
                     for (int j = 0; j < g; ++j) {
                         const std::complex<double> muj = oracle->take(&res.warnings);
                         all_shifts.push_back(muj);
@@ -1928,25 +1922,8 @@ void adi_advance(AdiRun& run, int budget) {
                         recs.push_back({iters_host, Xw->blocks.size(), 1, Rj});
                         ++since_sync; ++chunk_shifts;
                     }
-                    residual_norm_group(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
+                    residual_norm_group_diag(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
-                    run.fan_keep.push_back(Wcat.buf); run.fan_keep.push_back(EWcat.buf);
-                    if (chunk_timing) {
-                        static double tp = 0, tj = 0, tt = 0; static long ng = 0;
-                        const auto hp3 = std::chrono::steady_clock::now();
-                        tp += std::chrono::duration<double, std::micro>(hp1 - hp0).count(); tj += std::chrono::duration<double, std::micro>(hp2 - hp1).count();
-                        tt += std::chrono::duration<double, std::micro>(hp3 - hp2).count();
-                        if (++ng % 256 == 0) std::fprintf(stderr, "[fan host] per group: prep %.1f us, solve jobs %.1f us, tail %.1f us\n", tp / ng, tj / ng, tt / ng);
-                    }
-                    if (fan_timing) {
-                        (void)hipEventRecord(ft1, ctx->stream);
-                        const double host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h_t0).count();
-                        (void)hipEventSynchronize(ft1);
-                        float ms = 0; (void)hipEventElapsedTime(&ms, ft0, ft1);
-                        static int cnt = 0;
-                        if (++cnt % 16 == 8) std::fprintf(stderr, "[fan timing] g=%d  host enqueue %.1f us  device %.1f us\n", g, host_us, ms * 1e3);
-                        (void)hipEventDestroy(ft0); (void)hipEventDestroy(ft1);
-                    }
                     if (opt.compression && chunk_shifts >= chunk_limit) break;
                     if (!opt.compression && since_sync >= std::min(10, chunk_limit)) break;
                     continue;
@@ -2189,7 +2166,6 @@ void adi_advance(AdiRun& run, int budget) {
         size_t nblocks = blocks_before;
         int lc = lc_before;
         R = R_chunk_start;
-        run.fan_keep.clear();
         for (auto& r : recs) {
             if (r.iters_after <= h.iters) {
                 nblocks = r.nblocks; lc += r.nshifts;
@@ -2213,7 +2189,7 @@ void adi_advance(AdiRun& run, int budget) {
             // (panel steps ~ rank, GEMM traffic ~ columns: one late compression costs the GEMMs of two early ones and half the
             // panels) while the factor still fits the factor-form limit c + 64 <= n after the next chunk.
             static const bool defer_on = !(std::getenv("DRE_DEFER_COMPRESS") && std::atoi(std::getenv("DRE_DEFER_COMPRESS")) == 0);
-            const long rk = Xw->rank(), next = (long)opt.compression_interval * 2 * k;
+            const long rk = Xw->rank(), next = (long)std::max(opt.compression_interval * 2, run.chunk_limit + FAN_GMAX) * k;
             const bool defer = !cex && (n <= 512 ? rk <= 16L * n
                                        : defer_on && ((n <= ctx->compress_direct_max_n && rk <= 16L * n) ||
                                                       (n >= ctx->compress_factor_min_n && rk + next + 64 <= n)));

@@ -200,6 +200,77 @@ void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, co
                        X.p, X.ld, Y.p, Y.ld, X.cols, alpha, beta, st, Yt ? Yt->p : (double*)nullptr, Yt ? Yt->ld : 0);
     DRE_HIP(hipGetLastError());
 }
+// Fan groups (engine.hip): W = [W_1 .. W_g] (n x g k) are g independent solves with the same right-hand side R_0; the g ADI iterates they stand for are
+//   V_j = sum_{s<=j} c_js W_s,   R_j = R_0 - sum_{s<=j} d_js (E' W_s)      (adi.jl:158-171 re-associated through the resolvent identity)
+// — the product with E' and the mixing in ONE pass: a thread owns a row and FAN_CB columns of all g blocks, gathers the neighbour rows of the g
+// panels (CSR segment of the workgroup's 256 rows staged in LDS as in k_spmm_lds) and writes the 2 g outputs.  Replaces SpMM + k_fan_mix (two
+// launches, E' W written and read back).
+#define FAN_CB 2
+template <int G>
+__global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restrict__ ptr, const int* __restrict__ idx, const double* __restrict__ val, int k,
+                                                      const double* __restrict__ W, int ldw, const double* __restrict__ R0, int ldr,
+                                                      double* __restrict__ V, int ldv, double* __restrict__ Rc, int ldrc, FanCoef co, const AdiState* st) {
+    if (st && st->done) return;
+    __shared__ double vs[SPMM_LDS_NNZ];
+    __shared__ int is[SPMM_LDS_NNZ];
+    const int r0 = blockIdx.x * 256, r1 = min(n, r0 + 256);
+    const int p0 = ptr[r0], p1 = ptr[r1];
+    const bool staged = (p1 - p0) <= SPMM_LDS_NNZ;
+    if (staged)
+        for (int p = p0 + threadIdx.x; p < p1; p += 256) { vs[p - p0] = val[p]; is[p - p0] = idx[p]; }
+    __syncthreads();
+    const int i = r0 + threadIdx.x;
+    if (i >= n) return;
+    const int c0 = blockIdx.y * FAN_CB;
+    int col[FAN_CB];
+#pragma unroll
+    for (int c = 0; c < FAN_CB; ++c) col[c] = min(c0 + c, k - 1);        // (clamped: a ragged last block recomputes the last column and does not store it)
+    double ew[FAN_CB][G], w[FAN_CB][G], r[FAN_CB];
+#pragma unroll
+    for (int c = 0; c < FAN_CB; ++c) {
+        r[c] = R0[i + (size_t)col[c] * ldr];
+#pragma unroll
+        for (int s = 0; s < G; ++s) { ew[c][s] = 0.0; w[c][s] = W[i + (size_t)(s * k + col[c]) * ldw]; }
+    }
+    const int pb = ptr[i], pe = ptr[i + 1];
+    for (int p = pb; p < pe; ++p) {
+        const double v = staged ? vs[p - p0] : val[p];
+        const double* __restrict__ x = W + (staged ? is[p - p0] : idx[p]);
+        double t[FAN_CB][G];
+#pragma unroll
+        for (int c = 0; c < FAN_CB; ++c)
+#pragma unroll
+            for (int s = 0; s < G; ++s) t[c][s] = x[(size_t)(s * k + col[c]) * ldw];
+#pragma unroll
+        for (int c = 0; c < FAN_CB; ++c)
+#pragma unroll
+            for (int s = 0; s < G; ++s) ew[c][s] += v * t[c][s];
+    }
+#pragma unroll
+    for (int c = 0; c < FAN_CB; ++c) {
+        if (c0 + c >= k) break;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            double vv = 0.0, y = 0.0;
+#pragma unroll
+            for (int s = 0; s <= j; ++s) { vv += co.c[j][s] * w[c][s]; y += co.d[j][s] * ew[c][s]; }
+            V[i + (size_t)(j * k + c0 + c) * ldv] = vv;
+            Rc[i + (size_t)(j * k + c0 + c) * ldrc] = r[c] - y;
+        }
+    }
+}
+void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const AdiState* st) {
+    const int n = P.n;
+    DRE_REQUIRE(g >= 2 && g <= FAN_GMAX && W.rows == n && W.cols == g * k && V.cols == g * k && Rc.cols == g * k && R0.cols == k, "fan_spmm_mix: shapes");
+    TimedScope ts(ctx, "fan_spmm_mix", 12.0 * P.nnz + 4.0 * n + 8.0 * n * k * (3.0 * g + 1.0), 2.0 * (double)P.nnz * g * k + 2.0 * n * k * (double)g * (g + 1));
+    const dim3 grid(ceil_div(n, 256), ceil_div(k, FAN_CB)), block(256);
+#define DRE_FAN_CASE(G_) case G_: hipLaunchKernelGGL((k_fan_spmm_mix<G_>), grid, block, 0, ctx->stream, n, (const int*)P.ptr.p, (const int*)P.idx.p, (const double*)P.valEt.p, k, \
+                                                    (const double*)W.p, W.ld, (const double*)R0.p, R0.ld, V.p, V.ld, Rc.p, Rc.ld, co, st); break;
+    switch (g) { DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) }
+#undef DRE_FAN_CASE
+    DRE_HIP(hipGetLastError());
+}
+
 // Two operators on the SAME pattern applied to the same panel in one pass (the pencil keeps E' and A' on one union pattern):
 // Y1 = M1 X, Y2 = M2 X.  128 rows x 4 columns per workgroup: the panel rows are gathered once for both products, and the finer
 // decomposition fills the chip at small n (n = 371, 371 columns: 279 workgroups instead of 2 x 94).
@@ -312,6 +383,10 @@ struct MfArgs {
     const int *first, *size, *bptr, *bidx, *cmap_ptr, *cmap, *child_ptr, *child_idx, *lvl_nodes;
     const int64_t *front_off, *inv_off, *upd_off;
 };
+// Batched sweeps (round 4): blockIdx.z selects one of up to MF_ZMAX factorisations of the SAME pencil (same elimination tree, different shift)
+// with its own block of the work panel (z * wz doubles further) and of the update slab (z * uz) — the g independent solves of a fan group
+// (engine.hip) share every launch instead of running side by side on g streams.
+struct MfZ { const double* fronts[MF_ZMAX]; const double* inv[MF_ZMAX]; long wz, uz; };
 
 // One workgroup per front of the level: extend-add the children's Schur complements, eliminate the
 // s pivot columns (right-looking, no pivoting), then invert the two triangular diagonal blocks.
@@ -812,11 +887,14 @@ __device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restr
 // Win / ldwin / nin: the first nin right-hand-side columns are READ from Win (the caller's residual block) instead of W, so that the
 // caller does not have to copy them into the work panel first; everything is written to W (every row of the panel belongs to exactly one
 // front or to the dense top, so the sweeps write all of it).
-__global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+__global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begin, MfZ zb,
                                                           double* __restrict__ W, int ldw, int nrhs, double* __restrict__ upd, int64_t ldu,
                                                           const AdiState* st, const double* __restrict__ Win, int ldwin, int nin) {
     if (st && st->done) return;
     extern __shared__ double sm[];
+    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
+    const double* __restrict__ inv = zb.inv[blockIdx.z];
+    W += (size_t)blockIdx.z * zb.wz; upd += (size_t)blockIdx.z * zb.uz;
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
     const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
@@ -896,10 +974,13 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
     }
 }
 
-__global__ __launch_bounds__(1024) void k_mf_backward_tp(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+__global__ __launch_bounds__(1024) void k_mf_backward_tp(MfArgs a, int lvl_begin, MfZ zb,
                                                            double* __restrict__ W, int ldw, int nrhs, const AdiState* st) {
     if (st && st->done) return;
     extern __shared__ double sm[];
+    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
+    const double* __restrict__ inv = zb.inv[blockIdx.z];
+    W += (size_t)blockIdx.z * zb.wz;
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
     const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
@@ -1005,10 +1086,13 @@ __device__ __forceinline__ mf_v4d rt_tile(mf_v4d acc, const RtSrc& s, int r0, in
 // Backward: the long product is z = w_S - U12 x_B (K = b, the boundary: up to several hundred near the top of the tree) on only
 // ceil(s / 16) row tiles, so the waves of a workgroup SPLIT K: G = nw / tiles waves per tile, each over a 32-aligned share of the
 // boundary, partial tiles summed in a fixed order through LDS (`part`, nw x 256 doubles behind z).
-__global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, const double* __restrict__ fronts, const double* __restrict__ inv,
+__global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, MfZ zb,
                                                            double* __restrict__ W, int ldw, int nrhs, const AdiState* st, int split) {
     if (st && st->done) return;
     extern __shared__ double sm[];
+    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
+    const double* __restrict__ inv = zb.inv[blockIdx.z];
+    W += (size_t)blockIdx.z * zb.wz;
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
     const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
@@ -1563,8 +1647,9 @@ __global__ void k_copy_cols(int n, const double* __restrict__ src, int lds_, dou
 // g[p, c] = W[topidx[p], c] + sum of the update rows that the level-T nodes send to top variable p
 __global__ void k_top_gather(int ntop, int nrhs, const int* __restrict__ topidx, const int* __restrict__ gptr, const int64_t* __restrict__ gsrc,
                              const double* __restrict__ W, int ldw, const double* __restrict__ upd, int64_t ldu, double* __restrict__ g, int ldg,
-                             const AdiState* st, const double* __restrict__ Win, int ldwin, int nin) {
+                             const AdiState* st, const double* __restrict__ Win, int ldwin, int nin, long wz, long uz, long gz) {
     if (st && st->done) return;
+    W += (size_t)blockIdx.y * wz; upd += (size_t)blockIdx.y * uz; g += (size_t)blockIdx.y * gz;      // (batched solves: blockIdx.y = factor)
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)ntop * nrhs) return;
     const int p = idx % ntop; const size_t c = idx / ntop;
@@ -1647,7 +1732,12 @@ static long mf_latency_max_wg(bool) {
     return b;
 }
 struct MfIn { const double* p = nullptr; int ld = 0, n = 0; };       // leading right-hand-side columns that live outside the work panel
-static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, double* W, int ldw, int nrhs, double* upd, int64_t ldu,
+static MfZ mf_single(const Factor<double>& Fc) {
+    MfZ zb; std::memset(&zb, 0, sizeof(zb));
+    zb.fronts[0] = Fc.fronts.p; zb.inv[0] = Fc.inv.p;
+    return zb;
+}
+static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, double* W, int ldw, int nrhs, double* upd, int64_t ldu,
                             const AdiState* st, bool forward, int l_from, int l_to, MfIn in = MfIn()) {
     // forward: levels l_from down to l_to (l_from >= l_to);  backward: levels l_from up to l_to
     const Symbolic& S = P.sym;
@@ -1664,17 +1754,17 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc,
             // (n = 20209: 32.9 -> 31.5 ms of sweeps per 4 steps against 512 threads, 34.2 ms with 1024)
             static const int tp_threads = std::getenv("DRE_MF_FWD_TP_THREADS") ? std::atoi(std::getenv("DRE_MF_FWD_TP_THREADS")) : 256;
             int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
-            if (tp_threads > 0 && (long)nb * ncb > 2000) nthreads = tp_threads;
-            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n);
+            if (tp_threads > 0 && (long)nb * ncb * nz > 2000) nthreads = tp_threads;
+            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n);
         }
     } else {
         for (int l = l_from; l <= l_to; ++l) {
             const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
             const int fm = P.lvl_maxfront[l], sm_ = P.lvl_maxsep[l], spm = (sm_ + 15) & ~15;
-            if ((long)nb * ncb > mf_latency_max_wg(false)) {
+            if ((long)nb * ncb * nz > mf_latency_max_wg(false)) {
                 const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
                 const int nthreads = sm_ > 64 ? 512 : 256;
-                hipLaunchKernelGGL(k_mf_backward_tp, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st);
+                hipLaunchKernelGGL(k_mf_backward_tp, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st);
                 continue;
             }
             // waves: one per 16-row tile of the separator times up to four shares of the boundary (K-split of z = w_S - U12 x_B)
@@ -1684,7 +1774,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const Factor<double>& Fc,
             const size_t base = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double), parts = (size_t)nwv * 256 * sizeof(double);
             const int split = base + parts <= (size_t)150 * 1024;
             const size_t shm = base + (split ? parts : 0);
-            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], Fc.fronts.p, Fc.inv.p, W, ldw, nrhs, st, split);
+            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st, split);
         }
     }
 }
@@ -1704,8 +1794,8 @@ static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc)
         DRE_HIP(hipMemsetAsync(Wk.p, 0, (size_t)n * ch * sizeof(double), ctx->stream));
         DRE_HIP(hipMemsetAsync(upd.p, 0, (size_t)ldu * ch * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_top_unit_rows, dim3(ceil_div(ch, 256)), dim3(256), 0, ctx->stream, ch, c0, (const int*)tp.topidx.p, Wk.p, Wk.ld);
-        mf_sweep_levels(ctx, P, Fc, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, true, T - 1, 0);
-        mf_sweep_levels(ctx, P, Fc, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, false, 0, T - 1);
+        mf_sweep_levels(ctx, P, mf_single(Fc), 1, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, true, T - 1, 0);
+        mf_sweep_levels(ctx, P, mf_single(Fc), 1, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, false, 0, T - 1);
         const size_t tot = (size_t)ntop * ch;
         hipLaunchKernelGGL(k_top_collect, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, ch, c0, (const int*)tp.topidx.p,
                            (const double*)Wk.p, Wk.ld, Ti.p, Ti.ld);
@@ -1739,14 +1829,14 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     auto forward_to = [&](int l_to) {        // levels nlevels-1 .. l_to
         if (Tsub >= 0 && Tsub >= l_to) {
             mf_sub_sweep(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true);
-            if (Tsub - 1 >= l_to) mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, Tsub - 1, l_to);
-        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, l_to, in);
+            if (Tsub - 1 >= l_to) mf_sweep_levels(ctx, P, mf_single(Fc), 1, W, ldw, nrhs, upd.p, ldu, st, true, Tsub - 1, l_to);
+        } else mf_sweep_levels(ctx, P, mf_single(Fc), 1, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, l_to, in);
     };
     auto backward_from = [&](int l_from) {   // levels l_from .. nlevels-1
         if (Tsub >= 0 && Tsub >= l_from) {
-            if (Tsub - 1 >= l_from) mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, l_from, Tsub - 1);
+            if (Tsub - 1 >= l_from) mf_sweep_levels(ctx, P, mf_single(Fc), 1, W, ldw, nrhs, upd.p, ldu, st, false, l_from, Tsub - 1);
             mf_sub_sweep(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false);
-        } else mf_sweep_levels(ctx, P, Fc, W, ldw, nrhs, upd.p, ldu, st, false, l_from, S.nlevels - 1);
+        } else mf_sweep_levels(ctx, P, mf_single(Fc), 1, W, ldw, nrhs, upd.p, ldu, st, false, l_from, S.nlevels - 1);
     };
     if (Fc.topinv.empty()) {
         TimedScope ts(ctx, "mf_solve_real", bytes, flops);
@@ -1761,7 +1851,7 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             TimedScope ts(ctx, "mf_solve_real", bytes, flops);
             forward_to(T);
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
-                               (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n);
+                               (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n, 0L, 0L, 0L);
         }
         // DRE_TOP_FUSED=4|8|16: one K-split tile kernel (k_top_apply, that many waves) instead of split-K GEMM + slab reduction + scatter.  Measured
         // (round 3, tools/ab_general.sh): 22-24 us per launch whatever the wave count against 17.5 + 3.8 us at n = 5177 — the same wall-clock.  The
@@ -1814,6 +1904,67 @@ void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, const do
     }
     if (nin > 0) hipLaunchKernelGGL(k_copy_cols, dim3(ceil_div(P.n, 256), nin), dim3(256), 0, ctx->stream, P.n, Win, ldwin, W, ldw, st);
     mf_solve<double>(ctx, P, Fc, W, ldw, nrhs, st);
+}
+// g solves with DIFFERENT factors of the same pencil and the same leading right-hand sides, in shared launches (blockIdx.z = factor):
+//   W_z = F_z^-1 [Win(:, 0:nin) | W_z(:, nin:nrhs)],   W_z = columns z nrhs .. (z + 1) nrhs of the n x (g nrhs) panel W.
+// The sweeps are latency bound (a level launch keeps a fraction of the chip busy for ~9 us): g of them per launch cost about the same as one.
+// Returns false — nothing enqueued — where the batch form does not apply (scalar sweeps, statically pivoted factors, subtree plan).
+bool mf_solve_batch(Ctx* ctx, const Pencil& P, const Factor<double>* const* Fs, int g, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs,
+                    const AdiState* st) {
+    if (g < 1 || g > MF_ZMAX || nrhs <= 0 || !P.use_mfma_sweeps) return false;
+    for (int z = 0; z < g; ++z) if (Fs[z]->nperturbed > 0) return false;
+    const Symbolic& S = P.sym;
+    if (!P.sub.built) {
+        if (!P.top.built && ctx->top_inverse_max_rows > 0) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
+        sub_plan_build(ctx, P, P.top.T);
+    }
+    if (P.sub.Tsub >= 0) return false;
+    // the dense top: all factors with it or none (a reusable factor that lacks it gets it now, on this stream)
+    bool all_allowed = ctx->top_inverse_max_rows > 0 && P.top.built && P.top.T >= 2 && nrhs >= 8;
+    int have = 0;
+    for (int z = 0; z < g; ++z) { all_allowed = all_allowed && Fs[z]->allow_topinv; have += Fs[z]->topinv.empty() ? 0 : 1; }
+    if (have != g) {
+        if (all_allowed) { for (int z = 0; z < g; ++z) if (Fs[z]->topinv.empty()) { mf_build_topinv(ctx, P, *Fs[z]); Fs[z]->uses = 3; } have = g; }
+        else if (have != 0) return false;
+    }
+    const bool top = have == g;
+    MfIn in; in.p = Win; in.ld = ldwin; in.n = nin;
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    MfZ zb; std::memset(&zb, 0, sizeof(zb));
+    for (int z = 0; z < g; ++z) { zb.fronts[z] = Fs[z]->fronts.p; zb.inv[z] = Fs[z]->inv.p; }
+    zb.wz = (long)nrhs * ldw; zb.uz = (long)ldu * nrhs;
+    DevArr<double> upd(ctx, (size_t)ldu * nrhs * g);
+    const double bytes = g * (2.0 * 8.0 * (double)S.factor_nnz + 4.0 * 8.0 * (double)P.n * nrhs);
+    const double flops = g * (2.0 * 2.0 * (double)S.factor_nnz * nrhs);
+    if (!top) {
+        TimedScope ts(ctx, "mf_solve_real", bytes, flops, g);
+        mf_sweep_levels(ctx, P, zb, g, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, 0, in);
+        mf_sweep_levels(ctx, P, zb, g, W, ldw, nrhs, upd.p, ldu, st, false, 0, S.nlevels - 1);
+        DRE_HIP(hipGetLastError());
+        return true;
+    }
+    const TopPlan& tp = P.top;
+    const int ntop = tp.ntop, T = tp.T;
+    Mat gb(ctx, ntop, nrhs * g);
+    const size_t tot = (size_t)ntop * nrhs;
+    {
+        TimedScope ts(ctx, "mf_solve_real", bytes, flops, g);
+        mf_sweep_levels(ctx, P, zb, g, W, ldw, nrhs, upd.p, ldu, st, true, S.nlevels - 1, T, in);
+        hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256), g), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
+                           (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, gb.p, gb.ld, st, in.p, in.ld, in.n,
+                           zb.wz, zb.uz, (long)ntop * nrhs);
+    }
+    GemmZ gz; std::memset(&gz, 0, sizeof(gz));
+    for (int z = 0; z < g; ++z) { gz.A[z] = Fs[z]->topinv.p; gz.B[z] = gb.p + (size_t)z * ntop * nrhs; DRE_REQUIRE(Fs[z]->topinv.ld == Fs[0]->topinv.ld, "mf_solve_batch: top inverses of different shape"); }
+    int zs = 1;
+    BufP xpart = gemm_partials_z(ctx, false, false, ntop, nrhs, ntop, gz, g, Fs[0]->topinv.ld, gb.ld, &zs, st, "gemm_mf_top");
+    {
+        TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0, 0);
+        gemm_reduce_z(ctx, ntop, nrhs, zs, g, (const double*)xpart->p, (const int*)tp.topidx.p, W, ldw, zb.wz, st);
+        mf_sweep_levels(ctx, P, zb, g, W, ldw, nrhs, upd.p, ldu, st, false, T, S.nlevels - 1);
+    }
+    DRE_HIP(hipGetLastError());
+    return true;
 }
 template <typename T>
 static void mf_solve_once(Ctx* ctx, const Pencil& P, const Factor<T>& Fc, T* W, int ldw, int nrhs, const AdiState* st);

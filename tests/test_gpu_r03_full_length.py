@@ -186,9 +186,9 @@ def test_group_adi_chain_is_equivalent_to_one_launch_per_iteration(ctx, rail371,
 @pytest.mark.parametrize("save_state", [False, True])
 def test_fan_groups_give_the_sequential_iterates(ctx, rail371, save_state):
     """General path (multifrontal solves), Cyclic real shifts: up to `adi_fan` consecutive ADI iterations from independent solves with the same
-    right-hand side, combined by partial fractions of the shifted resolvents (engine.hip, k_fan_mix).  Same iterates as the sequential
-    recurrence of adi.jl:158-171 up to the amplified rounding: identical iteration counts, K(t) to 1e-9, for group sizes 2, 3 and 4 and with
-    the coefficient bound forcing cuts."""
+    right-hand side that share every launch (sparse.hip, mf_solve_batch), combined by partial fractions of the shifted resolvents in the pass
+    over E' (k_fan_spmm_mix).  Same iterates as the sequential recurrence of adi.jl:158-171 up to the amplified rounding: identical iteration
+    counts, K(t) to 1e-9, for group sizes 2 .. 8 and with the coefficient bound forcing cuts."""
     d, L, Dm = rail371
     prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 3900.0))
     alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(371))))
@@ -196,13 +196,13 @@ def test_fan_groups_give_the_sequential_iterates(ctx, rail371, save_state):
     try:
         ctx.set_option("dense_inverse_max_n", 0)            # multifrontal sweeps at this size too (the dense-inverse chain has its own kernels)
         ctx.set_option("dense_x_max_n", 0)
-        for g, coef in ((0, 64.0), (2, 64.0), (3, 64.0), (4, 64.0), (4, 3.0)):
+        for g, coef in ((0, 64.0), (2, 64.0), (3, 64.0), (4, 64.0), (4, 3.0), (5, 64.0), (8, 1e3)):
             ctx.set_option("adi_fan", g); ctx.set_option("adi_fan_max_coef", coef)
             sol, st = _quiet(D.solve_gdre, prob, alg, dt=-100.0, save_state=save_state, return_stats=True)
             runs[(g, coef)] = (sol, [x["iters"] for x in st["gales"]])
     finally:
         ctx.set_option("dense_inverse_max_n", 1536); ctx.set_option("dense_x_max_n", 1536)
-        ctx.set_option("adi_fan", 3); ctx.set_option("adi_fan_max_coef", 64.0)
+        ctx.set_option("adi_fan", 5); ctx.set_option("adi_fan_max_coef", 64.0)
     ref = runs[(0, 64.0)]
     for key, (sol, its) in runs.items():
         assert its == ref[1], (key, its, ref[1])
