@@ -810,6 +810,13 @@ int dre_comm_init(dre_ctx* ctx, int nranks, int rank, const void* id128) {
         ctx->c.comm->emulate = emu;
     });
 }
+int dre_comm_init_host(dre_ctx* ctx, int nranks, int rank, dre_comm_allgather_fn allgather, dre_comm_allreduce_fn allreduce, void* user) {
+    return guarded(ctx, [&] {
+        const int emu = ctx->c.comm ? ctx->c.comm->emulate : 0;
+        ctx->c.comm = comm_init_host(&ctx->c, nranks, rank, allgather, allreduce, user);
+        ctx->c.comm->emulate = emu;
+    });
+}
 int dre_comm_free(dre_ctx* ctx) {
     return guarded(ctx, [&] { if (ctx->c.comm) { DRE_HIP(hipStreamSynchronize(ctx->c.stream)); ctx->c.comm.reset(); } });
 }

@@ -34,7 +34,8 @@ Rccl& rccl() {
             if (!nm) continue;
             r.h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
-            r.err = dlerror() ? dlerror() : "dlopen failed";
+            const char* e = dlerror();               // (one call: dlerror() clears the message it returns)
+            r.err = e ? e : "dlopen failed";
         }
         if (!r.h) return;
         r.get_id = (fn_get_id)dlsym(r.h, "ncclGetUniqueId");
@@ -59,6 +60,24 @@ void chk(int rc, const char* what) {
 
 Comm::~Comm() {
     if (nccl && rccl().destroy) (void)rccl().destroy(nccl);
+    if (stage) (void)hipHostFree(stage);
+}
+static void* host_stage(Comm& c, size_t bytes) {
+    if (c.stage_bytes < bytes) {
+        if (c.stage) (void)hipHostFree(c.stage);
+        c.stage = nullptr; c.stage_bytes = 0;
+        DRE_HIP(hipHostMalloc(&c.stage, bytes, hipHostMallocDefault));
+        c.stage_bytes = bytes;
+    }
+    return c.stage;
+}
+std::shared_ptr<Comm> comm_init_host(Ctx*, int nranks, int rank, int (*ag)(void*, const void*, void*, size_t), int (*ar)(void*, void*, size_t), void* user) {
+    DRE_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "dre_comm_init_host: rank outside [0, nranks)");
+    DRE_REQUIRE(ag != nullptr && ar != nullptr, "dre_comm_init_host: both callbacks are required");
+    auto c = std::make_shared<Comm>();
+    c->nranks = nranks; c->rank = rank;
+    c->host_allgather = ag; c->host_allreduce = ar; c->host_user = user;
+    return c;
 }
 
 void comm_unique_id(void* out128) {
@@ -85,6 +104,18 @@ std::shared_ptr<Comm> comm_init(Ctx* ctx, int nranks, int rank, const void* id12
 
 void comm_allgather(Ctx* ctx, Comm& c, const double* send, double* recv, size_t count) {
     c.ncalls++;
+    if (c.nranks > 1 && c.host_allgather) {
+        // host transport: own block down, the caller's collective on host memory, everything up — synchronous (tests, RCCL-less hosts)
+        const size_t bytes = count * sizeof(double);
+        char* st = (char*)host_stage(c, bytes * (size_t)c.nranks);
+        DRE_HIP(hipMemcpyAsync(st + bytes * (size_t)c.rank, send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (c.host_allgather(c.host_user, st + bytes * (size_t)c.rank, st, bytes) != 0) throw Error(ERR_INTERNAL, "dre_comm: the host all-gather callback failed");
+        DRE_HIP(hipMemcpyAsync(recv, st, bytes * (size_t)c.nranks, hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        c.bytes_gathered += bytes * (size_t)(c.nranks - 1);
+        return;
+    }
     if (c.nranks == 1 || !c.nccl) {
         if (send != recv + (size_t)c.rank * count && count)
             DRE_HIP(hipMemcpyAsync(recv + (size_t)c.rank * count, send, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -98,6 +129,17 @@ void comm_allgather_inplace(Ctx* ctx, Comm& c, double* buf, size_t count) {
 }
 void comm_allreduce_sum(Ctx* ctx, Comm& c, double* buf, size_t count) {
     c.ncalls++;
+    if (c.nranks > 1 && c.host_allreduce) {
+        const size_t bytes = count * sizeof(double);
+        void* st = host_stage(c, bytes);
+        DRE_HIP(hipMemcpyAsync(st, buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (c.host_allreduce(c.host_user, st, count) != 0) throw Error(ERR_INTERNAL, "dre_comm: the host all-reduce callback failed");
+        DRE_HIP(hipMemcpyAsync(buf, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        c.bytes_reduced += bytes;
+        return;
+    }
     if (c.nranks == 1 || !c.nccl) return;
     c.bytes_reduced += count * sizeof(double);
     chk(rccl().allreduce(buf, buf, count, NCCL_FLOAT64, NCCL_SUM, c.nccl, ctx->stream), "ncclAllReduce");

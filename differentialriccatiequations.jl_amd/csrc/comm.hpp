@@ -15,12 +15,21 @@ struct Comm {
     void* nccl = nullptr;            // ncclComm_t (null for a single rank without RCCL: collectives are local copies)
     int emulate = 0;                 // > 1: ONE process plays this many ranks one after the other (tests of the blocking logic on one GPU)
     size_t bytes_gathered = 0, bytes_reduced = 0, ncalls = 0;
+    // HOST transport (dre_comm_init_host): the collectives are staged through pinned host memory and handed to the caller's callbacks — an MPI /
+    // gloo / anything channel behind the same comm_allgather entry the engine uses.  For hosts without RCCL and for the tests that run the
+    // library's sharded solve on TWO ranks with one GPU (RCCL refuses two ranks on one device).
+    int (*host_allgather)(void* user, const void* send, void* recv, size_t bytes_per_rank) = nullptr;   // recv: nranks blocks; send may point into recv
+    int (*host_allreduce)(void* user, void* buf, size_t count) = nullptr;                               // sum of doubles, in place
+    void* host_user = nullptr;
+    void* stage = nullptr;           // pinned
+    size_t stage_bytes = 0;
     ~Comm();
 };
 
 // 128 bytes (NCCL_UNIQUE_ID_BYTES); rank 0 creates it, the host program hands it to the other ranks (torch.distributed, MPI, a file ...)
 void comm_unique_id(void* out128);
 std::shared_ptr<Comm> comm_init(Ctx* ctx, int nranks, int rank, const void* id128);
+std::shared_ptr<Comm> comm_init_host(Ctx* ctx, int nranks, int rank, int (*ag)(void*, const void*, void*, size_t), int (*ar)(void*, void*, size_t), void* user);
 // in-place all-gather: every rank has written its block `rank` of `buf` (nranks blocks of `count` doubles each)
 void comm_allgather_inplace(Ctx* ctx, Comm& c, double* buf, size_t count);
 void comm_allgather(Ctx* ctx, Comm& c, const double* send, double* recv, size_t count);

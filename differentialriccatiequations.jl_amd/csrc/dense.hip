@@ -827,8 +827,7 @@ __global__ __launch_bounds__(1024) void k_frob2(int rows, int cols, const double
 }
 static double read_scalar(Ctx* ctx, const double* dev) {
     double h;
-    DRE_HIP(hipMemcpyAsync(&h, dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    ctx_fetch(ctx, dev, sizeof(double), &h);        // (signal kernel + spin on pinned memory: a fraction of a copy command + stream synchronisation)
     return h;
 }
 // large operands: partial sums over 64 workgroups, then a fixed-order sum (deterministic)
@@ -4151,6 +4150,9 @@ __global__ void k_fill_gauss(int n, int cols, unsigned long long seed, double* _
 //   * a live pivot at or below 1e-15 x the block's largest diagonal entry in the first pass, or below 1/4 in the second pass (the first
 //     pass lost more orthogonality than the second repairs: cond(Y_b) beyond ~1e7), raises *flag: the caller falls back to Householder panels.
 //   nullmask (optional, b entries): 1 for a null column, so that the caller can put a fresh random direction there (k_fill_gauss_masked).
+// (Round 4 experiment, measured and removed: a REGISTER form — lane = row, wave = 16-column block of A and Y, multipliers published through LDS,
+// row k of Y through v_readlane, one barrier per step — took 107-108 us per 64 x 64 block against 62-65 us for this LDS form, fully unrolled or
+// unrolled by 16: the 32 v_readlane + SGPR-operand FMAs per wave and step cost more than the LDS round trips they replace.)
 __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restrict__ G, int ldg, double* __restrict__ Rinv, int ldr, int* __restrict__ flag,
                                                   double* __restrict__ ref, int mode, int* __restrict__ nullmask, double relfloor, double* __restrict__ dbg) {
     extern __shared__ double chol_lds[];            // 2 x 64 x 65 doubles (dynamic: beyond the 64 KB static limit)
@@ -4452,15 +4454,14 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
     DevArr<LrBlockDev> dblocks(ctx, hb.size());
     DevArr<int> dcol(ctx, (size_t)c);
     DevArr<AdiState> st(ctx, 1);
+    AdiState h_up;                            // (the staging objects live until the function's first read-back: no synchronisation for the uploads)
     {
-        AdiState h;
-        std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 2);
-        h.abstol = abs_tol;
-        if (tol_is_floor) h.maxiters = BAND_TOL_FLOOR;
-        DRE_HIP(hipMemcpyAsync(st.p, &h, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
+        std::memset(&h_up, 0, sizeof(int) * 4 + sizeof(double) * 2);
+        h_up.abstol = abs_tol;
+        if (tol_is_floor) h_up.maxiters = BAND_TOL_FLOOR;
+        DRE_HIP(hipMemcpyAsync(st.p, &h_up, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipMemcpyAsync(dblocks.p, hb.data(), hb.size() * sizeof(LrBlockDev), hipMemcpyHostToDevice, ctx->stream));
         DRE_HIP(hipMemcpyAsync(dcol.p, hcol.data(), hcol.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));      // the host staging vectors go out of use here
     }
     Mat RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Yx(ctx, 16, c + 16);
     DevArr<double> parts(ctx, LR_PARTS);
@@ -4505,8 +4506,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
             k += b; ++np; ++issued;
         }
         AdiState h;
-        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(int) * 4 + sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        ctx_fetch(ctx, st.p, sizeof(int) * 4 + sizeof(double) * 2, &h);
         if (h.done) { J = h.iters; finished = true; }
         else if (np >= maxp) {
             // every column of L consumed: save the last panel's band blocks and stop

@@ -287,7 +287,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         hipLaunchKernelGGL(k_colpair_noise, dim3(A.cols), dim3(256), 0, ctx->stream, A.rows, (const double*)A.p, A.ld, (const double*)B.p, B.ld, nf.p + 1);
         hipLaunchKernelGGL(k_noise_floor, dim3(1), dim3(256), 0, ctx->stream, A.cols, noise_floor_fac(), (const double*)(nf.p + 1), nf.p);
     };
-    auto floor_host = [&]() { double h = 0.0; DRE_HIP(hipMemcpyAsync(&h, nf.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream)); DRE_HIP(hipStreamSynchronize(ctx->stream)); return h; };
+    auto floor_host = [&]() { double h = 0.0; ctx_fetch(ctx, nf.p, sizeof(double), &h); return h; };
     auto set_empty = [&]() {
         X.blocks.clear();
         X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true});
@@ -1407,6 +1407,7 @@ struct AdiRun {
     bool check_now = false;           // a lazily checked factor turned out to have replaced pivots: from now on every new factor is checked at once
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
+    bool chunk_from_hint = false;
     bool fan_off = false;             // the batched fan form does not apply to this solve's factors (sparse.hip, mf_solve_batch): one iteration at a time
     bool fan_smw_all = false;         // the SMW products of every cached shift of the cycle were formed with the first group's
     void check_used() {
@@ -1552,7 +1553,8 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     if (!cex && opt.compression && opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && cache->iters_hint > 0 &&
         n > ctx->dense_inv_max_n && n >= ctx->compress_factor_min_n && k > 0) {
         const long room = ((long)n - 64 - X->rank()) / k - 2L * opt.compression_interval - FAN_GMAX;
-        run.chunk_limit = (int)std::max<long>(opt.compression_interval, std::min<long>(cache->iters_hint + 2, room));
+        run.chunk_limit = (int)std::max<long>(opt.compression_interval, std::min<long>(cache->iters_hint + 1, room));
+        run.chunk_from_hint = true;       // exactly that many iterations: the last group of the chunk is cut short (a speculative group costs 14 launches)
     }
     // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
     // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
@@ -1815,15 +1817,20 @@ void adi_advance(AdiRun& run, int budget) {
                 ++scheduled;
             }
         };
-        const bool sharded_now = ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1 && k >= ctx->shard_min_cols;
-        const int fan_max = (opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && !sharded_now && cache->enabled && n > ctx->dense_inv_max_n)
+        // Fan groups (round 4: batched, and sharded over the ranks of a communicator BY SHIFT — north_star's "independent ADI shifts farmed across
+        // the GPUs"): the g solves of a group are independent, so rank r takes the group positions s = r (mod P), i.e. only ever factorises and
+        // keeps the shifts it owns (the factor farm of SURVEY 8e-4 without shipping factors), writes its W_s into slab r of the gathered panel and
+        // ONE in-place all-gather per GROUP (n g k doubles in all; round 3: one per iteration, columns sharded) completes it on every rank;
+        // mixing, norms, decisions, compression and K(t) are replicated and bit-identical on all ranks.
+        const int fan_P = ctx->comm ? std::max(1, std::max(ctx->comm->nranks, ctx->comm->emulate)) : 1;
+        const int fan_max = (opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n)
                                 ? std::min(ctx->adi_fan, FAN_GMAX) : 0;
         while (iters_host < opt.maxiters) {
-            // ---- fan group: the next g real shifts of the cycle at once (independent solves side by side, see k_fan_mix) ----------------
-            if (fan_max >= 2) {
+            // ---- fan group: the next g real shifts of the cycle at once (independent solves that share every launch) -------------------------
+            if (fan_max >= 2 && !run.fan_off) {
                 // (a group may cross the chunk limit — 3, 3, 3, 3 instead of 3, 3, 3, 1 iterations per chunk of 10 — unless the caller steps
-                // with a budget or the literal mode compresses at exact intervals)
-                const bool strict = cex || budget < (1 << 29);
+                // with a budget, the literal mode compresses at exact intervals or the chunk length is the previous solve's iteration count)
+                const bool strict = cex || budget < (1 << 29) || run.chunk_from_hint;
                 const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), strict ? chunk_limit - chunk_shifts : fan_max);
                 const auto ups = room >= 2 ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
                 int g = 0;
@@ -1836,48 +1843,59 @@ void adi_advance(AdiRun& run, int budget) {
                 }
                 FanCoef co;
                 while (g >= 2 && fan_coefficients(mus, g, &co) > ctx->adi_fan_max_coef) --g;
-                std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+                // which ranks this process plays: its own, or all of them one after the other (shard_emulate)
+                const bool emu = ctx->comm && ctx->comm->emulate > 1;
+                const int my_rank = ctx->comm ? ctx->comm->rank : 0;
+                auto mine = [&](int s_) { return fan_P == 1 || emu || (s_ % fan_P) == my_rank; };
+                std::vector<std::shared_ptr<FactorEntry<double>>> fes((size_t)std::max(g, 0));
                 if (lookahead && g >= 2) prefetch_ahead(std::complex<double>(0.0, 0.0), true);      // (first pass through the cycle: this group's and the next groups' factors; all waited for below)
                 for (int s_ = 0; s_ < g && g >= 2; ++s_) {
+                    if (!mine(s_)) continue;
                     if (lookahead) wait_prefetched(std::complex<double>(mus[s_], 0.0));
                     auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, !lookahead || run.check_now);
                     if (fe->dense) { g = 0; break; }              // the dense-inverse step has its own fused kernels
-                    fes.push_back(fe);
+                    fes[(size_t)s_] = fe;
                 }
-                if (g >= 2 && !run.fan_off) {
-                    // ---- batched fan group (round 4): the g solves share every launch (sparse.hip, mf_solve_batch: blockIdx.z = shift) instead of
-                    // running side by side on g streams — ~15 launches per GROUP where the stream form needed 13 per solve + 4 -----------------
+                if (g >= 2) {
                     const AdiState* dst = st.p;
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
-                    const Factor<double>* Fs[MF_ZMAX];
-                    for (int s_ = 0; s_ < g; ++s_) Fs[s_] = &fes[(size_t)s_]->f;
+                    const int gp = ceil_div(g, fan_P);                 // group positions per rank; W_s lives in slot (s mod P) gp + s div P
+                    FanSlots slots; std::memset(&slots, 0, sizeof(slots));
+                    for (int s_ = 0; s_ < g; ++s_) slots.s[s_] = (s_ % fan_P) * gp + s_ / fan_P;
+                    Mat Wcat(ctx, n, fan_P * gp * k);
                     bool ok = true;
-                    SmwZ sz; std::memset(&sz, 0, sizeof(sz));
-                    if (op.has_lr) {
-                        // SMW products of the group's shifts that this solve has not formed yet: W_U = M_s^-1 Vt for all of them in one batched
-                        // solve, the capacitance matrices inverted in one launch (smw.jl:19-28); at the first group of a solve every other shift of
-                        // the cycle whose factor exists rides along, so that a time step pays this chain once
-                        std::vector<std::pair<double, std::shared_ptr<FactorEntry<double>>>> need;
-                        for (int s_ = 0; s_ < g; ++s_) if (!smw_cache.count({mus[s_], 0.0})) need.push_back({mus[s_], fes[(size_t)s_]});
-                        if (!need.empty() && !run.fan_smw_all) {
-                            run.fan_smw_all = true;
-                            for (auto& mv : opt.shifts.values) {
-                                if (mv.imag() != 0.0 || (int)need.size() >= MF_ZMAX) continue;
-                                bool dup = smw_cache.count({mv.real(), 0.0}) > 0;
-                                for (auto& nd : need) dup = dup || nd.first == mv.real();
-                                if (dup) continue;
-                                auto itf = cache->real.find(std::make_tuple(op.tag, mv.real(), 0.0));
-                                if (itf == cache->real.end() || itf->second->dense || run.prefetch_ev.count({mv.real(), 0.0})) continue;
-                                need.push_back({mv.real(), itf->second});
+                    for (int r = 0; r < fan_P && ok; ++r) {
+                        if (!(fan_P == 1 || emu || r == my_rank)) continue;
+                        std::vector<int> pos;                          // this rank's group positions
+                        for (int s_ = r; s_ < g; s_ += fan_P) pos.push_back(s_);
+                        const int gr = (int)pos.size();
+                        if (gr == 0) continue;
+                        SmwZ sz; std::memset(&sz, 0, sizeof(sz));
+                        if (op.has_lr) {
+                            // SMW products of this rank's shifts that this solve has not formed yet: W_U = M_s^-1 Vt for all of them in one batched
+                            // solve, the capacitance matrices inverted in one launch (smw.jl:19-28); at the first group of a solve (one rank) every
+                            // other shift of the cycle whose factor exists rides along, so that a time step pays this chain once
+                            std::vector<std::pair<double, std::shared_ptr<FactorEntry<double>>>> need;
+                            for (int s_ : pos) if (!smw_cache.count({mus[s_], 0.0})) need.push_back({mus[s_], fes[(size_t)s_]});
+                            if (!need.empty() && !run.fan_smw_all && fan_P == 1) {
+                                run.fan_smw_all = true;
+                                for (auto& mv : opt.shifts.values) {
+                                    if (mv.imag() != 0.0 || (int)need.size() >= MF_ZMAX) continue;
+                                    bool dup = smw_cache.count({mv.real(), 0.0}) > 0;
+                                    for (auto& nd : need) dup = dup || nd.first == mv.real();
+                                    if (dup) continue;
+                                    auto itf = cache->real.find(std::make_tuple(op.tag, mv.real(), 0.0));
+                                    if (itf == cache->real.end() || itf->second->dense || run.prefetch_ev.count({mv.real(), 0.0})) continue;
+                                    need.push_back({mv.real(), itf->second});
+                                }
                             }
-                        }
-                        if (!need.empty()) {
-                            const int np = (int)need.size();
-                            const Factor<double>* Fp[MF_ZMAX];
-                            for (int z = 0; z < np; ++z) Fp[z] = &need[(size_t)z].second->f;
-                            Mat WUcat(ctx, n, np * m);
-                            ok = mf_solve_batch(ctx, P, Fp, np, op.Vt.p, op.Vt.ld, m, WUcat.p, WUcat.ld, m, dst);
-                            if (ok) {
+                            if (!need.empty()) {
+                                const int np = (int)need.size();
+                                const Factor<double>* Fp[MF_ZMAX];
+                                for (int z = 0; z < np; ++z) Fp[z] = &need[(size_t)z].second->f;
+                                Mat WUcat(ctx, n, np * m);
+                                ok = mf_solve_batch(ctx, P, Fp, np, op.Vt.p, op.Vt.ld, m, WUcat.p, WUcat.ld, m, dst);
+                                if (!ok) break;
                                 Mat smu(ctx, m, np * m);
                                 gemm(ctx, true, false, 1.0, op.U, WUcat, 0.0, smu, dst, "smw_small");
                                 SinvZ iz; std::memset(&iz, 0, sizeof(iz));
@@ -1891,27 +1909,42 @@ void adi_advance(AdiRun& run, int budget) {
                                 }
                                 hipLaunchKernelGGL(k_sinv_z, dim3(np), dim3(64), 0, ctx->stream, m, (const double*)smu.p, smu.ld, op.alpha, iz, dst, serr);
                             }
+                            for (int z = 0; z < gr; ++z) {
+                                const auto& en = smw_cache.find({mus[pos[(size_t)z]], 0.0})->second;
+                                sz.WU[z] = (const double*)en.WU; sz.ldwu[z] = en.ldwu; sz.Sinv[z] = (const double*)en.sinv->p;
+                            }
                         }
-                        for (int s_ = 0; s_ < g && ok; ++s_) {
-                            const auto& en = smw_cache.find({mus[s_], 0.0})->second;
-                            sz.WU[s_] = (const double*)en.WU; sz.ldwu[s_] = en.ldwu; sz.Sinv[s_] = (const double*)en.sinv->p;
+                        const Factor<double>* Fs[MF_ZMAX];
+                        for (int z = 0; z < gr; ++z) Fs[z] = &fes[(size_t)pos[(size_t)z]]->f;
+                        Mat Wr = Wcat.colsview(r * gp * k, gr * k);          // slab r: its solves side by side
+                        ok = mf_solve_batch(ctx, P, Fs, gr, R.p, R.ld, k, Wr.p, Wr.ld, k, dst);
+                        if (!ok) break;
+                        for (int s_ : pos) used_real.push_back(fes[(size_t)s_]);
+                        if (op.has_lr) {
+                            // W_s <- W_s - W_U,s (S_s^-1 (U' W_s))  for the rank's solves: one product U' [W_s ...], one apply launch (in place)
+                            Mat sm(ctx, m, gr * k);
+                            gemm(ctx, true, false, 1.0, op.U, Wr, 0.0, sm, dst, "smw_small");
+                            TimedScope ts(ctx, "smw_apply", 8.0 * n * gr * (2.0 * k + m), 2.0 * n * gr * (double)k * m, gr);
+                            hipLaunchKernelGGL(k_smw_apply_z, dim3(ceil_div(n, 256), ceil_div(k, SMW_CB), gr), dim3(256), 0, ctx->stream, n, m, k, Wr.p, Wr.ld, sz,
+                                               (const double*)sm.p, sm.ld, dst);
                         }
                     }
-                    Mat Wcat(ctx, n, g * k);
-                    if (ok) ok = mf_solve_batch(ctx, P, Fs, g, R.p, R.ld, k, Wcat.p, Wcat.ld, k, dst);
-                    if (!ok) { run.fan_off = true; continue; }        // (nothing was enqueued: this solve goes on one iteration at a time)
-                    for (int s_ = 0; s_ < g; ++s_) used_real.push_back(fes[(size_t)s_]);
-                    if (op.has_lr) {
-                        // W_s <- W_s - W_U,s (S_s^-1 (U' W_s))  for the g solves: one product U' [W_1 .. W_g], one apply launch (in place)
-                        Mat sm(ctx, m, g * k);
-                        gemm(ctx, true, false, 1.0, op.U, Wcat, 0.0, sm, dst, "smw_small");
-                        TimedScope ts(ctx, "smw_apply", 8.0 * n * g * (2.0 * k + m), 2.0 * n * g * (double)k * m, g);
-                        hipLaunchKernelGGL(k_smw_apply_z, dim3(ceil_div(n, 256), ceil_div(k, SMW_CB), g), dim3(256), 0, ctx->stream, n, m, k, Wcat.p, Wcat.ld, sz,
-                                           (const double*)sm.p, sm.ld, dst);
+                    // (nothing was enqueued where the batched form does not apply — the same decision on every rank: it depends on the pencil and
+                    // the context's options only — and this solve goes on one iteration at a time)
+                    if (!ok) {
+                        // (with real ranks the decision must not differ between them — it can only where a rank's own factors needed static pivots:
+                        // fail loudly instead of leaving the other ranks inside a collective)
+                        if (fan_P > 1 && !emu) throw Error(ERR_INTERNAL, "sharded fan group: the batched solves do not apply to this rank's factors (static pivots); "
+                                                                         "run with adi_fan = 0 for this pencil");
+                        run.fan_off = true; continue;
+                    }
+                    if (fan_P > 1 && !emu) {
+                        TimedScope ts(ctx, "comm_allgather_w", 8.0 * n * (double)fan_P * gp * k, 0.0);
+                        comm_allgather_inplace(ctx, *ctx->comm, Wcat.p, (size_t)n * gp * k);
                     }
                     // V_j = sum_s c_js W_s,  R_j = R_0 - sum_s d_js E' W_s  for the g iterations: one pass over E' and the panels
                     Mat Vcat(ctx, n, g * k), Rcat(ctx, n, g * k);
-                    fan_spmm_mix(ctx, P, Wcat, R, Vcat, Rcat, g, k, co, dst);
+                    fan_spmm_mix(ctx, P, Wcat, R, Vcat, Rcat, g, k, co, slots, dst);
                     for (int j = 0; j < g; ++j) {
                         const std::complex<double> muj = oracle->take(&res.warnings);
                         all_shifts.push_back(muj);
@@ -2153,8 +2186,7 @@ void adi_advance(AdiRun& run, int budget) {
         dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
         AdiState h;
         const auto ct1 = std::chrono::steady_clock::now();
-        DRE_HIP(hipMemcpyAsync(&h, st.p, sizeof(AdiState), hipMemcpyDeviceToHost, ctx->stream));
-        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        ctx_fetch(ctx, st.p, sizeof(AdiState), &h);
         if (chunk_timing) {
             static double enq = 0.0, wait = 0.0; static long nch = 0, nit_ = 0;
             const auto ct2 = std::chrono::steady_clock::now();

@@ -209,7 +209,7 @@ void spmm(Ctx* ctx, int n, const int* ptr, const int* idx, const double* val, co
 template <int G>
 __global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restrict__ ptr, const int* __restrict__ idx, const double* __restrict__ val, int k,
                                                       const double* __restrict__ W, int ldw, const double* __restrict__ R0, int ldr,
-                                                      double* __restrict__ V, int ldv, double* __restrict__ Rc, int ldrc, FanCoef co, const AdiState* st) {
+                                                      double* __restrict__ V, int ldv, double* __restrict__ Rc, int ldrc, FanCoef co, FanSlots sl, const AdiState* st) {
     if (st && st->done) return;
     __shared__ double vs[SPMM_LDS_NNZ];
     __shared__ int is[SPMM_LDS_NNZ];
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restri
     for (int c = 0; c < FAN_CB; ++c) {
         r[c] = R0[i + (size_t)col[c] * ldr];
 #pragma unroll
-        for (int s = 0; s < G; ++s) { ew[c][s] = 0.0; w[c][s] = W[i + (size_t)(s * k + col[c]) * ldw]; }
+        for (int s = 0; s < G; ++s) { ew[c][s] = 0.0; w[c][s] = W[i + (size_t)(sl.s[s] * k + col[c]) * ldw]; }
     }
     const int pb = ptr[i], pe = ptr[i + 1];
     for (int p = pb; p < pe; ++p) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restri
 #pragma unroll
         for (int c = 0; c < FAN_CB; ++c)
 #pragma unroll
-            for (int s = 0; s < G; ++s) t[c][s] = x[(size_t)(s * k + col[c]) * ldw];
+            for (int s = 0; s < G; ++s) t[c][s] = x[(size_t)(sl.s[s] * k + col[c]) * ldw];
 #pragma unroll
         for (int c = 0; c < FAN_CB; ++c)
 #pragma unroll
@@ -259,13 +259,14 @@ __global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restri
         }
     }
 }
-void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const AdiState* st) {
+void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const FanSlots& sl, const AdiState* st) {
     const int n = P.n;
-    DRE_REQUIRE(g >= 2 && g <= FAN_GMAX && W.rows == n && W.cols == g * k && V.cols == g * k && Rc.cols == g * k && R0.cols == k, "fan_spmm_mix: shapes");
+    DRE_REQUIRE(g >= 2 && g <= FAN_GMAX && W.rows == n && W.cols >= g * k && V.cols == g * k && Rc.cols == g * k && R0.cols == k, "fan_spmm_mix: shapes");
+    for (int s = 0; s < g; ++s) DRE_REQUIRE(sl.s[s] >= 0 && (sl.s[s] + 1) * k <= W.cols, "fan_spmm_mix: slot outside the panel");
     TimedScope ts(ctx, "fan_spmm_mix", 12.0 * P.nnz + 4.0 * n + 8.0 * n * k * (3.0 * g + 1.0), 2.0 * (double)P.nnz * g * k + 2.0 * n * k * (double)g * (g + 1));
     const dim3 grid(ceil_div(n, 256), ceil_div(k, FAN_CB)), block(256);
 #define DRE_FAN_CASE(G_) case G_: hipLaunchKernelGGL((k_fan_spmm_mix<G_>), grid, block, 0, ctx->stream, n, (const int*)P.ptr.p, (const int*)P.idx.p, (const double*)P.valEt.p, k, \
-                                                    (const double*)W.p, W.ld, (const double*)R0.p, R0.ld, V.p, V.ld, Rc.p, Rc.ld, co, st); break;
+                                                    (const double*)W.p, W.ld, (const double*)R0.p, R0.ld, V.p, V.ld, Rc.p, Rc.ld, co, sl, st); break;
     switch (g) { DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) }
 #undef DRE_FAN_CASE
     DRE_HIP(hipGetLastError());

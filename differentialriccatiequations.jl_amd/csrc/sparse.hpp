@@ -150,7 +150,9 @@ void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& F, const dou
 // partial-fraction coefficients of a fan group (engine.hip, fan_coefficients) and the fused  E' W + mixing  pass over the g solves
 #define FAN_GMAX 8
 struct FanCoef { double c[FAN_GMAX][FAN_GMAX], d[FAN_GMAX][FAN_GMAX]; };
-void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const AdiState* st = nullptr);
+struct FanSlots { int s[FAN_GMAX]; };       // solve s lives in columns s[s] k .. of the panel (shift-sharded groups: slab of the owning rank)
+void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const FanSlots& sl,
+                  const AdiState* st = nullptr);
 // g solves with different factors of the same pencil in shared launches: W_z = F_z^-1 [Win(:, 0:nin) | W_z(:, nin:nrhs)], W_z = columns
 // z nrhs .. of the n x (g nrhs) panel W.  false (nothing enqueued) where the batched form does not apply.
 bool mf_solve_batch(Ctx* ctx, const Pencil& P, const Factor<double>* const* Fs, int g, const double* Win, int ldwin, int nin, double* W, int ldw, int nrhs,

@@ -55,6 +55,35 @@ class Context:
         idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
         self.chk(self.lib.dre_comm_init(self.ptr, int(nranks), int(rank), idbuf))
 
+    def comm_init_host(self, nranks: int, rank: int, allgather, allreduce):
+        """The communicator over a HOST transport (dre_comm_init_host): `allgather(send, recv, nranks)` gets two NumPy uint8 views (this rank's
+        block, which lies inside `recv`, and the nranks blocks) and fills `recv`; `allreduce(buf)` sums a float64 view over the ranks in place.
+        Used where RCCL cannot be (two ranks on one GPU in the tests, hosts without RCCL); the data path then goes through host memory."""
+        import numpy as np
+        AG = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+        AR = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+        def _ag(user, send, recv, nbytes):
+            try:
+                r = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(int(nranks) * nbytes,))
+                s_ = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                allgather(s_, r, int(nranks))
+                return 0
+            except Exception:          # an exception must not unwind through the C frames
+                import traceback; traceback.print_exc()
+                return 1
+
+        def _ar(user, buf, count):
+            try:
+                b = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                allreduce(b)
+                return 0
+            except Exception:
+                import traceback; traceback.print_exc()
+                return 1
+        self._comm_cbs = (AG(_ag), AR(_ar))        # keep the thunks alive as long as the communicator
+        self.chk(self.lib.dre_comm_init_host(self.ptr, int(nranks), int(rank), C.cast(self._comm_cbs[0], C.c_void_p), C.cast(self._comm_cbs[1], C.c_void_p), None))
+
     def comm_free(self):
         self.chk(self.lib.dre_comm_free(self.ptr))
 

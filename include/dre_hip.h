@@ -280,15 +280,26 @@ int dre_adi_result_free(dre_adi_result* r);
  * the other ranks (torch.distributed / MPI / a file), every rank calls dre_comm_init(ctx, nranks, rank, id): the communicator belongs
  * to the context and its collectives are enqueued on the context's stream (no host synchronisation, no staging copies).
  * With a communicator of more than one rank attached, every solve entered through this ABI (dre_gdre_solve, dre_gale_solve,
- * dre_adi_*) runs the SAME device-resident loop on every rank with the shifted solves of the generic ADI step
- * (perform_single_step!, src/lyapunov/adi.jl:149-179; the multifrontal sweeps + SMW of src/blocklinear) column-sharded:
- * rank g solves its 16-column tiles of the residual block and ONE in-place all-gather per ADI step completes V on every rank;
+ * dre_adi_*) runs the SAME device-resident loop on every rank with the shifted solves of the ADI iteration
+ * (perform_single_step!, src/lyapunov/adi.jl:149-179; the multifrontal sweeps + SMW of src/blocklinear) sharded:
+ *  - Cyclic real shifts (fan groups: g consecutive iterations from g INDEPENDENT solves with the same right-hand side): BY SHIFT — rank r
+ *    solves the group positions s = r (mod P), so it only ever factorises the shifts it owns (src/blocklinear/backslash.jl:13 once per
+ *    owned shift and run), and ONE in-place all-gather per GROUP of g iterations completes the panel [W_1 .. W_g] on every rank;
+ *  - any other real-shift step: BY COLUMN — rank r solves its 16-column tiles of the residual block, one all-gather per ADI step;
  * residual update, norm, compression, shifts and the feedback K(t) are replicated and bit-identical on all ranks (the reference has
  * no multi-device path; test/cuda.jl runs one GPU).  librccl is loaded lazily by the first dre_comm_* call.
  * option "shard_min_cols" (default 32): narrower residual blocks are solved replicated; option "shard_emulate" = P: one process plays
  * P ranks one after the other (tests). */
 int dre_comm_unique_id(dre_ctx* ctx, void* id128);
 int dre_comm_init(dre_ctx* ctx, int nranks, int rank, const void* id128);      /* id128 may be NULL for nranks == 1 (no RCCL object) */
+/* The same communicator over a HOST transport: the collectives are staged through pinned host memory and handed to the caller's callbacks
+ * (MPI, gloo, ... — hosts without RCCL, and the two-rank tests of the sharded solve on ONE GPU: RCCL refuses two ranks on one device).
+ * allgather(user, send, recv, bytes_per_rank): recv holds nranks blocks, send points at this rank's block inside recv (in place);
+ * allreduce(user, buf, count): sum of `count` doubles in place.  Both return 0 on success; they are called from the thread that drives
+ * the solve, between two stream synchronisations. */
+typedef int (*dre_comm_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+typedef int (*dre_comm_allreduce_fn)(void* user, void* buf, size_t count);
+int dre_comm_init_host(dre_ctx* ctx, int nranks, int rank, dre_comm_allgather_fn allgather, dre_comm_allreduce_fn allreduce, void* user);
 int dre_comm_free(dre_ctx* ctx);
 /* info: [0]=nranks [1]=rank [2]=collective calls [3]=bytes received by all-gathers [4]=bytes reduced [5]=emulated ranks */
 int dre_comm_info(dre_ctx* ctx, int64_t* info);
