@@ -339,12 +339,15 @@ def main():
         total_iters /= world          # ONE problem: every rank counted the same iterations
 
     out = None
+    parity_failure = None
+    its_last = list(width["its"])
+    if strong and world > 1 and rank != 0:
+        one_solve(gather=False)      # strong mode: every ADI group enqueues a collective, so the profiled extra solve of rank 0 needs its partners
     if rank == 0:
-        its_last = width["its"]
         # ---- roofline leg: one extra identical solve with per-kernel HIP-event timing on the library stream
         ctx.prof_reset()
         ctx.prof_enable(True)
-        one_solve(gather=False)      # collectives stay matched across ranks: the profiled solve does not gather
+        one_solve(gather=False)      # replicas: the profiled solve does not gather (collectives stay matched); strong: all ranks run it (above)
         stats = ctx.prof_stats()
         ctx.prof_enable(False)
         if os.environ.get("DRE_BENCH_CLASSES"):        # builder's view: every kernel class of the profiled solve (stderr; the JSON line is unchanged)
@@ -352,7 +355,10 @@ def main():
                 print(f"[class] {k_:24s} launches {v_['launches']:6d}  ms {v_['ms']:9.3f}  avg_us {v_['ms'] * 1e3 / max(v_['launches'], 1):8.2f}", file=sys.stderr)
         roof = roofline_record(stats, n, m, pencil, total_iters / (args.steps * (1 if strong else world)), width["kw"], elapsed / args.steps)
         # ---- parity leg (after the timed region): the K(t) trajectory of the last timed solve of rank 0 against the committed oracle fixture
-        parity = parity_check(n, args.nsteps, Kdev.cpu().numpy(), its_last)
+        try:
+            parity = parity_check(n, args.nsteps, Kdev.cpu().numpy(), its_last)
+        except SystemExit as e:      # reported AFTER the final barrier: a parity failure must not strand the other ranks in it
+            parity, parity_failure = None, e
         # ---- general path leg: the sparse multifrontal path north_star names, in the driver-timed record
         general = None
         if world == 1 and n == 371 and not strong and not args.no_general_path:
@@ -433,6 +439,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failure is not None:
+        raise parity_failure
     if rank == 0:
         print(json.dumps(out))
 

@@ -434,8 +434,10 @@ class Backslash(BlockLinearSolver):
     """`Backslash()` (blocklinear/backslash.jl): the library's own sparse direct solver (multifrontal LU on the device)."""
 
     def solve(self, prob: BlockLinearProblem):
-        import scipy.sparse.linalg as spla
-        return spla.splu(sp.csc_matrix(prob.A)).solve(np.asarray(prob.B))
+        # `Backslash()` is a TAG in this package: the engine recognises it and runs its own multifrontal LU on the device (csrc/sparse.hip);
+        # there is no host implementation behind it and no CPU fallback — a subclass that wants a host solve must bring its own `solve`
+        raise DREError("Backslash() selects the library's device solver; it has no host-side solve().  Subclass BlockLinearSolver and "
+                       "implement solve() (or solve_device) for a custom inner solver (blocklinear/types.jl:46-60)")
 
 
 @dataclass
@@ -762,6 +764,7 @@ class ADISolver:
                 _call(self.observer, "observe_gale_metadata", "ADI shifts", mu)
             if st["iters"] > self._seen:
                 X, R = self.snapshot()
+                self._last_R = R                # adi.jl:84-87 hands residual(cache) to observe_gale_done! as well
                 _call(self.observer, "observe_gale_step", int(st["iters"]), X, R, st["res_norm"])
             self._seen = st["iters"]
         return self
@@ -793,7 +796,12 @@ class ADISolver:
             if self._live:
                 if not info["converged"]:
                     _call(self.observer, "observe_gale_failed")
-                R = None
+                R = getattr(self, "_last_R", None)        # the residual object after the last iteration (a copy: dre_adi_snapshot)
+                if R is None:
+                    try:
+                        _, R = self.snapshot()             # no iteration ran (converged at once): the initial residual
+                    except Exception:
+                        R = None
             else:
                 _replay_gale(self.observer, self.prob, self.alg, info)
                 R = None
@@ -970,7 +978,8 @@ def _solve_gdre_observed(prob, alg, order, inner, dt, save_state, observer, ctx,
             rhs = compress_(lowrank(G, S))                                                                # :44
             X = lyap(F, rhs, X)                                                                           # :47-49 (warm start)
         else:
-            F = lr_update(ScaledPencil(A, gamma * tau, E, -0.5), -gamma * tau, B, K)                     # lowrank_ros2.jl:41
+            # lr_update(A, alpha, U, V) = A + inv(alpha) U V (LowRankUpdate.jl:18-39): the reference passes inv(-gamma tau) for the term -gamma tau B K
+            F = lr_update(ScaledPencil(A, gamma * tau, E, -0.5), 1.0 / (-gamma * tau), B, K)             # lowrank_ros2.jl:41
             r = L.shape[1]
             G = np.hstack([Cm.T, np.asarray(A.T @ L), EtL])
             S = np.zeros((q + 2 * r,) * 2)

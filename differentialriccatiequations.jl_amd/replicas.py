@@ -5,8 +5,9 @@ does not shard.  Two modes use the same communicator (csrc/comm.hip):
 
 * replicas (weak scaling, `bench.py --gpus N`): every rank solves an independent problem; the K(t) feedback trajectories are gathered
   with `dre_comm_allgather` on the library stream (46 * 7 * n * 8 bytes per rank);
-* column-sharded (strong scaling, `bench.py --mode strong`): every rank runs the SAME device-resident time loop and the shifted solves of
-  each ADI step are split by 16-column tiles, one in-place all-gather per step (engine.hip, adi_advance).
+* sharded (strong scaling, `bench.py --mode strong`): every rank runs the SAME device-resident time loop; the g independent solves of a fan
+  group (Cyclic real shifts) are split BY SHIFT — rank r owns the group positions r mod P and factorises only those shifts — with one
+  in-place all-gather per group; other real-shift steps are split by 16-column tiles, one all-gather per step (engine.hip, adi_advance).
 
 `torch.distributed` (any backend; gloo in the CPU tests) is only the out-of-band channel that hands rank 0's 128-byte unique id to the
 other ranks and reduces the timing scalars — never the data path."""
@@ -19,8 +20,17 @@ def attach_communicator(ctx, rank: int, world: int):
     if world == 1:
         ctx.comm_init(1, 0, None)
         return
-    box = [ctx.comm_unique_id() if rank == 0 else None]
+    # rank 0 ALWAYS enters the broadcast: a failure to make the id (no RCCL) travels as its error text, so that every rank raises the same
+    # error instead of waiting in a collective rank 0 never joins
+    box = [None]
+    if rank == 0:
+        try:
+            box = [ctx.comm_unique_id()]
+        except Exception as e:
+            box = [f"ERROR: {e}"]
     dist.broadcast_object_list(box, src=0)
+    if isinstance(box[0], str):
+        raise RuntimeError(f"rank 0 could not create the RCCL unique id: {box[0]}")
     ctx.comm_init(world, rank, box[0])
 
 

@@ -1,4 +1,4 @@
-"""World-size-2 gloo worker: the sharded Rosenbrock-1 time loop (dre_amd.sharded.solve_gdre_ros1: column-sharded ADI with 16-column tiles,
+"""World-size-2 gloo worker: the sharded Rosenbrock-1 time loop (tests/host_sharding_model.py.solve_gdre_ros1: column-sharded ADI with 16-column tiles,
 row-sharded compression, replicated feedback) on the SteelProfile(371) surrogate, 3 time steps, against the ORACLE's committed K(t)
 (tests/golden/ros1_371_full.npz) and against the single-rank run of the same code (CPU stand-in ops)."""
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dre_amd as D   # noqa: E402   (surrogate generator only; no GPU is touched)
-from dre_amd.sharded import Comm, solve_gdre_ros1, tile_col_range   # noqa: E402
+from host_sharding_model import Comm, solve_gdre_ros1, tile_col_range   # noqa: E402
 from _numpy_ops import NumpyOps   # noqa: E402
 
 dist.init_process_group(backend="gloo")

@@ -1,4 +1,4 @@
-"""World-size-2 gloo worker: row-sharded randomized compression (dre_amd.sharded.RowShardedCompress) against the dense sum and the oracle's
+"""World-size-2 gloo worker: row-sharded randomized compression (tests/host_sharding_model.py.RowShardedCompress) against the dense sum and the oracle's
 compress! on a small ADI-like increment slab (CPU stand-in ops)."""
 import os
 import sys
@@ -10,7 +10,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from dre_amd.sharded import Comm, RowShardedCompress, row_range   # noqa: E402
+from host_sharding_model import Comm, RowShardedCompress, row_range   # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _numpy_ops import NumpyOps   # noqa: E402
 import dre_oracle as o   # noqa: E402

@@ -1,4 +1,4 @@
-"""World-size-2 gloo worker: column-sharded ADI (dre_amd.sharded) against the single-rank result on a small pencil (CPU stand-in ops)."""
+"""World-size-2 gloo worker: column-sharded ADI (tests/host_sharding_model.py) against the single-rank result on a small pencil (CPU stand-in ops)."""
 import os
 import sys
 
@@ -10,7 +10,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-from dre_amd.sharded import ColumnShardedADI, Comm, col_range, dense_solution   # noqa: E402
+from host_sharding_model import ColumnShardedADI, Comm, col_range, dense_solution   # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _numpy_ops import NumpyOps   # noqa: E402
 import dre_oracle as o   # noqa: E402

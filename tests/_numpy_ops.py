@@ -1,5 +1,5 @@
-"""CPU stand-in of the per-rank operator work of dre_amd.sharded (SciPy SuperLU + NumPy): TEST INFRASTRUCTURE for the world-size-2 gloo
-tests (no GPU on the CI box).  The product package has no CPU compute path; on a GPU the same interface is `dre_amd.sharded.HipOps`."""
+"""CPU stand-in of the per-rank operator work of tests/host_sharding_model.py (SciPy SuperLU + NumPy): TEST INFRASTRUCTURE for the world-size-2 gloo
+tests (no GPU on the CI box).  The product package has no CPU compute path; on a GPU the same interface is `tests/host_sharding_model.py.HipOps`."""
 import numpy as np
 import torch
 

@@ -1,4 +1,4 @@
-"""Host-driven model of the multi-GPU scheme: column-sharded low-rank ADI, row-sharded compression and the Rosenbrock-1 time loop over
+"""TEST INFRASTRUCTURE (moved out of the product package in round 4): host-driven model of the multi-GPU scheme: column-sharded low-rank ADI, row-sharded compression and the Rosenbrock-1 time loop over
 them.
 
 PRODUCTION PATH: the same column sharding lives INSIDE the library (csrc/engine.hip adi_advance + csrc/comm.hip: RCCL all-gather on the
@@ -130,7 +130,7 @@ class HipOps:
 
     def compress_factor(self, L: np.ndarray, D: np.ndarray):
         """compress!(lowrank(L, D)) (LDLt.jl:204-225), replicated: (L, D) with orthonormal L, diagonal D"""
-        from . import api
+        import dre_amd.api as api
         X = api.compress_(api.lowrank(L, D))
         a, Ln, Dn = X.alphas[0], X.Ls[0], X.Ds[0]
         return np.asarray(Ln), a * np.asarray(Dn)
@@ -185,7 +185,7 @@ class HipOps:
 
     def qr(self, A: torch.Tensor):
         import ctypes as C
-        from . import device as dev
+        import dre_amd.device as dev
         Ad, keep = self._to_lib(A)
         q, r = C.c_void_p(), C.c_void_p()
         self.ctx.chk(self.ctx.lib.dre_orthf(self.ctx.ptr, Ad.ptr, C.byref(q), C.byref(r)))
@@ -194,7 +194,7 @@ class HipOps:
 
     def eigh(self, S: torch.Tensor):
         import ctypes as C
-        from . import device as dev
+        import dre_amd.device as dev
         Sd, keep = self._to_lib(S)
         w, v = C.c_void_p(), C.c_void_p()
         self.ctx.chk(self.ctx.lib.dre_sym_eig(self.ctx.ptr, Sd.ptr, 4.0, C.byref(w), C.byref(v)))

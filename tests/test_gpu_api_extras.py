@@ -277,10 +277,10 @@ def test_user_block_solver_plugs_into_adi(ctx):                # blocklinear/typ
 
 
 def test_column_sharded_adi_device_ops_single_rank(ctx):
-    """dre_amd.sharded.HipOps (the per-rank work of the multi-GPU ADI through the C ABI + device-to-device exchange buffers) against the
+    """tests/host_sharding_model.py.HipOps (the per-rank work of the multi-GPU ADI through the C ABI + device-to-device exchange buffers) against the
     SciPy stand-in the gloo test uses, world size 1: same iterates, and the sharded bookkeeping (column / row ranges) covers everything."""
     import torch
-    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, col_range, dense_solution
+    from host_sharding_model import ColumnShardedADI, Comm, HipOps, col_range, dense_solution
     from _numpy_ops import NumpyOps
     d = D.steel_profile(371)
     L, Dm = D.initial_value(d)
@@ -302,11 +302,11 @@ def test_column_sharded_adi_device_ops_single_rank(ctx):
 
 
 def test_row_sharded_compression_device_ops_single_rank(ctx):
-    """dre_amd.sharded.RowShardedCompress with HipOps (GEMM, Householder QR and the symmetric eigensolver through the C ABI, tensors as
+    """tests/host_sharding_model.py.RowShardedCompress with HipOps (GEMM, Householder QR and the symmetric eigensolver through the C ABI, tensors as
     device-to-device exchange buffers) at world size 1: the increments of a device ADI run compress to the same X as the SciPy stand-in
     and as the dense sum (the world-size-2 exchange pattern is covered by the gloo test on CPU)."""
     import torch
-    from dre_amd.sharded import ColumnShardedADI, Comm, HipOps, RowShardedCompress
+    from host_sharding_model import ColumnShardedADI, Comm, HipOps, RowShardedCompress
     from _numpy_ops import NumpyOps
     d = D.steel_profile(371)
     L, Dm = D.initial_value(d)

@@ -105,7 +105,7 @@ def test_replica_gather_over_gloo_world_size_2():
 
 
 def test_column_sharded_adi_over_gloo_world_size_2():
-    """Multi-GPU inside ONE Lyapunov solve (dre_amd.sharded): column blocks of the residual are solved per rank,
+    """Multi-GPU inside ONE Lyapunov solve (tests/host_sharding_model.py): column blocks of the residual are solved per rank,
     one all_gather of V per ADI step, row-sharded Gram + k x k all_reduce for the norm.  Two CPU processes over gloo with the SciPy stand-in
     ops reproduce the single-rank iterates (same iteration count, same norms, same X), the dense Lyapunov residual and the oracle's ADI."""
     script = os.path.join(ROOT, "tests", "_gloo_sharded_worker.py")
@@ -117,7 +117,7 @@ def test_column_sharded_adi_over_gloo_world_size_2():
 
 
 def test_row_sharded_compression_over_gloo_world_size_2():
-    """compress! of the increment slab with the rows of the factor sharded (dre_amd.sharded.RowShardedCompress,
+    """compress! of the increment slab with the rows of the factor sharded (tests/host_sharding_model.py.RowShardedCompress,
     randomized range finder + TSQR over the ranks): two CPU processes over gloo reproduce the dense sum, the single-rank result and the
     eigenvalues the oracle's compress! keeps; the factor is orthonormal across the ranks; a too narrow sketch is rejected."""
     script = os.path.join(ROOT, "tests", "_gloo_rowshard_worker.py")
