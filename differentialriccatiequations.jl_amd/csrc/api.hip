@@ -179,6 +179,7 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "adi_group") ctx->c.adi_group = (int)value;
         else if (key == "adi_group_max_n") ctx->c.adi_group_max_n = (int)value;
         else if (key == "adi_fan") ctx->c.adi_fan = (int)value;
+        else if (key == "ros1_recurrence") ctx->c.ros1_recurrence = (int)value;
         else if (key == "adi_fan_max_coef") ctx->c.adi_fan_max_coef = value;
         else if (key == "shard_min_cols") ctx->c.shard_min_cols = (int)value;
         else if (key == "shard_emulate") {

@@ -173,6 +173,9 @@ struct Ctx {
     // pivot-free LU with growth detection only) and the number of refinement steps of a solve with a perturbed factor
     double pivot_static = 1.4901161193847656e-08;
     int pivot_refine_steps = 3;
+    // Rosenbrock-1 on the general path (multifrontal solves, Cyclic real shifts): warm-start residual and feedback from the ADI's own residual
+    // recurrence, X compressed on the side stream (engine.hip, ros1_recurrence_loop); 0: the reference's order of operations
+    int ros1_recurrence = 1;
     int x_side_stream = 1;
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)

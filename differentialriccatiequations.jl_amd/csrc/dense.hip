@@ -2255,6 +2255,59 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
     return read_scalar(ctx, out.p);
 }
 
+// |alpha| ||L D L'||_F through the Gram matrix into DEVICE memory (no synchronisation): the tolerance of the next Lyapunov solve is formed
+// on the side stream while the main stream already iterates (engine.hip, Rosenbrock-1 loop with the residual recurrence)
+void ldlt_norm_device(Ctx* ctx, const Mat& L, const Mat& D, double alpha, double* out_dev) {
+    if (L.cols == 0) { DRE_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), ctx->stream)); return; }
+    Mat G(ctx, L.cols, L.cols);
+    gemm(ctx, true, false, 1.0, L, L, 0.0, G, nullptr, "gemm_gram");
+    Mat TG(ctx, G.rows, G.cols);
+    gemm(ctx, false, false, 1.0, D, G, 0.0, TG, nullptr, "gemm_norm");
+    trace_sq(ctx, TG, alpha, nullptr, 0, out_dev);
+}
+// Deferred convergence decisions (adi.jl:115-123) for iterations 0 .. count whose norms were recorded while the tolerance was still being
+// formed elsewhere: abstol = reltol * (*normC) (or abstol_given >= 0), then the first recorded norm at or below it ends the solve.
+__global__ void k_decide_scan(AdiState* st, int count, const double* __restrict__ normC, double reltol, double abstol_given) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double abstol = abstol_given >= 0.0 ? abstol_given : reltol * normC[0];
+    st->abstol = abstol;
+    int it = count;
+    for (int i = 0; i <= count; ++i)
+        if (st->norms[i & 511] <= abstol) { it = i; break; }
+    st->iters = it;
+    st->res_norm = st->norms[it & 511];
+    st->done = (st->norms[it & 511] <= abstol || it >= st->maxiters) ? 1 : 0;
+}
+void adi_decide_scan(Ctx* ctx, AdiState* st, int count, const double* normC_dev, double reltol, double abstol_given) {
+    hipLaunchKernelGGL(k_decide_scan, dim3(1), dim3(64), 0, ctx->stream, st, count, normC_dev, reltol, abstol_given);
+    DRE_HIP(hipGetLastError());
+}
+// EV_j = (R_{j-1} - R_j) * inv2mu_j for up to 64 consecutive iterations whose residual factors lie side by side (Rs = [R_1 .. R_J], R_0 given
+// for the first one): E'V_j of the residual recurrence R_j = R_{j-1} - 2 mu_j E'V_j (adi.jl:171) without touching E or V
+struct EvScale { double inv2mu[64]; };
+__global__ __launch_bounds__(256) void k_ev_from_residuals(int n, int k, int J, const double* __restrict__ R0, int ldr0, const double* __restrict__ Rs, int ldrs,
+                                                           double* __restrict__ EV, int ldev, EvScale sc) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * k * J) return;
+    const int i = idx % n; const size_t col = idx / n;
+    const int j = (int)(col / k), c = (int)(col % k);
+    const double prev = j == 0 ? R0[i + (size_t)c * ldr0] : Rs[i + (size_t)(col - k) * ldrs];
+    EV[i + col * ldev] = (prev - Rs[i + col * ldrs]) * sc.inv2mu[j];
+}
+void ev_from_residuals(Ctx* ctx, int n, int k, int J, const Mat& R0, const Mat& Rs, Mat& EV, const double* mu) {
+    for (int j0 = 0; j0 < J; j0 += 64) {
+        const int jj = std::min(64, J - j0);
+        EvScale sc;
+        for (int j = 0; j < jj; ++j) sc.inv2mu[j] = 1.0 / (2.0 * mu[j0 + j]);
+        const double* r0 = j0 == 0 ? R0.p : Rs.p + (size_t)(j0 - 1) * k * Rs.ld;
+        const int ld0 = j0 == 0 ? R0.ld : Rs.ld;
+        const size_t tot = (size_t)n * k * jj;
+        hipLaunchKernelGGL(k_ev_from_residuals, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, n, k, jj, r0, ld0,
+                           (const double*)(Rs.p + (size_t)j0 * k * Rs.ld), Rs.ld, EV.p + (size_t)j0 * k * EV.ld, EV.ld, sc);
+    }
+    DRE_HIP(hipGetLastError());
+}
+
 // =============================================================================================
 // Blocked Householder QR (compact WY), panel width 16.
 // =============================================================================================

@@ -111,6 +111,9 @@ void residual_norm_group(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, 
 // the same from the g DIAGONAL blocks of the Gram matrix only (one z-batched product), the g norms in parallel workgroups, decisions in order
 void residual_norm_group_diag(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters0);
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after);
+void ldlt_norm_device(Ctx* ctx, const Mat& L, const Mat& D, double alpha, double* out_dev);          // |alpha| ||L D L'||_F into device memory, no synchronisation
+void adi_decide_scan(Ctx* ctx, AdiState* st, int count, const double* normC_dev, double reltol, double abstol_given);   // deferred decisions for iterations 0 .. count
+void ev_from_residuals(Ctx* ctx, int n, int k, int J, const Mat& R0, const Mat& Rs, Mat& EV, const double* mu);       // E'V_j = (R_{j-1} - R_j) / (2 mu_j)
 // fused dense-inverse ADI step (apply + residual recurrence + Gram matrix + convergence decision), see dense.hip
 // The norm kernel of iteration i can ride on the step kernel of iteration i + 1 (one more workgroup) instead of being a launch of
 // its own: `pend` carries the Gram slabs of the iteration whose norm is still due.  dense_norm_flush launches it on its own (before

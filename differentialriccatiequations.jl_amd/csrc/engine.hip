@@ -1408,6 +1408,9 @@ struct AdiRun {
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
     bool chunk_from_hint = false;
+    bool defer = false;               // the tolerance is still on its way (AdiOptions::normC_dev): kernels record norms, decisions follow at the chunk end
+    double reltol = 0.0;
+    bool hist_ok = true;
     bool fan_off = false;             // the batched fan form does not apply to this solve's factors (sparse.hip, mf_solve_batch): one iteration at a time
     bool fan_smw_all = false;         // the SMW products of every cached shift of the cycle were formed with the first group's
     void check_used() {
@@ -1451,16 +1454,30 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     const double ctf = opt.compress_tolfac;
     const bool cex = opt.compress_exact;
     const bool keep_blocks = !cex && n <= xblocks_max_n() && C.blocks.size() > 1 && initial_guess && !opt.ignore_initial_guess && !initial_guess->iszero();
-    double normC;
-    if (keep_blocks) normC = ldlt_norm_dense_small(ctx, C);       // the summands go into the residual as they are (gale_residual_blocks)
+    double normC = 0.0;
+    const bool defer = opt.given_residual && opt.abstol < 0 && opt.normC_dev != nullptr;      // ||C|| arrives in device memory, later
+    DRE_REQUIRE(!opt.given_residual || defer || opt.abstol >= 0, "ADI with a given residual needs abstol or a device-side ||C||");
+    if (opt.given_residual) { /* no right-hand side object */ }
+    else if (keep_blocks) normC = ldlt_norm_dense_small(ctx, C);       // the summands go into the residual as they are (gale_residual_blocks)
     else { ldlt_destructure(ctx, C, ctf, cex); normC = ldlt_norm(ctx, C); }
     const double reltol = opt.reltol >= 0 ? opt.reltol : n * EPS;
-    const double abstol = opt.abstol >= 0 ? opt.abstol : reltol * normC;
+    const double abstol = defer ? -1.0 : (opt.abstol >= 0 ? opt.abstol : reltol * normC);      // (-1: no norm is ever at or below it — the kernels only record)
+    run.defer = defer; run.reltol = reltol;
     LDLtP X = (opt.ignore_initial_guess || !initial_guess) ? ldlt_zero(n) : initial_guess;
+    LDLtP resid;
+    if (opt.given_residual) {
+        // the caller knows the warm-start residual in factored form (Rosenbrock-1 recurrence): truncated at the PREVIOUS step's level while this
+        // step's tolerance is still being formed; the solve returns the increment
+        resid = opt.given_residual;
+        X = ldlt_zero(n);
+        const double lag = opt.abstol_lag > 0.0 ? opt.abstol_lag : (opt.abstol >= 0.0 ? opt.abstol : -1.0);
+        if (resid->blocks.size() > 1) ldlt_compress(ctx, *resid, ctf, false, lag > 0.0 ? opt.residual_abs_frac * lag : -1.0);
+    } else {
     // Krylov mode: components of the warm-start residual far below the convergence tolerance are dropped
-    LDLtP resid = gale_residual_impl(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol,
+    resid = gale_residual_impl(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol,
                                      opt.warm_L.empty() ? nullptr : &opt.warm_L, opt.warm_EtL.empty() ? nullptr : &opt.warm_EtL,
                                      opt.rhs_lead_blocks, opt.rhs_e_coeff);
+    }
     ldlt_destructure(ctx, *resid, ctf, cex);
     LBlock rb = resid->blocks[0];
     Mat& R = run.R; Mat& Tm = run.Tm;
@@ -1468,7 +1485,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     const double alpha_res = rb.alpha;
     const int k = R.cols;
     const bool tdiag = rb.diag;      // a numerically diagonal T that is not flagged takes the general (dense-T) kernels: same result
-    const double norm0 = ldlt_norm_host(ctx, R, Tm, alpha_res);
+    const double norm0 = defer ? 1e300 : ldlt_norm_host(ctx, R, Tm, alpha_res);      // deferred: formed on the device below, read with the first chunk
     res.abstol = abstol; res.initial_norm = norm0; res.rhs_cols = k;
     res.norms.push_back(norm0); res.norm_iters.push_back(0);
     res.residual = resid;
@@ -1502,6 +1519,12 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     std::memset(&h0, 0, sizeof(h0));
     h0.maxiters = opt.maxiters; h0.abstol = abstol; h0.res_norm = norm0; h0.norms[0] = norm0;
     DRE_HIP(hipMemcpyAsync(st.p, &h0, sizeof(AdiState), hipMemcpyHostToDevice, ctx->stream));      // (whole block: the ticket of the fan groups' norm launch starts at 0)
+    if (defer) {
+        // norm of the initial residual as iteration 0 of the record, on the device (no host round trip)
+        Mat G0(ctx, k, k);
+        gemm(ctx, true, false, 1.0, R, R, 0.0, G0, nullptr, "gemm_gram");
+        ldlt_norm_update_state(ctx, G0, Tm, tdiag, alpha_res, st.p, 0);
+    }
     const int m = op.has_lr ? op.U.cols : 0;
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported (dre_hip.h, DRE_SMW_MAX_RANK)");
     auto& smw_cache = run.smw_cache;
@@ -1718,6 +1741,16 @@ void adi_advance(AdiRun& run, int budget) {
         const size_t blocks_before = Xw->blocks.size();
         const int lc_before = last_compression;
         const Mat R_chunk_start = R;
+        Mat hist_V, hist_R;                       // keep_history: the chunk's V_j and R_j side by side
+        const int iters_chunk_start = iters_host;
+        // the tolerance reltol ||C|| was not known when the solve began (AdiOptions::normC_dev): wait for it on this stream and take the decisions
+        // of adi.jl:115-123 for everything recorded so far, in iteration order
+        auto resolve_deferred = [&]() {
+            if (!run.defer) return;
+            if (opt.normC_wait) opt.normC_wait();
+            adi_decide_scan(ctx, st.p, iters_host, opt.normC_dev, run.reltol, opt.abstol);
+            run.defer = false;
+        };
         static const int chunk_timing = std::getenv("DRE_CHUNK_TIMING") ? std::atoi(std::getenv("DRE_CHUNK_TIMING")) : 0;
         const auto ct0 = std::chrono::steady_clock::now();
         int since_sync = 0, chunk_shifts = 0;
@@ -1832,7 +1865,8 @@ void adi_advance(AdiRun& run, int budget) {
                 // with a budget, the literal mode compresses at exact intervals or the chunk length is the previous solve's iteration count)
                 const bool strict = cex || budget < (1 << 29) || run.chunk_from_hint;
                 const int room = std::min(std::min(fan_max, opt.maxiters - iters_host), strict ? chunk_limit - chunk_shifts : fan_max);
-                const auto ups = room >= 2 ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
+                const int gmin = opt.keep_history ? 1 : 2;          // with a history even a single iteration takes this path (its R_j stays in the slab)
+                const auto ups = room >= gmin ? oracle->peek((size_t)room) : std::vector<std::complex<double>>();
                 int g = 0;
                 double mus[FAN_GMAX];
                 while (g < (int)ups.size() && g < room && ups[(size_t)g].imag() == 0.0) {
@@ -1843,20 +1877,22 @@ void adi_advance(AdiRun& run, int budget) {
                 }
                 FanCoef co;
                 while (g >= 2 && fan_coefficients(mus, g, &co) > ctx->adi_fan_max_coef) --g;
+                if (g == 1) (void)fan_coefficients(mus, 1, &co);
+                if (g < gmin) g = 0;
                 // which ranks this process plays: its own, or all of them one after the other (shard_emulate)
                 const bool emu = ctx->comm && ctx->comm->emulate > 1;
                 const int my_rank = ctx->comm ? ctx->comm->rank : 0;
                 auto mine = [&](int s_) { return fan_P == 1 || emu || (s_ % fan_P) == my_rank; };
                 std::vector<std::shared_ptr<FactorEntry<double>>> fes((size_t)std::max(g, 0));
-                if (lookahead && g >= 2) prefetch_ahead(std::complex<double>(0.0, 0.0), true);      // (first pass through the cycle: this group's and the next groups' factors; all waited for below)
-                for (int s_ = 0; s_ < g && g >= 2; ++s_) {
+                if (lookahead && g >= gmin) prefetch_ahead(std::complex<double>(0.0, 0.0), true);      // (first pass through the cycle: this group's and the next groups' factors; all waited for below)
+                for (int s_ = 0; s_ < g && g >= gmin; ++s_) {
                     if (!mine(s_)) continue;
                     if (lookahead) wait_prefetched(std::complex<double>(mus[s_], 0.0));
                     auto fe = get_factor<double>(ctx, op, cache, cache->real, std::complex<double>(mus[s_], 0.0), true, nullptr, !lookahead || run.check_now);
                     if (fe->dense) { g = 0; break; }              // the dense-inverse step has its own fused kernels
                     fes[(size_t)s_] = fe;
                 }
-                if (g >= 2) {
+                if (g >= gmin) {
                     const AdiState* dst = st.p;
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
                     const int gp = ceil_div(g, fan_P);                 // group positions per rank; W_s lives in slot (s mod P) gp + s div P
@@ -1943,7 +1979,15 @@ void adi_advance(AdiRun& run, int budget) {
                         comm_allgather_inplace(ctx, *ctx->comm, Wcat.p, (size_t)n * gp * k);
                     }
                     // V_j = sum_s c_js W_s,  R_j = R_0 - sum_s d_js E' W_s  for the g iterations: one pass over E' and the panels
-                    Mat Vcat(ctx, n, g * k), Rcat(ctx, n, g * k);
+                    Mat Vcat, Rcat;
+                    if (opt.keep_history) {
+                        // every iteration of the chunk side by side (the Rosenbrock-1 driver reads E'V_j = (R_{j-1} - R_j) / (2 mu_j) off these slabs)
+                        const int cap = chunk_limit + FAN_GMAX;
+                        if (hist_V.empty()) { hist_V = Mat(ctx, n, cap * k); hist_R = Mat(ctx, n, cap * k); }
+                        if (chunk_shifts + g <= cap) { Vcat = hist_V.colsview(chunk_shifts * k, g * k); Rcat = hist_R.colsview(chunk_shifts * k, g * k); }
+                        else run.hist_ok = false;
+                    }
+                    if (Vcat.p == nullptr) { Vcat = Mat(ctx, n, g * k); Rcat = Mat(ctx, n, g * k); }
                     fan_spmm_mix(ctx, P, Wcat, R, Vcat, Rcat, g, k, co, slots, dst);
                     for (int j = 0; j < g; ++j) {
                         const std::complex<double> muj = oracle->take(&res.warnings);
@@ -1962,6 +2006,12 @@ void adi_advance(AdiRun& run, int budget) {
                     continue;
                 }
             }
+            if (run.defer) {
+                // an iteration outside the fan path while the tolerance is still on its way: close the chunk first (its end resolves the tolerance)
+                if (!recs.empty()) break;
+                resolve_deferred();
+            }
+            run.hist_ok = false;                  // (its residual factor is updated in place: no history of this solve)
             std::complex<double> mu = oracle->take(&res.warnings);
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
@@ -2184,9 +2234,15 @@ void adi_advance(AdiRun& run, int budget) {
         }
         // synchronise once per chunk and find out how far the device really got
         dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
+        const bool was_deferred = run.defer;
+        resolve_deferred();
         AdiState h;
         const auto ct1 = std::chrono::steady_clock::now();
         ctx_fetch(ctx, st.p, sizeof(AdiState), &h);
+        if (was_deferred) {
+            run.abstol = h.abstol; res.abstol = h.abstol; res.initial_norm = h.norms[0];
+            if (!res.norms.empty()) res.norms[0] = h.norms[0];
+        }
         if (chunk_timing) {
             static double enq = 0.0, wait = 0.0; static long nch = 0, nit_ = 0;
             const auto ct2 = std::chrono::steady_clock::now();
@@ -2211,6 +2267,15 @@ void adi_advance(AdiRun& run, int budget) {
         last_compression = lc;
         res.iters = h.iters;
         res.res_norm = h.res_norm;
+        if (opt.keep_history && run.hist_ok) {
+            const int acc = std::max(0, std::min(h.iters, iters_host) - iters_chunk_start);        // accepted iterations of this chunk
+            if (acc > 0 && !hist_V.empty()) {
+                AdiHistChunk hc;
+                hc.R0 = R_chunk_start; hc.Rs = hist_R.colsview(0, acc * k); hc.Vs = hist_V.colsview(0, acc * k);
+                for (int j = 0; j < acc; ++j) hc.mu.push_back(all_shifts[(size_t)iters_chunk_start + j].real());
+                res.hist.push_back(std::move(hc));
+            } else if (acc > 0) run.hist_ok = false;
+        }
         if (h.smw_singular) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
         if (h.done || recs.empty()) finished = true;
         if (opt.compression && last_compression >= opt.compression_interval && (!finished || cex)) {
@@ -2228,6 +2293,7 @@ void adi_advance(AdiRun& run, int budget) {
             if (!defer) {
                 ldlt_compress(ctx, *Xw, ctf, cex);
                 last_compression = 0;
+                run.hist_ok = false;              // (the increments are no longer the V_j)
             }
         }
         if (resid && !resid->blocks.empty()) resid->blocks[0].L = R;      // (the factor may have moved to a fan group's buffer)
@@ -2248,6 +2314,7 @@ AdiResult adi_finish(AdiRun& run) {
     // look-ahead factorisations the solve did not get to use stay in a persistent cache (Cyclic lists): whatever runs on the main stream from
     // here on — the next Lyapunov solve finds them "known" — is ordered behind them
     for (auto& kv : run.prefetch_ev) (void)hipStreamWaitEvent(ctx->stream, kv.second.ev, 0);
+    res.hist_ok = opt.keep_history && run.hist_ok; res.Tm = run.Tm; res.alpha_res = run.alpha_res; res.tdiag = run.tdiag;
     if (run.finalized || run.res.rhs_cols == 0 || (run.iters_host == 0 && run.res.converged)) { run.finalized = true; return res; }
     run.finalized = true;
     auto check_used = [&]() { run.check_used(); };
@@ -2264,7 +2331,8 @@ AdiResult adi_finish(AdiRun& run) {
     res.shifts = all_shifts;
     res.X = Xw;
     res.converged = res.res_norm <= abstol;
-    if (run.max_growth > ctx->pivot_growth_warn) {
+    if (run.max_growth > ctx->pivot_growth_warn && opt.given_residual) res.warnings |= 16;      // (no right-hand side object to verify against)
+    else if (run.max_growth > ctx->pivot_growth_warn) {
         // The pivot-free LU met huge multipliers: the residual recurrence R <- R - 2 mu E'V may not describe X any more.  The claim is
         // checked once against the residual evaluated from scratch (lyapunov/residual.jl:3-31); a solve that only looks converged is
         // reported as not converged.
@@ -3420,6 +3488,255 @@ class SideWorker {
     bool busy_ = false, quit_ = false;
 };
 
+// =============================================================================================
+// Rosenbrock-1 time loop with the RESIDUAL RECURRENCE (round 4; general path: multifrontal solves, Cyclic real shifts).
+// Between two time steps the reference (lowrank_ros1.jl:35-60) compresses X (LDLt.jl:204-225), forms the feedback K = B'XE, the right-hand side
+// and the warm-start residual [G, E'L, F'L] from that compressed X (lyapunov/residual.jl:3-31) and compresses the residual: at n = 5177 that is
+// 4.7 of the 6 ms of a time step, all of it short dependent kernels, with the ADI iteration itself at 1.3 ms.  But step i's ADI already holds
+// everything step i + 1 needs.  With X_i = X_{i-1} + sum_j V_j (c_j T) V_j', c_j = -2 mu_j alpha, and the recurrence R_j = R_{j-1} - 2 mu_j E'V_j
+// (adi.jl:166-177):
+//     E'V_j = (R_{j-1} - R_j) / (2 mu_j)                                  — E' times every increment, without touching E or V
+//     K_i   = K_{i-1} + sum_j (B'V_j) (c_j T) (E'V_j)'                    — the feedback (lowrank_ros1.jl:53-57)
+//     Res_{i+1}(X_i) = alpha R_J T R_J'  -  dK' dK  +  (1/tau) sum_j (E'V_j) (c_j T) (E'V_j)',      dK = K_i - K_{i-1}
+// the last line because F_{i+1} = F_i - B dK and rhs_{i+1} - rhs_i = K_i'K_i - K_{i-1}'K_{i-1} + E'(X_i - X_{i-1})E/tau, and the cross terms with
+// K_i = B'X_iE collapse to -dK'dK.  (alpha R_J T R_J' is step i's residual at its last iterate: the ADI invariant.)  So the critical path of a
+// time step is: compress that factored residual (the same factor-form reduction as before, on [R_J, dK', E'V_1 .. E'V_J]) -> ADI.  X itself is
+// only an output: its compression (adi.jl:78-80, lowrank_ros1.jl:53) runs on the SIDE stream, driven by a parked host thread, beside the next
+// step, and the one thing the next solve needs from it — the tolerance reltol ||rhs_{i+1}||_F (adi.jl:61-62) — arrives in device memory
+// and is applied to the recorded norms at the end of the solve's first chunk (adi_advance, deferred decisions).
+// Same iterates as the reference's loop up to rounding: the identity is exact; what differs is that the truncation error of compressing X
+// (4 eps ||X||) no longer re-enters the next residual.  A step whose ADI leaves the fan path (complex shift, user solver, in-loop compression)
+// falls back to the reference's order for the next step.
+// =============================================================================================
+__global__ void k_blockdiag_scale_id(int m, double* __restrict__ D, double v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m * m) D[i] = (i % m == i / m) ? v : 0.0;
+}
+static bool ros1_recurrence_ok(Ctx* ctx, const GdreProblem& prob, int order, const AdiOptions& adi) {
+    static const bool env_on = !(std::getenv("DRE_ROS1_RECURRENCE") && std::atoi(std::getenv("DRE_ROS1_RECURRENCE")) == 0);
+    const int n = prob.P->n;
+    if (!env_on || !ctx->ros1_recurrence || order != 1 || adi.compress_exact || adi.inner_solve || adi.ignore_initial_guess || !adi.compression) return false;
+    if (adi.shifts.kind != ShiftSpec::CYCLIC || adi.shifts.values.empty() || adi.abstol >= 0.0) return false;
+    for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) return false;
+    if (n <= ctx->dense_inv_max_n || n < ctx->compress_factor_min_n || ctx->adi_fan < 2 || !prob.P->use_mfma_sweeps) return false;
+    return true;
+}
+static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, bool save_state, const AdiOptions& adi, int nsteps, GdreResult& out,
+                                 FactorCache& cache, const Feedback& fb0) {
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    const double ctf = adi.compress_tolfac;
+    // side context (own stream, pool, hints) + the parked thread that drives it
+    if (!ctx->side) {
+        auto sc = std::make_unique<Ctx>();
+        sc->device = ctx->device; sc->num_cus = ctx->num_cus;
+        sc->stream = create_stream(1);
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
+        sc->timer = std::make_unique<KernelTimer>();
+        sc->timer->enabled = ctx->prof_side;
+        ctx->side = std::move(sc);
+    }
+    Ctx* const side = ctx->side.get();
+    side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
+    side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
+    side->compress_factor_min_cols = ctx->compress_factor_min_cols; side->compress_sketch = ctx->compress_sketch;
+    side->compress_sketch_min_cols = ctx->compress_sketch_min_cols; side->compress_sketch_extra = ctx->compress_sketch_extra;
+    side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
+    side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
+    SideWorker worker;
+    std::vector<hipEvent_t> events;
+    auto new_event = [&]() { hipEvent_t e; DRE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); events.push_back(e); return e; };
+    struct EvGuard { std::vector<hipEvent_t>& v; ~EvGuard() { for (auto e : v) (void)hipEventDestroy(e); } } evguard{events};
+    // X as the side stream holds it: compressed up to the last finished job (only the worker writes it while a job is pending)
+    auto sideX = std::make_shared<LDLtP>(prob.X0);
+    std::vector<LDLtP> saved((size_t)nsteps + 1);
+    DevArr<double> normC_dev(ctx, 2);               // ||rhs||_F of the next step, written by the side stream (double buffered)
+    hipEvent_t ev_side_last = nullptr;              // end of the pending side job
+    bool job_pending = false;
+    auto join_side = [&]() {                        // host: the job is enqueued (and, its read-backs being synchronous, all but done); main stream: after it
+        if (!job_pending) return;
+        worker.wait();
+        DRE_HIP(hipStreamWaitEvent(ctx->stream, ev_side_last, 0));
+        job_pending = false;
+    };
+    struct JoinGuard { SideWorker& w; bool& p; ~JoinGuard() { if (p) { try { w.wait(); } catch (...) {} } } } jguard{worker, job_pending};
+
+    std::map<uint64_t, DevArr<double>> valF_by_tau;
+    Mat Kt = fb0.Kt;                                // K(t_{i-1})'
+    bool have_hist = false;
+    AdiResult prev;                                 // pieces of the previous solve the recurrence needs (hist, Tm, alpha_res, residual)
+    Mat prev_dKt;
+    double abstol_prev = -1.0;
+    for (int i = 1; i <= nsteps; ++i) {
+        const double tau = out.t[i - 1] - out.t[i];
+        GaleOperator op;
+        op.P = &P;
+        op.tag = tag_of(1, tau);
+        auto it = valF_by_tau.find(op.tag);
+        if (it == valF_by_tau.end()) {
+            DevArr<double> v(ctx, P.nnz);
+            vals_axpby(ctx, P.nnz, 1.0, P.valAt.p, -1.0 / (2.0 * tau), P.valEt.p, v.p);      // A - E/(2 tau)   (lowrank_ros1.jl:39)
+            it = valF_by_tau.emplace(op.tag, v).first;
+        }
+        op.valFt = it->second; op.cA = 1.0; op.cE = -1.0 / (2.0 * tau);
+        op.has_lr = true; op.U = prob.B; op.Vt = Kt; op.alpha = -1.0;
+        AdiOptions a2 = adi;
+        a2.final_compress = false; a2.keep_history = true;
+        AdiResult ar;
+        std::vector<LBlock> incr;
+        if (!have_hist) {
+            // the reference's order (first step, or after a solve without history): compressed X -> feedback pieces -> right-hand side -> ADI
+            join_side();
+            LDLtP X = *sideX;
+            Feedback fb = feedback(ctx, prob, *X, ctf, false);
+            const int r = fb.L.cols;
+            Mat G(ctx, n, q + r);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            { Mat d = G.colsview(q, r); copy_mat(ctx, fb.EtL, d); }
+            Mat S(ctx, q + r, q + r);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d = S.view(q, q, r, r);
+                copy_mat(ctx, fb.D, d, fb.alpha / tau);
+                gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
+            }
+            LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
+            if (X->iszero()) ldlt_compress(ctx, *rhs, ctf, false);
+            const size_t nb_prev = X->blocks.size();
+            ar = adi_solve(ctx, op, *rhs, X, a2, &cache);
+            bool intact = ar.X->blocks.size() >= nb_prev;
+            for (size_t bi = 0; intact && bi < nb_prev; ++bi) intact = ar.X->blocks[bi].L.p == X->blocks[bi].L.p;
+            if (intact) incr.assign(ar.X->blocks.begin() + (long)nb_prev, ar.X->blocks.end());
+            else { ar.hist_ok = false; *sideX = ar.X; }             // (the solve compressed in between: its X stands)
+        } else {
+            // the recurrence: [R_J, dK', E'V_1 .. E'V_J] with their inner blocks IS the warm-start residual of this step
+            auto resid = std::make_shared<LDLt>();
+            resid->n = n;
+            if (prev.residual && !prev.residual->blocks.empty() && prev.residual->blocks[0].L.cols > 0)
+                resid->blocks.push_back({prev.residual->blocks[0].L, prev.Tm, prev.alpha_res, prev.tdiag, false});
+            if (!prev.hist.empty()) {
+                Mat Im(ctx, m, m);
+                hipLaunchKernelGGL(k_blockdiag_scale_id, dim3(ceil_div(m * m, 64)), dim3(64), 0, ctx->stream, m, Im.p, 1.0);
+                resid->blocks.push_back({prev_dKt, Im, -1.0, true, false});
+                const int k = prev.Tm.rows;
+                for (auto& hc : prev.hist) {
+                    const int J = (int)hc.mu.size();
+                    Mat EV(ctx, n, J * k);
+                    ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                    for (int j = 0; j < J; ++j)
+                        resid->blocks.push_back({EV.colsview(j * k, k), prev.Tm, -2.0 * hc.mu[(size_t)j] * prev.alpha_res / tau, prev.tdiag, false});
+                }
+            }
+            a2.given_residual = resid;
+            a2.abstol_lag = abstol_prev;
+            a2.normC_dev = normC_dev.p + ((i - 1) & 1);
+            a2.normC_wait = [&]() { join_side(); };
+            LDLt none; none.n = n;
+            ar = adi_solve(ctx, op, none, nullptr, a2, &cache);
+            for (auto& b : ar.X->blocks) if (b.L.cols > 0) incr.push_back(b);
+            if (job_pending) join_side();                          // (a solve that never reached its chunk end — nothing to iterate — still owes the join)
+        }
+        out.adi_iters += ar.iters;
+        size_t hist_its = 0;
+        for (auto& hc : ar.hist) hist_its += hc.mu.size();
+        const bool hist = ar.hist_ok && hist_its == (size_t)ar.iters && (int)incr.size() == ar.iters;
+        Mat Kt_new;
+        if (hist) {
+            // K_i' = K_{i-1}' + sum_j (E'V_j) (c_j T) (V_j'B)
+            Mat dKt(ctx, n, m);
+            fill_mat(ctx, dKt, 0.0);
+            const int k = ar.Tm.rows;
+            for (auto& hc : ar.hist) {
+                const int J = (int)hc.mu.size();
+                Mat EV(ctx, n, J * k), VtB(ctx, J * k, m), Mx(ctx, J * k, m);
+                ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                gemm(ctx, true, false, 1.0, hc.Vs, prob.B, 0.0, VtB, nullptr, "gemm_feedback");
+                std::vector<GemmBatchDesc> descs;
+                for (int j = 0; j < J; ++j)
+                    descs.push_back({ar.Tm.p, VtB.p + (size_t)j * k, Mx.p + (size_t)j * k, nullptr, -2.0 * hc.mu[(size_t)j] * ar.alpha_res, k, m, k, ar.Tm.ld, VtB.ld, Mx.ld, 0});
+                gemm_batched(ctx, descs, "gemm_feedback");
+                gemm(ctx, false, false, 1.0, EV, Mx, 1.0, dKt, nullptr, "gemm_feedback");
+            }
+            Kt_new = Mat(ctx, n, m);
+            copy_mat(ctx, Kt, Kt_new);
+            { const size_t tot = (size_t)n * m; hipLaunchKernelGGL(k_axpy_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, 1.0, (const double*)dKt.p, Kt_new.p); }
+            prev_dKt = dKt;
+            // side job: X_i = compress(X_{i-1} + increments), then ||rhs_{i+1}||_F for the next solve's tolerance
+            join_side();                                            // (one job at a time; usually long finished)
+            hipEvent_t e_main = new_event(), e_side = new_event();
+            DRE_HIP(hipEventRecord(e_main, ctx->stream));
+            const double tau_next = i < nsteps ? out.t[i] - out.t[i + 1] : tau;
+            double* const slot = normC_dev.p + (i & 1);
+            const Mat Ct = prob.Ct, Bm = prob.B;
+            const bool want_save = save_state;
+            LDLtP* const saved_slot = &saved[(size_t)i];
+            worker.submit([=, &P]() {
+                DRE_HIP(hipSetDevice(side->device));
+                DRE_HIP(hipStreamWaitEvent(side->stream, e_main, 0));
+                auto Xs = std::make_shared<LDLt>();
+                Xs->n = n;
+                for (auto& b : (*sideX)->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
+                for (auto& b : incr) Xs->blocks.push_back(b);
+                if (Xs->blocks.empty()) Xs->blocks.push_back({Mat(side, n, 0), Mat(side, 0, 0), 1.0, true});
+                ldlt_destructure(side, *Xs, ctf, false);
+                *sideX = Xs;
+                if (want_save) *saved_slot = Xs;
+                // rhs_{i+1} = [C', E'L] blkdiag(I, BtLD'BtLD + alpha D / tau) [C', E'L]'   (lowrank_ros1.jl:42-43) -> its Frobenius norm, on the device
+                const LBlock& b = Xs->blocks[0];
+                const int r = b.L.cols;
+                Mat G(side, n, q + r), S(side, q + r, q + r);
+                { Mat d = G.colsview(0, q); copy_mat(side, Ct, d); }
+                set_identity(side, S, 0.0);
+                { Mat d = S.view(0, 0, q, q); set_identity(side, d, 1.0); }
+                if (r > 0) {
+                    Mat d = G.colsview(q, r);
+                    spmm(side, P, P.valEt.p, b.L, d, 1.0, 0.0);
+                    Mat BtL(side, m, r), BtLD(side, m, r);
+                    gemm(side, true, false, 1.0, Bm, b.L, 0.0, BtL);
+                    gemm(side, false, false, b.alpha, BtL, b.D, 0.0, BtLD);
+                    Mat d2 = S.view(q, q, r, r);
+                    copy_mat(side, b.D, d2, b.alpha / tau_next);
+                    gemm(side, true, false, 1.0, BtLD, BtLD, 1.0, d2);
+                }
+                ldlt_norm_device(side, G, S, 1.0, slot);
+                DRE_HIP(hipEventRecord(e_side, side->stream));
+                DRE_HIP(hipStreamSynchronize(side->stream));       // the increments' buffers go back to the MAIN pool when this closure dies
+            });
+            ev_side_last = e_side;
+            job_pending = true;
+        } else {
+            // no history (an iteration outside the fan path, a compression inside the solve): the reference's order for this step's tail
+            join_side();
+            if (!incr.empty() || (*sideX)->blocks.empty()) {
+                auto Xs = std::make_shared<LDLt>();
+                Xs->n = n;
+                for (auto& b : (*sideX)->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
+                for (auto& b : incr) Xs->blocks.push_back(b);
+                *sideX = Xs;
+            }
+            if ((*sideX).get() == prob.X0.get()) *sideX = std::make_shared<LDLt>(*prob.X0);
+            Feedback fb = feedback(ctx, prob, **sideX, ctf, false);
+            Kt_new = fb.Kt;
+            if (save_state) saved[(size_t)i] = *sideX;
+        }
+        abstol_prev = ar.abstol;
+        have_hist = hist;
+        Kt = Kt_new;
+        out.Kt.push_back(Kt);
+        prev = ar;                                   // (shallow: the slabs stay alive until the next residual is built)
+        prev.X.reset();
+        AdiResult rec = std::move(ar);
+        rec.X.reset(); rec.residual.reset(); rec.hist.clear();
+        out.gale.push_back(std::move(rec));
+    }
+    join_side();
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    if (save_state) for (int i = 1; i <= nsteps; ++i) out.X.push_back(saved[(size_t)i] ? saved[(size_t)i] : *sideX);
+    else out.X.push_back(*sideX);
+}
+
 GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {
     DRE_REQUIRE(order == 1 || order == 2, "only Ros1 and Ros2 have a low-rank formulation");
     DRE_REQUIRE(dt != 0.0, "dt must be nonzero");
@@ -3436,6 +3753,11 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     Feedback fb = feedback(ctx, prob, *X, ctf, cex);
     out.Kt.push_back(fb.Kt);
     FactorCache cache;
+    if (ros1_recurrence_ok(ctx, prob, order, adi) && nsteps >= 1) {
+        ros1_recurrence_loop(ctx, prob, dt, save_state, adi, nsteps, out, cache, fb);
+        out.nfactor = cache.nfactor;
+        return out;
+    }
     // Ros1 at small n: X stays "warm start + increments" between two compressions (every xevery-th step and at the end); right-hand side,
     // feedback and warm-start residual work on the block list (the direct-form compression does not care about the number of columns)
     const bool xside_env = ctx->x_side_stream != 0;

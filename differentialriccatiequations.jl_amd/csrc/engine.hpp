@@ -117,7 +117,17 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
     int rhs_lead_blocks = -1;        // internal (Ros1 driver): the right-hand side is  C = (first rhs_lead_blocks blocks) + rhs_e_coeff * E'XE
     double rhs_e_coeff = 0.0;        //   with X the warm start, so the residual folds the last term into F: (F + coeff/2 E)' X E + E' X (F + coeff/2 E)
+    // internal (Ros1 driver with the residual recurrence, engine.hip ros1_recurrence_loop): the warm-start residual arrives as a block list
+    // (no right-hand side, no initial guess: the solve returns the INCREMENT), the tolerance reltol * ||C||_F arrives later in device memory
+    // (the side stream forms it from the compressed X) and the convergence decisions of the first chunk are taken when it is there
+    std::shared_ptr<struct LDLt> given_residual;
+    const double* normC_dev = nullptr;
+    std::function<void()> normC_wait;    // makes the calling stream wait for *normC_dev
+    double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
+    bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
 };
+// iterations of one chunk of a solve with keep_history: V = [V_1 .. V_J], R = [R_1 .. R_J] (n x J k), R0 = the residual factor they started from
+struct AdiHistChunk { Mat R0, Rs, Vs; std::vector<double> mu; };
 struct AdiResult {
     LDLtP X;
     LDLtP residual;
@@ -129,6 +139,11 @@ struct AdiResult {
     std::vector<int> norm_iters;                  // iteration number of each entry of `norms`
     std::vector<std::complex<double>> shifts;     // shifts consumed
     int rhs_cols = 0;
+    // keep_history: the accepted iterations chunk by chunk, the inner matrix and scaling of the residual  alpha_res R T R'  (T never changes
+    // during a solve, adi.jl:150-177), and whether every iteration is in there (false: an iteration ran outside the fan path or X was compressed)
+    std::vector<AdiHistChunk> hist;
+    bool hist_ok = false;
+    Mat Tm; double alpha_res = 1.0; bool tdiag = false;
 };
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
                     FactorCache* cache);

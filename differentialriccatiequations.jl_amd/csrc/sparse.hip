@@ -261,13 +261,13 @@ __global__ __launch_bounds__(256) void k_fan_spmm_mix(int n, const int* __restri
 }
 void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const FanSlots& sl, const AdiState* st) {
     const int n = P.n;
-    DRE_REQUIRE(g >= 2 && g <= FAN_GMAX && W.rows == n && W.cols >= g * k && V.cols == g * k && Rc.cols == g * k && R0.cols == k, "fan_spmm_mix: shapes");
+    DRE_REQUIRE(g >= 1 && g <= FAN_GMAX && W.rows == n && W.cols >= g * k && V.cols == g * k && Rc.cols == g * k && R0.cols == k, "fan_spmm_mix: shapes");
     for (int s = 0; s < g; ++s) DRE_REQUIRE(sl.s[s] >= 0 && (sl.s[s] + 1) * k <= W.cols, "fan_spmm_mix: slot outside the panel");
     TimedScope ts(ctx, "fan_spmm_mix", 12.0 * P.nnz + 4.0 * n + 8.0 * n * k * (3.0 * g + 1.0), 2.0 * (double)P.nnz * g * k + 2.0 * n * k * (double)g * (g + 1));
     const dim3 grid(ceil_div(n, 256), ceil_div(k, FAN_CB)), block(256);
 #define DRE_FAN_CASE(G_) case G_: hipLaunchKernelGGL((k_fan_spmm_mix<G_>), grid, block, 0, ctx->stream, n, (const int*)P.ptr.p, (const int*)P.idx.p, (const double*)P.valEt.p, k, \
                                                     (const double*)W.p, W.ld, (const double*)R0.p, R0.ld, V.p, V.ld, Rc.p, Rc.ld, co, sl, st); break;
-    switch (g) { DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) }
+    switch (g) { DRE_FAN_CASE(1) DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) }
 #undef DRE_FAN_CASE
     DRE_HIP(hipGetLastError());
 }
