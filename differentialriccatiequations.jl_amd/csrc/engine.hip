@@ -1408,6 +1408,7 @@ struct AdiRun {
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
     bool chunk_from_hint = false;
+    bool abstol_pending = false;      // the tolerance was formed on the device (AdiOptions::normC_build): the host copy follows with the first chunk
     bool defer = false;               // the tolerance is still on its way (AdiOptions::normC_dev): kernels record norms, decisions follow at the chunk end
     double reltol = 0.0;
     bool hist_ok = true;
@@ -1524,6 +1525,12 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         Mat G0(ctx, k, k);
         gemm(ctx, true, false, 1.0, R, R, 0.0, G0, nullptr, "gemm_gram");
         ldlt_norm_update_state(ctx, G0, Tm, tdiag, alpha_res, st.p, 0);
+        if (opt.normC_build) {
+            // the tolerance is formed right here, on this stream: the decisions are live from iteration 0 on; the host reads it with the first chunk
+            opt.normC_build(R, Tm, alpha_res);
+            adi_decide_scan(ctx, st.p, 0, opt.normC_dev, reltol, -1.0);
+            run.defer = false; run.abstol_pending = true;
+        }
     }
     const int m = op.has_lr ? op.U.cols : 0;
     DRE_REQUIRE(m <= 32, "SMW: more than 32 low-rank columns not supported (dre_hip.h, DRE_SMW_MAX_RANK)");
@@ -1893,6 +1900,11 @@ void adi_advance(AdiRun& run, int budget) {
                     fes[(size_t)s_] = fe;
                 }
                 if (g >= gmin) {
+                    static const bool fht = std::getenv("DRE_FAN_HOST_TIMING") != nullptr;
+                    static double ft[6] = {0, 0, 0, 0, 0, 0}; static long fn_ = 0;
+                    auto fnow = []() { return std::chrono::steady_clock::now(); };
+                    auto fus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+                    const auto f0 = fnow();
                     const AdiState* dst = st.p;
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
                     const int gp = ceil_div(g, fan_P);                 // group positions per rank; W_s lives in slot (s mod P) gp + s div P
@@ -1953,7 +1965,9 @@ void adi_advance(AdiRun& run, int budget) {
                         const Factor<double>* Fs[MF_ZMAX];
                         for (int z = 0; z < gr; ++z) Fs[z] = &fes[(size_t)pos[(size_t)z]]->f;
                         Mat Wr = Wcat.colsview(r * gp * k, gr * k);          // slab r: its solves side by side
+                        const auto f1 = fnow();
                         ok = mf_solve_batch(ctx, P, Fs, gr, R.p, R.ld, k, Wr.p, Wr.ld, k, dst);
+                        if (fht) { ft[0] += fus(f0, f1); ft[1] += fus(f1, fnow()); }
                         if (!ok) break;
                         for (int s_ : pos) used_real.push_back(fes[(size_t)s_]);
                         if (op.has_lr) {
@@ -1978,6 +1992,7 @@ void adi_advance(AdiRun& run, int budget) {
                         TimedScope ts(ctx, "comm_allgather_w", 8.0 * n * (double)fan_P * gp * k, 0.0);
                         comm_allgather_inplace(ctx, *ctx->comm, Wcat.p, (size_t)n * gp * k);
                     }
+                    const auto f2 = fnow();
                     // V_j = sum_s c_js W_s,  R_j = R_0 - sum_s d_js E' W_s  for the g iterations: one pass over E' and the panels
                     Mat Vcat, Rcat;
                     if (opt.keep_history) {
@@ -1989,6 +2004,7 @@ void adi_advance(AdiRun& run, int budget) {
                     }
                     if (Vcat.p == nullptr) { Vcat = Mat(ctx, n, g * k); Rcat = Mat(ctx, n, g * k); }
                     fan_spmm_mix(ctx, P, Wcat, R, Vcat, Rcat, g, k, co, slots, dst);
+                    const auto f3 = fnow();
                     for (int j = 0; j < g; ++j) {
                         const std::complex<double> muj = oracle->take(&res.warnings);
                         all_shifts.push_back(muj);
@@ -1999,8 +2015,15 @@ void adi_advance(AdiRun& run, int budget) {
                         recs.push_back({iters_host, Xw->blocks.size(), 1, Rj});
                         ++since_sync; ++chunk_shifts;
                     }
+                    const auto f4 = fnow();
                     residual_norm_group_diag(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
+                    if (fht) {
+                        const auto f5 = fnow();
+                        ft[2] += fus(f2, f3); ft[3] += fus(f3, f4); ft[4] += fus(f4, f5); ft[5] += fus(f0, f5);
+                        if (++fn_ % 128 == 0) std::fprintf(stderr, "[fan host, us per group] before the solves %.1f | batched solves %.1f | mix %.1f | bookkeeping %.1f | norms %.1f | total %.1f\n",
+                                                           ft[0] / fn_, ft[1] / fn_, ft[2] / fn_, ft[3] / fn_, ft[4] / fn_, ft[5] / fn_);
+                    }
                     if (opt.compression && chunk_shifts >= chunk_limit) break;
                     if (!opt.compression && since_sync >= std::min(10, chunk_limit)) break;
                     continue;
@@ -2239,9 +2262,10 @@ void adi_advance(AdiRun& run, int budget) {
         AdiState h;
         const auto ct1 = std::chrono::steady_clock::now();
         ctx_fetch(ctx, st.p, sizeof(AdiState), &h);
-        if (was_deferred) {
+        if (was_deferred || run.abstol_pending) {
             run.abstol = h.abstol; res.abstol = h.abstol; res.initial_norm = h.norms[0];
             if (!res.norms.empty()) res.norms[0] = h.norms[0];
+            run.abstol_pending = false;
         }
         if (chunk_timing) {
             static double enq = 0.0, wait = 0.0; static long nch = 0, nit_ = 0;
@@ -2348,9 +2372,21 @@ AdiResult adi_finish(AdiRun& run) {
 
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
                     FactorCache* cache) {
+    static const bool tm = std::getenv("DRE_REC_TIMING") != nullptr;
+    static double tb = 0, ta = 0, tf = 0; static long ns = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     auto run = adi_begin(ctx, op, C, initial_guess, opt_in, cache);
+    const auto t1 = std::chrono::steady_clock::now();
     while (!run->finished) adi_advance(*run, 1 << 30);
-    return adi_finish(*run);
+    const auto t2 = std::chrono::steady_clock::now();
+    AdiResult r = adi_finish(*run);
+    if (tm) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        tb += us(t0, t1); ta += us(t1, t2); tf += us(t2, t3);
+        if (++ns % 12 == 0) std::fprintf(stderr, "[adi_solve host, us per solve] begin (residual) %.0f | advance %.0f | finish %.0f\n", tb / ns, ta / ns, tf / ns);
+    }
+    return r;
 }
 // The iterate and the residual object of a running solve as the reference's observer sees them at adi.jl:119 (Callbacks.jl:97-107):
 // X shares its factors with the solver (increments are never modified; a later compression replaces the list, not the buffers), the
@@ -3521,8 +3557,15 @@ static bool ros1_recurrence_ok(Ctx* ctx, const GdreProblem& prob, int order, con
     if (n <= ctx->dense_inv_max_n || n < ctx->compress_factor_min_n || ctx->adi_fan < 2 || !prob.P->use_mfma_sweeps) return false;
     return true;
 }
+// state of X as the side stream holds it: compressed up to time step `step` (one block), E' times its factor, completion event
+struct SideState { int step = 0; LDLtP X; Mat EtL; hipEvent_t ev = nullptr; };
+// what step s added to  E'XE / tau_{s+1}:  Q Dq Q' - aT-weighted R_J R_J' + dK'dK   (the compressed warm-start residual of step s + 1, the final
+// residual factor of step s, the change of the feedback) — kept until the side stream's X includes step s
+struct StepDelta { int s; double tau; Mat Q, Dq, Rj, Tj; double aj; Mat dKt; };
+
 static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, bool save_state, const AdiOptions& adi, int nsteps, GdreResult& out,
                                  FactorCache& cache, const Feedback& fb0) {
+    (void)dt;
     const Pencil& P = *prob.P;
     const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
     const double ctf = adi.compress_tolfac;
@@ -3545,22 +3588,66 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
     side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
     SideWorker worker;
-    std::vector<hipEvent_t> events;
-    auto new_event = [&]() { hipEvent_t e; DRE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); events.push_back(e); return e; };
-    struct EvGuard { std::vector<hipEvent_t>& v; ~EvGuard() { for (auto e : v) (void)hipEventDestroy(e); } } evguard{events};
-    // X as the side stream holds it: compressed up to the last finished job (only the worker writes it while a job is pending)
-    auto sideX = std::make_shared<LDLtP>(prob.X0);
+    // events: a ring (at most one job is in flight; a slot is reused eight jobs later)
+    hipEvent_t ring[16];
+    for (auto& e : ring) DRE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t* v; ~EvGuard() { for (int i = 0; i < 16; ++i) (void)hipEventDestroy(v[i]); } } evguard{ring};
+    long njobs = 0;
+    std::mutex smu;
+    auto cur = std::make_shared<SideState>();
+    cur->step = 0; cur->X = prob.X0; cur->EtL = fb0.EtL;
+    auto get_state = [&]() { std::lock_guard<std::mutex> lk(smu); return cur; };
     std::vector<LDLtP> saved((size_t)nsteps + 1);
-    DevArr<double> normC_dev(ctx, 2);               // ||rhs||_F of the next step, written by the side stream (double buffered)
-    hipEvent_t ev_side_last = nullptr;              // end of the pending side job
+    std::vector<LBlock> pend;                       // increments the side stream has not been handed yet
+    int pend_upto = 0;
     bool job_pending = false;
-    auto join_side = [&]() {                        // host: the job is enqueued (and, its read-backs being synchronous, all but done); main stream: after it
+    static const bool rec_timing = std::getenv("DRE_REC_TIMING") != nullptr;
+    double t_join = 0.0, t_solve = 0.0, t_tail = 0.0; long n_join = 0, n_jobs_t = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    auto join_side = [&]() {                        // host: the running job is finished (its read-backs are synchronous) and its state published
         if (!job_pending) return;
+        const auto a = now();
         worker.wait();
-        DRE_HIP(hipStreamWaitEvent(ctx->stream, ev_side_last, 0));
+        if (rec_timing) { t_join += us(a, now()); ++n_join; }
         job_pending = false;
     };
     struct JoinGuard { SideWorker& w; bool& p; ~JoinGuard() { if (p) { try { w.wait(); } catch (...) {} } } } jguard{worker, job_pending};
+    // hand everything pending to the side stream: X_upto = compress(X_base + increments), E' times its factor
+    auto submit_job = [&]() {
+        if (pend.empty() && pend_upto == get_state()->step) return;
+        join_side();
+        hipEvent_t e_main = ring[(2 * njobs) % 16], e_side = ring[(2 * njobs + 1) % 16];
+        ++njobs; ++n_jobs_t;
+        DRE_HIP(hipEventRecord(e_main, ctx->stream));
+        const auto base = get_state();
+        const std::vector<LBlock> blocks = pend;
+        const int target = pend_upto;
+        pend.clear();
+        LDLtP* const saved_slot = save_state ? &saved[(size_t)target] : nullptr;
+        auto* curp = &cur; auto* mup = &smu;
+        worker.submit([=, &P]() {
+            DRE_HIP(hipSetDevice(side->device));
+            DRE_HIP(hipStreamWaitEvent(side->stream, e_main, 0));
+            if (base->ev) DRE_HIP(hipStreamWaitEvent(side->stream, base->ev, 0));
+            auto Xs = std::make_shared<LDLt>();
+            Xs->n = n;
+            for (auto& b : base->X->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
+            for (auto& b : blocks) Xs->blocks.push_back(b);
+            if (Xs->blocks.empty()) Xs->blocks.push_back({Mat(side, n, 0), Mat(side, 0, 0), 1.0, true});
+            ldlt_destructure(side, *Xs, ctf, false);
+            auto st = std::make_shared<SideState>();
+            st->step = target; st->X = Xs; st->ev = e_side;
+            const LBlock& b = Xs->blocks[0];
+            st->EtL = Mat(side, n, b.L.cols);
+            if (b.L.cols > 0) spmm(side, P, P.valEt.p, b.L, st->EtL, 1.0, 0.0);
+            DRE_HIP(hipEventRecord(e_side, side->stream));
+            DRE_HIP(hipStreamSynchronize(side->stream));       // the increments' buffers go back to the MAIN pool when this closure dies
+            if (saved_slot) *saved_slot = Xs;
+            { std::lock_guard<std::mutex> lk(*mup); *curp = st; }
+        });
+        job_pending = true;
+    };
 
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     Mat Kt = fb0.Kt;                                // K(t_{i-1})'
@@ -3568,6 +3655,10 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     AdiResult prev;                                 // pieces of the previous solve the recurrence needs (hist, Tm, alpha_res, residual)
     Mat prev_dKt;
     double abstol_prev = -1.0;
+    std::vector<StepDelta> deltas;                  // steps the side stream's X does not include yet
+    DevArr<double> normC_dev(ctx, 1);
+    Mat Im(ctx, m, m);
+    set_identity(ctx, Im, 1.0);
     for (int i = 1; i <= nsteps; ++i) {
         const double tau = out.t[i - 1] - out.t[i];
         GaleOperator op;
@@ -3585,10 +3676,15 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         a2.final_compress = false; a2.keep_history = true;
         AdiResult ar;
         std::vector<LBlock> incr;
+        const auto ts0 = now();
         if (!have_hist) {
             // the reference's order (first step, or after a solve without history): compressed X -> feedback pieces -> right-hand side -> ADI
+            if (!pend.empty() || pend_upto != get_state()->step) submit_job();
             join_side();
-            LDLtP X = *sideX;
+            const auto st = get_state();
+            if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+            deltas.clear();
+            LDLtP X = st->X;
             Feedback fb = feedback(ctx, prob, *X, ctf, false);
             const int r = fb.L.cols;
             Mat G(ctx, n, q + r);
@@ -3609,16 +3705,22 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             bool intact = ar.X->blocks.size() >= nb_prev;
             for (size_t bi = 0; intact && bi < nb_prev; ++bi) intact = ar.X->blocks[bi].L.p == X->blocks[bi].L.p;
             if (intact) incr.assign(ar.X->blocks.begin() + (long)nb_prev, ar.X->blocks.end());
-            else { ar.hist_ok = false; *sideX = ar.X; }             // (the solve compressed in between: its X stands)
+            else {
+                // the solve compressed in between: its X stands (published as the side state of this step; nothing pending)
+                ar.hist_ok = false;
+                auto st2 = std::make_shared<SideState>();
+                st2->step = i; st2->X = ar.X;
+                { std::lock_guard<std::mutex> lk(smu); cur = st2; }
+                pend_upto = i;
+            }
         } else {
             // the recurrence: [R_J, dK', E'V_1 .. E'V_J] with their inner blocks IS the warm-start residual of this step
             auto resid = std::make_shared<LDLt>();
             resid->n = n;
-            if (prev.residual && !prev.residual->blocks.empty() && prev.residual->blocks[0].L.cols > 0)
-                resid->blocks.push_back({prev.residual->blocks[0].L, prev.Tm, prev.alpha_res, prev.tdiag, false});
+            Mat RJ;                                   // final residual factor of the previous solve
+            if (prev.residual && !prev.residual->blocks.empty() && prev.residual->blocks[0].L.cols > 0) RJ = prev.residual->blocks[0].L;
+            if (RJ.cols > 0) resid->blocks.push_back({RJ, prev.Tm, prev.alpha_res, prev.tdiag, false});
             if (!prev.hist.empty()) {
-                Mat Im(ctx, m, m);
-                hipLaunchKernelGGL(k_blockdiag_scale_id, dim3(ceil_div(m * m, 64)), dim3(64), 0, ctx->stream, m, Im.p, 1.0);
                 resid->blocks.push_back({prev_dKt, Im, -1.0, true, false});
                 const int k = prev.Tm.rows;
                 for (auto& hc : prev.hist) {
@@ -3631,23 +3733,72 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             }
             a2.given_residual = resid;
             a2.abstol_lag = abstol_prev;
-            a2.normC_dev = normC_dev.p + ((i - 1) & 1);
-            a2.normC_wait = [&]() { join_side(); };
+            a2.normC_dev = normC_dev.p;
+            // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
+            //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)
+            // with X_b the latest X the side stream has finished (b >= i - 4) — one Gram matrix of a few hundred columns
+            a2.normC_build = [&, i, tau, RJ](const Mat& Q, const Mat& Dq, double aq) {
+                StepDelta dl;
+                dl.s = i - 1; dl.tau = tau; dl.Q = Q; dl.Dq = Mat(ctx, Dq.rows, Dq.cols); copy_mat(ctx, Dq, dl.Dq, aq);
+                dl.Rj = RJ; dl.Tj = prev.Tm; dl.aj = prev.alpha_res; dl.dKt = prev.hist.empty() ? Mat() : prev_dKt;
+                deltas.push_back(dl);
+                auto st = get_state();
+                if ((i - 1) - st->step > 3) { join_side(); st = get_state(); }
+                if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+                while (!deltas.empty() && deltas.front().s <= st->step) deltas.erase(deltas.begin());
+                const LBlock& xb = st->X->blocks[0];
+                const int r = xb.L.cols;
+                int cols = q + m + r;
+                for (auto& d : deltas) cols += d.Q.cols + d.Rj.cols + (d.dKt.cols > 0 ? m : 0);
+                Mat F(ctx, n, cols), S(ctx, cols, cols);
+                fill_mat(ctx, S, 0.0);
+                std::vector<CopyDesc> cd;
+                int off = 0;
+                auto put = [&](const Mat& L, const Mat* D, double scale, bool identity) {
+                    if (L.cols == 0) return;
+                    Mat dst = F.colsview(off, L.cols);
+                    cd.push_back({L.p, dst.p, n, L.cols, L.ld, dst.ld});
+                    Mat ds = S.view(off, off, L.cols, L.cols);
+                    if (identity) set_identity(ctx, ds, scale); else copy_mat(ctx, *D, ds, scale);
+                    off += L.cols;
+                };
+                put(prob.Ct, nullptr, 1.0, true);
+                put(Kt, nullptr, 1.0, true);
+                put(st->EtL, &xb.D, xb.alpha / tau, false);
+                for (auto& d : deltas) {
+                    const double sc = d.tau / tau;
+                    put(d.Q, &d.Dq, sc, false);
+                    put(d.Rj, &d.Tj, -sc * d.aj, false);
+                    if (d.dKt.cols > 0) put(d.dKt, nullptr, sc, true);
+                }
+                copy_batched(ctx, cd);
+                ldlt_norm_device(ctx, F, S, 1.0, normC_dev.p);
+            };
             LDLt none; none.n = n;
             ar = adi_solve(ctx, op, none, nullptr, a2, &cache);
             for (auto& b : ar.X->blocks) if (b.L.cols > 0) incr.push_back(b);
-            if (job_pending) join_side();                          // (a solve that never reached its chunk end — nothing to iterate — still owes the join)
         }
         out.adi_iters += ar.iters;
+        const auto ts1 = now();
+        if (rec_timing) t_solve += us(ts0, ts1);
         size_t hist_its = 0;
         for (auto& hc : ar.hist) hist_its += hc.mu.size();
         const bool hist = ar.hist_ok && hist_its == (size_t)ar.iters && (int)incr.size() == ar.iters;
+        // the increments go to the side stream (a job per step with save_state; otherwise whenever the previous job is done)
+        if (pend_upto < i) { for (auto& b : incr) pend.push_back(b); pend_upto = i; }
         Mat Kt_new;
         if (hist) {
+            // side jobs: every step with save_state (every X(t) is an output); otherwise when the previous one is done AND `batch` steps have
+            // gathered (the tolerance formula above tolerates a lag of 3 steps; one compression of 2-3 steps' increments costs little more
+            // than one step's — its latency chains depend on the rank, not on the number of columns)
+            static const int batch = std::getenv("DRE_REC_BATCH") ? std::max(1, std::min(3, std::atoi(std::getenv("DRE_REC_BATCH")))) : 2;
+            if (save_state || (!worker.pending() && i - get_state()->step >= batch) || i == nsteps) submit_job();
             // K_i' = K_{i-1}' + sum_j (E'V_j) (c_j T) (V_j'B)
             Mat dKt(ctx, n, m);
-            fill_mat(ctx, dKt, 0.0);
+            Kt_new = Mat(ctx, n, m);
+            copy_mat(ctx, Kt, Kt_new);
             const int k = ar.Tm.rows;
+            bool first = true;
             for (auto& hc : ar.hist) {
                 const int J = (int)hc.mu.size();
                 Mat EV(ctx, n, J * k), VtB(ctx, J * k, m), Mx(ctx, J * k, m);
@@ -3657,70 +3808,26 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                 for (int j = 0; j < J; ++j)
                     descs.push_back({ar.Tm.p, VtB.p + (size_t)j * k, Mx.p + (size_t)j * k, nullptr, -2.0 * hc.mu[(size_t)j] * ar.alpha_res, k, m, k, ar.Tm.ld, VtB.ld, Mx.ld, 0});
                 gemm_batched(ctx, descs, "gemm_feedback");
-                gemm(ctx, false, false, 1.0, EV, Mx, 1.0, dKt, nullptr, "gemm_feedback");
+                gemm(ctx, false, false, 1.0, EV, Mx, first ? 0.0 : 1.0, dKt, nullptr, "gemm_feedback");
+                first = false;
             }
-            Kt_new = Mat(ctx, n, m);
-            copy_mat(ctx, Kt, Kt_new);
-            { const size_t tot = (size_t)n * m; hipLaunchKernelGGL(k_axpy_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, 1.0, (const double*)dKt.p, Kt_new.p); }
+            if (first) fill_mat(ctx, dKt, 0.0);
+            else { const size_t tot = (size_t)n * m; hipLaunchKernelGGL(k_axpy_inplace, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, 1.0, (const double*)dKt.p, Kt_new.p); }
             prev_dKt = dKt;
-            // side job: X_i = compress(X_{i-1} + increments), then ||rhs_{i+1}||_F for the next solve's tolerance
-            join_side();                                            // (one job at a time; usually long finished)
-            hipEvent_t e_main = new_event(), e_side = new_event();
-            DRE_HIP(hipEventRecord(e_main, ctx->stream));
-            const double tau_next = i < nsteps ? out.t[i] - out.t[i + 1] : tau;
-            double* const slot = normC_dev.p + (i & 1);
-            const Mat Ct = prob.Ct, Bm = prob.B;
-            const bool want_save = save_state;
-            LDLtP* const saved_slot = &saved[(size_t)i];
-            worker.submit([=, &P]() {
-                DRE_HIP(hipSetDevice(side->device));
-                DRE_HIP(hipStreamWaitEvent(side->stream, e_main, 0));
-                auto Xs = std::make_shared<LDLt>();
-                Xs->n = n;
-                for (auto& b : (*sideX)->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
-                for (auto& b : incr) Xs->blocks.push_back(b);
-                if (Xs->blocks.empty()) Xs->blocks.push_back({Mat(side, n, 0), Mat(side, 0, 0), 1.0, true});
-                ldlt_destructure(side, *Xs, ctf, false);
-                *sideX = Xs;
-                if (want_save) *saved_slot = Xs;
-                // rhs_{i+1} = [C', E'L] blkdiag(I, BtLD'BtLD + alpha D / tau) [C', E'L]'   (lowrank_ros1.jl:42-43) -> its Frobenius norm, on the device
-                const LBlock& b = Xs->blocks[0];
-                const int r = b.L.cols;
-                Mat G(side, n, q + r), S(side, q + r, q + r);
-                { Mat d = G.colsview(0, q); copy_mat(side, Ct, d); }
-                set_identity(side, S, 0.0);
-                { Mat d = S.view(0, 0, q, q); set_identity(side, d, 1.0); }
-                if (r > 0) {
-                    Mat d = G.colsview(q, r);
-                    spmm(side, P, P.valEt.p, b.L, d, 1.0, 0.0);
-                    Mat BtL(side, m, r), BtLD(side, m, r);
-                    gemm(side, true, false, 1.0, Bm, b.L, 0.0, BtL);
-                    gemm(side, false, false, b.alpha, BtL, b.D, 0.0, BtLD);
-                    Mat d2 = S.view(q, q, r, r);
-                    copy_mat(side, b.D, d2, b.alpha / tau_next);
-                    gemm(side, true, false, 1.0, BtLD, BtLD, 1.0, d2);
-                }
-                ldlt_norm_device(side, G, S, 1.0, slot);
-                DRE_HIP(hipEventRecord(e_side, side->stream));
-                DRE_HIP(hipStreamSynchronize(side->stream));       // the increments' buffers go back to the MAIN pool when this closure dies
-            });
-            ev_side_last = e_side;
-            job_pending = true;
         } else {
             // no history (an iteration outside the fan path, a compression inside the solve): the reference's order for this step's tail
+            submit_job();
             join_side();
-            if (!incr.empty() || (*sideX)->blocks.empty()) {
-                auto Xs = std::make_shared<LDLt>();
-                Xs->n = n;
-                for (auto& b : (*sideX)->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
-                for (auto& b : incr) Xs->blocks.push_back(b);
-                *sideX = Xs;
-            }
-            if ((*sideX).get() == prob.X0.get()) *sideX = std::make_shared<LDLt>(*prob.X0);
-            Feedback fb = feedback(ctx, prob, **sideX, ctf, false);
+            const auto st = get_state();
+            if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+            LDLtP X = st->X;
+            if (X.get() == prob.X0.get()) X = std::make_shared<LDLt>(*prob.X0);
+            Feedback fb = feedback(ctx, prob, *X, ctf, false);
             Kt_new = fb.Kt;
-            if (save_state) saved[(size_t)i] = *sideX;
+            if (save_state) saved[(size_t)i] = X;
+            deltas.clear();
         }
+        if (rec_timing) t_tail += us(ts1, now());
         abstol_prev = ar.abstol;
         have_hist = hist;
         Kt = Kt_new;
@@ -3731,10 +3838,17 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         rec.X.reset(); rec.residual.reset(); rec.hist.clear();
         out.gale.push_back(std::move(rec));
     }
+    submit_job();
     join_side();
-    DRE_HIP(hipStreamSynchronize(ctx->stream));
-    if (save_state) for (int i = 1; i <= nsteps; ++i) out.X.push_back(saved[(size_t)i] ? saved[(size_t)i] : *sideX);
-    else out.X.push_back(*sideX);
+    {
+        const auto st = get_state();
+        if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (rec_timing) std::fprintf(stderr, "[rec timing, us per step] solve (residual + ADI) %.0f | tail (feedback, job hand-over) %.0f | blocked in join %.0f (%ld joins, %ld jobs)\n",
+                                     t_solve / nsteps, t_tail / nsteps, t_join / nsteps, n_join, n_jobs_t);
+        if (save_state) for (int i = 1; i <= nsteps; ++i) out.X.push_back(saved[(size_t)i] ? saved[(size_t)i] : st->X);
+        else out.X.push_back(st->X);
+    }
 }
 
 GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {

@@ -123,6 +123,8 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     std::shared_ptr<struct LDLt> given_residual;
     const double* normC_dev = nullptr;
     std::function<void()> normC_wait;    // makes the calling stream wait for *normC_dev
+    // ... or it is formed on the solve's own stream as soon as the given residual is compressed to (Q, D, alpha): the callback enqueues that
+    std::function<void(const Mat& Q, const Mat& D, double alpha)> normC_build;
     double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
     bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
 };
