@@ -4215,15 +4215,17 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     for (int id = tid; id < 64 * 64; id += 256) { const int i = id & 63, j = id >> 6; A[i][j] = (i < b && j < b) ? G[i + (size_t)j * ldg] : 0.0; Y[i][j] = (i == j) ? 1.0 : 0.0; }
     __syncthreads();
-    if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0) *ref = m; }
+    if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0 || mode == 3) *ref = m; }
     __syncthreads();
-    const double floor_abs = mode == 2 ? 1e-20 : relfloor * (mode == 0 ? dmax_s : *ref);
+    // mode 3 (warm-started range finder, engine.hip warm_compress): the block is what a known basis left of a sketch — numerically rank deficient by
+    // design; a column whose pivot falls 14 orders below the block's scale is DEPENDENT (replaced by a random direction by the caller), not a breakdown
+    const double floor_abs = mode == 2 ? 1e-20 : (mode == 3 ? 1e-14 * dmax_s : relfloor * (mode == 0 ? dmax_s : *ref));
     // breakdown: judged where it shows.  First pass (modes 0, 1): only a pivot that is all rounding (<= 1e-15 of the block's scale; the Gram
     // matrix carries cond^2) is hopeless.  Second pass (mode 2): the block entered orthonormal up to the error of the first pass, so every live
     // pivot of its Gram matrix is ~1; one below 1/4 says the first pass lost more than CholeskyQR2 repairs.  (Measured on the rail
     // sketches: first-pass ratios down to 3e-14 still give second-pass pivots >= 0.99 and a probe residual of 2e-15; the earlier
     // first-pass bound of 1e-13 struck there and sent every later sketch of the run to Householder panels: 27 % of a 45-step run.)
-    const double thr = (mode == 2 ? 0.25 : 1e-15) * dmax_s;
+    const double thr = mode == 3 ? 0.0 : (mode == 2 ? 0.25 : 1e-15) * dmax_s;
     bool bad = false;
     double minpiv = dmax_s;                          // smallest live pivot (trace only; divided by the largest diagonal entry once, at the end)
     // step k (one barrier): with l_ik = A_ik / pivot,   A_ij -= l_ik A_jk  (k < j <= i: the Schur complement)   and

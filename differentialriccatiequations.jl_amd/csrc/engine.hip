@@ -142,7 +142,9 @@ static void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD) {
 // kernel, 14 launches per block, against 16 dependent latency-bound column steps per 16 columns of a Householder/TSQR panel.  Valid
 // while every block has cond <= ~3e6 AFTER the projections (columns of X Om: the decay of the spectrum over 64 indices); k_chol_inv raises
 // *flag otherwise and the caller redoes the factorisation with Householder panels.
-static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
+// j_start > 0: the first j_start columns of Q are ALREADY orthonormal (a warm-start basis); only the columns from there on are taken from Y,
+// projected against everything before them and orthonormalised
+static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev, int j_start = 0, bool permissive = false) {
     const int n = Y.rows, s = Y.cols, bs = 64;
     Mat G(ctx, bs, bs), Ri(ctx, bs, bs), T(ctx, n, bs);
     DevArr<double> ref(ctx, 1);              // scale of the sketch: largest squared column norm of the first block
@@ -150,7 +152,7 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
     static const bool trace = std::getenv("DRE_TRACE_CHOLQR") != nullptr;
     DevArr<double> dbg(ctx, 64);
     int nblk = 0;
-    for (int j0 = 0; j0 < s; j0 += bs) {
+    for (int j0 = j_start; j0 < s; j0 += bs) {
         const int b = std::min(bs, s - j0);
         Mat Yb = Y.colsview(j0, b), Qb = Q.colsview(j0, b), Tb = T.colsview(0, b), Gb = G.view(0, 0, b, b), Rb = Ri.view(0, 0, b, b);
         // project, normalise, project AGAIN, normalise again: the second projection acts on the well-conditioned T, so the loss of
@@ -163,7 +165,7 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev) {
         };
         project(Yb);
         gemm(ctx, true, false, 1.0, Yb, Yb, 0.0, Gb, nullptr, "gemm_orth");
-        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, j0 == 0 ? 0 : 1, nullmask.p, trace && nblk < 32 ? dbg.p + 2 * nblk : nullptr);
+        chol_inv(ctx, Gb, Rb, flag_dev, ref.p, permissive ? 3 : (j0 == j_start ? 0 : 1), nullmask.p, trace && nblk < 32 ? dbg.p + 2 * nblk : nullptr);
         gemm(ctx, false, false, 1.0, Yb, Rb, 0.0, Tb, nullptr, "gemm_orth");
         // a column that was rounding noise relative to the whole sketch (sketch wider than the numerical rank) becomes a fresh random direction:
         // Q stays orthonormal in all its columns, as a Householder Q would, and the band reduction of Q'XQ sorts the direction out
@@ -242,6 +244,63 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
     ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += s; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
     ctx->band_hint[skey] = sb.J;
+    X.blocks.clear();
+    if (sb.J == 0) { X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true}); return true; }
+    Mat Bq = sym_band_basis(ctx, sb);                 // s x J
+    Mat Lnew(ctx, n, sb.J);
+    gemm(ctx, false, false, 1.0, Q, Bq, 0.0, Lnew, nullptr, "gemm_sketch");
+    X.blocks.push_back({Lnew, sb.D, 1.0, false, true});
+    return true;
+}
+
+// Compression of a wide factored sum X = L blockdiag(alpha_b D_b) L' whose range is KNOWN to lie close to that of an orthonormal basis Q0 (n x q0):
+// the warm-start residual of a Rosenbrock step against the previous step's (ros1_recurrence_loop) — the subspace moves slowly between time
+// steps.  Range finder with a warm start: Q = [Q0, orth((I - Q0 Q0') X Om)] with only sx fresh directions, S = Q'XQ (a hundred rows), its
+// early-terminating band reduction with the absolute tolerance, L <- Q Qb.  Six passes over the factor as GEMMs + one 64-column Cholesky-QR
+// block, against ~5 panels x 13 dependent launches of the factor-form reduction (1.5 ms -> ~0.6 ms at n = 5177, c = 2300).  A 16-column Gaussian
+// probe measures what the basis missed, ||(I - QQ') X||_F ~ sqrt(n / 16) ||(I - QQ') X Om_p||_F: accepted below abs_tol (the level the caller
+// truncates at anyway); otherwise the caller runs the full reduction.  *missed returns the estimate.
+static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed) {
+    const int n = X.n, c = X.rank(), q0 = Q0.cols, sp = sx + 16, s = q0 + sx;
+    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    if (c == 0 || q0 < 16 || s <= 64 || s + 80 > n || abs_tol <= 0.0 || Q0.rows != n) {
+        if (trace) std::fprintf(stderr, "[warm compress] not applicable: c=%d q0=%d sx=%d abs_tol=%g\n", c, q0, sx, abs_tol);
+        return false;
+    }
+    Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    Mat Om(ctx, n, sp), W1(ctx, sp, c), W2(ctx, sp, c), Y(ctx, n, s + 16);
+    fill_gauss(ctx, Om, 0x6A09E667F3BCC909ull);
+    gemm(ctx, true, false, 1.0, Om, Lcat, 0.0, W1, nullptr, "gemm_sketch");             // Om' L
+    mul_blockdiag(ctx, W1, X, W2);                                                       // Om' L Dt
+    Mat Yx = Y.colsview(q0, sp);                                                         // X Om lands behind the warm-start columns
+    gemm(ctx, false, true, 1.0, Lcat, W2, 0.0, Yx, nullptr, "gemm_sketch");
+    Mat Yr = Y.colsview(0, s), Z = Y.colsview(s, 16);
+    DevArr<double> nrm(ctx, 2);
+    DevArr<long long> cflag(ctx, 1);
+    DRE_HIP(hipMemsetAsync(cflag.p, 0, sizeof(long long), ctx->stream));
+    Mat Q(ctx, n, s);
+    { Mat d = Q.colsview(0, q0); copy_mat(ctx, Q0, d); }
+    orth_cholqr(ctx, Yr, Q, reinterpret_cast<int*>(cflag.p), q0, true);
+    {
+        Mat QtZ(ctx, s, 16);
+        gemm(ctx, true, false, 1.0, Q, Z, 0.0, QtZ, nullptr, "gemm_sketch");
+        gemm(ctx, false, false, -1.0, Q, QtZ, 1.0, Z, nullptr, "gemm_sketch");
+        frob2_device(ctx, Z, nrm.p + 1);
+    }
+    Mat B(ctx, s, c), BD(ctx, s, c), S(ctx, s, s);
+    gemm(ctx, true, false, 1.0, Q, Lcat, 0.0, B, nullptr, "gemm_sketch");               // Q' L
+    mul_blockdiag(ctx, B, X, BD);
+    gemm(ctx, false, true, 1.0, BD, B, 0.0, S, nullptr, "gemm_compress");               // Q' X Q
+    symmetrize(ctx, S);
+    SymBand sb = sym_band_reduce(ctx, S, tolfac, abs_tol);
+    double h[2] = {0.0, 0.0};
+    long long cf = 0;
+    ctx_fetch(ctx, nrm.p, 2 * sizeof(double), h, cflag.p, sizeof(long long), &cf);
+    const double est = std::sqrt(std::max(h[1], 0.0) * (double)n / 16.0);
+    if (missed) *missed = est;
+    const bool ok = (cf & 1) == 0 && est <= abs_tol && sb.J + 16 <= s;
+    if (trace) std::fprintf(stderr, "[warm compress] n=%d c=%d q0=%d sx=%d -> J=%d  missed %.2e (tolerance %.2e)  %s\n", n, c, q0, sx, sb.J, est, abs_tol, ok ? "accepted" : "REJECTED");
+    if (!ok) return false;
     X.blocks.clear();
     if (sb.J == 0) { X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true}); return true; }
     Mat Bq = sym_band_basis(ctx, sb);                 // s x J
@@ -1472,7 +1531,19 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         resid = opt.given_residual;
         X = ldlt_zero(n);
         const double lag = opt.abstol_lag > 0.0 ? opt.abstol_lag : (opt.abstol >= 0.0 ? opt.abstol : -1.0);
-        if (resid->blocks.size() > 1) ldlt_compress(ctx, *resid, ctf, false, lag > 0.0 ? opt.residual_abs_frac * lag : -1.0);
+        if (resid->blocks.size() > 1) {
+            bool done = false;
+            static const bool warm_on = !(std::getenv("DRE_WARM_COMPRESS") && std::atoi(std::getenv("DRE_WARM_COMPRESS")) == 0);
+            if (warm_on && opt.warm_basis.cols > 0 && lag > 0.0 && cache->warm_strikes < 2) {
+                const int sx = cache->warm_sx > 0 ? cache->warm_sx : 32;
+                double missed = 0.0;
+                done = warm_compress(ctx, *resid, opt.warm_basis, ctf, opt.residual_abs_frac * lag, sx, &missed);
+                if (done) cache->warm_strikes = 0;
+                else if (sx < 64) cache->warm_sx = 64;          // more fresh directions next time; two failures in a row at 64: the full reduction from then on
+                else cache->warm_strikes += 1;
+            }
+            if (!done) ldlt_compress(ctx, *resid, ctf, false, lag > 0.0 ? opt.residual_abs_frac * lag : -1.0);
+        }
     } else {
     // Krylov mode: components of the warm-start residual far below the convergence tolerance are dropped
     resid = gale_residual_impl(ctx, op, C, X, ctf, cex, cex ? -1.0 : opt.residual_abs_frac * abstol,
@@ -3733,6 +3804,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             }
             a2.given_residual = resid;
             a2.abstol_lag = abstol_prev;
+            if (!prev.hist.empty()) a2.warm_basis = prev.hist[0].R0;      // the compressed residual the previous solve started from: orthonormal
             a2.normC_dev = normC_dev.p;
             // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
             //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)

@@ -71,6 +71,7 @@ struct FactorCache {
     bool enabled = true;
     std::vector<std::tuple<uint64_t, double, double>> fresh;   // keys created by the running Lyapunov solve (evicted unless the shift list persists)
     int iters_hint = 0;        // ADI iterations of the previous Lyapunov solve served by this cache (speculation depth of the next one)
+    int warm_sx = 0, warm_strikes = 0;   // warm-started residual compression (engine.hip, warm_compress): fresh directions per step, consecutive rejections
     void clear() { real.clear(); cplx_.clear(); }
 };
 struct GaleOperator {
@@ -127,6 +128,7 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     std::function<void(const Mat& Q, const Mat& D, double alpha)> normC_build;
     double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
     bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
+    Mat warm_basis;                      // orthonormal basis of the PREVIOUS step's compressed warm-start residual (warm-started range finder for this one's)
 };
 // iterations of one chunk of a solve with keep_history: V = [V_1 .. V_J], R = [R_1 .. R_J] (n x J k), R0 = the residual factor they started from
 struct AdiHistChunk { Mat R0, Rs, Vs; std::vector<double> mu; };
