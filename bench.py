@@ -12,8 +12,11 @@ communicator (RCCL over xGMI, dre_comm_allgather on the library stream).  `--mod
 every rank, the shifted solves of every ADI step column-sharded inside the library (meant for --n 5177 / 20209).
 
 Legs after the timed region (rank 0): `roofline` (one profiled solve, HIP events per kernel class on the library's streams), `parity` (K(t)
-of the timed solve against the oracle's committed full-length fixture; the run FAILS on a mismatch), `general_path` (N = 1, n = 371 only: the
-sparse multifrontal path at SteelProfile(5177), 12 steps, with its own roofline and parity), `cpu_baseline` (the NumPy/SciPy oracle, N = 1).
+of the timed solve against the oracle's committed full-length fixture; the run FAILS on a mismatch), and at N = 1, n = 371 one leg per remaining
+BASELINE config, each with its own roofline, parity and set-up times: `general_path` (SteelProfile(5177), 12 steps — the leg of rounds 2-3),
+`general_path_45` (configs[3] at its stated 45 steps), `general_path_20209` (configs[4]: save_state, 12 steps), `ros2_1357_projection`
+(configs[2]: Ros2 with the default Projection(2) shifts, complex pairs); `cpu_baseline` (the NumPy/SciPy oracle, N = 1; configs[0]'s dense
+Rosenbrock solver is timed there too).
 
 Prints ONE JSON line (rank 0).
 """
@@ -140,7 +143,8 @@ def parity_check(n, nsteps, Kdev_host, its):
     """K(t) of the solve that was just timed against the oracle's committed trajectory (tests/golden/make_fixtures_r03.py): delta of
     Stuff.jl:21 at the last time step (criterion of test/cuda.jl:95-99: < 1e-7) and the worst over all steps, plus the ADI iteration counts
     of every Lyapunov solve.  Fixtures exist for the metric's configuration (n = 371, 45 steps), n = 1357 (45 steps) and n = 5177 (12 steps)."""
-    name = {(371, 45): "ros1_371_full", (1357, 45): "ros1_1357_full", (5177, 12): "ros1_5177_long"}.get((n, nsteps))
+    name = {(371, 45): "ros1_371_full", (1357, 45): "ros1_1357_full", (5177, 12): "ros1_5177_long", (5177, 45): "ros1_5177_full",
+            (20209, 12): "ros1_20209_ss12"}.get((n, nsteps))
     if name is None:
         return None
     g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
@@ -163,15 +167,19 @@ def parity_check(n, nsteps, Kdev_host, its):
     return rec
 
 
-def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1):
-    """The general sparse path (multifrontal sweeps, factored X, sketch compression — everything the n <= 1536 dense special case is not),
-    measured in the same run: SteelProfile(5177) Ros1 LRSIF, 12 time steps, Cyclic real shifts; parity against ros1_5177_long.npz."""
+def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1, save_state=False, config=None):
+    """The general sparse path (multifrontal sweeps, factored X, residual recurrence, sketch compression — everything the n <= 1536 dense special
+    case is not), measured in the same run: SteelProfile(n) Ros1 LRSIF, Cyclic real shifts; parity against the oracle's fixture of that length.
+    `setup_ms` = dre_pencil_create (nested-dissection ordering + symbolic analysis + upload; the reference pays its analysis inside every
+    factorize call, blocklinear/backslash.jl:13), `first_solve_ms` = the cold solve (the ten numeric factorisations, top inverses, pool growth)."""
     import torch
     lib = ctx.lib
     d = D.steel_profile(n)
     L, Dm = D.initial_value(d)
     shifts = np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy"))
+    ctx.sync(); tsu = time.perf_counter()
     pencil = D.Pencil(d.E, d.A, ctx)
+    ctx.sync(); setup_ms = (time.perf_counter() - tsu) * 1e3
     Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
     X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm, 1.0)
     opt, keep = D.device.make_adi_options(shift_kind=0, shifts=list(shifts), maxiters=200)
@@ -182,7 +190,7 @@ def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1):
 
     def one():
         r = C.c_void_p()
-        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, t0 + dt * nsteps, dt, 1, 0, C.byref(opt), C.byref(r)))
+        ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, t0, t0 + dt * nsteps, dt, 1, 1 if save_state else 0, C.byref(opt), C.byref(r)))
         ii = (C.c_int64 * 7)()
         lib.dre_gdre_result_info(r, ii)
         ctx.chk(lib.dre_gdre_result_K_device(ctx.ptr, r, C.c_void_p(Kdev.data_ptr())))
@@ -194,7 +202,10 @@ def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1):
         lib.dre_gdre_result_free(r)
         rec.update(its=its, kw=kw, nfac=int(ii[3]))
         return int(ii[2])
-    for _ in range(warmup):
+    ctx.sync(); tf = time.perf_counter()
+    one()
+    ctx.sync(); first_ms = (time.perf_counter() - tf) * 1e3
+    for _ in range(max(warmup - 1, 0)):
         one()
     ctx.sync(); torch.cuda.synchronize()
     ts = time.perf_counter()
@@ -207,10 +218,62 @@ def general_path(D, ctx, args, n=5177, nsteps=12, steps=3, warmup=1):
     ctx.prof_enable(False)
     roof = roofline_record(stats, n, m, pencil, iters / steps, rec["kw"], el / steps)
     par = parity_check(n, nsteps, Kdev.cpu().numpy(), rec["its"])
-    return dict(workload=f"SteelProfile({n}) surrogate, Ros1 LRSIF, Cyclic real shifts, {nsteps} time steps (tspan=(4500,{t0 + dt * nsteps:g}), dt=-100): "
-                         "multifrontal sweeps + factored X + sketch compression", n=n, nsteps=nsteps, steps=steps, warmup=warmup,
+    return dict(config=config,
+                workload=f"SteelProfile({n}) surrogate, Ros1 LRSIF, Cyclic real shifts, {nsteps} time steps (tspan=(4500,{t0 + dt * nsteps:g}), dt=-100)"
+                         f"{', save_state=true' if save_state else ''}: batched multifrontal fan groups + residual recurrence + side-stream compression of X",
+                n=n, nsteps=nsteps, steps=steps, warmup=warmup, save_state=bool(save_state),
                 value=iters / el, unit="ADI iterations/s", ms_per_step=el / steps * 1e3, adi_iterations_per_solve=iters / steps,
+                setup_ms=setup_ms, first_solve_ms=first_ms,
                 sparse_factorizations_per_solve=rec["nfac"], roofline=roof, parity=par)
+
+
+def ros2_projection_leg(D, ctx, steps=2):
+    """BASELINE configs[2] as written: SteelProfile(1357) Ros2 LRSIF with the DEFAULT ADI() = Projection(2) shifts (complex pairs on the
+    non-symmetric surrogate variant), 10 steps of dt = -20; parity against tests/golden/ros2_1357_proj.npz (the oracle's K(t) where the oracle
+    converges, the dense Ros2 solver's K(t) everywhere)."""
+    import warnings
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ros2_1357_proj.npz"))
+    n = 1357
+    d = D.steel_profile(n, convection=float(g["convection"]))
+    L, Dm = D.initial_value(d)
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4300.0))
+    alg = D.Ros2(D.ADI(maxiters=200))
+    warnings.simplefilter("ignore")
+    D.set_default_context(ctx)
+    ctx.sync(); t = time.perf_counter()
+    sol, st = D.solve_gdre(prob, alg, dt=float(g["dt"]), return_stats=True, ctx=ctx)
+    first_ms = (time.perf_counter() - t) * 1e3
+    best = None
+    for _ in range(steps):
+        ctx.sync(); t = time.perf_counter()
+        sol, st = D.solve_gdre(prob, alg, dt=float(g["dt"]), return_stats=True, ctx=ctx)
+        el = time.perf_counter() - t
+        best = el if best is None else min(best, el)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    D.solve_gdre(prob, alg, dt=float(g["dt"]), ctx=ctx)
+    stats = ctx.prof_stats(); ctx.prof_enable(False)
+
+    def delta(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(a), np.linalg.norm(b)))
+    its = [x["iters"] for x in st["gales"]]
+    ncx = sum(int(np.sum(np.abs(np.imag(x["shifts"])) > 0)) for x in st["gales"])
+    par = dict(fixture="tests/golden/ros2_1357_proj.npz", delta_K_vs_oracle_steps_1_8=max(delta(sol.K[i], g["K"][i]) for i in range(1, 9)),
+               delta_K_vs_dense_ros2_worst=max(delta(sol.K[i], g["K_dense"][i]) for i in range(1, 11)),
+               adi_iterations=int(sum(its)), adi_iterations_oracle=int(g["iters_per_solve"].sum()),
+               lyapunov_solves_converged=f"{sum(int(x['converged']) for x in st['gales'])}/{len(its)}", oracle_solves_converged=f"{int((~g['failed']).sum())}/{len(g['failed'])}",
+               complex_shift_share=ncx / max(sum(its), 1), criterion="delta < 1e-7 where the oracle converges (test/cuda.jl:95-99); counts within a Projection batch")
+    if not (par["delta_K_vs_oracle_steps_1_8"] < 1e-7 and par["delta_K_vs_dense_ros2_worst"] < 1e-6):
+        raise SystemExit(f"bench.py: PARITY FAILURE (configs[2]): {par}")
+    tot = sum(v["ms"] for v in stats.values())
+    name, sk = max(stats.items(), key=lambda kv: kv[1]["ms"])
+    avg_s = sk["ms"] * 1e-3 / max(sk["launches"], 1)
+    roof = dict(bound="hbm", kernel=name, achieved=sk["bytes"] / max(sk["launches"], 1) / max(avg_s, 1e-12) / 1e9, peak=8000.0, unit="GB/s", traffic=None,
+                avg_launch_us=avg_s * 1e6, launches=sk["launches"], share_of_device_time=sk["ms"] / max(tot, 1e-12),
+                by_kernel_ms={k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]})
+    roof["frac"] = roof["achieved"] / 8000.0
+    return dict(config="BASELINE configs[2]", workload="SteelProfile(1357) surrogate + convection (non-symmetric), Ros2 LRSIF, default ADI() = Projection(2) shifts "
+                "(complex pairs), 10 time steps of dt=-20, 20 Lyapunov solves", n=n, nsteps=10, value=sum(its) / best, unit="ADI iterations/s",
+                ms_per_step=best * 1e3, first_solve_ms=first_ms, adi_iterations_per_solve=sum(its), roofline=roof, parity=par)
 
 
 def launch_ranks(args):
@@ -260,7 +323,9 @@ def main():
 
     ctx = D.Context(local_rank)
     lib = ctx.lib
+    ctx.sync(); t_su = time.perf_counter()
     pencil = D.Pencil(d.E, d.A, ctx)
+    ctx.sync(); setup_ms = (time.perf_counter() - t_su) * 1e3       # dre_pencil_create: ordering + symbolic analysis + upload (outside the timed region)
     strong = args.mode == "strong"
     # The communicator lives INSIDE the library (RCCL over xGMI on the library stream).  replicas: it gathers the K(t) trajectories;
     # strong: it carries the one all-gather of V per ADI step of the column-sharded solve.  torch.distributed only hands the unique id around.
@@ -360,9 +425,12 @@ def main():
         except SystemExit as e:      # reported AFTER the final barrier: a parity failure must not strand the other ranks in it
             parity, parity_failure = None, e
         # ---- general path leg: the sparse multifrontal path north_star names, in the driver-timed record
-        general = None
+        general = general45 = general20k = ros2leg = None
         if world == 1 and n == 371 and not strong and not args.no_general_path:
-            general = general_path(D, ctx, args)
+            general = general_path(D, ctx, args, config="BASELINE configs[3], first 12 of its 45 steps (the leg of rounds 2-3)")
+            general45 = general_path(D, ctx, args, nsteps=45, steps=2, warmup=1, config="BASELINE configs[3] at its stated length (one GPU)")
+            general20k = general_path(D, ctx, args, n=20209, nsteps=12, steps=2, warmup=1, save_state=True, config="BASELINE configs[4] (one GPU), 12 of 45 steps")
+            ros2leg = ros2_projection_leg(D, ctx)
         # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample.
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
         # so a two-step probe picks the fastest of a few thread counts and the sample runs with that one.
@@ -402,7 +470,16 @@ def main():
                 it2, tc2 = cpu_run(nsteps_cpu, best, reuse=True)
                 fair = dict(value=it2 / tc2, unit="ADI iterations/s",
                             note="same sample and threads, sparse LU factors reused per shift like the engine (the reference refactorises every ADI step)")
-            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=best, kind="port", factor_caching_variant=fair,
+            # BASELINE configs[0]: the DENSE Rosenbrock-1 solver on the CPU (reference plumbing, src/riccati/dense_ros1.jl:30-49), a bounded sample
+            dense0 = None
+            if n <= 400:
+                with threadpool_limits(limits=best):
+                    td = time.perf_counter()
+                    o.solve(o.GDREProblem(d.E, d.A, d.B, d.C, o.lowrank(L, Dm).dense(), (t0, t0 + dt * 5)), o.Ros1(), dt=dt)
+                    td = time.perf_counter() - td
+                dense0 = dict(config="BASELINE configs[0]", workload=f"SteelProfile({n}) dense Ros1 on the CPU (oracle), 5 of 45 time steps", s_per_time_step=td / 5.0,
+                              threads=best)
+            cpu = dict(value=cpu_it / tc, unit="ADI iterations/s", cores=best, kind="port", factor_caching_variant=fair, dense_ros1_config0=dense0,
                        thread_probe_it_per_s={str(k): round(v, 1) for k, v in probe.items()},
                        sample=f"{nsteps_cpu} of {args.nsteps} Rosenbrock steps of the same workload ({cpu_it} ADI iterations, {tc:.1f} s), "
                               f"NumPy/SciPy oracle with {best} BLAS thread(s) ({'fastest of the probed counts' if not big else 'single probe at this size'}; {ncpu} host CPUs), "
@@ -435,7 +512,11 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "general_path": general,
+            "general_path_45": general45,
+            "general_path_20209": general20k,
+            "ros2_1357_projection": ros2leg,
         }
+        out["setup_ms"] = setup_ms
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
