@@ -115,6 +115,7 @@ PROTOTYPES = {
     "dre_adi_finish": (C.c_int, [_vp, _vp, _pvp]),
     "dre_comm_unique_id": (C.c_int, [_vp, _vp]),
     "dre_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "dre_ctx_set_orthf": (C.c_int, [_vp, _vp, _vp]),
     "dre_comm_init_host": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "dre_comm_free": (C.c_int, [_vp]),
     "dre_comm_info": (C.c_int, [_vp, _pi64]),

@@ -388,6 +388,9 @@ int dre_spmm(dre_ctx* ctx, const dre_pencil* p, int which, double alpha, const d
         copy_mat(&ctx->c, Yu, Y->m);
     });
 }
+int dre_ctx_set_orthf(dre_ctx* ctx, dre_orthf_fn fn, void* user) {
+    return guarded(ctx, [&] { ctx->c.orthf_fn = fn; ctx->c.orthf_user = user; if (ctx->c.side) { ctx->c.side->orthf_fn = fn; ctx->c.side->orthf_user = user; } });
+}
 int dre_orthf(dre_ctx* ctx, const dre_dense* L, dre_dense** Qo, dre_dense** Ro) {
     return guarded(ctx, [&] {
         Ctx* c = &ctx->c;

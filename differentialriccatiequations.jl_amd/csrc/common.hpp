@@ -211,6 +211,13 @@ struct Ctx {
     // Residual blocks narrower than shard_min_cols are solved replicated (a rank cannot do less than one 16-column tile).
     std::shared_ptr<Comm> comm;
     int shard_min_cols = 32;
+    // user-supplied orthogonalisation (the reference's extension point DifferentialRiccatiEquations.orthf, src/LDLt.jl:227-245, overridden in
+    // test/cuda.jl:32-37): L (n x c) -> Q (n x p, orthonormal columns), R (p x c), p = min(n, c), L = Q R; device pointers, column-major.
+    // Honoured by the literal compression (compress_exact / dre_ldlt_compress) and by dre_ldlt_norm.  Called with this stream idle; must
+    // return when its own work is complete.
+    int (*orthf_fn)(void* user, int n, int c, const double* L, int ldl, double* Q, int ldq, double* R, int ldr) = nullptr;
+    void* orthf_user = nullptr;
+    long orthf_calls = 0;
     void sync() { DRE_HIP(hipStreamSynchronize(stream)); }
 };
 

@@ -400,9 +400,23 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         X.blocks.push_back({Bq, sb.D, 1.0, false, true});
         return;
     }
-    Mat Lcat, S, V0, VT0;
+    Mat Lcat, S, V0, VT0, Quser;
     QRFact qr;
-    if (wide) {
+    const bool userq = exact && ctx->orthf_fn != nullptr;
+    if (userq) {
+        // the caller's orthf (LDLt.jl:211: Q, R = orthf(L)), then S = R D R' as in the reference
+        Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+        const int pq = std::min(n, c);
+        Quser = Mat(ctx, n, pq);
+        Mat Ru(ctx, pq, c), RD(ctx, pq, c);
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        const int rc = ctx->orthf_fn(ctx->orthf_user, n, c, Lcat.p, Lcat.ld, Quser.p, Quser.ld, Ru.p, Ru.ld);
+        ctx->orthf_calls++;
+        if (rc != 0) throw Error(ERR_INTERNAL, "the user-supplied orthf returned " + std::to_string(rc));
+        mul_blockdiag(ctx, Ru, X, RD);
+        S = Mat(ctx, pq, pq);
+        gemm(ctx, false, true, 1.0, RD, Ru, 0.0, S, nullptr, "gemm_compress");
+    } else if (wide) {
         // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
         Mat LD;
         static const int rot_min_n = std::getenv("DRE_LEAD_ROTATION_MIN_N") ? std::atoi(std::getenv("DRE_LEAD_ROTATION_MIN_N")) : 65;
@@ -477,7 +491,10 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         }
     }
     Mat Lnew;
-    if (wide) {
+    if (userq) {
+        Lnew = Mat(ctx, n, r);
+        gemm(ctx, false, false, 1.0, Quser, B, 0.0, Lnew, nullptr, "gemm_compress");          // L <- Q V_keep  (LDLt.jl:220-221)
+    } else if (wide) {
         Lnew = B;
         lead_rotate_back(ctx, V0, VT0, Lnew);
     } else {
@@ -517,6 +534,14 @@ double ldlt_norm(Ctx* ctx, LDLt& X) {
 // such as the Arnoldi vectors of the low-rank GMRES.  X itself is left untouched (the compression works on a shallow copy).
 double ldlt_norm_accurate(Ctx* ctx, const LDLt& X) {
     if (X.rank() == 0) return 0.0;
+    if (ctx->orthf_fn) {
+        // LDLt.jl:77-89 with the caller's orthf: |alpha| ||R D R'||_F  (= the norm of the literally compressed object)
+        LDLt Y = X;
+        ldlt_compress(ctx, Y, 4.0, true);
+        if (Y.rank() == 0) return 0.0;
+        auto& b = Y.blocks[0];
+        return ldlt_norm_host(ctx, b.L, b.D, b.alpha);
+    }
     if (X.blocks.size() == 1 && X.blocks[0].ortho) {        // already compressed: L'L = I, nothing can cancel
         auto& b0 = X.blocks[0];
         return ldlt_norm_host(ctx, b0.L, b0.D, b0.alpha);

@@ -55,6 +55,25 @@ class Context:
         idbuf = C.create_string_buffer(unique_id, 128) if unique_id is not None else None
         self.chk(self.lib.dre_comm_init(self.ptr, int(nranks), int(rank), idbuf))
 
+    def set_orthf(self, fn):
+        """The reference's extension point `orthf(L) -> (Q, R)` (src/LDLt.jl:227-245, overridden in test/cuda.jl:32-37) for this context:
+        `fn(n, c, L_ptr, ldl, Q_ptr, ldq, R_ptr, ldr) -> 0` with raw DEVICE pointers (dre_orthf_fn of include/dre_hip.h); None restores the
+        library's Householder QR.  Honoured by the literal compression (`compress_exact`, `compress_`) and by `norm`."""
+        if fn is None:
+            self._orthf_cb = None
+            self.chk(self.lib.dre_ctx_set_orthf(self.ptr, None, None))
+            return
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int)
+
+        def _cb(user, n, c, L, ldl, Q, ldq, R, ldr):
+            try:
+                return int(fn(n, c, L, ldl, Q, ldq, R, ldr) or 0)
+            except Exception:
+                import traceback; traceback.print_exc()
+                return 1
+        self._orthf_cb = CB(_cb)
+        self.chk(self.lib.dre_ctx_set_orthf(self.ptr, C.cast(self._orthf_cb, C.c_void_p), None))
+
     def comm_init_host(self, nranks: int, rank: int, allgather, allreduce):
         """The communicator over a HOST transport (dre_comm_init_host): `allgather(send, recv, nranks)` gets two NumPy uint8 views (this rank's
         block, which lies inside `recv`, and the nranks blocks) and fills `recv`; `allreduce(buf)` sums a float64 view over the ranks in place.

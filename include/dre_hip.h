@@ -135,6 +135,13 @@ int dre_gemm(dre_ctx* ctx, int transA, int transB, double alpha, const dre_dense
 int dre_spmm(dre_ctx* ctx, const dre_pencil* p, int which, double alpha, const dre_dense* X, double beta, dre_dense* Y);
 /* orthf(L) -> Q, R  (src/LDLt.jl:237-245) */
 int dre_orthf(dre_ctx* ctx, const dre_dense* L, dre_dense** Q, dre_dense** R);
+/* The reference's EXTENSION POINT `DifferentialRiccatiEquations.orthf(L) -> (Q, R)` (src/LDLt.jl:227-245; test/cuda.jl:32-37 substitutes an SVD):
+ * a user-supplied orthogonalisation for this context.  L is n x c (device, column-major, leading dimension ldl); the callback fills Q (n x p,
+ * orthonormal columns) and R (p x c) with p = min(n, c) and L = Q R, and returns 0.  It is called with the context's stream idle and must return
+ * when its own work is complete.  Honoured wherever the engine runs the reference's arithmetic: the literal compression (ADI option
+ * compress_exact, dre_ldlt_compress: src/LDLt.jl:211) and dre_ldlt_norm (src/LDLt.jl:84).  fn = NULL restores the library's Householder QR. */
+typedef int (*dre_orthf_fn)(void* user, int n, int c, const double* L, int ldl, double* Q, int ldq, double* R, int ldr);
+int dre_ctx_set_orthf(dre_ctx* ctx, dre_orthf_fn fn, void* user);
 /* eigen(Symmetric(S)) with early-terminating tridiagonalisation (src/LDLt.jl:214); returns the j computed
  * eigenpairs (all those above tolfac*eps*||S||_F in magnitude), values ascending */
 int dre_sym_eig(dre_ctx* ctx, const dre_dense* S, double tolfac, dre_dense** values, dre_dense** vectors);

@@ -136,3 +136,56 @@ def test_ros2_with_a_state_observer_equals_the_device_resident_loop(ctx, rail371
     for a, b in zip(sol.K, ref.K):
         assert D.delta(a, b) < 1e-9
     assert len(ob.done) == 6 and all(ok for _, ok in ob.done) and len(ob.ranks) > 6
+
+
+def test_user_supplied_orthf_is_honoured_by_compression_and_norm(ctx):
+    """The reference's extension point `orthf(L) -> (Q, R)` (src/LDLt.jl:227-245): test/cuda.jl:32-37 substitutes an SVD-based one.  Here the
+    substitute runs on the host (download, numpy SVD, upload through raw device pointers — `dre_orthf_fn` of include/dre_hip.h) and must be
+    what `compress_` (LDLt.jl:211) and `norm` (LDLt.jl:84) use: same compressed object and norm as with the library's Householder QR, and a
+    literal-mode ADI solve (compress_exact) that goes through it as well."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    calls = []
+
+    def orthf(n, c, Lp, ldl, Qp, ldq, Rp, ldr):
+        L = np.empty((c, ldl))                                    # column-major n x c with leading dimension ldl
+        assert hip.hipMemcpy(L.ctypes.data, Lp, L.nbytes, 2) == 0 # device -> host
+        Lm = L[:, :n].T
+        U, sv, Vt = np.linalg.svd(Lm, full_matrices=False)        # L = U S V': Q = U, R = S V'   (test/cuda.jl:33-36)
+        p = min(n, c)
+        Q = np.zeros((p, ldq)); Q[:, :n] = U[:, :p].T
+        R = np.zeros((c, ldr)); R[:, :p] = (sv[:p, None] * Vt[:p]).T
+        assert hip.hipMemcpy(Qp, Q.ctypes.data, Q.nbytes, 1) == 0 and hip.hipMemcpy(Rp, R.ctypes.data, R.nbytes, 1) == 0
+        calls.append((n, c))
+        return 0
+    rng = np.random.default_rng(5)
+    n, k = 60, 9
+    L = rng.standard_normal((n, k)); Dm = rng.standard_normal((k, k)); Dm = Dm + Dm.T
+    W4 = rng.standard_normal((4, 4))
+
+    def mk():
+        return D.lowrank(L, Dm) + D.lowrank(L[:, :4] @ W4, np.eye(4))          # rank 9, 13 columns (compress_ works in place: a fresh object each time)
+    Xd = mk().dense()
+    ref = D.compress_(mk())
+    nref = D.norm(mk())
+    try:
+        ctx.set_orthf(orthf)
+        got = D.compress_(mk())
+        ngot = D.norm(mk())
+        assert calls and all(c[0] == n for c in calls)
+        assert got.rank() == ref.rank() == 9
+        assert np.linalg.norm(got.dense() - ref.dense()) <= 1e-12 * np.linalg.norm(ref.dense())
+        assert abs(ngot - nref) <= 1e-12 * nref and abs(ngot - np.linalg.norm(Xd)) <= 1e-12 * nref
+        # a literal-mode Lyapunov solve runs its compressions through the hook, too
+        d = D.steel_profile(371)
+        L0, D0 = D.initial_value(d)
+        ncalls = len(calls)
+        prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L0, D0), (4500.0, 4400.0))
+        p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+        sol = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p), compress_exact=True)), dt=-100.0)
+        assert len(calls) > ncalls
+    finally:
+        ctx.set_orthf(None)
+    sol0 = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p), compress_exact=True)), dt=-100.0)
+    assert D.delta(sol.K[-1], sol0.K[-1]) < 1e-10
