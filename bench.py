@@ -39,7 +39,8 @@ KERNEL_SYMBOL = {"qr_panel": "k_qr_panel", "qr_panel_tsqr": "k_tsqr", "gemm_band
                  "mf_factor_real": "k_front_factor", "spmm_csr": "k_spmm", "band_rem": "k_band_rem", "ldlt_norm": "k_gram_norm",
                  "gemm_lrband": "k_gemm", "lrband_rows": "k_rows_blockdiag", "lrband_decide": "k_lr_", "adi_fast_iter": "k_adi_fast", "adi_group_iter": "k_adi_group",
                  "adi_fast_flush": "k_adi_fast", "band_z": "k_band_z", "band_upd": "k_band_upd", "adi_eff_stack": "k_eff_stack",
-                 "gemm_xupdate": "k_gemm"}
+                 "gemm_xupdate": "k_gemm", "fan_spmm_mix": "k_fan_spmm_mix", "smw_apply": "k_smw_apply", "gemm_mf_top": "k_gemm_z", "gemm_sketch": "k_gemm",
+                 "gemm_orth": "k_gemm", "mf_factor_complex": "k_front_factor", "mf_solve_complex": "k_mf_"}
 
 
 def parse():
@@ -78,7 +79,7 @@ def roofline_record(stats, n, m, pencil, its_solve, kw, wall):
         roof = dict(bound="hbm", kernel=name, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None)
     roof["algorithmic_bytes_per_launch"] = s["bytes"] / max(s["launches"], 1)
     roof["algorithmic_flops_per_launch"] = s["flops"] / max(s["launches"], 1)
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             pmc_file = f"pmc_traffic_{rnd}_n{n}.json"
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
@@ -114,7 +115,7 @@ def roofline_record(stats, n, m, pencil, its_solve, kw, wall):
                 roof.pop("traffic_source", None)
                 roof["largest_share_kernel"] = {k: top_share[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches",
                                                                           "share_of_device_time", "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch") if k in top_share}
-                for rnd in ("r03", "r02"):
+                for rnd in ("r04", "r03", "r02"):
                     try:
                         pmc = json.load(open(os.path.join(ROOT, "profiles", f"pmc_traffic_{rnd}_n{n}.json")))
                         sym = KERNEL_SYMBOL.get(cls)
