@@ -80,30 +80,25 @@ int dre_ctx_create(int device, dre_ctx** out) {
         hipDeviceProp_t prop;
         DRE_HIP(hipGetDeviceProperties(&prop, device));
         ctx->c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (const char* e = std::getenv("DRE_DENSE_INV_MAX_N")) ctx->c.dense_inv_max_n = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_MAX_N")) ctx->c.compress_direct_max_n = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_DIRECT_RATIO")) ctx->c.compress_direct_ratio = std::atof(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_N")) ctx->c.compress_factor_min_n = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_FACTOR_MIN_COLS")) ctx->c.compress_factor_min_cols = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH")) ctx->c.compress_sketch = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_MIN_COLS")) ctx->c.compress_sketch_min_cols = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_EXTRA")) ctx->c.compress_sketch_extra = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_CHOLQR")) ctx->c.compress_sketch_cholqr = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_SPARSE")) ctx->c.compress_sketch_sparse = std::atoi(e);
-        if (const char* e = std::getenv("DRE_COMPRESS_SKETCH_RATIO")) ctx->c.compress_sketch_ratio = std::atof(e);
-        if (const char* e = std::getenv("DRE_TOP_INVERSE_MAX_ROWS")) ctx->c.top_inverse_max_rows = std::atoi(e);
-        if (const char* e = std::getenv("DRE_MF_SUBTREE")) ctx->c.mf_subtree = std::atoi(e);
-        if (const char* e = std::getenv("DRE_SETUP_STREAMS")) ctx->c.setup_streams = std::atoi(e);
-        if (const char* e = std::getenv("DRE_X_SIDE_STREAM")) ctx->c.x_side_stream = std::atoi(e);
-        if (const char* e = std::getenv("DRE_DENSE_X_MAX_N")) ctx->c.dense_x_max_n = std::atoi(e);
-        if (const char* e = std::getenv("DRE_ADI_GROUP")) ctx->c.adi_group = std::atoi(e);
-        if (const char* e = std::getenv("DRE_ADI_GROUP_MAX_N")) ctx->c.adi_group_max_n = std::atoi(e);
-        if (const char* e = std::getenv("DRE_ADI_FAN")) ctx->c.adi_fan = std::atoi(e);
-        if (const char* e = std::getenv("DRE_ADI_FAN_MAX_COEF")) ctx->c.adi_fan_max_coef = std::atof(e);
-        if (const char* e = std::getenv("DRE_X_COMPRESS_EVERY")) ctx->c.x_compress_every = std::atoi(e);
         ctx->c.timer = std::make_unique<KernelTimer>();
     });
     if (rc != DRE_OK) { g_noctx_error = ctx->c.last_error; delete ctx; return rc; }
+    // DRE_OPTIONS="name=value,name=value": the options of dre_ctx_set_option for every context of the process (tools/option_matrix.sh runs
+    // the test suite under each configuration this way); an unknown name is an error like in the call
+    if (const char* e = std::getenv("DRE_OPTIONS")) {
+        std::string all = e;
+        size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            pos = end + 1;
+            const size_t eq = item.find('=');
+            if (item.empty() || eq == std::string::npos) continue;
+            const int rc2 = dre_ctx_set_option(ctx, item.substr(0, eq).c_str(), std::atof(item.substr(eq + 1).c_str()));
+            if (rc2 != DRE_OK) { g_noctx_error = "DRE_OPTIONS: " + ctx->c.last_error; dre_ctx_destroy(ctx); return rc2; }
+        }
+    }
     *out = ctx;
     return DRE_OK;
 }

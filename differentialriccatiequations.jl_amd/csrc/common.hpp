@@ -265,6 +265,16 @@ struct Mat {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Diagnostics on stderr: DRE_TRACE=<keyword>[,<keyword>...] (or "all").  Keywords: compress, cholqr, proj, prefetch, subtree (what a code path
+// decided), phase, chunk, rec, fan (host/device timings of the loops).  The engine's TUNABLES are options (dre_ctx_set_option; DRE_OPTIONS=
+// "name=value,..." sets them for every context created by the process) — environment variables do not select kernels.
+inline bool env_trace(const char* key) {
+    const char* e = std::getenv("DRE_TRACE");
+    if (!e || !*e) return false;
+    const std::string s = std::string(",") + e + ",";
+    return s.find(",all,") != std::string::npos || s.find(std::string(",") + key + ",") != std::string::npos;
+}
+
 // raise the dynamic shared memory limit of a kernel once per context (device)
 // Streams of a library context by role.  HIP maps streams onto a handful of hardware queues round-robin PER PRIORITY LEVEL; with everything at
 // the default priority the fifth, sixth ... stream of a process lands on the queue of the main stream and its kernels are serialised with the
@@ -273,7 +283,7 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // LOSS at depth 8 (n = 1357 Ros2: 2 830 against 3 250 it/s — low-priority factorisations are starved by the main stream's kernels and arrive
 // late), so equal priorities stay the default.   role: 0 main, 1 side, 2 helper.
 inline hipStream_t create_stream(int role) {
-    static const bool on = std::getenv("DRE_STREAM_PRIORITIES") && std::atoi(std::getenv("DRE_STREAM_PRIORITIES")) != 0;
+    static const bool on = false;
     hipStream_t st = nullptr;
     int least = 0, greatest = 0;
     if (on && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {

@@ -308,164 +308,13 @@ __global__ void k_gemm_reduce(int M, int N, int splits, double alpha, const doub
     *c = (beta == 0.0) ? alpha * s : alpha * s + beta * (*c);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Tall-skinny  C = alpha A' B  (A: K x M, B: K x N column-major, K >> M, N): the Gram matrix of the residual factor (norm(::LDLt) in Gram form,
-// every ADI iteration), U'W of the Sherman-Morrison-Woodbury correction, V'Z / Q'L products of the compressions.  The general split-K GEMM
-// cuts K into up to 512 slabs of a 64 x 64 tile (16.8 MB of partial slabs for a 64 x 64 result at n = 20209, then an 8-us reduction).
-// Here every WAVE walks groups of 16 consecutive rows: lane (lr, lk) loads rows 16 g + 4 lk .. 4 lk + 3 of column 16 t + lr — 32 contiguous
-// bytes, the 16 lanes of a column group cover one 128-byte line — and those four values are the operands of four MFMA K-steps (the K index
-// of a step is a free choice as long as A and B agree).  A wave keeps up to 4 x 4 accumulator tiles, prefetches the next row group while
-// the current one multiplies, and writes ONE partial per tile (no LDS, no barrier); a second launch sums the partials in a fixed order.
-// ---------------------------------------------------------------------------------------------
-#define TSMM_T 4
-__global__ __launch_bounds__(256) void k_tsmm(int K, int M, int N, const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
-                                              double* __restrict__ part, int nwaves, int nbi, int sym, const AdiState* st) {
-    if (st && st->done) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
-    const int w = blockIdx.x * 4 + wave;                     // this wave's first row group (stride nwaves)
-    const int bi = blockIdx.y % nbi, bj = blockIdx.y / nbi;  // block of TSMM_T x TSMM_T tiles
-    if (sym && bi > bj) return;
-    const int tma = (M + 15) >> 4, tnb = (N + 15) >> 4;
-    const int na = min(TSMM_T, tma - bi * TSMM_T), nb = min(TSMM_T, tnb - bj * TSMM_T);
-    const double* ap[TSMM_T]; const double* bp[TSMM_T];
-    bool aok[TSMM_T], bok[TSMM_T];
-#pragma unroll
-    for (int i = 0; i < TSMM_T; ++i) {
-        const int ca = (bi * TSMM_T + i) * 16 + lr, cb = (bj * TSMM_T + i) * 16 + lr;
-        aok[i] = i < na && ca < M; bok[i] = i < nb && cb < N;
-        ap[i] = A + (size_t)(aok[i] ? ca : 0) * lda + 4 * lk;
-        bp[i] = B + (size_t)(bok[i] ? cb : 0) * ldb + 4 * lk;
-    }
-    v4d acc[TSMM_T][TSMM_T];
-#pragma unroll
-    for (int i = 0; i < TSMM_T; ++i)
-#pragma unroll
-        for (int j = 0; j < TSMM_T; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int ngrp = (K + 15) >> 4;
-    const bool diag = sym && bi == bj;                       // symmetric result, diagonal block: tiles below the diagonal are mirrored by the reduction
-    double a0[TSMM_T][4], b0[TSMM_T][4], a1[TSMM_T][4], b1[TSMM_T][4];
-    auto load = [&](double (&av)[TSMM_T][4], double (&bv)[TSMM_T][4], int g) {
-        const int r0 = 16 * g;
-#pragma unroll
-        for (int i = 0; i < TSMM_T; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = min(r0 + 4 * lk + q, K - 1) - 4 * lk;       // clamped (masked at use)
-                av[i][q] = ap[i][r]; bv[i][q] = bp[i][r];
-            }
-    };
-    auto mma = [&](const double (&av)[TSMM_T][4], const double (&bv)[TSMM_T][4], int g) {
-        const int r0 = 16 * g + 4 * lk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool rok = r0 + q < K;
-#pragma unroll
-            for (int i = 0; i < TSMM_T; ++i) {
-                const double x = (rok && aok[i]) ? av[i][q] : 0.0;
-#pragma unroll
-                for (int j = 0; j < TSMM_T; ++j)
-                    if (!(diag && i > j)) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, (rok && bok[j]) ? bv[j][q] : 0.0, acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-    int g = w;
-    if (g < ngrp) load(a0, b0, g);
-    for (; g < ngrp; g += 2 * nwaves) {
-        const int g1 = g + nwaves;
-        if (g1 < ngrp) load(a1, b1, g1);
-        mma(a0, b0, g);
-        if (g1 < ngrp) {
-            if (g1 + nwaves < ngrp) load(a0, b0, g1 + nwaves);
-            mma(a1, b1, g1);
-        }
-    }
-    // the four waves of the workgroup are summed through LDS (fixed order) and ONE partial per tile and workgroup is written:
-    //   part[((blk * 16 + i * 4 + j) * nwg + wg) * 256 + q * 64 + lane]
-    extern __shared__ double tsm[];                          // [16 tiles][4 waves][256]
-#pragma unroll
-    for (int i = 0; i < TSMM_T; ++i)
-#pragma unroll
-        for (int j = 0; j < TSMM_T; ++j) {
-            if (diag && i > j) continue;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tsm[((size_t)(i * TSMM_T + j) * 4 + wave) * 256 + q * 64 + lane] = acc[i][j][q];
-        }
-    __syncthreads();
-    const int nwg = nwaves >> 2;
-    double* __restrict__ pp = part + ((size_t)blockIdx.y * TSMM_T * TSMM_T * nwg + blockIdx.x) * 256;
-    for (int t = 0; t < TSMM_T * TSMM_T; ++t) {
-        const int i = t / TSMM_T, j = t - i * TSMM_T;
-        if (i >= na || j >= nb || (diag && i > j)) continue;
-        const double* __restrict__ r = tsm + (size_t)t * 4 * 256 + threadIdx.x;
-        pp[(size_t)t * nwg * 256 + threadIdx.x] = (r[0] + r[256]) + (r[512] + r[768]);
-    }
-}
-__global__ __launch_bounds__(256) void k_tsmm_reduce(int M, int N, int nwaves, int nbi, int sym, double alpha, double beta, const double* __restrict__ part,
-                                                     double* __restrict__ C, int ldc, const AdiState* st) {
-    if (st && st->done) return;
-    // 16 lanes per output element: lane l sums the partials l, l + 16, ... (independent loads, eight in flight), then a fixed-order
-    // butterfly over the 16 lanes — the sum of a few hundred partials is a handful of memory round trips instead of one per partial
-    const int l = threadIdx.x & 15;
-    const size_t idx = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool ok = idx < (size_t)M * N;
-    const size_t id = ok ? idx : 0;
-    const int i = id % M, j = id / M;
-    int ti = i >> 4, tj = j >> 4, il = i & 15, jl = j & 15;
-    if (sym && ti > tj) { const int t = ti; ti = tj; tj = t; const int u = il; il = jl; jl = u; }     // mirror tile
-    const int bi = ti / TSMM_T, bj = tj / TSMM_T, blk = bi + bj * nbi;
-    const int li = ti - bi * TSMM_T, lj = tj - bj * TSMM_T;
-    // element (il, jl) of a tile: accumulator register q = il >> 2 at lane (il & 3) * 16 + jl
-    const double* __restrict__ p = part + ((size_t)(blk * TSMM_T * TSMM_T + li * TSMM_T + lj) * nwaves) * 256 + (il >> 2) * 64 + (il & 3) * 16 + jl;
-    double s = 0.0;
-    int w = l;
-    for (; w + 7 * 16 < nwaves; w += 8 * 16) {
-        double q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = p[(size_t)(w + 16 * u) * 256];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += q[u];
-    }
-    for (; w < nwaves; w += 16) s += p[(size_t)w * 256];
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
-    if (ok && l == 0) {
-        double* c = C + i + (size_t)j * ldc;
-        *c = (beta == 0.0) ? alpha * s : alpha * s + beta * (*c);
-    }
-}
-// Measured (round 3, tools/ab_general.sh): NOT faster than the split-K GEMM it was meant to replace — Gram of a 5177 x 64 factor 21 us against
-// 16 us, 20209 x 64: 31 against 24 us (one wave per SIMD at 244 VGPRs, eight scalar loads per tile and row group); whole solves within 1 %.
-// Kept behind DRE_TSMM=1 as a recorded experiment; the default path is the split-K GEMM.
-static bool tsmm_enabled() {
-    static const bool v = std::getenv("DRE_TSMM") && std::atoi(std::getenv("DRE_TSMM")) != 0;
-    return v;
-}
-// true: handled.  sym: A and B are the same matrix (only the upper block triangle is computed, the rest mirrored)
-static bool gemm_tsmm(Ctx* ctx, int M, int N, int K, double alpha, const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc,
-                      const AdiState* st) {
-    if (!tsmm_enabled() || K < 2048 || M > 256 || N > 512 || (long)K < 8L * std::max(M, N)) return false;
-    const bool sym = (A == B && lda == ldb && M == N);
-    const int tma = ceil_div(M, 16), tnb = ceil_div(N, 16);
-    const int nbi = ceil_div(tma, TSMM_T), nbj = ceil_div(tnb, TSMM_T);
-    const int ngrp = ceil_div(K, 16);
-    // waves: enough to fill the chip once with the block grid, at most one row group each, at least ~4 row groups per wave for the large sizes
-    // workgroups (4 waves each): ~2 row groups per wave, at most 2 x CUs workgroups over all tile blocks
-    int nwg = std::max(1, std::min(std::max(1, 2 * ctx->num_cus / std::max(1, nbi * nbj)), ceil_div(ngrp, 8)));
-    const int nwaves = 4 * nwg;
-    auto pb = std::make_shared<Buf>(ctx, (size_t)nbi * nbj * TSMM_T * TSMM_T * nwg * 256 * sizeof(double));
-    const size_t lds = (size_t)TSMM_T * TSMM_T * 4 * 256 * sizeof(double);
-    lds_attr(ctx, (const void*)k_tsmm, 140 * 1024);
-    hipLaunchKernelGGL(k_tsmm, dim3(nwg, nbi * nbj), dim3(256), lds, ctx->stream, K, M, N, A, lda, B, ldb, (double*)pb->p, nwaves, nbi, sym ? 1 : 0, st);
-    hipLaunchKernelGGL(k_tsmm_reduce, dim3((unsigned)(((size_t)M * N + 15) / 16)), dim3(256), 0, ctx->stream, M, N, nwg, nbi, sym ? 1 : 0, alpha, beta,
-                       (const double*)pb->p, C, ldc, st);
-    DRE_HIP(hipGetLastError());
-    return true;
-}
-
+// (A tall-skinny  C = alpha A'B  kernel — every wave walks groups of 16 rows, up to 4 x 4 accumulator tiles, one partial per wave, no LDS — was
+// built in round 3 for the Gram matrices / U'W / V'Z products and measured NOT faster than the split-K GEMM below: Gram of a 5177 x 64 factor
+// 21 us with either.  Removed in round 4; CHANGELOG.)
 void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
           int ldb, double beta, double* C, int ldc, const AdiState* st, const char* tag, double* tile_sumsq) {
     if (M <= 0 || N <= 0) return;
     TimedScope ts(ctx, tag, 8.0 * ((double)M * K + (double)K * N + 2.0 * M * N), 2.0 * M * N * (double)K);
-    if (tA && !tB && !tile_sumsq && gemm_tsmm(ctx, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, st)) return;
     const int tm = ceil_div(M, GB_M), tn = ceil_div(N, GB_N);
     // These GEMMs are latency bound (one memory round trip per K-tile), so K is split until the grid fills the
     // chip or every block is down to two K-tiles; partial slabs are reduced in a fixed order (deterministic).
@@ -876,7 +725,7 @@ void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, si
 }
 void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1,
                        const void* d2, size_t b2, void* h2) {
-    static const bool spin_on = !(std::getenv("DRE_FETCH_SPIN") && std::atoi(std::getenv("DRE_FETCH_SPIN")) == 0);   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
+    static const bool spin_on = true;   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
     const size_t tot = (b0 + b1 + b2) / 8;
     DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
     if (spin_on && !ctx->fetch_host) {
@@ -1495,7 +1344,7 @@ void adi_fast_build(Ctx* ctx, int n, int m, const std::vector<const double*>& st
     const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
     bool all_lr = m >= 1 && m <= 8;
     for (auto w : wks) if (!w) all_lr = false;
-    static const bool use_mfma = !(std::getenv("DRE_EFF_STACK_MFMA") && std::atoi(std::getenv("DRE_EFF_STACK_MFMA")) == 0);
+    static const bool use_mfma = true;
     if (all_lr && use_mfma) {
         const int ntile = (kst + 3) >> 2;
         for (size_t b0 = 0; b0 < stacks.size(); b0 += 16) {
@@ -2210,17 +2059,6 @@ void residual_norm_group_diag(Ctx* ctx, const Mat& Rcat, int g, int k, const Mat
 }
 void residual_norm_step(Ctx* ctx, const Mat& R, const Mat& T, bool tdiag, double alpha, AdiState* st, int iters_after) {
     const int k = R.cols;
-    if (k <= 96 && tsmm_enabled() && R.rows >= 2048) {
-        // tall R: the Gram matrix through the tall-skinny kernel (one partial per wave), then the one-workgroup norm on a single slab
-        Mat G(ctx, k, k);
-        gemm(ctx, true, false, 1.0, R, R, 0.0, G, st, "gemm_gram");
-        TimedScope ts(ctx, "ldlt_norm", 8.0 * k * k, 4.0 * (double)k * k * k);
-        const int kp = (k + 31) & ~31;
-        const size_t shm = 2 * (size_t)kp * kp * sizeof(double);
-        lds_attr(ctx, (const void*)k_gram_norm, 150 * 1024);
-        hipLaunchKernelGGL(k_gram_norm, dim3(1), dim3(1024), shm, ctx->stream, k, 1, (const double*)G.p, T.p, T.ld, tdiag ? 1 : 0, alpha, st, iters_after);
-        return;
-    }
     if (k > 96) {
         Mat G(ctx, k, k);
         gemm(ctx, true, false, 1.0, R, R, 0.0, G, st, "gemm_gram");
@@ -3181,7 +3019,7 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
     }
 }
 static bool qr_panel16_enabled() {
-    static const bool v = !(std::getenv("DRE_QR_PANEL16") && std::atoi(std::getenv("DRE_QR_PANEL16")) == 0);
+    static const bool v = true;
     return v;
 }
 
@@ -3988,7 +3826,7 @@ __global__ __launch_bounds__(64) void k_band_init(AdiState* st, double abs_tol, 
     st->abstol = job.parts ? at_dev : (abs_tol_dev ? abs_tol_dev[0] : abs_tol);
     st->res_norm = 0.0;
 }
-// debug (DRE_CLOCK_PROBE=1): shader clock while the solve runs = delta s_memtime / delta s_memrealtime x 100 MHz over ~10 us of dependent ALU work
+// debug (DRE_TRACE=clock): shader clock while the solve runs = delta s_memtime / delta s_memrealtime x 100 MHz over ~10 us of dependent ALU work
 __global__ void k_clock_probe(long long* out) {
     const long long c0 = clock64(), w0 = wall_clock64();
     double x = 1.0 + threadIdx.x;
@@ -3997,7 +3835,7 @@ __global__ void k_clock_probe(long long* out) {
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
 }
 static bool band_fused_enabled() {
-    static const bool v = !(std::getenv("DRE_BAND_FUSED") && std::atoi(std::getenv("DRE_BAND_FUSED")) == 0);
+    static const bool v = true;
     return v;
 }
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev, BandSpec* spec, const double* ext_part, int ext_nparts,
@@ -4025,7 +3863,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
         hipLaunchKernelGGL(k_band_init, dim3(1), dim3(64), 0, ctx->stream, st.p, abs_tol, abs_tol_dev, tol_is_floor ? 1 : 0, job);
     }
     {
-        static const bool cp = std::getenv("DRE_CLOCK_PROBE") != nullptr;
+        static const bool cp = env_trace("clock");
         static int cp_count = 0;
         if (cp && q > 300 && (++cp_count % 40) == 20) {
             DevArr<long long> o(ctx, 4);
@@ -4465,7 +4303,7 @@ __global__ void k_lr_extract_band(int J, const double* __restrict__ BS, double* 
 // unit vectors,  L <- Q0' L  with Q0 = I - VT0 V0' from the QR of L[:, 0:16].  Without it the reduction starts from arbitrary unit
 // vectors and needs about one panel (16 columns of rank) more to reach the same remainder; the QR path gets this order for free.
 bool lead_rotation_enabled() {
-    static const bool on = !(std::getenv("DRE_LEAD_ROTATION") && std::atoi(std::getenv("DRE_LEAD_ROTATION")) == 0);
+    static const bool on = true;
     return on;
 }
 void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0) {
@@ -4495,7 +4333,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
     SymBand out;
     out.q = n; out.nb = b;
     const int maxp = ceil_div(c, b) + 1;                 // rank(S) <= c: after that many panels nothing is left
-    static const double safety = std::getenv("DRE_LR_SAFETY") ? std::atof(std::getenv("DRE_LR_SAFETY")) : 2.0;
+    static const double safety = 2.0;
     const int cap = maxp * b;
     out.V = Mat(ctx, n, cap); out.VT = Mat(ctx, n, cap); out.T = Mat(ctx, b, cap);
     fill_mat(ctx, out.V, 0.0);

@@ -164,10 +164,10 @@ inline int adi_fast_pick_nt(int n, int k) {
 // kernel variant and column tiles per workgroup: the K-split tiles win while a launch is latency bound (n < 768 or residuals narrower than 128 columns); beyond that the LDS-staged
 // full-K strips with two column tiles per wave keep >= 1 wave per SIMD busy without re-gathering R
 inline void adi_fast_pick(int n, int k, int* mode, int* nt) {
-    static const int wide_min_n = std::getenv("DRE_ADI_WIDE_MIN_N") ? std::atoi(std::getenv("DRE_ADI_WIDE_MIN_N")) : 768;
+    static const int wide_min_n = 768;
     if (n >= wide_min_n && k >= 128) { *mode = 1; *nt = 2; }       // measured at n = 1357: k = 64: 41 us (K-split) vs 53 us; k = 160: 77 vs 55 us; k = 294: 131 vs 80 us
     else {
-        static const int force_nt = std::getenv("DRE_ADI_FAST_NT") ? std::atoi(std::getenv("DRE_ADI_FAST_NT")) : 0;
+        static const int force_nt = 0;
         *mode = 0; *nt = force_nt > 0 ? force_nt : adi_fast_pick_nt(n, k);
     }
 }

@@ -149,7 +149,7 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev, int j_start = 0
     Mat G(ctx, bs, bs), Ri(ctx, bs, bs), T(ctx, n, bs);
     DevArr<double> ref(ctx, 1);              // scale of the sketch: largest squared column norm of the first block
     DevArr<int> nullmask(ctx, bs);
-    static const bool trace = std::getenv("DRE_TRACE_CHOLQR") != nullptr;
+    static const bool trace = env_trace("cholqr");
     DevArr<double> dbg(ctx, 64);
     int nblk = 0;
     for (int j0 = j_start; j0 < s; j0 += bs) {
@@ -187,7 +187,7 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev, int j_start = 0
 
 static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) {
     const int n = X.n, c = X.rank(), sp = s + 16;
-    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    static const bool trace = env_trace("compress");
     Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
     Mat W1(ctx, sp, c), W2(ctx, sp, c), Y(ctx, n, sp);
     const long spkey = skey - 2;                       // band_hint: sketches with the sparse sign test matrix the probe rejected at this order (two strikes: Gaussian)
@@ -262,7 +262,7 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
 // truncates at anyway); otherwise the caller runs the full reduction.  *missed returns the estimate.
 static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed) {
     const int n = X.n, c = X.rank(), q0 = Q0.cols, sp = sx + 16, s = q0 + sx;
-    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    static const bool trace = env_trace("compress");
     if (c == 0 || q0 < 16 || s <= 64 || s + 80 > n || abs_tol <= 0.0 || Q0.rows != n) {
         if (trace) std::fprintf(stderr, "[warm compress] not applicable: c=%d q0=%d sx=%d abs_tol=%g\n", c, q0, sx, abs_tol);
         return false;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void k_noise_floor(int c, double fac, const do
     if (threadIdx.x == 0) floor_out[0] = fac * 2.220446049250313e-16 * sqrt((red[0] + red[1]) + (red[2] + red[3]));
 }
 static double noise_floor_fac() {
-    static const double f = std::getenv("DRE_NOISE_FLOOR_FAC") ? std::atof(std::getenv("DRE_NOISE_FLOOR_FAC")) : 4.0;    // 0.03 ... 4: same K(t) to 2e-14 (tools/dbg_ros2_full.py)
+    static const double f = 4.0;    // 0.03 ... 4: same K(t) to 2e-14 (tools/dbg_ros2_full.py)
     return f;
 }
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode) {
@@ -356,7 +356,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
     // (two thirds of all panel factorisations at n = 371) at the price of one GEMM.
     // (a handful of columns: the QR path keeps the rank <= c, the direct form can only stop at panel boundaries of the n x n problem)
     const bool wide = c >= n || (!exact && ((n <= 512 && c > 64) || (n <= ctx->compress_direct_max_n && (double)c * ctx->compress_direct_ratio >= (double)n)));
-    if (std::getenv("DRE_TRACE_COMPRESS")) std::fprintf(stderr, "[compress enter] n=%d c=%d wide=%d exact=%d abs_tol=%g factor_min_n=%d min_cols=%d sketch=%d/%d\n", n, c, (int)wide, (int)exact, abs_tol, ctx->compress_factor_min_n, ctx->compress_factor_min_cols, ctx->compress_sketch, ctx->compress_sketch_min_cols);
+    if (env_trace("compress")) std::fprintf(stderr, "[compress enter] n=%d c=%d wide=%d exact=%d abs_tol=%g factor_min_n=%d min_cols=%d sketch=%d/%d\n", n, c, (int)wide, (int)exact, abs_tol, ctx->compress_factor_min_n, ctx->compress_factor_min_cols, ctx->compress_sketch, ctx->compress_sketch_min_cols);
     const long skey = -(4000000000L + (long)n);          // band_hint: rank of the previous wide-factor compression at this order
     const bool sketchable = !wide && !exact && !nfloor && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && c >= ctx->compress_sketch_min_cols && c + 64 <= n;
     if (sketchable) {
@@ -419,7 +419,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
     } else if (wide) {
         // more columns than rows: Q = I, "R" = L (any orthogonal-times-anything factorisation is admissible)
         Mat LD;
-        static const int rot_min_n = std::getenv("DRE_LEAD_ROTATION_MIN_N") ? std::atoi(std::getenv("DRE_LEAD_ROTATION_MIN_N")) : 65;
+        static const int rot_min_n = 65;
         if (!exact && lead_rotation_enabled() && c >= 32 && n >= rot_min_n) {
             // start the reduction from the dominant directions (dense.hip, lead_rotate): Q = Q0 instead of I.  L and L D sit side
             // by side so that one batched launch fills both and one block reflector rotates both
@@ -510,7 +510,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         ldlt_concatenate(ctx, X);
         return;
     }
-    static const bool trace = std::getenv("DRE_TRACE_COMPRESS") != nullptr;
+    static const bool trace = env_trace("compress");
     if (trace) std::fprintf(stderr, "[compress] n=%d c=%d -> r=%d  (%s, order %d)\n", n, c, r, wide ? "direct" : "qr", S.rows);
     X.blocks.clear();
     X.blocks.push_back({Lnew, Dnew, 1.0, exact, true});
@@ -873,7 +873,7 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         DRE_HIP(hipMemcpy2DAsync(hR.data(), kq * sizeof(double), qr.R.p, qr.R.ld * sizeof(double), kq * sizeof(double), w, hipMemcpyDeviceToHost, ctx->stream));
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         std::vector<double> Us, sv;
-        static const bool trace = std::getenv("DRE_TRACE_PROJ") != nullptr;
+        static const bool trace = env_trace("proj");
         auto t0 = std::chrono::steady_clock::now();
         // orth(N) keeps the left singular vectors with sigma > n eps (Stuff.jl:13-19).  With N = Q R and R square, every sigma(R) > n eps means
         // span(N) = span(Q): the Ritz values of the projected pencil do not depend on WHICH orthonormal basis of that subspace is used, so the
@@ -881,7 +881,7 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
         // only run when R may be rank deficient: sigma_min is estimated by four steps of inverse iteration on R'R (triangular solves) and
         // compared with 100 n eps.
         bool full_rank = false;
-        static const bool skip_svd = !(std::getenv("DRE_PROJ_SKIP_SVD") && std::atoi(std::getenv("DRE_PROJ_SKIP_SVD")) == 0);
+        static const bool skip_svd = true;
         if (skip_svd && kq == w && w >= 1) {
             double dmin = 1e300;
             for (int i = 0; i < w; ++i) dmin = std::min(dmin, std::fabs(hR[i + (size_t)i * kq]));
@@ -1008,7 +1008,7 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
 // =============================================================================================
 // largest n for which the Ros1 driver carries X as a block list (right-hand side, feedback and residual on the summands)
 static int xblocks_max_n() {
-    static const int v = std::getenv("DRE_XBLOCKS_MAX_N") ? std::atoi(std::getenv("DRE_XBLOCKS_MAX_N")) : 1536;
+    static const int v = 1536;
     return v;
 }
 // P = F / s + s E,  M = F / s - s E  with  s^4 = ||F||_F^2 / ||E||_F^2  read from device memory (nrm2[0], nrm2[1])
@@ -1291,13 +1291,6 @@ __global__ void k_join_cplx(int rows, int cols, const double* __restrict__ re, c
     int r = id % rows, c = id / rows;
     dst[r + (size_t)c * ldd] = {re[r + (size_t)c * lds_], im ? im[r + (size_t)c * lds_] : 0.0};
 }
-__global__ void k_split_cplx2(int rows, int cols, const cplx* __restrict__ src, int lds_, double* __restrict__ re, double* __restrict__ im, int ldd) {
-    size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= (size_t)rows * cols) return;
-    int r = id % rows, c = id / rows;
-    const cplx z = src[r + (size_t)c * lds_];
-    re[r + (size_t)c * ldd] = z.re; im[r + (size_t)c * ldd] = z.im;
-}
 // The plug-in point of the reference's BlockLinearSolver protocol: the user solves the sparse shifted system for the block right-hand
 // side W (n x ncols, solver ordering, overwritten by the solution).  The panel is handed over in the caller's row ordering after a
 // stream synchronisation; the callback must have finished its own device work when it returns.
@@ -1558,7 +1551,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         const double lag = opt.abstol_lag > 0.0 ? opt.abstol_lag : (opt.abstol >= 0.0 ? opt.abstol : -1.0);
         if (resid->blocks.size() > 1) {
             bool done = false;
-            static const bool warm_on = !(std::getenv("DRE_WARM_COMPRESS") && std::atoi(std::getenv("DRE_WARM_COMPRESS")) == 0);
+            static const bool warm_on = true;
             if (warm_on && opt.warm_basis.cols > 0 && lag > 0.0 && cache->warm_strikes < 2) {
                 const int sx = cache->warm_sx > 0 ? cache->warm_sx : 32;
                 double missed = 0.0;
@@ -1684,7 +1677,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     }
     // ---- fast chain (dense.hip, k_adi_fast): every shift of the cycle is real and already has its stacked dense inverse for the
     // current low-rank factor (i.e. from the second time step of a run on) and the residual is at most 96 columns wide ----------
-    static const bool fast_env = !(std::getenv("DRE_ADI_FAST") && std::atoi(std::getenv("DRE_ADI_FAST")) == 0);
+    static const bool fast_env = true;
     bool fast = fast_env && !opt_in.inner_solve && opt_in.shifts.kind == ShiftSpec::CYCLIC && k >= 1 && k <= ADI_FAST_MAX_K && n <= ctx->dense_inv_max_n && cache->enabled;
     auto& fast_fe = run.fast_fe;            // per position of the cycle
     auto& fast_pack = run.fast_pack;
@@ -1746,7 +1739,7 @@ void adi_advance(AdiRun& run, int budget) {
     auto& resid = run.resid;
     const int chunk_limit = std::max(1, std::min(std::min(run.chunk_limit, budget), 480));     // (< 512: ring of the norm history)
     auto check_used = [&]() { run.check_used(); };
-    static const bool lazy_norm = !(std::getenv("DRE_LAZY_NORM") && std::atoi(std::getenv("DRE_LAZY_NORM")) == 0);
+    static const bool lazy_norm = true;
     (void)P; (void)opt_in; (void)serr; (void)lazy_norm;
     if (run.fast) {
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
@@ -1773,7 +1766,7 @@ void adi_advance(AdiRun& run, int budget) {
             a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
             a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = tdiag ? 1 : 0; a.alpha = alpha_res; a.st = st.p; a.nws = nws.p;
             // the residual also in the B-operand lane order (dense.hpp, AdiFastArgs::Rpc): slot 0 = the chunk's input, slot j = after iteration j
-            static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
+            static const bool packed_r = true;
             const bool use_pk = packed_r && a.mode == 0;
             const size_t rpd = adi_fast_rpack_doubles(n, k);
             DevArr<double> Rpk(ctx, use_pk ? rpd * (size_t)(nit + 1) : 1);
@@ -1854,14 +1847,14 @@ void adi_advance(AdiRun& run, int budget) {
             adi_decide_scan(ctx, st.p, iters_host, opt.normC_dev, run.reltol, opt.abstol);
             run.defer = false;
         };
-        static const int chunk_timing = std::getenv("DRE_CHUNK_TIMING") ? std::atoi(std::getenv("DRE_CHUNK_TIMING")) : 0;
+        static const int chunk_timing = (env_trace("chunk") ? 1 : 0);
         const auto ct0 = std::chrono::steady_clock::now();
         int since_sync = 0, chunk_shifts = 0;
         const bool single_use = opt_in.shifts.kind != ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled;
         // Cyclic lists on the multifrontal path: the factorisations of the FIRST pass through the cycle (one workgroup per front: ~0.5 ms each at
         // n = 5177, 1.4 ms at n = 20209, a handful of CUs busy) also run ahead on the helper streams instead of one after the other in front of
         // their first use; from the second pass on every factor is cached and the look-ahead finds nothing to do.
-        static const bool cyc_ahead_env = !(std::getenv("DRE_CYCLIC_LOOKAHEAD") && std::atoi(std::getenv("DRE_CYCLIC_LOOKAHEAD")) == 0);
+        static const bool cyc_ahead_env = true;
         const bool sharded_la = ctx->comm && std::max(ctx->comm->nranks, ctx->comm->emulate) > 1;
         const bool cyc_ahead = cyc_ahead_env && opt_in.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n && !sharded_la;
         const bool lookahead = single_use || cyc_ahead;
@@ -1876,7 +1869,7 @@ void adi_advance(AdiRun& run, int budget) {
         // factorise the next few shifts of the batch on the helper streams (one workgroup per front: a factorisation uses a handful of CUs
         // for ~200 us at n = 371 — 45 % of the kernel time of a default-ADI run when it sits on the main stream)
         auto prefetch_ahead = [&](std::complex<double> cur, bool fan_call = false) {
-            static const int depth_env = std::getenv("DRE_PREFETCH_FACTORS") ? std::atoi(std::getenv("DRE_PREFETCH_FACTORS")) : -1;
+            static const int depth_env = -1;
             const int nh = depth_env >= 0 ? std::min(depth_env, 16) : (ctx->setup_streams >= 1 ? std::max(8, ctx->setup_streams) : 0);
             if (!lookahead || nh < 1) return;
             auto ups = oracle->peek((size_t)2 * nh + 3);
@@ -1894,7 +1887,7 @@ void adi_advance(AdiRun& run, int budget) {
                 it = run.prefetch_ev.erase(it);
             }
             int scheduled = (int)run.prefetch_ev.size();
-            static const bool trace_pf = std::getenv("DRE_TRACE_PREFETCH") != nullptr;
+            static const bool trace_pf = env_trace("prefetch");
             if (trace_pf) {
                 static long calls = 0, nups = 0, pend = 0;
                 ++calls; nups += (long)ups.size(); pend += scheduled;
@@ -1944,7 +1937,7 @@ void adi_advance(AdiRun& run, int budget) {
                     auto fnew = get_factor<double>(hc, op, cache, cache->real, nx, false, nullptr, run.check_now);
                     // a Cyclic factor will be used in every time step: its dense top-of-tree inverse is built right behind the factorisation, on
                     // the helper stream (mf_solve would build it inside the third solve that uses the factor, on the critical path)
-                    static const bool top_ahead = !(std::getenv("DRE_TOPINV_AHEAD") && std::atoi(std::getenv("DRE_TOPINV_AHEAD")) == 0);
+                    static const bool top_ahead = true;
                     if (cyc_ahead && top_ahead) mf_prepare_topinv(hc, *op.P, fnew->f);
                 }
                 DRE_HIP(hipEventRecord(ev, hc->stream));
@@ -1996,7 +1989,7 @@ void adi_advance(AdiRun& run, int budget) {
                     fes[(size_t)s_] = fe;
                 }
                 if (g >= gmin) {
-                    static const bool fht = std::getenv("DRE_FAN_HOST_TIMING") != nullptr;
+                    static const bool fht = env_trace("fan");
                     static double ft[6] = {0, 0, 0, 0, 0, 0}; static long fn_ = 0;
                     auto fnow = []() { return std::chrono::steady_clock::now(); };
                     auto fus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -2143,7 +2136,7 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<double>> fe;
                 if (!user_inner) {
-                    if (single_use && std::getenv("DRE_TRACE_PREFETCH")) {
+                    if (single_use && env_trace("prefetch")) {
                         static long hit = 0, miss = 0;
                         (cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] real shifts: %ld found ready, %ld factorised inline\n", hit, miss);
@@ -2287,7 +2280,7 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<cplx>> fe;
                 if (!user_inner) {
-                    if (single_use && std::getenv("DRE_TRACE_PREFETCH")) {
+                    if (single_use && env_trace("prefetch")) {
                         static long hit = 0, miss = 0;
                         (cache->cplx_.count(std::make_tuple(op.tag, mu.real(), mu.imag())) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] complex pairs: %ld found ready, %ld factorised inline\n", hit, miss);
@@ -2405,7 +2398,7 @@ void adi_advance(AdiRun& run, int budget) {
             // The same holds for the direct form up to compress_direct_max_n (one GEMM over all columns) and for the factor form
             // (panel steps ~ rank, GEMM traffic ~ columns: one late compression costs the GEMMs of two early ones and half the
             // panels) while the factor still fits the factor-form limit c + 64 <= n after the next chunk.
-            static const bool defer_on = !(std::getenv("DRE_DEFER_COMPRESS") && std::atoi(std::getenv("DRE_DEFER_COMPRESS")) == 0);
+            static const bool defer_on = true;
             const long rk = Xw->rank(), next = (long)std::max(opt.compression_interval * 2, run.chunk_limit + FAN_GMAX) * k;
             const bool defer = !cex && (n <= 512 ? rk <= 16L * n
                                        : defer_on && ((n <= ctx->compress_direct_max_n && rk <= 16L * n) ||
@@ -2468,7 +2461,7 @@ AdiResult adi_finish(AdiRun& run) {
 
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
                     FactorCache* cache) {
-    static const bool tm = std::getenv("DRE_REC_TIMING") != nullptr;
+    static const bool tm = env_trace("rec");
     static double tb = 0, ta = 0, tf = 0; static long ns = 0;
     const auto t0 = std::chrono::steady_clock::now();
     auto run = adi_begin(ctx, op, C, initial_guess, opt_in, cache);
@@ -3237,7 +3230,7 @@ struct DenseXState {
     struct Landing { AdiState st; double tols[4]; int serr; };
     Landing* land = nullptr;
     // optional phase timing (DRE_PHASE_TIMING=1): events at the phase boundaries of every step, summed at the end
-    bool phase_on = std::getenv("DRE_PHASE_TIMING") != nullptr;
+    bool phase_on = env_trace("phase");
     std::vector<hipEvent_t> pev;
     std::vector<int> ptag;
     void mark(Ctx* ctx, int tag) {
@@ -3304,7 +3297,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // DRE_SIDE_EARLY=1: enqueue the side stream's work (SMW products, thin recursion, fold) before the assembly instead of inside the band
     // reduction's first read-back.  Measured at n = 371 with the group chain: 21.7 ms per solve early against 21.2 ms in the read-back slot (the
     // host calls delay the main stream's first kernels by more than the earlier start gains) — off by default.
-    static const int side_early_env = std::getenv("DRE_SIDE_EARLY") ? std::atoi(std::getenv("DRE_SIDE_EARLY")) : -1;
+    static const int side_early_env = -1;
     const bool side_early = wctx != ctx && side_early_env > 0;
     if (side_early) side_setup();
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
@@ -3325,7 +3318,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // computed by the reduction's control-block launch
     spec.tol_parts = part.p; spec.tol_nparts = nt * nt; spec.tol_reltol = reltol; spec.tol_abstol = adi.abstol; spec.tol_frac = adi.residual_abs_frac;
     spec.tols_out = tols.p;
-    static const bool side_in_fetch = !(std::getenv("DRE_SIDE_IN_FETCH") && std::atoi(std::getenv("DRE_SIDE_IN_FETCH")) == 0);
+    static const bool side_in_fetch = true;
     const bool defer_side = wctx != ctx && side_in_fetch && !side_early;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
     if (defer_side) spec.extra = side_setup;
     else if (!side_early) side_setup();
@@ -3358,7 +3351,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
         Mat Tm = sb.D;
         DevArr<double> nws(ctx, ADI_FAST_NWS);
-        static const bool packed_r = !(std::getenv("DRE_ADI_PACKED_R") && std::atoi(std::getenv("DRE_ADI_PACKED_R")) == 0);
+        static const bool packed_r = true;
         int mode0 = 0, nt0 = 0;
         adi_fast_pick(n, k, &mode0, &nt0);
         const bool use_pk = packed_r && mode0 == 0;
@@ -3640,12 +3633,8 @@ class SideWorker {
 // (4 eps ||X||) no longer re-enters the next residual.  A step whose ADI leaves the fan path (complex shift, user solver, in-loop compression)
 // falls back to the reference's order for the next step.
 // =============================================================================================
-__global__ void k_blockdiag_scale_id(int m, double* __restrict__ D, double v) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m * m) D[i] = (i % m == i / m) ? v : 0.0;
-}
 static bool ros1_recurrence_ok(Ctx* ctx, const GdreProblem& prob, int order, const AdiOptions& adi) {
-    static const bool env_on = !(std::getenv("DRE_ROS1_RECURRENCE") && std::atoi(std::getenv("DRE_ROS1_RECURRENCE")) == 0);
+    static const bool env_on = true;
     const int n = prob.P->n;
     if (!env_on || !ctx->ros1_recurrence || order != 1 || adi.compress_exact || adi.inner_solve || adi.ignore_initial_guess || !adi.compression) return false;
     if (adi.shifts.kind != ShiftSpec::CYCLIC || adi.shifts.values.empty() || adi.abstol >= 0.0) return false;
@@ -3697,7 +3686,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     std::vector<LBlock> pend;                       // increments the side stream has not been handed yet
     int pend_upto = 0;
     bool job_pending = false;
-    static const bool rec_timing = std::getenv("DRE_REC_TIMING") != nullptr;
+    static const bool rec_timing = env_trace("rec");
     double t_join = 0.0, t_solve = 0.0, t_tail = 0.0; long n_join = 0, n_jobs_t = 0;
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -3888,7 +3877,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             // side jobs: every step with save_state (every X(t) is an output); otherwise when the previous one is done AND `batch` steps have
             // gathered (the tolerance formula above tolerates a lag of 3 steps; one compression of 2-3 steps' increments costs little more
             // than one step's — its latency chains depend on the rank, not on the number of columns)
-            static const int batch = std::getenv("DRE_REC_BATCH") ? std::max(1, std::min(3, std::atoi(std::getenv("DRE_REC_BATCH")))) : 2;
+            static const int batch = 2;
             if (save_state || (!worker.pending() && i - get_state()->step >= batch) || i == nsteps) submit_job();
             // K_i' = K_{i-1}' + sum_j (E'V_j) (c_j T) (V_j'B)
             Mat dKt(ctx, n, m);
@@ -4005,7 +3994,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
     bool sx_init = false, x_is_dense = false;
 
-    const bool wall_on = std::getenv("DRE_PHASE_TIMING") != nullptr;
+    const bool wall_on = env_trace("phase");
     auto wall_now = [&]() { if (wall_on) DRE_HIP(hipStreamSynchronize(ctx->stream)); return std::chrono::steady_clock::now(); };
     const auto w_begin = wall_now();
     auto w_first = w_begin;
@@ -4079,7 +4068,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             const bool last = (i == nsteps);
             a2.final_compress = xside ? false : (last || (i % xevery == 0));
             a2.warm_L = fb.L; a2.warm_EtL = fb.EtL;            // the feedback already concatenated X and applied E'
-            static const bool fold_e = !(std::getenv("DRE_FOLD_E") && std::atoi(std::getenv("DRE_FOLD_E")) == 0);
+            static const bool fold_e = true;
             if (fold_e) { a2.rhs_lead_blocks = 2; a2.rhs_e_coeff = 1.0 / tau; }     // rhs = [C'C, K'K] + E'XE / tau
             // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
             LDLtP Xc;

@@ -34,8 +34,6 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
         }
     }
     int leaf = leaf_size > 0 ? leaf_size : (n <= 2000 ? 24 : 32);
-    if (leaf_size <= 0) if (const char* e = std::getenv("DRE_LEAF_SIZE")) leaf = std::max(1, atoi(e));   // tuning knob
-    if (const char* e = std::getenv("DRE_MF_SCALAR")) P->use_mfma_sweeps = atoi(e) == 0;
     P->sym = symbolic_analyze(n, uptr, uidx, leaf);
     const Symbolic& S = P->sym;
     P->nnz = (int)S.idx.size();
@@ -87,33 +85,6 @@ std::unique_ptr<Pencil> pencil_create(Ctx* ctx, int n, const int64_t* Ep, const 
 // (column-major panels) and the gathered X rows hit L2.
 // =============================================================================================
 #define SPMM_CB 8
-__global__ __launch_bounds__(256) void k_spmm(int n, const int* __restrict__ ptr, const int* __restrict__ idx,
-                                              const double* __restrict__ val, const double* __restrict__ X, int ldx,
-                                              double* __restrict__ Y, int ldy, int ncols, double alpha, double beta,
-                                              const AdiState* st) {
-    if (st && st->done) return;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c0 = blockIdx.y * SPMM_CB;
-    const int c1 = min(ncols, c0 + SPMM_CB);
-    const int pb = ptr[i], pe = ptr[i + 1];
-    double acc[SPMM_CB];
-#pragma unroll
-    for (int c = 0; c < SPMM_CB; ++c) acc[c] = 0.0;
-    for (int p = pb; p < pe; ++p) {
-        const double v = val[p];
-        const double* x = X + idx[p] + (size_t)c0 * ldx;
-#pragma unroll
-        for (int c = 0; c < SPMM_CB; ++c)
-            if (c0 + c < c1) acc[c] += v * x[(size_t)c * ldx];
-    }
-#pragma unroll
-    for (int c = 0; c < SPMM_CB; ++c)
-        if (c0 + c < c1) {
-            double* y = Y + i + (size_t)(c0 + c) * ldy;
-            *y = (beta == 0.0) ? alpha * acc[c] : alpha * acc[c] + beta * (*y);
-        }
-}
 // LDS-staged variant: the CSR segment (column indices + values) of the workgroup's 256 consecutive rows is one contiguous range of
 // the arrays; it is loaded cooperatively (fully coalesced) into LDS once and every thread then walks its own row in LDS.  The gathered
 // rows of the dense panel X stay L2 gathers (the nested-dissection ordering keeps the neighbours of a row close).
@@ -1516,7 +1487,6 @@ static void sub_plan_build(Ctx* ctx, const Pencil& P, int Tmin) {
     // root level: the chain of a workgroup costs ~2.2 us per node (measured: MFMA / LDS latency of two dependent tile products) plus ~6 us of
     // set-up, a level launch above the subtrees ~17.5 us; deeper roots mean shorter chains and more level launches
     int forced = -1;
-    if (const char* e = std::getenv("DRE_MF_SUBTREE_LEVEL")) forced = std::atoi(e);
     int bestL = -1; double bestcost = 1e300;
     for (int Lv = std::max(Tmin, 1); Lv < S.nlevels; ++Lv) {
         int nnmax = 0;
@@ -1564,7 +1534,7 @@ static void sub_plan_build(Ctx* ctx, const Pencil& P, int Tmin) {
         sp.Tsub = Lv; sp.nsub = (int)(tab.size() / 4);
         sp.prows_max = sa.prows_cap; sp.nn_max = sa.nn_cap; sp.lm_max = sa.lm_cap; sp.b_max = sa.b_cap; sp.s_max = sa.s_cap;
         sp.lds_fwd = fwd; sp.lds_bwd = bwd;
-        if (std::getenv("DRE_TRACE_SUBTREE"))
+        if (env_trace("subtree"))
             std::fprintf(stderr, "[subtree sweeps] n=%d levels=%d Tsub=%d subtrees=%d panel rows<=%d nodes<=%d b<=%d s<=%d LDS fwd %zu bwd %zu\n", P.n, S.nlevels, Lv,
                          sp.nsub, sa.prows_cap, sa.nn_cap, sa.b_cap, sa.s_cap, fwd, bwd);
         return;
@@ -1577,7 +1547,7 @@ static void mf_sub_sweep(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, do
     SubArgs sa{sp.sub.p, sp.lmap.p, sp.prows_max, sp.nn_max, sp.lm_max, sp.b_max, sp.s_max};
     const int ncb = ceil_div(nrhs, MFM_KC);
     const bool small = sp.s_max <= 32 && sp.b_max <= 32 * SUB_NW;        // every fragment of every node fits the prefetch depth
-    static const bool probe_on = std::getenv("DRE_SUB_PROBE") != nullptr;   // debug: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
+    static const bool probe_on = env_trace("subprobe");   // debug: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
     static int probe_count = 0;
     DevArr<long long> probe;
     long long* pp = nullptr;
@@ -1658,56 +1628,8 @@ __global__ void k_top_gather(int ntop, int nrhs, const int* __restrict__ topidx,
     for (int j = gptr[p]; j < gptr[p + 1]; ++j) v += upd[gsrc[j] + c * (size_t)ldu];
     g[p + c * ldg] = v;
 }
-__global__ void k_top_scatter(int ntop, int nrhs, const int* __restrict__ topidx, const double* __restrict__ x, int ldx, double* __restrict__ W, int ldw,
-                              const AdiState* st) {
-    if (st && st->done) return;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)ntop * nrhs) return;
-    const int p = idx % ntop; const size_t c = idx / ntop;
-    W[topidx[p] + c * ldw] = x[p + c * ldx];
-}
-// x = Sinv g with the result SCATTERED into the panel:  W[topidx[p], c] = sum_q Sinv[p, q] g[q, c]  — the dense top of the elimination tree as ONE
-// launch behind the gather (was: split-K GEMM + reduction of the slabs + scatter).  Tile workgroups (16 rows x 16 columns), the four waves
-// split K = ntop and meet through LDS (the k_adi_fast tile scheme); A fragments are 128-byte row segments of the column-major inverse.
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_top_apply(int ntop, int nrhs, const double* __restrict__ Sinv, int lds_, const double* __restrict__ g, int ldg,
-                                                       const int* __restrict__ topidx, double* __restrict__ W, int ldw, const AdiState* st) {
-    const int done_flag = st ? st->done : 0;
-    __shared__ double part[NW][4][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
-    const int p0 = blockIdx.x * 16, c0 = blockIdx.y * 16;
-    const int kst = (ntop + 3) >> 2, per = (kst + NW - 1) / NW;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int t0 = wv * per, t1 = min(kst, t0 + per);
-    const int row = p0 + lr, col = c0 + lr;
-    const bool rok = row < ntop, cok = col < nrhs;
-    const double* __restrict__ ap = Sinv + (rok ? row : 0);
-    const double* __restrict__ bp = g + (size_t)(cok ? col : 0) * ldg;
-    mf_v4d acc = (mf_v4d){0.0, 0.0, 0.0, 0.0};
-    for (int tb = t0; tb < t1; tb += 24) {
-        double av[24], bv[24];
-#pragma unroll
-        for (int u = 0; u < 24; ++u) {
-            const int q = min(4 * min(tb + u, t1 - 1) + lk, ntop - 1);
-            av[u] = ap[(size_t)q * lds_]; bv[u] = bp[q];
-        }
-#pragma unroll
-        for (int u = 0; u < 24; ++u) {
-            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < ntop;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok) ? av[u] : 0.0, (kok && cok) ? bv[u] : 0.0, acc, 0, 0, 0);
-        }
-    }
-    if (done_flag) return;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
-    __syncthreads();
-    if (wave >= 4) return;
-    double v = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += part[w][wave][lane];      // fixed order
-    const int orow = p0 + lk + 4 * wave;          // thread (wave = r, lane) finishes element (row lk + 4 r, column lr)
-    if (orow < ntop && cok) W[topidx[orow] + (size_t)col * ldw] = v;
-}
+// (A fused top product — x = Sinv g scattered into the panel by one K-split tile kernel, 4 / 8 / 16 waves — was built in round 3 and measured at
+// the same wall-clock as split-K GEMM + slab reduction (22-24 us against 17.5 + 3.8 at n = 5177); removed in round 4.)
 __global__ void k_top_unit_rows(int nrhs, int c0, const int* __restrict__ topidx, double* __restrict__ W, int ldw) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nrhs) W[topidx[c0 + j] + (size_t)j * ldw] = 1.0;
@@ -1729,7 +1651,7 @@ static void mf_build_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc)
 // within 2 % of each other, 0 costs 15 % / 9 % of the solve time.  A latency variant of the FORWARD kernel (same loads, early prefetch)
 // was built and lost at every threshold (its K ranges are short: s <= 64), so the forward sweep has the one kernel.
 static long mf_latency_max_wg(bool) {
-    static const long b = std::getenv("DRE_MF_LAT_BWD") ? std::atol(std::getenv("DRE_MF_LAT_BWD")) : 1500;
+    static const long b = 1500;
     return b;
 }
 struct MfIn { const double* p = nullptr; int ld = 0, n = 0; };       // leading right-hand-side columns that live outside the work panel
@@ -1753,7 +1675,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, do
             const size_t shm = ((size_t)((std::max(fm + 16, spm) + 4) | 1) + (size_t)((spm + 4) | 1)) * MFM_KC * sizeof(double);
             // wide levels (more workgroups than the chip holds at once) are throughput bound: four waves per front keep more fronts resident
             // (n = 20209: 32.9 -> 31.5 ms of sweeps per 4 steps against 512 threads, 34.2 ms with 1024)
-            static const int tp_threads = std::getenv("DRE_MF_FWD_TP_THREADS") ? std::atoi(std::getenv("DRE_MF_FWD_TP_THREADS")) : 256;
+            static const int tp_threads = 256;
             int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
             if (tp_threads > 0 && (long)nb * ncb * nz > 2000) nthreads = tp_threads;
             hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n);
@@ -1854,25 +1776,6 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             hipLaunchKernelGGL(k_top_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, ntop, nrhs, (const int*)tp.topidx.p,
                                (const int*)tp.gptr.p, (const int64_t*)tp.gsrc.p, (const double*)W, ldw, (const double*)upd.p, ldu, g.p, g.ld, st, in.p, in.ld, in.n, 0L, 0L, 0L);
         }
-        // DRE_TOP_FUSED=4|8|16: one K-split tile kernel (k_top_apply, that many waves) instead of split-K GEMM + slab reduction + scatter.  Measured
-        // (round 3, tools/ab_general.sh): 22-24 us per launch whatever the wave count against 17.5 + 3.8 us at n = 5177 — the same wall-clock.  The
-        // product streams the 18.9 MB inverse from HBM (40 shifts x 18.9 MB are not MALL resident): a variant with one workgroup per 16-row strip and
-        // all column tiles (inverse read once, 96 workgroups) took 34 us — too few bytes in flight; the 504-workgroup split-K GEMM stays the default.
-        static const int fused_top = std::getenv("DRE_TOP_FUSED") ? std::atoi(std::getenv("DRE_TOP_FUSED")) : 0;
-        if (fused_top) {
-            {
-                TimedScope ts(ctx, "gemm_mf_top", 8.0 * ((double)ntop * ntop + 2.0 * ntop * nrhs), 2.0 * ntop * (double)ntop * nrhs);
-                const dim3 grid(ceil_div(ntop, 16), ceil_div(nrhs, 16));
-                if (fused_top >= 16) hipLaunchKernelGGL((k_top_apply<16>), grid, dim3(1024), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
-                                                        (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
-                else if (fused_top >= 8) hipLaunchKernelGGL((k_top_apply<8>), grid, dim3(512), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
-                                                            (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
-                else hipLaunchKernelGGL((k_top_apply<4>), grid, dim3(256), 0, ctx->stream, ntop, nrhs, (const double*)Fc.topinv.p, Fc.topinv.ld,
-                                        (const double*)g.p, g.ld, (const int*)tp.topidx.p, W, ldw, st);
-            }
-            TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
-            backward_from(T);
-        } else {
         // x_top = inv(S) g as split-K slabs; their fixed-order sum lands directly in the rows of the panel (no x, no scatter launch)
         int zs = 1;
         BufP xpart = gemm_partials(ctx, false, false, ntop, nrhs, ntop, Fc.topinv.p, Fc.topinv.ld, g.p, g.ld, &zs, st, "gemm_mf_top");
@@ -1880,7 +1783,6 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
             TimedScope ts(ctx, "mf_solve_real", 0.0, 0.0);
             gemm_reduce_rows(ctx, ntop, nrhs, zs, (const double*)xpart->p, (const int*)tp.topidx.p, W, ldw, st);
             backward_from(T);
-        }
         }
     }
     DRE_HIP(hipGetLastError());

@@ -158,7 +158,6 @@ Symbolic symbolic_analyze(int n, const std::vector<int>& ptr, const std::vector<
     {
         int dc = 0;
         while (((long)std::max(1, leaf_size) << (dc + 1)) <= (long)n) ++dc;        // floor(log2(n / leaf_size))
-        if (const char* e = std::getenv("DRE_ND_DEPTH_CAP")) dc = std::atoi(e);    // tuning knob (a huge value: no cap)
         D.depth_cap = std::max(1, dc);
     }
     std::vector<int> all(n);
@@ -174,7 +173,8 @@ Symbolic symbolic_analyze(int n, const std::vector<int>& ptr, const std::vector<
     // of up to 187 pivots: their factorisation and their sweeps cost far more than the launches saved); n = 5177: 137.7 -> 142.5 ms.
     {
         int amalg = 0;
-        if (const char* e = std::getenv("DRE_ND_AMALGAMATE")) amalg = std::atoi(e);
+        // (2:1 supernode amalgamation of the separator tree: built and measured in round 2 — 12 -> 5 levels at n = 20209 but +58 % factor entries,
+        //  132 -> 236 ms; kept as code for deep narrow trees, switched off)
         if (amalg) {
             const int T0 = (int)D.node_verts.size();
             int root = -1;

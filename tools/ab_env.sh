@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment switches on one configuration (GPU box): usage tools/ab_env.sh "<bench args>" "ENV=.. ENV=.." ...   (interleaved, 2 rounds)
+# A/B of options on one configuration (GPU box): usage tools/ab_env.sh "<bench args>" "DRE_OPTIONS=name=value,.." ...   (interleaved, 2 rounds)
 cd "$GRAFT_REPO_ROOT"
 bargs=$1; shift
 for round in $(seq ${AB_ROUNDS:-2}); do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of general-path switches at n = 5177 (12 steps) and n = 20209 (12 steps); run on the GPU box.  usage: tools/ab_general.sh "ENV=.. ENV=.." ...
+# A/B of general-path switches at n = 5177 (12 steps) and n = 20209 (12 steps); run on the GPU box.  usage: tools/ab_general.sh "DRE_OPTIONS=name=value,.." ...
 cd "$GRAFT_REPO_ROOT"
 for cfg in "$@"; do
   for nn in "5177 3" "20209 2"; do

@@ -2,7 +2,7 @@
 # A/B on the metric's configuration (run on the GPU box): usage tools/ab_group.sh "ENV=.. ENV=.." ...   (default: group chain off / auto)
 set -e
 cd "$GRAFT_REPO_ROOT"
-[ $# -eq 0 ] && set -- "DRE_ADI_GROUP=0" "DRE_ADI_GROUP=1"
+[ $# -eq 0 ] && set -- "DRE_OPTIONS=adi_group=0" "DRE_OPTIONS=adi_group=1"
 python -m pytest tests/test_gpu_r03_full_length.py -x -q -m gpu -k "metric or falls_back or group" > gpurun_out/ab_t.log 2>&1 || { tail -30 gpurun_out/ab_t.log; exit 1; }
 tail -1 gpurun_out/ab_t.log
 for cfg in "$@"; do
@@ -15,4 +15,4 @@ print(sys.argv[1], round(d["value"]), "it/s", round(d["ms_per_step"],2), "ms", d
 PY
   done
 done
-env DRE_PHASE_TIMING=1 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-general-path 2>&1 >/dev/null | grep "wall, ms" | tail -2
+env DRE_TRACE=phase python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-general-path 2>&1 >/dev/null | grep "wall, ms" | tail -2

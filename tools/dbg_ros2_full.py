@@ -1,4 +1,4 @@
-"""Diagnostic: Ros2 n=371 45 steps, HIP (default mode) vs oracle fixture per step.  DRE_NOISE_FLOOR_FAC scales the formation-noise floor."""
+"""Diagnostic: Ros2 n=371 45 steps, HIP (default mode) vs oracle fixture per step.  (the formation-noise floor factor was an environment switch in round 3; 0.03 ... 4 gave the same K(t), 4 is built in)."""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

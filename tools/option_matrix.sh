@@ -1,10 +1,12 @@
 #!/bin/bash
 # The GPU suite under the non-default code paths (run on the GPU box): every configuration must stay green.
+# Options travel as DRE_OPTIONS="name=value,..." (dre_ctx_set_option for every context of the process); there are no kernel-selecting
+# environment variables any more (round 4).
 cd "$GRAFT_REPO_ROOT"
 rc=0
-for cfg in "DRE_ADI_GROUP=0" "DRE_ADI_GROUP=2" "DRE_X_SIDE_STREAM=0" "DRE_DENSE_X_MAX_N=0" "DRE_SETUP_STREAMS=0 DRE_SIDE_EARLY=1" "DRE_TSMM=1 DRE_TOP_FUSED=8" \
-           "DRE_ADI_FAN=0 DRE_PREFETCH_FACTORS=0" "DRE_ADI_FAN=4 DRE_ADI_FAN_MAX_COEF=8 DRE_PREFETCH_FACTORS=3 DRE_STREAM_PRIORITIES=1" "DRE_DENSE_INV_MAX_N=0 DRE_DENSE_X_MAX_N=0 DRE_ADI_FAN=4"; do
-  env $cfg python -m pytest tests -x -q -m gpu > gpurun_out/om.log 2>&1
+for cfg in "adi_group=0" "adi_group=2" "x_side_stream=0" "dense_x_max_n=0" "setup_streams=0" "adi_fan=0" "adi_fan=8,adi_fan_max_coef=8" \
+           "ros1_recurrence=0" "dense_inverse_max_n=0,dense_x_max_n=0,adi_fan=4" "compress_sketch=0" "top_inverse_max_rows=0"; do
+  DRE_OPTIONS="$cfg" python -m pytest tests -x -q -m gpu > gpurun_out/om.log 2>&1
   r=$?
   echo "$cfg -> rc=$r  $(tail -1 gpurun_out/om.log)"
   [ $r -ne 0 ] && { rc=1; tail -25 gpurun_out/om.log; }
