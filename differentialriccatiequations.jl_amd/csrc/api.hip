@@ -136,6 +136,7 @@ int dre_ctx_destroy(dre_ctx* ctx) {
         }
         owner.helpers.clear(); owner.helper_ev.clear();
         if (owner.helper_e0) { (void)hipEventDestroy(owner.helper_e0); owner.helper_e0 = nullptr; }
+        for (auto& e : owner.aux_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     };
     drop_helpers(ctx->c);
     ctx->c.timer.reset();

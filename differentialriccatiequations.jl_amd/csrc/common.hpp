@@ -163,9 +163,9 @@ struct Ctx {
     int adi_group = 1;
     int adi_group_max_n = 768;
     // fan groups of the general path (engine.hip): up to adi_fan consecutive real-shift iterations from independent solves that share every
-    // launch (0 / 1 = off, at most 8); a group is cut where the partial-fraction coefficients exceed adi_fan_max_coef
-    int adi_fan = 5;
-    double adi_fan_max_coef = 64.0;
+    // launch (0 / 1 = off, at most 10 = a whole cycle of the usual lists); a group is cut where the partial-fraction coefficients exceed adi_fan_max_coef
+    int adi_fan = 8;
+    double adi_fan_max_coef = 128.0;
     // pivot-free multifrontal LU: multipliers beyond pivot_growth_warn flag the ADI result (DRE_WARN_PIVOT_GROWTH) and trigger a true-residual
     // verification; beyond pivot_growth_fail the factorisation is rejected (DRE_ERR_SINGULAR)
     double pivot_growth_warn = 1e8, pivot_growth_fail = 1e13;
@@ -189,6 +189,7 @@ struct Ctx {
     std::vector<std::unique_ptr<Ctx>> helpers;
     std::vector<hipEvent_t> helper_ev;
     hipEvent_t helper_e0 = nullptr;
+    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fork / join events of work that runs on a helper stream beside the main one
     int setup_streams = 5;      // 0 / 1: everything on the calling context's stream
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remembered per context, not per process
     bool attr_adi_fast = false;
@@ -199,6 +200,7 @@ struct Ctx {
     FetchZone* fetch_host = nullptr;   // host address
     FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it
     unsigned long long fetch_seq = 0;
+    bool fetch_spin = true;            // false: ctx_fetch blocks in hipStreamSynchronize instead of spinning (the side context: its driver thread must not burn a core beside the main thread)
     // kernels whose dynamic-LDS limit was raised for this context's device (hipFuncSetAttribute is per device, so the record is per
     // context, not per process)
     std::unordered_map<const void*, int> lds_attr_done;

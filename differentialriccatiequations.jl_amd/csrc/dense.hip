@@ -728,7 +728,7 @@ void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const voi
     static const bool spin_on = true;   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
     const size_t tot = (b0 + b1 + b2) / 8;
     DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
-    if (spin_on && !ctx->fetch_host) {
+    if (spin_on && ctx->fetch_spin && !ctx->fetch_host) {
         void* hp = nullptr;
         if (hipHostMalloc(&hp, sizeof(Ctx::FetchZone), hipHostMallocMapped) == hipSuccess) {
             void* dp = nullptr;
@@ -738,7 +738,7 @@ void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const voi
             } else (void)hipHostFree(hp);
         }
     }
-    if (!spin_on || !ctx->fetch_host) {
+    if (!spin_on || !ctx->fetch_spin || !ctx->fetch_host) {
         if (b0) DRE_HIP(hipMemcpyAsync(h0, d0, b0, hipMemcpyDeviceToHost, ctx->stream));
         if (b1) DRE_HIP(hipMemcpyAsync(h1, d1, b1, hipMemcpyDeviceToHost, ctx->stream));
         if (b2) DRE_HIP(hipMemcpyAsync(h2, d2, b2, hipMemcpyDeviceToHost, ctx->stream));

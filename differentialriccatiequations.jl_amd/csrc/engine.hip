@@ -1440,6 +1440,25 @@ __global__ __launch_bounds__(64) void k_sinv_z(int m, const double* __restrict__
     if (st && st->done) return;
     sinv_body<double>(m, small + (size_t)blockIdx.x * m * lds_, lds_, alpha, iz.out[blockIdx.x], err);
 }
+// helper context h of a context (own stream and pool), created on first use
+static Ctx* helper_ctx(Ctx* ctx, int h) {
+    while ((int)ctx->helpers.size() <= h) {
+        auto hc = std::make_unique<Ctx>();
+        hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+        hc->stream = create_stream(2);
+        hc->timer = std::make_unique<KernelTimer>();
+        hipEvent_t ev;
+        DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+    }
+    Ctx* hc = ctx->helpers[(size_t)h].get();
+    hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+    return hc;
+}
+static hipEvent_t aux_event(Ctx* ctx, int i) {
+    if (!ctx->aux_ev[i]) DRE_HIP(hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
+    return ctx->aux_ev[i];
+}
 struct StepRec { int iters_after; size_t nblocks; int nshifts; Mat Rafter; };      // Rafter: the residual factor after this iteration where it is NOT updated in place (fan groups)
 struct AdiRun {
     Ctx* ctx = nullptr;
@@ -1485,6 +1504,7 @@ struct AdiRun {
     size_t prefetch_rr = 0;
     bool helpers_ready = false;
     bool chunk_from_hint = false;
+    hipEvent_t tol_event = nullptr;   // the tolerance is being formed on a helper stream: wait for this event, then decide iteration 0 (apply_tolerance)
     bool abstol_pending = false;      // the tolerance was formed on the device (AdiOptions::normC_build): the host copy follows with the first chunk
     bool defer = false;               // the tolerance is still on its way (AdiOptions::normC_dev): kernels record norms, decisions follow at the chunk end
     double reltol = 0.0;
@@ -1552,7 +1572,9 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         if (resid->blocks.size() > 1) {
             bool done = false;
             static const bool warm_on = true;
-            if (warm_on && opt.warm_basis.cols > 0 && lag > 0.0 && cache->warm_strikes < 2) {
+            // (not attempted where it cannot apply — a basis of fewer than 16 columns, q0 + sx <= 64 — so that such a step does not count as a rejection)
+            if (warm_on && opt.warm_basis.cols >= 16 && lag > 0.0 && cache->warm_strikes < 2 &&
+                opt.warm_basis.cols + (cache->warm_sx > 0 ? cache->warm_sx : 32) > 64) {
                 const int sx = cache->warm_sx > 0 ? cache->warm_sx : 32;
                 double missed = 0.0;
                 done = warm_compress(ctx, *resid, opt.warm_basis, ctf, opt.residual_abs_frac * lag, sx, &missed);
@@ -1616,8 +1638,14 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         ldlt_norm_update_state(ctx, G0, Tm, tdiag, alpha_res, st.p, 0);
         if (opt.normC_build) {
             // the tolerance is formed right here, on this stream: the decisions are live from iteration 0 on; the host reads it with the first chunk
-            opt.normC_build(R, Tm, alpha_res);
-            adi_decide_scan(ctx, st.p, 0, opt.normC_dev, reltol, -1.0);
+            // ... on a helper stream, beside the SMW set-up and the first group's sweeps; the main stream picks it up in front of its first norm
+            Ctx* hc = helper_ctx(ctx, 0);
+            hipEvent_t e0 = aux_event(ctx, 0), e1 = aux_event(ctx, 1);
+            DRE_HIP(hipEventRecord(e0, ctx->stream));
+            DRE_HIP(hipStreamWaitEvent(hc->stream, e0, 0));
+            opt.normC_build(hc, R, Tm, alpha_res);
+            DRE_HIP(hipEventRecord(e1, hc->stream));
+            run.tol_event = e1;
             run.defer = false; run.abstol_pending = true;
         }
     }
@@ -1659,6 +1687,33 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
             hipLaunchKernelGGL(k_fold_sinv_batched, dim3(ceil_div(2 * n * m, 256), (unsigned)hb.size()), dim3(256), 0, ctx->stream, 2 * n, m, 2 * n + m,
                                (const SmwBatch*)db.p, (const AdiState*)st.p);
             for (auto& pe : pending) smw_cache.emplace(std::make_pair(pe.first, 0.0), pe.second);
+        }
+    }
+
+    // General path, Cyclic real list, one rank: every shift of the cycle that has no factor yet is factorised NOW, all of them in shared
+    // launches (sparse.hip, mf_factor_batch: one launch per tree level for the whole list) together with their dense top inverses — round 3
+    // ran them as ten chains on five helper streams: 4 + 1.6 + 1.6 ms of the first time step at n = 5177 went into waiting for them.
+    if (opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n && ctx->adi_fan >= 2 && P.use_mfma_sweeps &&
+        !(ctx->comm && ctx->comm->nranks > 1 && ctx->comm->emulate <= 1)) {
+        std::vector<double> todo;
+        for (auto& mu : opt.shifts.values) {
+            if (mu.imag() != 0.0) { todo.clear(); break; }
+            bool dup = cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) > 0;
+            for (double t : todo) dup = dup || t == mu.real();
+            if (!dup && (int)todo.size() < MF_ZMAX) todo.push_back(mu.real());
+        }
+        if (todo.size() >= 2) {
+            std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+            std::vector<Factor<double>*> fp;
+            for (double t : todo) { (void)t; fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); }
+            mf_factor_batch(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), (int)todo.size());
+            for (size_t z = 0; z < todo.size(); ++z) {
+                fes[z]->f.allow_topinv = true;
+                const auto key = std::make_tuple(op.tag, todo[z], 0.0);
+                cache->real[key] = fes[z]; cache->fresh.push_back(key); cache->nfactor++;
+                run.used_real.push_back(fes[z]);                 // pivots / growth are read back with the first chunk
+            }
+            mf_topinv_batch(ctx, P, fp.data(), (int)todo.size());
         }
     }
 
@@ -1841,7 +1896,14 @@ void adi_advance(AdiRun& run, int budget) {
         const int iters_chunk_start = iters_host;
         // the tolerance reltol ||C|| was not known when the solve began (AdiOptions::normC_dev): wait for it on this stream and take the decisions
         // of adi.jl:115-123 for everything recorded so far, in iteration order
+        auto apply_tolerance = [&]() {
+            if (!run.tol_event) return;
+            DRE_HIP(hipStreamWaitEvent(ctx->stream, run.tol_event, 0));
+            adi_decide_scan(ctx, st.p, 0, opt.normC_dev, run.reltol, -1.0);
+            run.tol_event = nullptr;
+        };
         auto resolve_deferred = [&]() {
+            apply_tolerance();
             if (!run.defer) return;
             if (opt.normC_wait) opt.normC_wait();
             adi_decide_scan(ctx, st.p, iters_host, opt.normC_dev, run.reltol, opt.abstol);
@@ -2105,6 +2167,7 @@ void adi_advance(AdiRun& run, int budget) {
                         ++since_sync; ++chunk_shifts;
                     }
                     const auto f4 = fnow();
+                    apply_tolerance();
                     residual_norm_group_diag(ctx, Rcat, g, k, Tm, tdiag, alpha_res, st.p, iters_host - g);
                     R = Rcat.colsview((g - 1) * k, k);
                     if (fht) {
@@ -2118,6 +2181,7 @@ void adi_advance(AdiRun& run, int budget) {
                     continue;
                 }
             }
+            apply_tolerance();
             if (run.defer) {
                 // an iteration outside the fan path while the tolerance is still on its way: close the chunk first (its end resolves the tolerance)
                 if (!recs.empty()) break;
@@ -3672,6 +3736,8 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->compress_sketch_min_cols = ctx->compress_sketch_min_cols; side->compress_sketch_extra = ctx->compress_sketch_extra;
     side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
     side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
+    side->fetch_spin = false;
+    side->orthf_fn = ctx->orthf_fn; side->orthf_user = ctx->orthf_user;
     SideWorker worker;
     // events: a ring (at most one job is in flight; a slot is reused eight jobs later)
     hipEvent_t ring[16];
@@ -3823,21 +3889,21 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
             //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)
             // with X_b the latest X the side stream has finished (b >= i - 4) — one Gram matrix of a few hundred columns
-            a2.normC_build = [&, i, tau, RJ](const Mat& Q, const Mat& Dq, double aq) {
+            a2.normC_build = [&, i, tau, RJ](Ctx* hc, const Mat& Q, const Mat& Dq, double aq) {
                 StepDelta dl;
-                dl.s = i - 1; dl.tau = tau; dl.Q = Q; dl.Dq = Mat(ctx, Dq.rows, Dq.cols); copy_mat(ctx, Dq, dl.Dq, aq);
+                dl.s = i - 1; dl.tau = tau; dl.Q = Q; dl.Dq = Mat(hc, Dq.rows, Dq.cols); copy_mat(hc, Dq, dl.Dq, aq);
                 dl.Rj = RJ; dl.Tj = prev.Tm; dl.aj = prev.alpha_res; dl.dKt = prev.hist.empty() ? Mat() : prev_dKt;
                 deltas.push_back(dl);
                 auto st = get_state();
-                if ((i - 1) - st->step > 3) { join_side(); st = get_state(); }
-                if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+                if ((i - 1) - st->step > 5) { join_side(); st = get_state(); }
+                if (st->ev) DRE_HIP(hipStreamWaitEvent(hc->stream, st->ev, 0));
                 while (!deltas.empty() && deltas.front().s <= st->step) deltas.erase(deltas.begin());
                 const LBlock& xb = st->X->blocks[0];
                 const int r = xb.L.cols;
                 int cols = q + m + r;
                 for (auto& d : deltas) cols += d.Q.cols + d.Rj.cols + (d.dKt.cols > 0 ? m : 0);
-                Mat F(ctx, n, cols), S(ctx, cols, cols);
-                fill_mat(ctx, S, 0.0);
+                Mat F(hc, n, cols), S(hc, cols, cols);
+                fill_mat(hc, S, 0.0);
                 std::vector<CopyDesc> cd;
                 int off = 0;
                 auto put = [&](const Mat& L, const Mat* D, double scale, bool identity) {
@@ -3845,7 +3911,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                     Mat dst = F.colsview(off, L.cols);
                     cd.push_back({L.p, dst.p, n, L.cols, L.ld, dst.ld});
                     Mat ds = S.view(off, off, L.cols, L.cols);
-                    if (identity) set_identity(ctx, ds, scale); else copy_mat(ctx, *D, ds, scale);
+                    if (identity) set_identity(hc, ds, scale); else copy_mat(hc, *D, ds, scale);
                     off += L.cols;
                 };
                 put(prob.Ct, nullptr, 1.0, true);
@@ -3857,8 +3923,8 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                     put(d.Rj, &d.Tj, -sc * d.aj, false);
                     if (d.dKt.cols > 0) put(d.dKt, nullptr, sc, true);
                 }
-                copy_batched(ctx, cd);
-                ldlt_norm_device(ctx, F, S, 1.0, normC_dev.p);
+                copy_batched(hc, cd);
+                ldlt_norm_device(hc, F, S, 1.0, normC_dev.p);
             };
             LDLt none; none.n = n;
             ar = adi_solve(ctx, op, none, nullptr, a2, &cache);

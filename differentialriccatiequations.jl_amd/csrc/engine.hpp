@@ -125,7 +125,8 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     const double* normC_dev = nullptr;
     std::function<void()> normC_wait;    // makes the calling stream wait for *normC_dev
     // ... or it is formed on the solve's own stream as soon as the given residual is compressed to (Q, D, alpha): the callback enqueues that
-    std::function<void(const Mat& Q, const Mat& D, double alpha)> normC_build;
+    // (it runs on a HELPER stream of the context, beside the first solves of the iteration: `hc` is that stream's context)
+    std::function<void(Ctx* hc, const Mat& Q, const Mat& D, double alpha)> normC_build;
     double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
     bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
     Mat warm_basis;                      // orthonormal basis of the PREVIOUS step's compressed warm-start residual (warm-started range finder for this one's)

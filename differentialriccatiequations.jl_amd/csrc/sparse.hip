@@ -238,7 +238,7 @@ void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V
     const dim3 grid(ceil_div(n, 256), ceil_div(k, FAN_CB)), block(256);
 #define DRE_FAN_CASE(G_) case G_: hipLaunchKernelGGL((k_fan_spmm_mix<G_>), grid, block, 0, ctx->stream, n, (const int*)P.ptr.p, (const int*)P.idx.p, (const double*)P.valEt.p, k, \
                                                     (const double*)W.p, W.ld, (const double*)R0.p, R0.ld, V.p, V.ld, Rc.p, Rc.ld, co, sl, st); break;
-    switch (g) { DRE_FAN_CASE(1) DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) }
+    switch (g) { DRE_FAN_CASE(1) DRE_FAN_CASE(2) DRE_FAN_CASE(3) DRE_FAN_CASE(4) DRE_FAN_CASE(5) DRE_FAN_CASE(6) DRE_FAN_CASE(7) DRE_FAN_CASE(8) DRE_FAN_CASE(9) DRE_FAN_CASE(10) }
 #undef DRE_FAN_CASE
     DRE_HIP(hipGetLastError());
 }
@@ -376,9 +376,19 @@ __device__ __forceinline__ cplx static_pivot(cplx piv, double fl) {
     if (a == 0.0) return cplx{fl, 0.0};
     return cplx{piv.re / a * fl, piv.im / a * fl};
 }
+// Batched factorisations (round 4): blockIdx.y selects one of up to MF_ZMAX factors of the same pencil (same tree, different shift) — the ten
+// factorisations of a Cyclic list share every level launch instead of running as ten chains on five streams (4 ms -> ~1 ms of the first time step
+// at n = 5177).  ctrl = the factor's 64-byte control block: [0] growth (u64)  [8] floor, max|entry|  [24] err  [28] npert (mf_factor).
+struct FactorZ { void* fronts[MF_ZMAX]; void* inv[MF_ZMAX]; void* ctrl[MF_ZMAX]; };
 template <typename T>
-__global__ void k_front_factor(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv, int* __restrict__ err, unsigned long long* __restrict__ growth,
-                               const double* __restrict__ pivfloor, int* __restrict__ npert) {
+__global__ void k_front_factor(MfArgs a, int lvl_begin, FactorZ fz, int use_floor) {
+    T* __restrict__ fronts = (T*)fz.fronts[blockIdx.y];
+    T* __restrict__ inv = (T*)fz.inv[blockIdx.y];
+    char* const cb = (char*)fz.ctrl[blockIdx.y];
+    unsigned long long* __restrict__ growth = (unsigned long long*)cb;
+    const double* __restrict__ pivfloor = use_floor ? (const double*)(cb + 8) : nullptr;
+    int* __restrict__ err = (int*)(cb + 24);
+    int* __restrict__ npert = (int*)(cb + 28);
     const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -455,9 +465,14 @@ template <> __device__ __forceinline__ cplx group16_sum<cplx>(cplx v) {
 // (inv_lds).  Same arithmetic (right-looking LU without pivoting), same outputs as k_front_factor.
 #define FF_NB 16
 template <typename T>
-__global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl_begin, T* __restrict__ fronts, T* __restrict__ inv,
-                                                               int* __restrict__ err, int inv_lds, unsigned long long* __restrict__ growth,
-                                                               const double* __restrict__ pivfloor, int* __restrict__ npert) {
+__global__ __launch_bounds__(1024) void k_front_factor_blocked(MfArgs a, int lvl_begin, FactorZ fz, int inv_lds, int use_floor) {
+    T* __restrict__ fronts = (T*)fz.fronts[blockIdx.y];
+    T* __restrict__ inv = (T*)fz.inv[blockIdx.y];
+    char* const cb = (char*)fz.ctrl[blockIdx.y];
+    unsigned long long* __restrict__ growth = (unsigned long long*)cb;
+    const double* __restrict__ pivfloor = use_floor ? (const double*)(cb + 8) : nullptr;
+    int* __restrict__ err = (int*)(cb + 24);
+    int* __restrict__ npert = (int*)(cb + 28);
     extern __shared__ double ffraw[];
     double gmax = 0.0;
     T* sm = reinterpret_cast<T*>(ffraw);
@@ -604,6 +619,8 @@ static MfArgs mf_args(const Pencil& P) {
 }
 
 template <typename T>
+static void mf_factor_levels(Ctx* ctx, const Pencil& P, const FactorZ& fz, int nz);
+template <typename T>
 void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out) {
     DRE_REQUIRE(P.has_device, "mf_factor: pencil has no device data");
     const Symbolic& S = P.sym;
@@ -621,13 +638,20 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
         out.npert.buf = blk; out.npert.p = (int*)((char*)blk->p + 28); out.npert.n = 1;
     }
     out.topinv = Mat(); out.uses = 0;          // a new factorisation invalidates the dense top inverse
-    DevArr<int>& err = out.err;
     DRE_HIP(hipMemsetAsync(out.growth.p, 0, 64, ctx->stream));
     out.nperturbed = -1;
     out.ref_valF = valF; out.ref_valE = valE; out.ref_cF = cF; out.ref_cE = cE;
-    const double* pf = ctx->pivot_static > 0.0 ? out.pivfloor.p : nullptr;
     hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE, out.fronts.p,
                        ctx->pivot_static, ctx->pivot_static > 0.0 ? out.pivfloor.p : (double*)nullptr);
+    FactorZ fz; std::memset(&fz, 0, sizeof(fz));
+    fz.fronts[0] = out.fronts.p; fz.inv[0] = out.inv.p; fz.ctrl[0] = out.growth.p;
+    mf_factor_levels<T>(ctx, P, fz, 1);
+    DRE_HIP(hipGetLastError());
+}
+template <typename T>
+static void mf_factor_levels(Ctx* ctx, const Pencil& P, const FactorZ& fz, int nz) {
+    const Symbolic& S = P.sym;
+    const int use_floor = ctx->pivot_static > 0.0 ? 1 : 0;
     MfArgs a = mf_args(P);
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int nb = S.lvl_ptr[l + 1] - S.lvl_ptr[l];
@@ -639,11 +663,39 @@ void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE
             const int inv_lds = inv_b <= lim ? 1 : 0;
             const size_t shm = std::max(panel_b, inv_lds ? inv_b : (size_t)0);
             lds_attr(ctx, (const void*)k_front_factor_blocked<double>, 150 * 1024); lds_attr(ctx, (const void*)k_front_factor_blocked<cplx>, 150 * 1024);
-            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, inv_lds, out.growth.p, pf, out.npert.p);
+            hipLaunchKernelGGL((k_front_factor_blocked<T>), dim3(nb, nz), dim3(fmax > 64 ? 1024 : 256), shm, ctx->stream, a, S.lvl_ptr[l], fz, inv_lds, use_floor);
         } else {
-            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], out.fronts.p, out.inv.p, err.p, out.growth.p, pf, out.npert.p);
+            hipLaunchKernelGGL((k_front_factor<T>), dim3(nb, nz), dim3(nt), 0, ctx->stream, a, S.lvl_ptr[l], fz, use_floor);
         }
     }
+}
+// nz real factorisations  M_z = cF F' + cE_z E'  of the same pencil in shared launches (assembly per factor, every tree level once)
+void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, double cF, const double* cE, Factor<double>* const* outs, int nz) {
+    DRE_REQUIRE(P.has_device && nz >= 1 && nz <= MF_ZMAX, "mf_factor_batch: batch size");
+    const Symbolic& S = P.sym;
+    TimedScope ts(ctx, "mf_factor_real", 8.0 * 2.0 * S.fronts_size * nz, 0, nz);
+    FactorZ fz; std::memset(&fz, 0, sizeof(fz));
+    for (int z = 0; z < nz; ++z) {
+        Factor<double>& out = *outs[z];
+        if (!out.fronts.p) out.fronts = DevArr<double>(ctx, (size_t)std::max<int64_t>(S.fronts_size, 1));
+        if (!out.inv.p) out.inv = DevArr<double>(ctx, (size_t)std::max<int64_t>(S.inv_size, 1));
+        DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(double), ctx->stream));
+        if (!out.err.p) {
+            auto blk = std::make_shared<Buf>(ctx, 64);
+            out.growth.buf = blk; out.growth.p = (unsigned long long*)blk->p; out.growth.n = 1;
+            out.pivfloor.buf = blk; out.pivfloor.p = (double*)((char*)blk->p + 8); out.pivfloor.n = 2;
+            out.err.buf = blk; out.err.p = (int*)((char*)blk->p + 24); out.err.n = 1;
+            out.npert.buf = blk; out.npert.p = (int*)((char*)blk->p + 28); out.npert.n = 1;
+        }
+        out.topinv = Mat(); out.uses = 0;
+        DRE_HIP(hipMemsetAsync(out.growth.p, 0, 64, ctx->stream));
+        out.nperturbed = -1;
+        out.ref_valF = valF; out.ref_valE = valE; out.ref_cF = cF; out.ref_cE = cE[z];
+        hipLaunchKernelGGL((k_assemble<double>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE[z], out.fronts.p,
+                           ctx->pivot_static, ctx->pivot_static > 0.0 ? out.pivfloor.p : (double*)nullptr);
+        fz.fronts[z] = out.fronts.p; fz.inv[z] = out.inv.p; fz.ctrl[z] = out.growth.p;
+    }
+    mf_factor_levels<double>(ctx, P, fz, nz);
     DRE_HIP(hipGetLastError());
 }
 template <typename T>
@@ -1788,6 +1840,60 @@ static void mf_solve_mfma(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, d
     DRE_HIP(hipGetLastError());
 }
 
+// the dense top inverses of nz factors in shared launches (unit right-hand sides on the top variables, sweeps over the top levels only)
+__global__ void k_top_unit_rows_z(int nrhs, int c0, const int* __restrict__ topidx, double* __restrict__ W, int ldw, long wz) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nrhs) W[(size_t)blockIdx.y * wz + topidx[c0 + j] + (size_t)j * ldw] = 1.0;
+}
+struct TopOutZ { double* Ti[MF_ZMAX]; };
+__global__ void k_top_collect_z(int ntop, int nrhs, int c0, const int* __restrict__ topidx, const double* __restrict__ W, int ldw, long wz, TopOutZ out, int ldt) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ntop * nrhs) return;
+    const int p = idx % ntop; const size_t c = idx / ntop;
+    out.Ti[blockIdx.y][p + (c0 + c) * ldt] = W[(size_t)blockIdx.y * wz + topidx[p] + c * ldw];
+}
+void mf_topinv_batch(Ctx* ctx, const Pencil& P, Factor<double>* const* Fs, int nz) {
+    if (!P.use_mfma_sweeps || ctx->top_inverse_max_rows <= 0 || nz < 1) return;
+    if (!P.top.built) top_plan_build(ctx, P, ctx->top_inverse_max_rows);
+    if (!P.sub.built) sub_plan_build(ctx, P, P.top.T);
+    if (P.top.T < 2) return;
+    const TopPlan& tp = P.top;
+    const Symbolic& S = P.sym;
+    const int ntop = tp.ntop, T = tp.T, n = P.n;
+    const int64_t ldu = std::max<int64_t>(S.upd_rows, 1);
+    // at most ~2 GB of work panels at a time
+    const int chunk = 512;
+    const size_t per_z = ((size_t)n + (size_t)ldu) * chunk * sizeof(double);
+    const int zmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)MF_ZMAX, ((size_t)2 << 30) / std::max<size_t>(per_z, 1)));
+    for (int z0 = 0; z0 < nz; z0 += zmax) {
+        const int g = std::min(zmax, nz - z0);
+        TimedScope ts(ctx, "mf_top_inverse", 8.0 * (double)ntop * ntop * g, 0.0, g);
+        MfZ zb; std::memset(&zb, 0, sizeof(zb));
+        TopOutZ out; std::memset(&out, 0, sizeof(out));
+        std::vector<Mat> Tis;
+        for (int z = 0; z < g; ++z) {
+            Tis.push_back(Mat(ctx, ntop, ntop));
+            out.Ti[z] = Tis.back().p;
+            zb.fronts[z] = Fs[z0 + z]->fronts.p; zb.inv[z] = Fs[z0 + z]->inv.p;
+        }
+        for (int c0 = 0; c0 < ntop; c0 += chunk) {
+            const int ch = std::min(chunk, ntop - c0);
+            Mat Wk(ctx, n, ch * g);
+            DevArr<double> upd(ctx, (size_t)ldu * ch * g);
+            zb.wz = (long)ch * Wk.ld; zb.uz = (long)ldu * ch;
+            DRE_HIP(hipMemsetAsync(Wk.p, 0, (size_t)n * ch * g * sizeof(double), ctx->stream));
+            DRE_HIP(hipMemsetAsync(upd.p, 0, (size_t)ldu * ch * g * sizeof(double), ctx->stream));
+            hipLaunchKernelGGL(k_top_unit_rows_z, dim3(ceil_div(ch, 256), g), dim3(256), 0, ctx->stream, ch, c0, (const int*)tp.topidx.p, Wk.p, Wk.ld, zb.wz);
+            mf_sweep_levels(ctx, P, zb, g, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, true, T - 1, 0);
+            mf_sweep_levels(ctx, P, zb, g, Wk.p, Wk.ld, ch, upd.p, ldu, nullptr, false, 0, T - 1);
+            const size_t tot = (size_t)ntop * ch;
+            hipLaunchKernelGGL(k_top_collect_z, dim3((unsigned)((tot + 255) / 256), g), dim3(256), 0, ctx->stream, ntop, ch, c0, (const int*)tp.topidx.p,
+                               (const double*)Wk.p, Wk.ld, zb.wz, out, ntop);
+        }
+        for (int z = 0; z < g; ++z) { Fs[z0 + z]->topinv = Tis[(size_t)z]; Fs[z0 + z]->uses = 3; }
+    }
+    DRE_HIP(hipGetLastError());
+}
 void mf_prepare_topinv(Ctx* ctx, const Pencil& P, const Factor<double>& Fc) {
     if (!P.use_mfma_sweeps || !Fc.allow_topinv || ctx->top_inverse_max_rows <= 0 || !Fc.topinv.empty()) return;
     if (!P.top.built) top_plan_build(ctx, P, ctx->top_inverse_max_rows);

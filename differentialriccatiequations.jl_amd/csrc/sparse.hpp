@@ -132,6 +132,10 @@ struct Factor {
 // Numeric multifrontal LU (no pivoting) of  M = cF * F' + cE * E'  where valF/valE live on the pencil's pattern.
 template <typename T>
 void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out);
+// nz real factorisations  M_z = cF F' + cE[z] E'  of the same pencil in shared launches (every tree level once for all of them), and their
+// dense top inverses likewise
+void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, double cF, const double* cE, Factor<double>* const* outs, int nz);
+void mf_topinv_batch(Ctx* ctx, const Pencil& P, Factor<double>* const* Fs, int nz);
 // Synchronises and throws ERR_SINGULAR if the factorisation met a zero pivot.
 // Also returns the pivot growth (largest multiplier); throws ERR_SINGULAR beyond ctx->pivot_growth_fail.
 template <typename T>
@@ -148,7 +152,7 @@ void mf_solve_from(Ctx* ctx, const Pencil& P, const Factor<double>& F, const dou
                    const AdiState* st = nullptr);
 
 // partial-fraction coefficients of a fan group (engine.hip, fan_coefficients) and the fused  E' W + mixing  pass over the g solves
-#define FAN_GMAX 8
+#define FAN_GMAX 10
 struct FanCoef { double c[FAN_GMAX][FAN_GMAX], d[FAN_GMAX][FAN_GMAX]; };
 struct FanSlots { int s[FAN_GMAX]; };       // solve s lives in columns s[s] k .. of the panel (shift-sharded groups: slab of the owning rank)
 void fan_spmm_mix(Ctx* ctx, const Pencil& P, const Mat& W, const Mat& R0, Mat& V, Mat& Rc, int g, int k, const FanCoef& co, const FanSlots& sl,

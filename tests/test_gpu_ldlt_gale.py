@@ -206,13 +206,13 @@ def test_fan_groups_on_a_gale_with_low_rank_update(ctx):
                     warnings.simplefilter("ignore")
                     X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=mi, reltol=1e-10), return_info=True)
                 res[(fan, mi)] = (X, info)
-        ctx.set_option("adi_fan", 5)
+        ctx.set_option("adi_fan", 8)
         s = D.init(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=200, reltol=1e-10))
         while not D.isdone(s):
             D.step_(s)
         Xs = s.X
     finally:
-        ctx.set_option("dense_inverse_max_n", 1536); ctx.set_option("adi_fan", 5)
+        ctx.set_option("dense_inverse_max_n", 1536); ctx.set_option("adi_fan", 8)
     X0, i0 = res[(0, 200)]
     assert i0["converged"]
     def dense(X):

@@ -202,7 +202,7 @@ def test_fan_groups_give_the_sequential_iterates(ctx, rail371, save_state):
             runs[(g, coef)] = (sol, [x["iters"] for x in st["gales"]])
     finally:
         ctx.set_option("dense_inverse_max_n", 1536); ctx.set_option("dense_x_max_n", 1536)
-        ctx.set_option("adi_fan", 5); ctx.set_option("adi_fan_max_coef", 64.0)
+        ctx.set_option("adi_fan", 8); ctx.set_option("adi_fan_max_coef", 128.0)
     ref = runs[(0, 64.0)]
     for key, (sol, its) in runs.items():
         assert its == ref[1], (key, its, ref[1])
