@@ -1512,6 +1512,21 @@ struct AdiRun {
     bool fan_off = false;             // the batched fan form does not apply to this solve's factors (sparse.hip, mf_solve_batch): one iteration at a time
     bool fan_smw_all = false;         // the SMW products of every cached shift of the cycle were formed with the first group's
     void check_used() {
+        {   // the unchecked real factors with ONE synchronisation (the ten factorisations of a freshly factorised cycle: ten read-backs before)
+            std::vector<const Factor<double>*> fs; std::vector<FactorEntry<double>*> es;
+            for (auto& f : used_real) {
+                bool seen = false;
+                for (auto* e : es) seen = seen || e == f.get();
+                if (!f->checked && !seen) { fs.push_back(&f->f); es.push_back(f.get()); }
+            }
+            if (fs.size() >= 2) {
+                const std::vector<double> gr = mf_check_batch(ctx, fs);
+                for (size_t i = 0; i < es.size(); ++i) {
+                    es[i]->growth = gr[i]; es[i]->checked = true;
+                    if (es[i]->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); }
+                }
+            }
+        }
         for (auto& f : used_real) {
             if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; if (f->f.nperturbed > 0) { check_now = true; max_growth = std::max(max_growth, 1e300); } }
             max_growth = std::max(max_growth, f->growth);
