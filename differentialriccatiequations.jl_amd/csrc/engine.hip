@@ -260,7 +260,10 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
 // block, against ~5 panels x 13 dependent launches of the factor-form reduction (1.5 ms -> ~0.6 ms at n = 5177, c = 2300).  A 16-column Gaussian
 // probe measures what the basis missed, ||(I - QQ') X||_F ~ sqrt(n / 16) ||(I - QQ') X Om_p||_F: accepted below abs_tol (the level the caller
 // truncates at anyway); otherwise the caller runs the full reduction.  *missed returns the estimate.
-static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed) {
+// rel_accept > 0: the probe is judged RELATIVE to its own size (what the basis missed of X Om_p over X Om_p <= rel_accept, the criterion of
+// sketch_compress: 64 eps is the rounding floor of the projection) instead of against abs_tol — the compression of X itself, whose
+// tolerance 4 eps ||X|| lies below that floor.
+static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed, double rel_accept = 0.0) {
     const int n = X.n, c = X.rank(), q0 = Q0.cols, sp = sx + 16, s = q0 + sx;
     static const bool trace = env_trace("compress");
     if (c == 0 || q0 < 16 || s <= 64 || s + 80 > n || abs_tol <= 0.0 || Q0.rows != n) {
@@ -276,6 +279,7 @@ static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, doubl
     gemm(ctx, false, true, 1.0, Lcat, W2, 0.0, Yx, nullptr, "gemm_sketch");
     Mat Yr = Y.colsview(0, s), Z = Y.colsview(s, 16);
     DevArr<double> nrm(ctx, 2);
+    frob2_device(ctx, Z, nrm.p);
     DevArr<long long> cflag(ctx, 1);
     DRE_HIP(hipMemsetAsync(cflag.p, 0, sizeof(long long), ctx->stream));
     Mat Q(ctx, n, s);
@@ -298,7 +302,8 @@ static bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, doubl
     ctx_fetch(ctx, nrm.p, 2 * sizeof(double), h, cflag.p, sizeof(long long), &cf);
     const double est = std::sqrt(std::max(h[1], 0.0) * (double)n / 16.0);
     if (missed) *missed = est;
-    const bool ok = (cf & 1) == 0 && est <= abs_tol && sb.J + 16 <= s;
+    const double est_rel = h[0] > 0.0 ? std::sqrt(std::max(h[1], 0.0) / h[0]) : 0.0;
+    const bool ok = (cf & 1) == 0 && (rel_accept > 0.0 ? est_rel <= rel_accept : est <= abs_tol) && sb.J + 16 <= s;
     if (trace) std::fprintf(stderr, "[warm compress] n=%d c=%d q0=%d sx=%d -> J=%d  missed %.2e (tolerance %.2e)  %s\n", n, c, q0, sx, sb.J, est, abs_tol, ok ? "accepted" : "REJECTED");
     if (!ok) return false;
     X.blocks.clear();
@@ -3764,6 +3769,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     cur->step = 0; cur->X = prob.X0; cur->EtL = fb0.EtL;
     auto get_state = [&]() { std::lock_guard<std::mutex> lk(smu); return cur; };
     std::vector<LDLtP> saved((size_t)nsteps + 1);
+    int xwarm_sx = 32, xwarm_strikes = 0;           // warm-started compression of X on the side stream (touched by the worker only)
     std::vector<LBlock> pend;                       // increments the side stream has not been handed yet
     int pend_upto = 0;
     bool job_pending = false;
@@ -3792,6 +3798,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         pend.clear();
         LDLtP* const saved_slot = save_state ? &saved[(size_t)target] : nullptr;
         auto* curp = &cur; auto* mup = &smu;
+        int* const xw_sx = &xwarm_sx; int* const xw_strikes = &xwarm_strikes;
         worker.submit([=, &P]() {
             DRE_HIP(hipSetDevice(side->device));
             DRE_HIP(hipStreamWaitEvent(side->stream, e_main, 0));
@@ -3801,7 +3808,20 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             for (auto& b : base->X->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
             for (auto& b : blocks) Xs->blocks.push_back(b);
             if (Xs->blocks.empty()) Xs->blocks.push_back({Mat(side, n, 0), Mat(side, 0, 0), 1.0, true});
-            ldlt_destructure(side, *Xs, ctf, false);
+            // X_b's basis nearly spans the new X (the solution moves slowly between time steps): the warm-started range finder of the residual
+            // compression, with the relative tolerance of compress! as an absolute one (||X_b||_F = ||D_b||_F: L_b is orthonormal); the full
+            // sketch compression where the probe rejects it
+            bool done = false;
+            if (!blocks.empty() && base->X->blocks.size() == 1 && base->X->blocks[0].ortho && base->X->blocks[0].L.cols >= 64 && *xw_strikes < 2) {
+                const LBlock& bb = base->X->blocks[0];
+                const double nb = frob_norm_host(side, bb.D) * std::fabs(bb.alpha);
+                double missed = 0.0;
+                done = nb > 0.0 && warm_compress(side, *Xs, bb.L, ctf, ctf * EPS * nb, *xw_sx, &missed, 64.0 * EPS);
+                if (done) *xw_strikes = 0;
+                else if (*xw_sx < 64) *xw_sx = 64;
+                else *xw_strikes += 1;
+            }
+            if (!done) ldlt_destructure(side, *Xs, ctf, false);
             auto st = std::make_shared<SideState>();
             st->step = target; st->X = Xs; st->ev = e_side;
             const LBlock& b = Xs->blocks[0];
