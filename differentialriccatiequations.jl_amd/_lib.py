@@ -136,9 +136,11 @@ PROTOTYPES = {
     "dre_gdre_result_times": (C.c_int, [_vp, _pd]),
     "dre_gdre_result_K": (C.c_int, [_vp, _vp, C.c_int, _pd, C.c_int]),
     "dre_gdre_result_K_device": (C.c_int, [_vp, _vp, _vp]),
+    "dre_gdre_result_K_all": (C.c_int, [_vp, _vp, _pd]),
     "dre_gdre_result_X": (C.c_int, [_vp, C.c_int, _pvp]),
     "dre_gdre_result_gale": (C.c_int, [_vp, C.c_int, _pi64, _pd]),
     "dre_gdre_result_gale_history": (C.c_int, [_vp, C.c_int, _pi64, _pd, _pi32, _pd, _pd]),
+    "dre_gdre_result_gales_all": (C.c_int, [_vp, _pi64, _pd, _pd, _pi32, _pd, _pd]),
     "dre_gdre_result_free": (C.c_int, [_vp]),
     "dre_host_eigvals": (C.c_int, [C.c_int, _pd, _pd, _pd]),
     "dre_host_gen_eigvals": (C.c_int, [C.c_int, _pd, _pd, _pd, _pd]),

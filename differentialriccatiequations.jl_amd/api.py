@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import time
 import warnings
 import dataclasses
 from dataclasses import dataclass, field
@@ -873,13 +874,16 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     if _needs_state(observer):
         return _solve_gdre_observed(prob, alg, order, inner, dt, save_state, observer, ctx, return_stats)
     _call(observer, "observe_gdre_start", prob, alg)
+    _t0 = time.perf_counter()
     pencil = _pencil_for(prob.E, prob.A, ctx)
     opt, keep = _adi_options(inner, pencil, None, prob.E, prob.A)
     X0d = prob.X0._to_device(ctx, pencil)
     Bd, Cd = ctx.upload(prob.B), ctx.upload(prob.C)
     r = C.c_void_p()
+    _t1 = time.perf_counter()
     ctx.chk(ctx.lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0d.ptr, float(prob.tspan[0]), float(prob.tspan[1]),
                                    float(dt), order, int(bool(save_state)), C.byref(opt), C.byref(r)))
+    _t2 = time.perf_counter()
     lib = ctx.lib
     try:
         ii = (C.c_int64 * 7)()
@@ -887,31 +891,33 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
         nt, nx, iters, nfac, ngale, m, n = list(ii)
         t = np.zeros(nt)
         lib.dre_gdre_result_times(r, t.ctypes.data_as(C.POINTER(C.c_double)))
-        Ks = []
-        for i in range(nt):
-            K = np.zeros((m, n), order="F")
-            ctx.chk(lib.dre_gdre_result_K(ctx.ptr, r, i, K.ctypes.data_as(C.POINTER(C.c_double)), m))
-            Ks.append(K)
+        Kall = np.zeros((nt, n, m))            # block i = K(t_i), m x n column-major: one export launch + one copy for the whole trajectory
+        ctx.chk(lib.dre_gdre_result_K_all(ctx.ptr, r, Kall.ctypes.data_as(C.POINTER(C.c_double))))
+        Ks = [Kall[i].T for i in range(nt)]
         Xs = [prob.X0]                    # first(sol.X) === prob.X0  (test/rail.jl:40)
         for i in range(1, nx):
             xp = C.c_void_p()
             lib.dre_gdre_result_X(r, i, C.byref(xp))
             Xs.append(LDLt([], [], [], _handle=dev.DeviceLDLt(ctx, xp, pencil)))
         gales = []
-        for j in range(ngale):
-            gi = (C.c_int64 * 4)()
-            gd = (C.c_double * 2)()
-            lib.dre_gdre_result_gale(r, j, gi, gd)
-            cnt = (C.c_int64 * 2)()
-            lib.dre_gdre_result_gale_history(r, j, cnt, None, None, None, None)
-            norms, nit = np.zeros(cnt[0]), np.zeros(cnt[0], dtype=np.int32)
-            sre, sim = np.zeros(max(cnt[1], 1)), np.zeros(max(cnt[1], 1))
-            lib.dre_gdre_result_gale_history(r, j, cnt, norms.ctypes.data_as(C.POINTER(C.c_double)), nit.ctypes.data_as(C.POINTER(C.c_int32)),
-                                             sre.ctypes.data_as(C.POINTER(C.c_double)), sim.ctypes.data_as(C.POINTER(C.c_double)))
-            gales.append(dict(iters=gi[0], converged=bool(gi[1]), warnings=gi[2], rhs_cols=gi[3], res_norm=gd[0], abstol=gd[1],
-                              norms=norms, norm_iters=nit, shifts=(sre + 1j * sim)[:cnt[1]]))
+        if ngale:
+            pd, pi64, pi32 = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+            gi, gd = np.zeros((ngale, 6), dtype=np.int64), np.zeros((ngale, 2))
+            lib.dre_gdre_result_gales_all(r, gi.ctypes.data_as(pi64), gd.ctypes.data_as(pd), None, None, None, None)
+            nn, ns = int(gi[:, 4].sum()), int(gi[:, 5].sum())
+            norms, nit = np.zeros(max(nn, 1)), np.zeros(max(nn, 1), dtype=np.int32)
+            sre, sim = np.zeros(max(ns, 1)), np.zeros(max(ns, 1))
+            lib.dre_gdre_result_gales_all(r, None, None, norms.ctypes.data_as(pd), nit.ctypes.data_as(pi32), sre.ctypes.data_as(pd), sim.ctypes.data_as(pd))
+            shifts = sre + 1j * sim
+            on = os_ = 0
+            for j in range(ngale):
+                cn, cs = int(gi[j, 4]), int(gi[j, 5])
+                gales.append(dict(iters=int(gi[j, 0]), converged=bool(gi[j, 1]), warnings=int(gi[j, 2]), rhs_cols=int(gi[j, 3]), res_norm=float(gd[j, 0]),
+                                  abstol=float(gd[j, 1]), norms=norms[on:on + cn], norm_iters=nit[on:on + cn], shifts=shifts[os_:os_ + cs]))
+                on += cn; os_ += cs
     finally:
         lib.dre_gdre_result_free(r)
+    _t3 = time.perf_counter()
     per_step = ngale // max(nt - 1, 1) if nt > 1 else 0
     _call(observer, "observe_gdre_step", t[0], Xs[0], Ks[0])
     for i in range(1, nt):
@@ -928,7 +934,8 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     _call(observer, "observe_gdre_done")
     sol = DRESolution(Xs, Ks, t)
     if return_stats:
-        return sol, dict(adi_iters=iters, factorizations=nfac, gales=gales)
+        return sol, dict(adi_iters=iters, factorizations=nfac, gales=gales,
+                         host_ms=dict(upload=(_t1 - _t0) * 1e3, solve=(_t2 - _t1) * 1e3, results=(_t3 - _t2) * 1e3, hooks=(time.perf_counter() - _t3) * 1e3))
     return sol
 
 

@@ -142,6 +142,7 @@ int dre_ctx_destroy(dre_ctx* ctx) {
     ctx->c.timer.reset();
     ctx->c.pool.trim();
     if (ctx->c.fetch_host) { (void)hipHostFree((void*)ctx->c.fetch_host); ctx->c.fetch_host = nullptr; }
+    if (ctx->c.dense_land) { (void)hipHostFree(ctx->c.dense_land); ctx->c.dense_land = nullptr; }
     (void)hipStreamDestroy(ctx->c.stream);
     delete ctx;
     return DRE_OK;
@@ -170,6 +171,8 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "mf_subtree") ctx->c.mf_subtree = (int)value;
         else if (key == "setup_streams") ctx->c.setup_streams = (int)value;
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
+        else if (key == "side_after_panels") ctx->c.side_after_panels = (int)value;
+        else if (key == "setup_batched") ctx->c.setup_batched = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
         else if (key == "dense_x_max_k") ctx->c.dense_x_max_k = (int)value;
         else if (key == "adi_group") ctx->c.adi_group = (int)value;
@@ -883,16 +886,51 @@ int dre_gdre_result_K(dre_ctx* ctx, const dre_gdre_result* r, int i, double* K_h
         download_mat(c, K, K_host, ld);
     });
 }
+// K(t_i)(j, old) = Kt_i(iperm[old], j) for up to 64 time points per launch (the table of factors travels as kernel arguments): the whole
+// trajectory leaves the solver ordering in one pass instead of a permutation and a transposition launch per time point
+struct KTrajBatch { const double* Kt[64]; int ld[64]; };
+__global__ void k_traj_export(int n, int m, const int* __restrict__ iperm, KTrajBatch bt, double* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * m) return;
+    const int j = idx % m, old = idx / m;
+    const int src = iperm ? iperm[old] : old;
+    out[(size_t)blockIdx.y * n * m + idx] = bt.Kt[blockIdx.y][src + (size_t)j * bt.ld[blockIdx.y]];
+}
+static void export_trajectory(Ctx* c, const dre_gdre_result* r, double* K_dev) {
+    const int nt = (int)r->r.Kt.size();
+    if (nt == 0) return;
+    const int n = r->r.Kt[0].rows, m = r->r.Kt[0].cols;
+    if (n * m == 0) return;
+    for (int i0 = 0; i0 < nt; i0 += 64) {
+        KTrajBatch bt;
+        const int nb = std::min(64, nt - i0);
+        for (int i = 0; i < 64; ++i) {
+            const Mat& K = r->r.Kt[(size_t)(i0 + std::min(i, nb - 1))];
+            DRE_REQUIRE(K.rows == n && K.cols == m, "K trajectory: inconsistent shapes");
+            bt.Kt[i] = K.p; bt.ld[i] = K.ld;
+        }
+        hipLaunchKernelGGL(k_traj_export, dim3((unsigned)((n * m + 255) / 256), (unsigned)nb), dim3(256), 0, c->stream, n, m,
+                           r->pen ? (const int*)r->pen->p->iperm.p : (const int*)nullptr, bt, K_dev + (size_t)i0 * n * m);
+    }
+    DRE_HIP(hipGetLastError());
+}
 int dre_gdre_result_K_device(dre_ctx* ctx, const dre_gdre_result* r, double* K_dev) {
     return guarded(ctx, [&] {
         Ctx* c = &ctx->c;
+        export_trajectory(c, r, K_dev);
+        c->sync();
+    });
+}
+int dre_gdre_result_K_all(dre_ctx* ctx, const dre_gdre_result* r, double* K_host) {
+    return guarded(ctx, [&] {
+        Ctx* c = &ctx->c;
         const int nt = (int)r->r.Kt.size();
-        for (int i = 0; i < nt; ++i) {
-            Mat Ktu = to_user_order(c, r->pen, r->r.Kt[i]);      // n x m
-            Mat K;
-            K.p = K_dev + (size_t)i * Ktu.rows * Ktu.cols; K.rows = Ktu.cols; K.cols = Ktu.rows; K.ld = Ktu.cols;
-            transpose_mat(c, Ktu, K);
-        }
+        if (nt == 0) return;
+        const size_t tot = (size_t)nt * r->r.Kt[0].rows * r->r.Kt[0].cols;
+        if (tot == 0) return;
+        DevArr<double> stage(c, tot);
+        export_trajectory(c, r, stage.p);
+        DRE_HIP(hipMemcpyAsync(K_host, stage.p, tot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         c->sync();
     });
 }
@@ -914,6 +952,21 @@ int dre_gdre_result_gale_history(const dre_gdre_result* r, int j, int64_t* count
     if (counts) { counts[0] = (int64_t)g.norms.size(); counts[1] = (int64_t)g.shifts.size(); }
     for (size_t i = 0; i < g.norms.size(); ++i) { if (norms) norms[i] = g.norms[i]; if (norm_iters) norm_iters[i] = g.norm_iters[i]; }
     for (size_t i = 0; i < g.shifts.size(); ++i) { if (sre) sre[i] = g.shifts[i].real(); if (sim) sim[i] = g.shifts[i].imag(); }
+    return DRE_OK;
+}
+int dre_gdre_result_gales_all(const dre_gdre_result* r, int64_t* iinfo, double* dinfo, double* norms, int32_t* norm_iters, double* sre, double* sim) {
+    size_t on = 0, os = 0;
+    for (size_t j = 0; j < r->r.gale.size(); ++j) {
+        const AdiResult& g = r->r.gale[j];
+        if (iinfo) {
+            int64_t* ii = iinfo + 6 * j;
+            ii[0] = g.iters; ii[1] = g.converged; ii[2] = g.warnings; ii[3] = g.rhs_cols; ii[4] = (int64_t)g.norms.size(); ii[5] = (int64_t)g.shifts.size();
+        }
+        if (dinfo) { dinfo[2 * j] = g.res_norm; dinfo[2 * j + 1] = g.abstol; }
+        for (size_t i = 0; i < g.norms.size(); ++i) { if (norms) norms[on + i] = g.norms[i]; if (norm_iters) norm_iters[on + i] = g.norm_iters[i]; }
+        for (size_t i = 0; i < g.shifts.size(); ++i) { if (sre) sre[os + i] = g.shifts[i].real(); if (sim) sim[os + i] = g.shifts[i].imag(); }
+        on += g.norms.size(); os += g.shifts.size();
+    }
     return DRE_OK;
 }
 int dre_gdre_result_free(dre_gdre_result* r) { delete r; return DRE_OK; }

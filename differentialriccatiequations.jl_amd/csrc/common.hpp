@@ -177,6 +177,11 @@ struct Ctx {
     // recurrence, X compressed on the side stream (engine.hip, ros1_recurrence_loop); 0: the reference's order of operations
     int ros1_recurrence = 1;
     int x_side_stream = 1;
+    // dense-X time loop: the side stream's set-up (SMW products, stacks) is enqueued after this many panels of the residual's band
+    // reduction (the device is busy with them); -1: inside the reduction's read-back
+    int side_after_panels = -1;
+    // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (engine.hip, cycle_setup_batched)
+    int setup_batched = 1;
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;
@@ -198,6 +203,7 @@ struct Ctx {
     // command + hipStreamSynchronize per read-back
     struct FetchZone { volatile unsigned long long seq; unsigned long long pad[7]; unsigned long long words[1024]; };
     FetchZone* fetch_host = nullptr;   // host address
+    void* dense_land = nullptr;        // pinned landing zone of the dense-X time loop (engine.hip, DenseXState): allocated once per context
     FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it
     unsigned long long fetch_seq = 0;
     bool fetch_spin = true;            // false: ctx_fetch blocks in hipStreamSynchronize instead of spinning (the side context: its driver thread must not burn a core beside the main thread)

@@ -3030,13 +3030,15 @@ static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb,
     if (rows <= 512 && rows >= 16 && jb == 16 && j0 == 0 && qr_panel16_enabled()) {
         TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = ((size_t)1024 + (size_t)rows * 17) * sizeof(double);
-        if (rows <= 256) {
-            lds_attr(ctx, (const void*)k_qr_panel16<4>, 96 * 1024);
-            hipLaunchKernelGGL((k_qr_panel16<4>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out, zero_above);
-        } else {
-            lds_attr(ctx, (const void*)k_qr_panel16<8>, 96 * 1024);
-            hipLaunchKernelGGL((k_qr_panel16<8>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out, zero_above);
-        }
+        // NR = rows per lane and column: the column loop's work and its dependent chains scale with it (n = 371: 6 instead of 8)
+#define DRE_QR16_CASE(NRV) { lds_attr(ctx, (const void*)k_qr_panel16<NRV>, 96 * 1024); \
+            hipLaunchKernelGGL((k_qr_panel16<NRV>), dim3(1), dim3(256), shm, ctx->stream, A, lda, rows, V, ldv, T, ldt, VT, ldvt, st, part, nparts, kpanel, tolfac, part_out, zero_above); }
+        if (rows <= 256) DRE_QR16_CASE(4)
+        else if (rows <= 320) DRE_QR16_CASE(5)
+        else if (rows <= 384) DRE_QR16_CASE(6)
+        else if (rows <= 448) DRE_QR16_CASE(7)
+        else DRE_QR16_CASE(8)
+#undef DRE_QR16_CASE
         return;
     }
     if (rows <= QR_LDS_ROWS) {
@@ -3946,6 +3948,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 if (first_round && hit != ctx->band_hint.end() && issued == chunk - 1 && issued >= 1) { deferred_k = k; break; }
                 fused_update(k);
                 k += b; ++np; ++issued;
+                if (spec && first_round && spec->extra && !spec->ran && spec->extra_after >= 1 && issued == spec->extra_after) { spec->ran = true; spec->extra(); }
                 continue;
             } else {
             int zs = 1;

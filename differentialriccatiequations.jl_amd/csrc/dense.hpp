@@ -258,6 +258,7 @@ struct BandSpec {
     // further host work to slot into the wait for the control block (runs once, after the speculative kernels were enqueued; ran = true)
     std::function<void()> extra;
     bool ran = false;
+    int extra_after = -1;      // >= 1: run `extra` right after that many panels (with their updates) were enqueued instead of inside the read-back
     // optional job of the control-block launch (the dense time loop's tolerances; saves a launch): with nc = sqrt(sum tol_parts),
     // at = tol_abstol >= 0 ? tol_abstol : tol_reltol nc  ->  tols_out = {at, tol_frac at, nc}; the reduction's absolute tolerance is tols_out[1]
     const double* tol_parts = nullptr; int tol_nparts = 0; double tol_reltol = 0.0, tol_abstol = -1.0, tol_frac = 1.0; double* tols_out = nullptr;

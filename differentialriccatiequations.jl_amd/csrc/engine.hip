@@ -2912,6 +2912,80 @@ static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& 
     if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe.dinv, 0.0, bot, nullptr, "gemm_dinv"); }
     fe.stack = stk; fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
 }
+// Acceptance norms of the batched set-up below, as partial sums the host adds up: out[17 z] = ||F + mu_z E||_F^2 (value arrays),
+// out[17 z + 1 .. 17 z + 16] = sums of squares of sixteen column slabs of N_z (n x n, leading dimension ldw)
+struct SetupNormZ { double mu[MF_ZMAX]; };
+__global__ __launch_bounds__(256) void k_setup_norms_z(int nnz, const double* __restrict__ valF, const double* __restrict__ valE, SetupNormZ mz, int n,
+                                                       const double* __restrict__ W, int ldw, long wz, double* __restrict__ out) {
+    const int z = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    double s = 0.0;
+    if (part == 0) {
+        const double mu = mz.mu[z];
+        for (int i = tid; i < nnz; i += 256) { const double v = valF[i] + mu * valE[i]; s += v * v; }
+    } else {
+        const double* __restrict__ Wz = W + (size_t)z * wz;
+        const int cw = (n + 15) / 16, c0 = (part - 1) * cw, c1 = min(n, c0 + cw);
+        for (int c = c0; c < c1; ++c)
+            for (int r = tid; r < n; r += 256) { const double v = Wz[r + (size_t)c * ldw]; s += v * v; }
+    }
+    __shared__ double sh[4];
+    s = wave_sum_t<double>(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[17 * z + part] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// Set-up of a whole real Cyclic list on the dense-inverse path (n <= dense_inv_max_n) in SHARED launches: every missing factorisation
+// (mf_factor_batch: one launch per tree level for all shifts), the explicit inverses N_z = M_z^-1 through one batched solve with the identity
+// as common right-hand side (mf_solve_batch), the stacked inverses [N_z; E'N_z; U'N_z] of all shifts as ONE matrix (one SpMM, one GEMM) and
+// the acceptance norms — ~25 launches instead of ~30 per shift on helper streams (1.6 of the 2.2 ms of the first time step at n = 371).
+// Fills the factor cache; shifts it cannot take (already cached, more than MF_ZMAX, sweeps without the matrix cores) go through get_factor.
+static void cycle_setup_batched(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache) {
+    const Pencil& P = *op.P;
+    const int n = P.n, mm = op.has_lr ? op.U.cols : 0;
+    if (!cache->enabled || !P.use_mfma_sweeps || n > ctx->dense_inv_max_n || ctx->setup_batched <= 0) return;
+    std::vector<double> todo;
+    for (auto& mu : values) {
+        bool dup = cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) > 0;
+        for (double t : todo) dup = dup || t == mu.real();
+        if (!dup && (int)todo.size() < MF_ZMAX) todo.push_back(mu.real());
+    }
+    const int g = (int)todo.size();
+    if (g < 2) return;
+    std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+    std::vector<Factor<double>*> fp;
+    std::vector<const Factor<double>*> cf;
+    for (int z = 0; z < g; ++z) { fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); cf.push_back(&fes.back()->f); }
+    mf_factor_batch(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), g);
+    Mat STK(ctx, 2 * n + mm, n * g), Id(ctx, n, n);
+    set_identity(ctx, Id, 1.0);
+    if (!mf_solve_batch(ctx, P, cf.data(), g, Id.p, Id.ld, n, STK.p, STK.ld, n)) return;       // (the factors are dropped: get_factor redoes them one by one)
+    DevArr<double> nr(ctx, (size_t)17 * g);
+    SetupNormZ mz; std::memset(&mz, 0, sizeof(mz));
+    for (int z = 0; z < g; ++z) mz.mu[z] = todo[(size_t)z];
+    hipLaunchKernelGGL(k_setup_norms_z, dim3((unsigned)g, 17), dim3(256), 0, ctx->stream, P.nnz, (const double*)op.valFt.p, (const double*)P.valEt.p, mz, n,
+                       (const double*)STK.p, STK.ld, (long)n * STK.ld, nr.p);
+    {
+        Mat top = STK.view(0, 0, n, n * g), mid = STK.view(n, 0, n, n * g);
+        spmm(ctx, P, P.valEt.p, top, mid, 1.0, 0.0, nullptr);
+        if (mm) { Mat bot = STK.view(2 * n, 0, mm, n * g); gemm(ctx, true, false, 1.0, op.U, top, 0.0, bot, nullptr, "gemm_dinv"); }
+    }
+    std::vector<double> hp((size_t)17 * g), h((size_t)2 * g, 0.0);
+    ctx_fetch(ctx, nr.p, hp.size() * sizeof(double), hp.data());
+    for (int z = 0; z < g; ++z) { h[2 * z] = hp[17 * z]; for (int i = 1; i <= 16; ++i) h[2 * z + 1] += hp[17 * z + i]; }
+    const std::vector<double> gr = mf_check_batch(ctx, cf);
+    for (int z = 0; z < g; ++z) {
+        auto& fe = *fes[(size_t)z];
+        fe.growth = gr[(size_t)z]; fe.checked = true;
+        fe.f.allow_topinv = true;
+        const double cond_est = std::sqrt(h[2 * z]) * std::sqrt(h[2 * z + 1]);
+        if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) {
+            fe.stack = STK.view(0, z * n, 2 * n + mm, n); fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
+            fe.dinv = STK.view(0, z * n, n, n); fe.dense = true;
+        }
+        const auto key = std::make_tuple(op.tag, todo[(size_t)z], 0.0);
+        cache->real[key] = fes[(size_t)z]; cache->fresh.push_back(key); cache->nfactor++;
+    }
+}
 static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache, CycleOps& co,
                               std::vector<Mat>* wks_store = nullptr /* persistent 2n x m buffers per position of the cycle (group chain) */,
                               const std::vector<Mat>* spack = nullptr /* packed stacks per position (group chain): thin products without k_gemm */,
@@ -2925,6 +2999,7 @@ static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vecto
     std::vector<SmwBatch> hb;
     std::vector<const double*> stacks, wks; std::vector<double*> outs;
     for (auto& mu : values) if (mu.imag() != 0.0) return false;
+    cycle_setup_batched(ctx, op, values, cache);
     {
         // Every factorisation and dense inverse of the cycle is enqueued before the single read-back of the acceptance norms.  Each of
         // them is a chain of ~25 small kernels (assembly, one factorisation launch per tree level, n unit right-hand sides, norms) that
@@ -3303,6 +3378,41 @@ static void group_ops_prepare(Ctx* ctx, const std::vector<std::complex<double>>&
     DRE_HIP(hipGetLastError());
 }
 
+// One parked host thread per GDRE solve for work that is DRIVEN beside the main loop (the side-stream compression of X has host read-backs of
+// its own, so it cannot simply be enqueued): jobs are handed over through a condition variable — no thread is spawned per time step.
+class SideWorker {
+  public:
+    ~SideWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+    void submit(std::function<void()> job) {
+        if (!th_.joinable()) th_ = std::thread([this] { run(); });
+        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; }
+        cv_.notify_all();
+    }
+    bool pending() { std::lock_guard<std::mutex> lk(m_); return busy_; }
+    void wait() {       // returns when the submitted job is finished; rethrows what it threw
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return !busy_; });
+        if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; job = std::move(job_); job_ = nullptr; }
+            std::exception_ptr e;
+            try { job(); } catch (...) { e = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(m_); busy_ = false; err_ = e; }
+            done_.notify_all();
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void()> job_;
+    std::exception_ptr err_;
+    bool busy_ = false, quit_ = false;
+};
+
 struct DenseXState {
     Mat X;        // n x n, symmetric
     Mat P1;       // E' X
@@ -3335,8 +3445,13 @@ struct DenseXState {
         for (auto e : pev) (void)hipEventDestroy(e);
         pev.clear(); ptag.clear();
     }
-    DenseXState() { if (hipHostMalloc((void**)&land, sizeof(Landing), hipHostMallocDefault) != hipSuccess) land = nullptr; }
-    ~DenseXState() { if (land) (void)hipHostFree(land); }
+    // (the zone belongs to the context: a pinned allocation and its release cost ~0.1 ms each, per solve)
+    void attach(Ctx* ctx) {
+        if (!ctx->dense_land && hipHostMalloc(&ctx->dense_land, 16384, hipHostMallocDefault) != hipSuccess) ctx->dense_land = nullptr;
+        static_assert(sizeof(Landing) <= 16384, "landing zone");
+        land = (Landing*)ctx->dense_land;
+    }
+    DenseXState() = default;
     DenseXState(const DenseXState&) = delete;
     DenseXState& operator=(const DenseXState&) = delete;
 };
@@ -3404,7 +3519,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     spec.tols_out = tols.p;
     static const bool side_in_fetch = true;
     const bool defer_side = wctx != ctx && side_in_fetch && !side_early;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
-    if (defer_side) spec.extra = side_setup;
+    if (defer_side) { spec.extra = side_setup; spec.extra_after = ctx->side_after_panels; }
     else if (!side_early) side_setup();
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     if (defer_side && !spec.ran) side_setup();
@@ -3662,40 +3777,6 @@ static LDLtP dense_to_ldlt(Ctx* ctx, int n, const Mat& Xd, double ctf) {
     return X;
 }
 
-// One parked host thread per GDRE solve for work that is DRIVEN beside the main loop (the side-stream compression of X has host read-backs of
-// its own, so it cannot simply be enqueued): jobs are handed over through a condition variable — no thread is spawned per time step.
-class SideWorker {
-  public:
-    ~SideWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
-    void submit(std::function<void()> job) {
-        if (!th_.joinable()) th_ = std::thread([this] { run(); });
-        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; }
-        cv_.notify_all();
-    }
-    bool pending() { std::lock_guard<std::mutex> lk(m_); return busy_; }
-    void wait() {       // returns when the submitted job is finished; rethrows what it threw
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return !busy_; });
-        if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
-    }
-  private:
-    void run() {
-        for (;;) {
-            std::function<void()> job;
-            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; job = std::move(job_); job_ = nullptr; }
-            std::exception_ptr e;
-            try { job(); } catch (...) { e = std::current_exception(); }
-            { std::lock_guard<std::mutex> lk(m_); busy_ = false; err_ = e; }
-            done_.notify_all();
-        }
-    }
-    std::thread th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    std::function<void()> job_;
-    std::exception_ptr err_;
-    bool busy_ = false, quit_ = false;
-};
 
 // =============================================================================================
 // Rosenbrock-1 time loop with the RESIDUAL RECURRENCE (round 4; general path: multifrontal solves, Cyclic real shifts).
@@ -4092,6 +4173,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                   n <= ctx->dense_x_max_n && n <= ctx->dense_inv_max_n && m <= 32 && !adi.shifts.values.empty();
     for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
     DenseXState sx;
+    sx.attach(ctx);
     SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
     bool sx_init = false, x_is_dense = false;
 
@@ -4295,6 +4377,9 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         out.Kt.push_back(fb.Kt);
     }
     const auto w_loop = wall_now();
+    if (env_trace("pool"))
+        std::fprintf(stderr, "[pool] main: %ld misses, %.1f MB; side: %ld misses, %.1f MB\n", ctx->pool.misses(), ctx->pool.total_bytes() / 1048576.0,
+                     side ? side->pool.misses() : 0L, side ? side->pool.total_bytes() / 1048576.0 : 0.0);
     sx.report();
     if (x_is_dense) X = dense_to_ldlt(ctx, n, sx.X, ctf);
     if (!save_state) out.X.push_back(X);

@@ -325,12 +325,19 @@ int dre_gdre_result_K(dre_ctx* ctx, const dre_gdre_result* r, int i, double* K_h
 /* whole trajectory K(t_0..t_end) as nt consecutive m x n column-major blocks written to DEVICE memory owned by the
  * caller (e.g. a torch tensor's data_ptr) so that it can be handed to RCCL without a host round trip */
 int dre_gdre_result_K_device(dre_ctx* ctx, const dre_gdre_result* r, double* K_dev);
+/* the same nt blocks written to HOST memory (nt * m * n doubles): one export launch and one copy instead of nt calls of dre_gdre_result_K
+ * (sol.K of DRESolution, src/riccati/lowrank_ros1.jl:65) */
+int dre_gdre_result_K_all(dre_ctx* ctx, const dre_gdre_result* r, double* K_host);
 int dre_gdre_result_X(const dre_gdre_result* r, int i, dre_ldlt** X);   /* shares the factors (sol.X[1] === prob.X0) */
 /* per Lyapunov solve j: iinfo [0]=iters [1]=converged [2]=warnings [3]=rhs columns; dinfo [0]=res_norm [1]=abstol */
 int dre_gdre_result_gale(const dre_gdre_result* r, int j, int64_t* iinfo, double* dinfo);
 /* per-iteration record of Lyapunov solve j for the observer replay (observe_gale_step! / observe_gale_metadata!, src/lyapunov/adi.jl:65,103,119,192):
  * counts [0]=number of recorded norms (index 0 = initial residual) [1]=shifts consumed; pass NULL arrays to query the counts */
 int dre_gdre_result_gale_history(const dre_gdre_result* r, int j, int64_t* counts, double* norms, int32_t* norm_iters, double* shifts_re, double* shifts_im);
+/* every Lyapunov solve of the result at once: iinfo 6 per solve ([0..3] as dre_gdre_result_gale, [4]=recorded norms, [5]=shifts consumed), dinfo 2 per
+ * solve; the histories concatenated in solve order.  Call with NULL history arrays first to size them from iinfo. */
+int dre_gdre_result_gales_all(const dre_gdre_result* r, int64_t* iinfo, double* dinfo, double* norms, int32_t* norm_iters, double* shifts_re,
+                              double* shifts_im);
 int dre_gdre_result_free(dre_gdre_result* r);
 
 /* ---- host helpers exposed for CPU tests of the Projection shift pipeline ---------------------- */
