@@ -182,6 +182,8 @@ struct Ctx {
     int side_after_panels = -1;
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (engine.hip, cycle_setup_batched)
     int setup_batched = 1;
+    // self-generated shift lists: the upcoming factorisations that are not in flight yet go out in shared launches (engine.hip, prefetch_ahead)
+    int prefetch_batch = 4;    // low-water mark: refill (in one batch) when at most this many are in flight; 0 = off
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;

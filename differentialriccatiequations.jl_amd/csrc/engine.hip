@@ -1726,7 +1726,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
             std::vector<std::shared_ptr<FactorEntry<double>>> fes;
             std::vector<Factor<double>*> fp;
             for (double t : todo) { (void)t; fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); }
-            mf_factor_batch(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), (int)todo.size());
+            mf_factor_batch<double>(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), (int)todo.size());
             for (size_t z = 0; z < todo.size(); ++z) {
                 fes[z]->f.allow_topinv = true;
                 const auto key = std::make_tuple(op.tag, todo[z], 0.0);
@@ -1976,6 +1976,88 @@ void adi_advance(AdiRun& run, int budget) {
                 if (calls % 500 == 0) std::fprintf(stderr, "[prefetch] %ld calls: %.2f upcoming shifts known per call, %.2f factorisations already in flight per call (depth %d)\n",
                                                    calls, (double)nups / calls, (double)pend / calls, nh);
             }
+            auto helpers_up = [&]() {
+                if (run.helpers_ready) return;
+                while ((int)ctx->helpers.size() < nh) {
+                    auto hc = std::make_unique<Ctx>();
+                    hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+                    hc->stream = create_stream(2);
+                    hc->timer = std::make_unique<KernelTimer>();
+                    hipEvent_t ev;
+                    DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+                }
+                if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
+                DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));         // the operator's value arrays are ready here
+                for (int h = 0; h < nh; ++h) {
+                    Ctx* hc = ctx->helpers[(size_t)h].get();
+                    hc->pivot_static = ctx->pivot_static; hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
+                    hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->mf_subtree = ctx->mf_subtree;
+                    hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+                    DRE_HIP(hipStreamWaitEvent(hc->stream, ctx->helper_e0, 0));
+                }
+                run.helpers_ready = true;
+            };
+            // Self-generated shift lists (Projection: ~13 upcoming shifts are known at every call): the factorisations that are not yet in flight
+            // go out TOGETHER, one set of level launches per kind (real / complex) on one helper stream, instead of one chain of ~15 launches
+            // per shift — the host spends ~250 us of every iteration of such a run on launch calls, and a single factorisation (~370 us at
+            // n = 1357, one workgroup per front) leaves the device as idle as sixteen of them.
+            if (single_use && !run.check_now && ctx->prefetch_batch > 0) {
+                // (refilled only when few are left in flight: the window of known shifts advances by one per iteration, so filling it at every call
+                // would again send the factorisations out one by one)
+                if (scheduled > ctx->prefetch_batch) return;
+                std::vector<std::complex<double>> tr, tc;
+                const int room = MF_ZMAX - scheduled;
+                for (size_t i = 0; i < ups.size() && (int)(tr.size() + tc.size()) < room; ++i) {
+                    const std::complex<double> nx = ups[i];
+                    const bool cx = nx.imag() != 0.0;
+                    const auto ck = std::make_tuple(op.tag, nx.real(), nx.imag());
+                    const bool known = cx ? cache->cplx_.count(ck) > 0 : cache->real.count(ck) > 0;
+                    if (cx) ++i;
+                    if (known || (nx == cur && !fan_call)) continue;
+                    auto& lst = cx ? tc : tr;
+                    bool dup = false;
+                    for (auto& t : lst) dup = dup || t == nx;
+                    if (!dup) lst.push_back(nx);
+                }
+                auto mark = [&](Ctx* hc, std::complex<double> nx) {
+                    hipEvent_t ev;
+                    if (!run.ev_pool.empty()) { ev = run.ev_pool.back(); run.ev_pool.pop_back(); }
+                    else DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    DRE_HIP(hipEventRecord(ev, hc->stream));
+                    run.prefetch_ev[{nx.real(), nx.imag()}] = AdiRun::Prefetched{ev, 0};
+                    ++scheduled;
+                };
+                if (tr.size() >= 2) {
+                    helpers_up();
+                    Ctx* hc = ctx->helpers[run.prefetch_rr++ % (size_t)nh].get();
+                    std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+                    std::vector<Factor<double>*> fp;
+                    std::vector<double> ce;
+                    for (auto& t : tr) { fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); ce.push_back(t.real()); }
+                    mf_factor_batch<double>(hc, P, op.valFt.p, P.valEt.p, 1.0, ce.data(), fp.data(), (int)tr.size());
+                    for (size_t z = 0; z < tr.size(); ++z) {
+                        fes[z]->f.allow_topinv = cache->enabled;
+                        const auto key = std::make_tuple(op.tag, tr[z].real(), 0.0);
+                        cache->real[key] = fes[z]; cache->fresh.push_back(key); cache->nfactor++;
+                        mark(hc, tr[z]);
+                    }
+                }
+                if (tc.size() >= 2) {
+                    helpers_up();
+                    Ctx* hc = ctx->helpers[run.prefetch_rr++ % (size_t)nh].get();
+                    std::vector<std::shared_ptr<FactorEntry<cplx>>> fes;
+                    std::vector<Factor<cplx>*> fp;
+                    std::vector<cplx> ce;
+                    for (auto& t : tc) { fes.push_back(std::make_shared<FactorEntry<cplx>>()); fp.push_back(&fes.back()->f); ce.push_back(make_scalar<cplx>(t.real(), t.imag())); }
+                    mf_factor_batch<cplx>(hc, P, op.valFt.p, P.valEt.p, make_scalar<cplx>(1.0, 0.0), ce.data(), fp.data(), (int)tc.size());
+                    for (size_t z = 0; z < tc.size(); ++z) {
+                        const auto key = std::make_tuple(op.tag, tc[z].real(), tc[z].imag());
+                        cache->cplx_[key] = fes[z]; cache->fresh.push_back(key); cache->nfactor++;
+                        mark(hc, tc[z]);
+                    }
+                }
+            }
             for (size_t i = 0; i < ups.size() && scheduled < nh; ++i) {
                 const std::complex<double> nx = ups[i];
                 const bool cx = nx.imag() != 0.0;
@@ -1987,27 +2069,7 @@ void adi_advance(AdiRun& run, int budget) {
                 // caller factorises it inline on its own stream — handing it to a helper here would put an unfinished factor into the cache that
                 // the caller picks up without an event to wait for
                 if (nx == cur && !fan_call) continue;
-                if (!run.helpers_ready) {
-                    while ((int)ctx->helpers.size() < nh) {
-                        auto hc = std::make_unique<Ctx>();
-                        hc->device = ctx->device; hc->num_cus = ctx->num_cus;
-                        hc->stream = create_stream(2);
-                        hc->timer = std::make_unique<KernelTimer>();
-                        hipEvent_t ev;
-                        DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-                        ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
-                    }
-                    if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
-                    DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));         // the operator's value arrays are ready here
-                    for (int h = 0; h < nh; ++h) {
-                        Ctx* hc = ctx->helpers[(size_t)h].get();
-                        hc->pivot_static = ctx->pivot_static; hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
-                        hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->mf_subtree = ctx->mf_subtree;
-                        hc->timer->enabled = ctx->timer && ctx->timer->enabled;
-                        DRE_HIP(hipStreamWaitEvent(hc->stream, ctx->helper_e0, 0));
-                    }
-                    run.helpers_ready = true;
-                }
+                helpers_up();
                 Ctx* hc = ctx->helpers[run.prefetch_rr++ % (size_t)nh].get();
                 hipEvent_t ev;
                 if (!run.ev_pool.empty()) { ev = run.ev_pool.back(); run.ev_pool.pop_back(); }
@@ -2955,7 +3017,7 @@ static void cycle_setup_batched(Ctx* ctx, const GaleOperator& op, const std::vec
     std::vector<Factor<double>*> fp;
     std::vector<const Factor<double>*> cf;
     for (int z = 0; z < g; ++z) { fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); cf.push_back(&fes.back()->f); }
-    mf_factor_batch(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), g);
+    mf_factor_batch<double>(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), g);
     Mat STK(ctx, 2 * n + mm, n * g), Id(ctx, n, n);
     set_identity(ctx, Id, 1.0);
     if (!mf_solve_batch(ctx, P, cf.data(), g, Id.p, Id.ld, n, STK.p, STK.ld, n)) return;       // (the factors are dropped: get_factor redoes them one by one)

@@ -670,16 +670,17 @@ static void mf_factor_levels(Ctx* ctx, const Pencil& P, const FactorZ& fz, int n
     }
 }
 // nz real factorisations  M_z = cF F' + cE_z E'  of the same pencil in shared launches (assembly per factor, every tree level once)
-void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, double cF, const double* cE, Factor<double>* const* outs, int nz) {
+template <typename T>
+void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, const T* cE, Factor<T>* const* outs, int nz) {
     DRE_REQUIRE(P.has_device && nz >= 1 && nz <= MF_ZMAX, "mf_factor_batch: batch size");
     const Symbolic& S = P.sym;
-    TimedScope ts(ctx, "mf_factor_real", 8.0 * 2.0 * S.fronts_size * nz, 0, nz);
+    TimedScope ts(ctx, sizeof(T) == 8 ? "mf_factor_real" : "mf_factor_complex", (double)sizeof(T) * 2.0 * S.fronts_size * nz, 0, nz);
     FactorZ fz; std::memset(&fz, 0, sizeof(fz));
     for (int z = 0; z < nz; ++z) {
-        Factor<double>& out = *outs[z];
-        if (!out.fronts.p) out.fronts = DevArr<double>(ctx, (size_t)std::max<int64_t>(S.fronts_size, 1));
-        if (!out.inv.p) out.inv = DevArr<double>(ctx, (size_t)std::max<int64_t>(S.inv_size, 1));
-        DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(double), ctx->stream));
+        Factor<T>& out = *outs[z];
+        if (!out.fronts.p) out.fronts = DevArr<T>(ctx, (size_t)std::max<int64_t>(S.fronts_size, 1));
+        if (!out.inv.p) out.inv = DevArr<T>(ctx, (size_t)std::max<int64_t>(S.inv_size, 1));
+        DRE_HIP(hipMemsetAsync(out.fronts.p, 0, (size_t)S.fronts_size * sizeof(T), ctx->stream));
         if (!out.err.p) {
             auto blk = std::make_shared<Buf>(ctx, 64);
             out.growth.buf = blk; out.growth.p = (unsigned long long*)blk->p; out.growth.n = 1;
@@ -691,13 +692,15 @@ void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double
         DRE_HIP(hipMemsetAsync(out.growth.p, 0, 64, ctx->stream));
         out.nperturbed = -1;
         out.ref_valF = valF; out.ref_valE = valE; out.ref_cF = cF; out.ref_cE = cE[z];
-        hipLaunchKernelGGL((k_assemble<double>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE[z], out.fronts.p,
+        hipLaunchKernelGGL((k_assemble<T>), dim3(ceil_div(P.nnz, 256)), dim3(256), 0, ctx->stream, P.nnz, P.dev.asm_dest.p, valF, valE, cF, cE[z], out.fronts.p,
                            ctx->pivot_static, ctx->pivot_static > 0.0 ? out.pivfloor.p : (double*)nullptr);
         fz.fronts[z] = out.fronts.p; fz.inv[z] = out.inv.p; fz.ctrl[z] = out.growth.p;
     }
-    mf_factor_levels<double>(ctx, P, fz, nz);
+    mf_factor_levels<T>(ctx, P, fz, nz);
     DRE_HIP(hipGetLastError());
 }
+template void mf_factor_batch<double>(Ctx*, const Pencil&, const double*, const double*, double, const double*, Factor<double>* const*, int);
+template void mf_factor_batch<cplx>(Ctx*, const Pencil&, const double*, const double*, cplx, const cplx*, Factor<cplx>* const*, int);
 template <typename T>
 double mf_check(Ctx* ctx, const Factor<T>& F) {
     if (!F.err.p) return 0.0;

@@ -134,7 +134,8 @@ template <typename T>
 void mf_factor(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, T cE, Factor<T>& out);
 // nz real factorisations  M_z = cF F' + cE[z] E'  of the same pencil in shared launches (every tree level once for all of them), and their
 // dense top inverses likewise
-void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, double cF, const double* cE, Factor<double>* const* outs, int nz);
+template <typename T>
+void mf_factor_batch(Ctx* ctx, const Pencil& P, const double* valF, const double* valE, T cF, const T* cE, Factor<T>* const* outs, int nz);     // T = double, cplx
 void mf_topinv_batch(Ctx* ctx, const Pencil& P, Factor<double>* const* Fs, int nz);
 // Synchronises and throws ERR_SINGULAR if the factorisation met a zero pivot.
 // Also returns the pivot growth (largest multiplier); throws ERR_SINGULAR beyond ctx->pivot_growth_fail.
