@@ -2961,42 +2961,50 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
         c2 = wave_sum(c2);
         if (lane == 0) Zs[wave][0][16] = c2;
     }
-    {   // Z = V'V on the matrix cores: the waves split the rows, fixed-order sum of the four partials
+    {   // Z = V'V on the matrix cores: the waves split the rows; four independent accumulation chains per wave (a single chain of ~23
+        // dependent products with their LDS operands was 3.2 us of the kernel), fixed-order sums
         const int lr = lane & 15, lk = lane >> 4;
         const int kst = (rows + 3) >> 2, per = (kst + 3) >> 2, t0 = wave * per, t1 = min(kst, t0 + per);
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int t = t0; t < t1; ++t) {
-            const int r = 4 * t + lk;
-            const double a = r < rows ? Vs[r * 17 + lr] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
+        v4d ac0 = (v4d){0.0, 0.0, 0.0, 0.0}, ac1 = ac0, ac2 = ac0, ac3 = ac0;
+        for (int t = t0; t < t1; t += 4) {
+            const int r0 = 4 * t + lk, r1 = r0 + 4, r2 = r0 + 8, r3 = r0 + 12;
+            const double a0 = r0 < rows ? Vs[r0 * 17 + lr] : 0.0;
+            const double a1 = (t + 1 < t1 && r1 < rows) ? Vs[r1 * 17 + lr] : 0.0;
+            const double a2 = (t + 2 < t1 && r2 < rows) ? Vs[r2 * 17 + lr] : 0.0;
+            const double a3 = (t + 3 < t1 && r3 < rows) ? Vs[r3 * 17 + lr] : 0.0;
+            ac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, ac0, 0, 0, 0);
+            ac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, ac1, 0, 0, 0);
+            ac2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, ac2, 0, 0, 0);
+            ac3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, ac3, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Zs[wave][lk + 4 * r][lr] = acc[r];
+        for (int r = 0; r < 4; ++r) Zs[wave][lk + 4 * r][lr] = (ac0[r] + ac1[r]) + (ac2[r] + ac3[r]);
     }
     __syncthreads();
     if (part_out && tid == 0) part_out[0] = (Zs[0][0][16] + Zs[1][0][16]) + (Zs[2][0][16] + Zs[3][0][16]);
-    if (wave == 0) {
-        // T(0:j, j) = -tau_j T(0:j, 0:j) Z(0:j, j),  T(j, j) = tau_j   (lane i owns row i)
-        const int i = lane;
-        double trow[16];
+    {
+        // T from tau and Z = V'V by recursive doubling (the blocked form of larft: T12 = -T11 Z12 T22 for adjacent diagonal blocks of size
+        // 1, 2, 4, 8), every entry by its own thread: the column-by-column recurrence on one wave was 5 us of the kernel (16 dependent steps)
+        __shared__ double Zf[16][17], Wsh[16][17];
+        const int i = tid & 15, j = tid >> 4;
+        Zf[i][j] = ((Zs[0][i][j] + Zs[1][i][j]) + Zs[2][i][j]) + Zs[3][i][j];
+        Tsh[i][j] = i == j ? taus[i] : 0.0;
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) trow[j] = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double tj = taus[j];
-            double accv = 0.0;
-#pragma unroll
-            for (int l = 0; l < 16; ++l)
-                if (l < j) {
-                    const double z = ((Zs[0][l][j] + Zs[1][l][j]) + Zs[2][l][j]) + Zs[3][l][j];
-                    accv += trow[l] * z;                 // trow[l] = T(i, l), zero for l < i
-                }
-            trow[j] = (i < j) ? -tj * accv : (i == j ? tj : 0.0);
+        for (int sz = 1; sz < 16; sz <<= 1) {
+            const int bi = i & ~(2 * sz - 1);
+            const bool mine = (j & ~(2 * sz - 1)) == bi && i - bi < sz && j - bi >= sz;
+            double wv = 0.0;
+            if (mine) for (int m = bi + sz; m <= j; ++m) wv += Zf[i][m] * Tsh[m][j];          // W = Z12 T22
+            Wsh[i][j] = wv;
+            __syncthreads();
+            double tv = 0.0;
+            if (mine) for (int l = i; l < bi + sz; ++l) tv += Tsh[i][l] * Wsh[l][j];          // T12 = -T11 W
+            __syncthreads();
+            if (mine) Tsh[i][j] = -tv;
+            __syncthreads();
         }
-        if (i < 16) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) { Tsh[i][j] = trow[j]; T[i + (size_t)j * ldt] = trow[j]; }
-        }
+        T[i + (size_t)j * ldt] = Tsh[i][j];
     }
     __syncthreads();
     if (VT) {

@@ -89,8 +89,9 @@ def test_ros2_371_45_steps(ctx, rail371, save_state, exact):
     counts RISE again from step 17 on (40 -> 67 per step) because abstol = n eps ||R1|| follows the noise.  This test found a real bug of
     round 2 (the default mode fed the raw summands to the Gram-form norm: 0 iterations and a frozen K from step ~22, 1.2e-6 off); the
     stage-1 right-hand side is now always compressed to one orthonormal block, truncated at max(relative tolerance, formation noise).
-    Literal mode (compress_exact: the reference's arithmetic at every compression): the oracle's count of every time step within one
-    iteration.  Default mode: identical counts while the right-hand side is above the noise (17 steps), within 12 afterwards
+    Literal mode (compress_exact: the reference's arithmetic at every compression): the oracle's count of every time step within two
+    iterations (the counts of the noise-dominated steps follow the rounding of the compression: a different summation order in the panel
+    kernel — T by recursive doubling, round 4 — moved the rise 57 -> 58 -> 60 -> 61 by one step, K(t) unchanged at 1e-14).  Default mode: identical counts while the right-hand side is above the noise (17 steps), within 12 afterwards
     (the engine truncates at 4x the formation noise instead of iterating on it), K(t) to 1e-7 (observed 2e-14) in both."""
     d, L, Dm = rail371
     g = np.load(os.path.join(GOLDEN, "ros2_371_full.npz"))
@@ -98,7 +99,7 @@ def test_ros2_371_45_steps(ctx, rail371, save_state, exact):
     sol, st = D.solve_gdre(prob, D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(list(g["shifts"])), compress_exact=exact)), dt=-100.0, save_state=save_state,
                            return_stats=True)
     assert all(x["converged"] for x in st["gales"])
-    worst = _check_full(sol, st, g, 371, 2, 1e-10, exact_counts=3 if exact else 17, slack=1 if exact else 12)
+    worst = _check_full(sol, st, g, 371, 2, 1e-10, exact_counts=3 if exact else 17, slack=2 if exact else 12)
     assert worst < 1e-11
 
 
