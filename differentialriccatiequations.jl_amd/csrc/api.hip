@@ -643,7 +643,7 @@ static GaleOperator make_operator(Ctx* c, const dre_pencil* p, double cA, double
     }
     return op;
 }
-// The sketch of a wide factor (engine.hip sketch_compress) is chosen from what earlier compressions at the same order left in the context:
+// The sketch of a wide factor (ldlt.hip sketch_compress) is chosen from what earlier compressions at the same order left in the context:
 // the rank hint and the fallback counters.  A solve entered through the ABI starts from a clean slate, so that two identical calls return
 // identical bits whatever ran on the context before (the explicit compression entry dre_ldlt_compress_fast keeps the history: that is
 // its documented behaviour).

@@ -135,7 +135,7 @@ struct Ctx {
     int compress_factor_min_n = 2561;
     int compress_factor_min_cols = 96;
     // wide factors (c >= compress_sketch_min_cols and c >= compress_sketch_ratio x sketch width) of a PSD-like sum are compressed through a randomized range
-    // finder (engine.hip, sketch_compress): three GEMM passes over the n x c factor instead of four per 16 columns of rank; the sketch width
+    // finder (ldlt.hip, sketch_compress): three GEMM passes over the n x c factor instead of four per 16 columns of rank; the sketch width
     // is the rank of the previous compression of this kind + compress_sketch_extra; 0 disables
     int compress_sketch = 1;
     int compress_sketch_min_cols = 320;
@@ -151,14 +151,14 @@ struct Ctx {
     // two forms measure the same (sparse.hip)
     int mf_subtree = 0;
     // Ros1, n <= 1536, no save_state: X is carried as "compressed warm start + ADI increments"; its compression runs on a second stream
-    // beside the next time step (x_side_stream) or only every x_compress_every-th step (engine.hip, gdre_solve)
+    // beside the next time step (x_side_stream) or only every x_compress_every-th step (gdre.hip, gdre_solve)
     // Ros1 without save_state, real Cyclic shifts, n <= dense_x_max_n: X is carried as a dense symmetric n x n matrix between the time steps
-    // (engine.hip, ros1_dense_step); 0 disables
+    // (gdre.hip, ros1_dense_step); 0 disables
     int dense_x_max_n = 1536;
     // residual factors wider than this leave the dense-X loop for the factored path (0: the fast chain's own limit ADI_FAST_MAX_K); also the
     // switch the tests use to force that fallback in the middle of a run
     int dense_x_max_k = 0;
-    // group chain of the dense-X loop (dense.hip k_adi_group, engine.hip group_ops_prepare): g ADI iterations per launch.  1 = auto (largest
+    // group chain of the dense-X loop (dense.hip k_adi_group, gdre.hip group_ops_prepare): g ADI iterations per launch.  1 = auto (largest
     // divisor of the cycle length up to 5), 0 = off (one launch per iteration), g >= 2 = that group size if it divides the cycle length
     int adi_group = 1;
     int adi_group_max_n = 768;
@@ -174,25 +174,25 @@ struct Ctx {
     double pivot_static = 1.4901161193847656e-08;
     int pivot_refine_steps = 3;
     // Rosenbrock-1 on the general path (multifrontal solves, Cyclic real shifts): warm-start residual and feedback from the ADI's own residual
-    // recurrence, X compressed on the side stream (engine.hip, ros1_recurrence_loop); 0: the reference's order of operations
+    // recurrence, X compressed on the side stream (gdre.hip, ros1_recurrence_loop); 0: the reference's order of operations
     int ros1_recurrence = 1;
     int x_side_stream = 1;
     // dense-X time loop: the side stream's set-up (SMW products, stacks) is enqueued after this many panels of the residual's band
     // reduction (the device is busy with them); -1: inside the reduction's read-back
     int side_after_panels = -1;
-    // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (engine.hip, cycle_setup_batched)
+    // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)
     int setup_batched = 1;
     // self-generated shift lists: the upcoming factorisations that are not in flight yet go out in shared launches (engine.hip, prefetch_ahead)
     int prefetch_batch = 4;    // low-water mark: refill (in one batch) when at most this many are in flight; 0 = off
     int x_compress_every = 1;
     // band reduction: number of panels the previous reduction of the same kind needed (speculation depth of the next one)
     std::map<long, int> band_hint;
-    // second context (own stream, pool, hints) for work that runs beside the main stream (engine.hip: side-stream compression of X);
+    // second context (own stream, pool, hints) for work that runs beside the main stream (gdre.hip: side-stream compression of X);
     // created on first use, lives as long as this context
     std::unique_ptr<Ctx> side;
     hipEvent_t side_e1 = nullptr, side_e2 = nullptr;
     // helper contexts (own stream and pool each) for independent chains of small kernels that would otherwise queue up behind each other
-    // on one stream — the factorisations and dense inverses of the shifts of a cycle (engine.hip, cycle_ops_prepare); created on first use
+    // on one stream — the factorisations and dense inverses of the shifts of a cycle (gdre.hip, cycle_ops_prepare); created on first use
     std::vector<std::unique_ptr<Ctx>> helpers;
     std::vector<hipEvent_t> helper_ev;
     hipEvent_t helper_e0 = nullptr;
@@ -205,7 +205,7 @@ struct Ctx {
     // command + hipStreamSynchronize per read-back
     struct FetchZone { volatile unsigned long long seq; unsigned long long pad[7]; unsigned long long words[1024]; };
     FetchZone* fetch_host = nullptr;   // host address
-    void* dense_land = nullptr;        // pinned landing zone of the dense-X time loop (engine.hip, DenseXState): allocated once per context
+    void* dense_land = nullptr;        // pinned landing zone of the dense-X time loop (gdre.hip, DenseXState): allocated once per context
     FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it
     unsigned long long fetch_seq = 0;
     bool fetch_spin = true;            // false: ctx_fetch blocks in hipStreamSynchronize instead of spinning (the side context: its driver thread must not burn a core beside the main thread)

@@ -9,7 +9,7 @@ namespace dre {
 // Termination tolerance of the band reductions.  st->abstol > 0: absolute; <= 0: relative, tolfac * eps * ||S||_F.  Floor mode
 // (st->maxiters == BAND_TOL_FLOOR, set by k_band_init / lr_band_reduce): max(relative, st->abstol) — the caller's estimate of the rounding
 // noise with which S was FORMED (sums with cancellation: ||S|| << ||L||^2 ||D||, where the relative tolerance alone would keep the noise
-// as signal; engine.hip, ldlt_compress COMPRESS_NOISE_FLOOR).
+// as signal; ldlt.hip, ldlt_compress COMPRESS_NOISE_FLOOR).
 #define BAND_TOL_FLOOR 0x7F100D
 __device__ inline double band_tol(const AdiState* st, double tolfac, double base) {
     const double rel = tolfac * 2.220446049250313e-16 * sqrt(base), a = st->abstol;
@@ -725,10 +725,9 @@ void ctx_fetch(Ctx* ctx, const void* d0, size_t b0, void* h0, const void* d1, si
 }
 void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const void* d0, size_t b0, void* h0, const void* d1, size_t b1, void* h1,
                        const void* d2, size_t b2, void* h2) {
-    static const bool spin_on = true;   // neutral on a fast host, saves the wake-up latency of hipStreamSynchronize on a slow one
     const size_t tot = (b0 + b1 + b2) / 8;
     DRE_REQUIRE(b0 % 8 == 0 && b1 % 8 == 0 && b2 % 8 == 0 && tot <= 1024, "ctx_fetch: ranges must be multiples of 8 bytes, 8 KB in all");
-    if (spin_on && ctx->fetch_spin && !ctx->fetch_host) {
+    if (ctx->fetch_spin && !ctx->fetch_host) {       // (spinning is neutral on a fast host and saves the wake-up latency of hipStreamSynchronize on a slow one)
         void* hp = nullptr;
         if (hipHostMalloc(&hp, sizeof(Ctx::FetchZone), hipHostMallocMapped) == hipSuccess) {
             void* dp = nullptr;
@@ -738,7 +737,7 @@ void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const voi
             } else (void)hipHostFree(hp);
         }
     }
-    if (!spin_on || !ctx->fetch_spin || !ctx->fetch_host) {
+    if (!ctx->fetch_spin || !ctx->fetch_host) {
         if (b0) DRE_HIP(hipMemcpyAsync(h0, d0, b0, hipMemcpyDeviceToHost, ctx->stream));
         if (b1) DRE_HIP(hipMemcpyAsync(h1, d1, b1, hipMemcpyDeviceToHost, ctx->stream));
         if (b2) DRE_HIP(hipMemcpyAsync(h2, d2, b2, hipMemcpyDeviceToHost, ctx->stream));
@@ -1344,8 +1343,7 @@ void adi_fast_build(Ctx* ctx, int n, int m, const std::vector<const double*>& st
     const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
     bool all_lr = m >= 1 && m <= 8;
     for (auto w : wks) if (!w) all_lr = false;
-    static const bool use_mfma = true;
-    if (all_lr && use_mfma) {
+    if (all_lr) {
         const int ntile = (kst + 3) >> 2;
         for (size_t b0 = 0; b0 < stacks.size(); b0 += 16) {
             EffStackBatch bt;
@@ -1814,7 +1812,7 @@ void adi_fast_iter(Ctx* ctx, const AdiFastArgs& a) {
 // Group ADI chain (round 3): g consecutive ADI iterations in ONE launch.
 //   R_i = Pi_i R_0,  V_i = Om_i R_0   with  Pi_i = P_{p+i-1} ... P_p,  P_s = I - 2 mu_s E' A_s,  Om_i = A_{p+i} Pi_i,  A_s = (F' + mu_s E')^-1
 // (perform_single_step!, adi.jl:149-179, applied g times: same iterates, the operator products are formed once per time step on the side
-// stream — engine.hip, group_ops_prepare).  The launch-per-iteration chain at n = 371 is bound by the dependent kernel boundary and the
+// stream — gdre.hip, group_ops_prepare).  The launch-per-iteration chain at n = 371 is bound by the dependent kernel boundary and the
 // memory round trips of a 6-us kernel, not by its 32 MFLOP; the group stack [Om_0 .. Om_{g-1}; Pi_1 .. Pi_g] (2 g blocks of n x n, packed in
 // the MFMA A-operand order like the single-iteration stack) turns g of those launches into one with 2 g times the tile workgroups.
 // Riders: the Gram matrices of the g residuals the PREVIOUS launch produced, and the norms + decisions (adi.jl:115-123, taken in iteration
@@ -2094,7 +2092,7 @@ double ldlt_norm_host(Ctx* ctx, const Mat& L, const Mat& D, double alpha) {
 }
 
 // |alpha| ||L D L'||_F through the Gram matrix into DEVICE memory (no synchronisation): the tolerance of the next Lyapunov solve is formed
-// on the side stream while the main stream already iterates (engine.hip, Rosenbrock-1 loop with the residual recurrence)
+// on the side stream while the main stream already iterates (gdre.hip, Rosenbrock-1 loop with the residual recurrence)
 void ldlt_norm_device(Ctx* ctx, const Mat& L, const Mat& D, double alpha, double* out_dev) {
     if (L.cols == 0) { DRE_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), ctx->stream)); return; }
     Mat G(ctx, L.cols, L.cols);
@@ -3026,16 +3024,12 @@ __global__ __launch_bounds__(256) void k_qr_panel16(double* __restrict__ A, int 
         }
     }
 }
-static bool qr_panel16_enabled() {
-    static const bool v = true;
-    return v;
-}
 
 static void launch_qr_panel(Ctx* ctx, double* A, int lda, int m, int j0, int jb, double* V, int ldv, double* T, int ldt,
                             double* VT, int ldvt, AdiState* st, const double* part = nullptr, int nparts = 0, int kpanel = 0,
                             double tolfac = 0.0, double* part_out = nullptr, int zero_above = 0) {
     const int rows = m - j0;
-    if (rows <= 512 && rows >= 16 && jb == 16 && j0 == 0 && qr_panel16_enabled()) {
+    if (rows <= 512 && rows >= 16 && jb == 16 && j0 == 0) {
         TimedScope ts(ctx, "qr_panel", 8.0 * rows * jb * 4.0, 2.0 * rows * jb * jb);
         const size_t shm = ((size_t)1024 + (size_t)rows * 17) * sizeof(double);
         // NR = rows per lane and column: the column loop's work and its dependent chains scale with it (n = 371: 6 instead of 8)
@@ -3542,72 +3536,6 @@ __global__ void k_band_decide(int k, int nparts, const double* __restrict__ part
     const double tol = band_tol(st, tolfac, st->res_norm);
     if (r2 <= tol * tol) { st->done = 1; st->iters = k; }
 }
-// Wm = Z - V * (T' (V' Z)) / 2  assembled next to V:  P1 = [Wm, V], P2 = [V, Wm]  (m x 2b each), one workgroup.
-// Z arrives as `splits` split-K slabs (m x b, ld m) that are summed here in a fixed order (no separate reduce launch);
-// ZLDS: Z and V are staged in LDS (m <= 540).  Wave j owns column j and keeps b independent accumulators.
-template <bool ZLDS>
-__global__ __launch_bounds__(1024) void k_band_w(int m, int b, int splits, const double* __restrict__ Zpart, const double* __restrict__ Vp, int ldv,
-                                                 const double* __restrict__ Tp, int ldt, double* __restrict__ P1, double* __restrict__ P2,
-                                                 int ldp, const AdiState* st) {
-    if (st->done) return;
-    extern __shared__ double wsm[];
-    __shared__ double Msh[QR_NB][QR_NB + 1], Nsh[QR_NB][QR_NB + 1];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    const int ldz = ZLDS ? (m | 1) : ldp;
-    double* Zs = ZLDS ? wsm : P1;                          // without LDS staging Z is parked in P1's first b columns
-    const double* Vs = ZLDS ? wsm + (size_t)ldz * b : Vp;
-    const int ldvs = ZLDS ? ldz : ldv;
-    for (int c = wave; c < b; c += nw)
-        for (int r = lane; r < m; r += 64) {
-            double z = 0.0;
-            {
-                const double* zp = Zpart + r + (size_t)c * m;
-                const size_t sl = (size_t)m * b;
-                int sidx = 0;
-                for (; sidx + 3 < splits; sidx += 4) {
-                    const double p0 = zp[sidx * sl], p1 = zp[(sidx + 1) * sl], p2 = zp[(sidx + 2) * sl], p3 = zp[(sidx + 3) * sl];
-                    z = (((z + p0) + p1) + p2) + p3;
-                }
-                for (; sidx < splits; ++sidx) z += zp[sidx * sl];
-            }
-            Zs[r + (size_t)c * ldz] = z;
-            if (ZLDS) wsm[(size_t)ldz * b + r + (size_t)c * ldz] = Vp[r + (size_t)c * ldv];
-        }
-    __syncthreads();
-    for (int j = wave; j < b; j += nw) {                    // M(:, j) = V' Z(:, j)
-        double acc[QR_NB];
-#pragma unroll
-        for (int i = 0; i < QR_NB; ++i) acc[i] = 0.0;
-        for (int r = lane; r < m; r += 64) {
-            const double zj = Zs[r + (size_t)j * ldz];
-#pragma unroll
-            for (int i = 0; i < QR_NB; ++i) acc[i] += Vs[r + (size_t)i * ldvs] * zj;
-        }
-#pragma unroll
-        for (int i = 0; i < QR_NB; ++i) { const double t = wave_sum(acc[i]); if (lane == 0) Msh[i][j] = t; }
-    }
-    __syncthreads();
-    if (tid < b * b) {
-        const int i = tid % b, j = tid / b;                 // N = T' M
-        double acc = 0.0;
-        for (int l = 0; l <= i; ++l) acc += Tp[l + (size_t)i * ldt] * Msh[l][j];
-        Nsh[i][j] = acc;
-    }
-    __syncthreads();
-    for (int c = wave; c < b; c += nw)
-        for (int r = lane; r < m; r += 64) {
-            double a0 = Zs[r + (size_t)c * ldz], a1 = 0.0;
-#pragma unroll
-            for (int l = 0; l < QR_NB; l += 2) {
-                a0 -= 0.5 * Vs[r + (size_t)l * ldvs] * Nsh[l][c];
-                a1 -= 0.5 * Vs[r + (size_t)(l + 1) * ldvs] * Nsh[l + 1][c];
-            }
-            const double acc = a0 + a1;
-            const double v = Vs[r + (size_t)c * ldvs];
-            P1[r + (size_t)c * ldp] = acc;       P1[r + (size_t)(b + c) * ldp] = v;
-            P2[r + (size_t)c * ldp] = v;         P2[r + (size_t)(b + c) * ldp] = acc;
-        }
-}
 // Large panels (m > 540): the same update row-parallel over many workgroups.  Z is already reduced (m x b), the b x b
 // matrix M = V' Z arrives as split-K slabs; every workgroup forms N = T' M redundantly and owns 256 rows.
 __global__ __launch_bounds__(256) void k_band_w_rows(int m, int splits, const double* __restrict__ Z, int ldz, const double* __restrict__ Mpart,
@@ -3823,7 +3751,7 @@ __global__ void k_extract_band(int J, int b, int kred, const double* __restrict_
 struct BandTolJob { const double* parts; int nparts; double reltol, abstol, frac; double* out; };
 __global__ __launch_bounds__(64) void k_band_init(AdiState* st, double abs_tol, const double* __restrict__ abs_tol_dev, int floor_mode, BandTolJob job) {
     double at_dev = 0.0;
-    if (job.parts) {       // tolerances of the dense time loop's Lyapunov solve (engine.hip, ros1_dense_step): adi.jl:61-62
+    if (job.parts) {       // tolerances of the dense time loop's Lyapunov solve (gdre.hip, ros1_dense_step): adi.jl:61-62
         double s = 0.0;
         for (int i = threadIdx.x; i < job.nparts; i += 64) s += job.parts[i];
         s = wave_sum(s);
@@ -3844,10 +3772,6 @@ __global__ void k_clock_probe(long long* out) {
     const long long c1 = clock64(), w1 = wall_clock64();
     if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (long long)x; }
 }
-static bool band_fused_enabled() {
-    static const bool v = true;
-    return v;
-}
 SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const double* abs_tol_dev, BandSpec* spec, const double* ext_part, int ext_nparts,
                         bool tol_is_floor) {
     DRE_REQUIRE(S.rows == S.cols, "sym_band_reduce: square matrix expected");
@@ -3859,7 +3783,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     out.VT = Mat(ctx, q, q);
     out.T = Mat(ctx, b, q);
     // small orders: every panel goes through the 16-column register kernel, which zeroes the rows of V above its panel itself
-    const bool panel_zeroes = q - b <= 512 && q - b >= 16 && qr_panel16_enabled();
+    const bool panel_zeroes = q - b <= 512 && q - b >= 16;
     if (!panel_zeroes) fill_mat(ctx, out.V, 0.0);
     // all panels factored by a single-workgroup panel kernel: the termination norm of the next panel is assembled from the update
     // GEMM's per-tile sums of squares plus the coupling term written by the panel kernel — no separate norm launch
@@ -3950,7 +3874,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 TimedScope ts(ctx, "band_w", 8.0 * m * b * 6.0, 2.0 * m * b * b);
                 hipLaunchKernelGGL(k_band_w_rows, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, m, ms, Z.p, Z.ld, (const double*)mpart->p,
                                    Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
-            } else if (band_fused_enabled()) {
+            } else {
                 // the last panel of a speculative chunk is the one whose prologue is expected to detect termination: its two-sided update
                 // is only enqueued if the read-back says the reduction goes on
                 if (first_round && hit != ctx->band_hint.end() && issued == chunk - 1 && issued >= 1) { deferred_k = k; break; }
@@ -3958,19 +3882,6 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
                 k += b; ++np; ++issued;
                 if (spec && first_round && spec->extra && !spec->ran && spec->extra_after >= 1 && issued == spec->extra_after) { spec->ran = true; spec->extra(); }
                 continue;
-            } else {
-            int zs = 1;
-            BufP zpart = gemm_partials(ctx, false, false, m, b, m, S22.p, S22.ld, VTp.p, VTp.ld, &zs, st.p, "gemm_band");
-            {
-                TimedScope ts(ctx, "band_w", 8.0 * m * b * (zs + 5.0), 2.0 * m * b * b * 2.0);
-                if (m <= 540) {
-                    const size_t shm = 2 * (size_t)(m | 1) * b * sizeof(double);
-                    lds_attr(ctx, (const void*)k_band_w<true>, 150 * 1024);
-                    hipLaunchKernelGGL((k_band_w<true>), dim3(1), dim3(1024), shm, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
-                } else {
-                    hipLaunchKernelGGL((k_band_w<false>), dim3(1), dim3(1024), 0, ctx->stream, m, b, zs, (const double*)zpart->p, Vp.p, Vp.ld, Tp.p, Tp.ld, P1.p, P2.p, P1.ld, st.p);
-                }
-            }
             }
             gemm(ctx, false, true, -1.0, P1, P2, 1.0, S22, st.p, "gemm_band", fused_rem ? part.p + 1 : nullptr);    // S22 -= [W V] [V W]'
             if (fused_rem) nparts = 1 + gemm_num_tiles(m, m);
@@ -4066,7 +3977,7 @@ __global__ __launch_bounds__(256) void k_chol_inv(int b, const double* __restric
     __syncthreads();
     if (tid == 0) { double m = 0.0; for (int i = 0; i < b; ++i) m = fmax(m, A[i][i]); dmax_s = m; if (mode == 0 || mode == 3) *ref = m; }
     __syncthreads();
-    // mode 3 (warm-started range finder, engine.hip warm_compress): the block is what a known basis left of a sketch — numerically rank deficient by
+    // mode 3 (warm-started range finder, ldlt.hip warm_compress): the block is what a known basis left of a sketch — numerically rank deficient by
     // design; a column whose pivot falls 14 orders below the block's scale is DEPENDENT (replaced by a random direction by the caller), not a breakdown
     const double floor_abs = mode == 2 ? 1e-20 : (mode == 3 ? 1e-14 * dmax_s : relfloor * (mode == 0 ? dmax_s : *ref));
     // breakdown: judged where it shows.  First pass (modes 0, 1): only a pivot that is all rounding (<= 1e-15 of the block's scale; the Gram
@@ -4134,7 +4045,7 @@ void chol_inv(Ctx* ctx, const Mat& G, Mat& Rinv, int* flag_dev, double* ref_dev,
     hipLaunchKernelGGL(k_chol_inv, dim3(1), dim3(256), shm, ctx->stream, G.rows, (const double*)G.p, G.ld, Rinv.p, Rinv.ld, flag_dev, ref_dev, mode, nullmask_dev, relfloor, dbg_dev);
     DRE_HIP(hipGetLastError());
 }
-// Structured sparse sign test matrix Om (n x s) for the range finder of engine.hip sketch_compress: row i has SKETCH_ZETA entries
+// Structured sparse sign test matrix Om (n x s) for the range finder of ldlt.hip sketch_compress: row i has SKETCH_ZETA entries
 // +-1/sqrt(SKETCH_ZETA), in the columns (i + off_t) mod s with independent pseudo-random signs (one byte of sign bits per row, k_sign_bits).
 // W(0:s, j) = Om' L(:, j): one workgroup per column of L, thread h owns the rows i = h (mod s) — coalesced reads of the column, ZETA private
 // accumulators, which are the buckets (h + off_t) mod s; they meet through LDS in a fixed order (deterministic, no atomics).  One pass over
@@ -4313,10 +4224,6 @@ __global__ void k_lr_extract_band(int J, const double* __restrict__ BS, double* 
 // coordinates so that the leading 16 columns of L — the dominant directions of a previously compressed summand — span the first 16
 // unit vectors,  L <- Q0' L  with Q0 = I - VT0 V0' from the QR of L[:, 0:16].  Without it the reduction starts from arbitrary unit
 // vectors and needs about one panel (16 columns of rank) more to reach the same remainder; the QR path gets this order for free.
-bool lead_rotation_enabled() {
-    static const bool on = true;
-    return on;
-}
 void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0) {
     const int n = L.rows, c = L.cols, b = QR_NB;
     DRE_REQUIRE(c >= b && n >= 2 * b, "lead_rotate: at least 16 columns and 32 rows");
@@ -4369,7 +4276,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
     }
     Mat RB(ctx, 32, c), RD(ctx, 32, c), PP(ctx, n, 32), BS(ctx, 32, cap), Yx(ctx, 16, c + 16);
     DevArr<double> parts(ctx, LR_PARTS);
-    if (lead_rotation_enabled() && c >= 32) lead_rotate(ctx, Lw, out.V0, out.VT0);
+    if (c >= 32) lead_rotate(ctx, Lw, out.V0, out.VT0);
     {
         Mat G = Lx.colsview(c, 16);
         const size_t tot = (size_t)n * 16;

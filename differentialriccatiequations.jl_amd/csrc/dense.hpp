@@ -269,7 +269,6 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol = -1.0, 
 Mat sym_band_basis(Ctx* ctx, const SymBand& b);     // q x J, the first J columns of Qb
 // The same reduction for S = L blockdiag(alpha_b D_b) L' given in factor form (L: n x c, overwritten), c + 64 <= n:
 // neither S nor a QR of L is formed; the termination norm is a 16-probe randomized estimate (dense.hip).
-bool lead_rotation_enabled();
 void lead_rotate(Ctx* ctx, Mat& L, Mat& V0, Mat& VT0);                        // L <- Q0' L,  Q0 = I - VT0 V0' from QR(L[:, 0:16])
 void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B);      // B <- Q0 B
 struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };

@@ -71,7 +71,7 @@ struct FactorCache {
     bool enabled = true;
     std::vector<std::tuple<uint64_t, double, double>> fresh;   // keys created by the running Lyapunov solve (evicted unless the shift list persists)
     int iters_hint = 0;        // ADI iterations of the previous Lyapunov solve served by this cache (speculation depth of the next one)
-    int warm_sx = 0, warm_strikes = 0;   // warm-started residual compression (engine.hip, warm_compress): fresh directions per step, consecutive rejections
+    int warm_sx = 0, warm_strikes = 0;   // warm-started residual compression (ldlt.hip, warm_compress): fresh directions per step, consecutive rejections
     void clear() { real.clear(); cplx_.clear(); }
 };
 struct GaleOperator {
@@ -118,7 +118,7 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
     int rhs_lead_blocks = -1;        // internal (Ros1 driver): the right-hand side is  C = (first rhs_lead_blocks blocks) + rhs_e_coeff * E'XE
     double rhs_e_coeff = 0.0;        //   with X the warm start, so the residual folds the last term into F: (F + coeff/2 E)' X E + E' X (F + coeff/2 E)
-    // internal (Ros1 driver with the residual recurrence, engine.hip ros1_recurrence_loop): the warm-start residual arrives as a block list
+    // internal (Ros1 driver with the residual recurrence, gdre.hip ros1_recurrence_loop): the warm-start residual arrives as a block list
     // (no right-hand side, no initial guess: the solve returns the INCREMENT), the tolerance reltol * ||C||_F arrives later in device memory
     // (the side stream forms it from the compressed X) and the convergence decisions of the first chunk are taken when it is there
     std::shared_ptr<struct LDLt> given_residual;

@@ -1,0 +1,1678 @@
+#include <chrono>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <exception>
+// Device-resident low-rank Rosenbrock/ADI engine (see engine.hpp).
+#include "engine.hpp"
+#include "comm.hpp"
+#include <functional>
+
+#include <algorithm>
+#include <numeric>
+
+#include "hostla.hpp"
+#include "profiling.hpp"
+
+#include "engine_internal.hpp"
+
+namespace dre {
+
+// =============================================================================================
+// Rosenbrock drivers
+// =============================================================================================
+struct Feedback { Mat L, D, BtLD, EtL, Kt; double alpha; bool diag; };
+
+static Feedback feedback(Ctx* ctx, const GdreProblem& prob, LDLt& X, double ctf, bool cex) {
+    // alpha, L, D = X;  BtLD = (B'L) D [*alpha];  K = BtLD (L'E)     (lowrank_ros1.jl:25-28,53-56)
+    const Pencil& P = *prob.P;
+    ldlt_destructure(ctx, X, ctf, cex);
+    const LBlock& b = X.blocks[0];
+    Feedback f;
+    f.L = b.L; f.D = b.D; f.alpha = b.alpha; f.diag = b.diag;
+    const int r = b.L.cols, m = prob.B.cols;
+    Mat BtL(ctx, m, r);
+    gemm(ctx, true, false, 1.0, prob.B, b.L, 0.0, BtL);
+    f.BtLD = Mat(ctx, m, r);
+    gemm(ctx, false, false, b.alpha, BtL, b.D, 0.0, f.BtLD);
+    f.EtL = Mat(ctx, P.n, r);
+    spmm(ctx, P, P.valEt.p, b.L, f.EtL, 1.0, 0.0);
+    f.Kt = Mat(ctx, P.n, m);
+    if (r > 0) gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
+    else fill_mat(ctx, f.Kt, 0.0);
+    return f;
+}
+
+// The same for a block list X = sum_b alpha_b L_b D_b L_b' that is NOT compressed first (small n, Ros1 between two compressions of X):
+// L = [L_1 ... L_p] concatenated, BtLD = (B'L) blockdiag(alpha_b D_b), K' = (E'L) BtLD'.
+static Feedback feedback_blocks(Ctx* ctx, const GdreProblem& prob, const LDLt& X) {
+    const Pencil& P = *prob.P;
+    Feedback f;
+    const int c = X.rank(), m = prob.B.cols;
+    f.L = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    f.alpha = 1.0; f.diag = false;
+    Mat BtL(ctx, m, c);
+    gemm(ctx, true, false, 1.0, prob.B, f.L, 0.0, BtL);
+    f.BtLD = Mat(ctx, m, c);
+    mul_blockdiag(ctx, BtL, X, f.BtLD);
+    f.EtL = Mat(ctx, P.n, c);
+    spmm(ctx, P, P.valEt.p, f.L, f.EtL, 1.0, 0.0);
+    f.Kt = Mat(ctx, P.n, m);
+    gemm(ctx, false, true, 1.0, f.EtL, f.BtLD, 0.0, f.Kt);
+    return f;
+}
+
+// =============================================================================================
+// Ros1 with X carried as a dense symmetric n x n matrix between the time steps (small n).
+// At these sizes every compression already forms the n x n matrix L D L' (the factors have more columns than rows: warm start
+// + ~17 ADI increments of ~64 columns each), so the factored form buys nothing between two steps: the compression of X after
+// every Lyapunov solve (adi.jl:78-80) — a strictly sequential chain of ~9 Householder panels per step that bounded the whole time
+// loop — disappears, and the warm-start residual of the step's Lyapunov equation (lyapunov/residual.jl:3-31 applied to
+// lowrank_ros1.jl:39-47) collapses to the Riccati residual
+//     Res = C'C + K'K + E'XE/tau + F'XE + E'XF = C'C - K'K + A'XE + (A'XE)'          (F = A - E/(2 tau) - B K,  K = B'XE),
+// three SpMMs and one fused assembly kernel.  The ADI iteration itself is unchanged (low-rank residual factor, low-rank increments,
+// adi.jl:97-179); X_i = X_{i-1} + sum_j (-2 mu_j) V_j T V_j' is one GEMM.  The LDL' form of X is produced once at the end (and by
+// the generic path whenever save_state asks for every X(t)).
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_dense_residual(int n, int q, int m, const double* __restrict__ Ct, int ldc, const double* __restrict__ Kt, int ldk,
+                                                        const double* __restrict__ M, int ldm, const double* __restrict__ EY, int ldey, double inv_tau,
+                                                        double* __restrict__ Res, int ldres, double* __restrict__ part) {
+    __shared__ double red[17];
+    const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+    double s = 0.0, s2 = 0.0;
+    if (i < n && j < n) {
+        double cc = 0.0, kk = 0.0;
+        for (int l = 0; l < q; ++l) cc += Ct[i + (size_t)l * ldc] * Ct[j + (size_t)l * ldc];
+        for (int l = 0; l < m; ++l) kk += Kt[i + (size_t)l * ldk] * Kt[j + (size_t)l * ldk];
+        const double mm = M[i + (size_t)j * ldm] + M[j + (size_t)i * ldm];
+        const double ey = 0.5 * (EY[i + (size_t)j * ldey] + EY[j + (size_t)i * ldey]);
+        const double res = (cc - kk) + mm;
+        Res[i + (size_t)j * ldres] = res;
+        const double rhs = (cc + kk) + inv_tau * ey;              // right-hand side of the step's Lyapunov equation (lowrank_ros1.jl:42-43)
+        s = rhs * rhs;
+        s2 = res * res;
+    }
+    // block_sum (dense.hip) is not visible here: fixed-order reduction through LDS
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    s = wave_sum_d(s);
+    s2 = wave_sum_d(s2);
+    if (lane == 0) { red[wave] = s; red[4 + wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t slot = blockIdx.x + (size_t)gridDim.x * blockIdx.y, ntot = (size_t)gridDim.x * gridDim.y;
+        part[slot] = (red[0] + red[1]) + (red[2] + red[3]);
+        part[ntot + slot] = (red[4] + red[5]) + (red[6] + red[7]);      // ||Res||_F^2: the first termination norm of the band reduction
+    }
+}
+// control block of the Lyapunov solve: residual = R D R' with orthonormal R, so its norm is ||D||_F
+// Workgroup 0: control block of the Lyapunov solve.  Workgroups 1..: the initial residual R (n x J) in the B-operand lane order of the fast
+// chain (dense.hpp, AdiFastArgs::Rpc; four 64-entry blocks per workgroup) — rides on this launch instead of a launch of its own.
+__global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st,
+                                                        double* __restrict__ nws, int nws_n, int n, int ct, int nblk, const double* __restrict__ R, int ldr,
+                                                        double* __restrict__ Rp) {
+    if (blockIdx.x > 0) {
+        const int blk = (blockIdx.x - 1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (blk >= nblk) return;
+        const int t = blk / ct, j = blk - t * ct;
+        const int row = 4 * t + (lane >> 4), col = 16 * j + (lane & 15);
+        Rp[(size_t)blk * 64 + lane] = (row < n && col < J) ? R[row + (size_t)col * ldr] : 0.0;
+        return;
+    }
+    __shared__ double red[4];
+    for (int i = threadIdx.x; i < nws_n; i += 256) nws[i] = 0.0;        // meeting point of the fast chain's norm workgroups (was a memset of its own)
+    double s = 0.0;
+    for (int id = threadIdx.x; id < J * J; id += 256) { const double x = D[id % J + (size_t)(id / J) * ldd]; s += x * x; }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        st->iters = 0; st->maxiters = maxiters; st->smw_singular = 0;
+        st->abstol = tols[0]; st->res_norm = nrm; st->norms[0] = nrm;
+        st->done = (nrm <= tols[0]) ? 1 : 0;
+    }
+}
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+// 16-row strip of  W = Apk X  (X: n x ncols <= 32, column-major), K split over the four waves; returns this thread's element (row lk + 4 wave,
+// column 16 j + lr) of both column tiles in v0 / v1
+__device__ __forceinline__ void group_thin_tile(const double* __restrict__ Apk_strip, const double* __restrict__ X, int ldx, int n, int ncols,
+                                                double (*part)[2][4][64], double& v0, double& v1) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int kst = (n + 3) >> 2, per = (kst + 3) >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int t0 = wv * per, t1 = min(kst, t0 + per);
+    const bool c0ok = lr < ncols, c1ok = 16 + lr < ncols;
+    const double* __restrict__ ap = Apk_strip + lane;
+    const double* __restrict__ x0 = X + (size_t)(c0ok ? lr : 0) * ldx;
+    const double* __restrict__ x1 = X + (size_t)(c1ok ? 16 + lr : 0) * ldx;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], b0[24], b1[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int t = min(tb + u, t1 - 1);
+            const int c = min(4 * t + lk, n - 1);
+            av[u] = ap[(size_t)t * 64]; b0[u] = x0[c]; b1[u] = x1[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < n;
+            const double a = kok ? av[u] : 0.0;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kok && c0ok) ? b0[u] : 0.0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (kok && c1ok) ? b1[u] : 0.0, acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[wave][0][r][lane] = acc0[r]; part[wave][1][r][lane] = acc1[r]; }
+    __syncthreads();
+    v0 = ((part[0][0][wave][lane] + part[1][0][wave][lane]) + part[2][0][wave][lane]) + part[3][0][wave][lane];
+    v1 = ((part[0][1][wave][lane] + part[1][1][wave][lane]) + part[2][1][wave][lane]) + part[3][1][wave][lane];
+}
+// W_s = stack_s X for every shift s of the cycle in one launch (X: n x ncols <= 32, the same for all): the SMW products N K', E'N K', B'N K'
+struct StackThinBatch { const double* Apk[16]; double* W[16]; };
+__global__ __launch_bounds__(256) void k_stack_thin(int M, int n, int ncols, const double* __restrict__ X, int ldx, int ldw, StackThinBatch bt) {
+    __shared__ double part[4][2][4][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int kst = (n + 3) >> 2;
+    double v0, v1;
+    group_thin_tile(bt.Apk[blockIdx.y] + (size_t)blockIdx.x * kst * 64, X, ldx, n, ncols, part, v0, v1);
+    const int orow = blockIdx.x * 16 + lk + 4 * wave;
+    if (orow >= M) return;
+    double* __restrict__ W = bt.W[blockIdx.y];
+    if (lr < ncols) W[orow + (size_t)lr * ldw] = v0;
+    if (16 + lr < ncols) W[orow + (size_t)(16 + lr) * ldw] = v1;
+}
+// SMW products of every shift of a real Cyclic list for the low-rank factor (U, Vt) of `op`, and the SMW-folded packed stacks of the
+// fast chain (dense.hip).  Factors, dense inverses and stacked inverses come from the cache (built on first use).  false: some shift
+// cannot take the dense-inverse path (complex, or its inverse was rejected by the condition estimate).
+struct CycleOps {
+    std::vector<const double*> wks_pos; // per position of the cycle: [N K' Sinv; E'N K' Sinv] (2n x m, leading dimension 2n) of its shift, or null (no low-rank part)
+    std::vector<const double*> gpack;   // group chain: packed group stack per start position (index = start / g), empty = not available
+    int group_g = 0;
+    bool single_built = true;           // the single-iteration packed stacks (k_adi_fast) exist; false: build_single makes them on demand
+    std::function<void(Ctx*)> build_single;
+    std::vector<double*> pack;          // per position of the cycle
+    std::vector<std::shared_ptr<FactorEntry<double>>> fe;
+    std::vector<Mat> keep;
+    std::vector<BufP> keepb;
+    DevArr<int> serr;
+    DevArr<long long> serr8;      // the breakdown flag as an 8-byte word (read back together with the control block)
+};
+static void ensure_stack(Ctx* ctx, const GaleOperator& op, FactorEntry<double>& fe) {
+    const Pencil& P = *op.P;
+    const int n = P.n, mm = op.has_lr ? op.U.cols : 0;
+    if (!fe.stack.empty() && fe.stack_m == mm && (!mm || fe.stack_U == (const void*)op.U.p)) return;
+    Mat stk(ctx, 2 * n + mm, n);
+    { Mat top = stk.view(0, 0, n, n); copy_mat(ctx, fe.dinv, top); }
+    { Mat mid = stk.view(n, 0, n, n); spmm(ctx, P, P.valEt.p, fe.dinv, mid, 1.0, 0.0, nullptr); }
+    if (mm) { Mat bot = stk.view(2 * n, 0, mm, n); gemm(ctx, true, false, 1.0, op.U, fe.dinv, 0.0, bot, nullptr, "gemm_dinv"); }
+    fe.stack = stk; fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
+}
+// Acceptance norms of the batched set-up below, as partial sums the host adds up: out[17 z] = ||F + mu_z E||_F^2 (value arrays),
+// out[17 z + 1 .. 17 z + 16] = sums of squares of sixteen column slabs of N_z (n x n, leading dimension ldw)
+struct SetupNormZ { double mu[MF_ZMAX]; };
+__global__ __launch_bounds__(256) void k_setup_norms_z(int nnz, const double* __restrict__ valF, const double* __restrict__ valE, SetupNormZ mz, int n,
+                                                       const double* __restrict__ W, int ldw, long wz, double* __restrict__ out) {
+    const int z = blockIdx.x, part = blockIdx.y, tid = threadIdx.x;
+    double s = 0.0;
+    if (part == 0) {
+        const double mu = mz.mu[z];
+        for (int i = tid; i < nnz; i += 256) { const double v = valF[i] + mu * valE[i]; s += v * v; }
+    } else {
+        const double* __restrict__ Wz = W + (size_t)z * wz;
+        const int cw = (n + 15) / 16, c0 = (part - 1) * cw, c1 = min(n, c0 + cw);
+        for (int c = c0; c < c1; ++c)
+            for (int r = tid; r < n; r += 256) { const double v = Wz[r + (size_t)c * ldw]; s += v * v; }
+    }
+    __shared__ double sh[4];
+    s = wave_sum_d(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) out[17 * z + part] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// Set-up of a whole real Cyclic list on the dense-inverse path (n <= dense_inv_max_n) in SHARED launches: every missing factorisation
+// (mf_factor_batch: one launch per tree level for all shifts), the explicit inverses N_z = M_z^-1 through one batched solve with the identity
+// as common right-hand side (mf_solve_batch), the stacked inverses [N_z; E'N_z; U'N_z] of all shifts as ONE matrix (one SpMM, one GEMM) and
+// the acceptance norms — ~25 launches instead of ~30 per shift on helper streams (1.6 of the 2.2 ms of the first time step at n = 371).
+// Fills the factor cache; shifts it cannot take (already cached, more than MF_ZMAX, sweeps without the matrix cores) go through get_factor.
+static void cycle_setup_batched(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache) {
+    const Pencil& P = *op.P;
+    const int n = P.n, mm = op.has_lr ? op.U.cols : 0;
+    if (!cache->enabled || !P.use_mfma_sweeps || n > ctx->dense_inv_max_n || ctx->setup_batched <= 0) return;
+    std::vector<double> todo;
+    for (auto& mu : values) {
+        bool dup = cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) > 0;
+        for (double t : todo) dup = dup || t == mu.real();
+        if (!dup && (int)todo.size() < MF_ZMAX) todo.push_back(mu.real());
+    }
+    const int g = (int)todo.size();
+    if (g < 2) return;
+    std::vector<std::shared_ptr<FactorEntry<double>>> fes;
+    std::vector<Factor<double>*> fp;
+    std::vector<const Factor<double>*> cf;
+    for (int z = 0; z < g; ++z) { fes.push_back(std::make_shared<FactorEntry<double>>()); fp.push_back(&fes.back()->f); cf.push_back(&fes.back()->f); }
+    mf_factor_batch<double>(ctx, P, op.valFt.p, P.valEt.p, 1.0, todo.data(), fp.data(), g);
+    Mat STK(ctx, 2 * n + mm, n * g), Id(ctx, n, n);
+    set_identity(ctx, Id, 1.0);
+    if (!mf_solve_batch(ctx, P, cf.data(), g, Id.p, Id.ld, n, STK.p, STK.ld, n)) return;       // (the factors are dropped: get_factor redoes them one by one)
+    DevArr<double> nr(ctx, (size_t)17 * g);
+    SetupNormZ mz; std::memset(&mz, 0, sizeof(mz));
+    for (int z = 0; z < g; ++z) mz.mu[z] = todo[(size_t)z];
+    hipLaunchKernelGGL(k_setup_norms_z, dim3((unsigned)g, 17), dim3(256), 0, ctx->stream, P.nnz, (const double*)op.valFt.p, (const double*)P.valEt.p, mz, n,
+                       (const double*)STK.p, STK.ld, (long)n * STK.ld, nr.p);
+    {
+        Mat top = STK.view(0, 0, n, n * g), mid = STK.view(n, 0, n, n * g);
+        spmm(ctx, P, P.valEt.p, top, mid, 1.0, 0.0, nullptr);
+        if (mm) { Mat bot = STK.view(2 * n, 0, mm, n * g); gemm(ctx, true, false, 1.0, op.U, top, 0.0, bot, nullptr, "gemm_dinv"); }
+    }
+    std::vector<double> hp((size_t)17 * g), h((size_t)2 * g, 0.0);
+    ctx_fetch(ctx, nr.p, hp.size() * sizeof(double), hp.data());
+    for (int z = 0; z < g; ++z) { h[2 * z] = hp[17 * z]; for (int i = 1; i <= 16; ++i) h[2 * z + 1] += hp[17 * z + i]; }
+    const std::vector<double> gr = mf_check_batch(ctx, cf);
+    for (int z = 0; z < g; ++z) {
+        auto& fe = *fes[(size_t)z];
+        fe.growth = gr[(size_t)z]; fe.checked = true;
+        fe.f.allow_topinv = true;
+        const double cond_est = std::sqrt(h[2 * z]) * std::sqrt(h[2 * z + 1]);
+        if (cond_est == cond_est && cond_est < 1e7 && fe.f.nperturbed <= 0) {
+            fe.stack = STK.view(0, z * n, 2 * n + mm, n); fe.stack_U = (const void*)op.U.p; fe.stack_m = mm;
+            fe.dinv = STK.view(0, z * n, n, n); fe.dense = true;
+        }
+        const auto key = std::make_tuple(op.tag, todo[(size_t)z], 0.0);
+        cache->real[key] = fes[(size_t)z]; cache->fresh.push_back(key); cache->nfactor++;
+    }
+}
+static bool cycle_ops_prepare(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, FactorCache* cache, CycleOps& co,
+                              std::vector<Mat>* wks_store = nullptr /* persistent 2n x m buffers per position of the cycle (group chain) */,
+                              const std::vector<Mat>* spack = nullptr /* packed stacks per position (group chain): thin products without k_gemm */,
+                              bool defer_single = false /* the single-iteration packs are only needed by a fallback chunk: build on demand */) {
+    const Pencil& P = *op.P;
+    const int n = P.n, m = op.has_lr ? op.U.cols : 0;
+    if (m > 32) return false;
+    std::map<double, double*> by_mu;
+    std::map<double, const double*> wks_by_mu;
+    std::vector<GemmBatchDesc> descs;
+    std::vector<SmwBatch> hb;
+    std::vector<const double*> stacks, wks; std::vector<double*> outs;
+    for (auto& mu : values) if (mu.imag() != 0.0) return false;
+    cycle_setup_batched(ctx, op, values, cache);
+    {
+        // Every factorisation and dense inverse of the cycle is enqueued before the single read-back of the acceptance norms.  Each of
+        // them is a chain of ~25 small kernels (assembly, one factorisation launch per tree level, n unit right-hand sides, norms) that
+        // uses a few CUs: the chains of different shifts go to different helper streams and run side by side.
+        DeferredDense dd;
+        dd.cap = std::min<int>((int)values.size(), 256);
+        dd.norms = DevArr<double>(ctx, (size_t)2 * dd.cap);
+        int todo = 0;
+        for (auto& mu : values) if (!cache->enabled || !cache->real.count(std::make_tuple(op.tag, mu.real(), mu.imag()))) ++todo;
+        const int nh = (cache->enabled && todo > 1) ? std::min(todo, std::max(0, ctx->setup_streams)) : 0;
+        if (nh > 1) {
+            while ((int)ctx->helpers.size() < nh) {
+                auto hc = std::make_unique<Ctx>();
+                hc->device = ctx->device; hc->num_cus = ctx->num_cus;
+                hc->stream = create_stream(2);
+                hc->timer = std::make_unique<KernelTimer>();
+                hipEvent_t ev;
+                DRE_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                ctx->helpers.push_back(std::move(hc)); ctx->helper_ev.push_back(ev);
+            }
+            if (!ctx->helper_e0) DRE_HIP(hipEventCreateWithFlags(&ctx->helper_e0, hipEventDisableTiming));
+            DRE_HIP(hipEventRecord(ctx->helper_e0, ctx->stream));         // the operator's value arrays are ready here
+            for (int h = 0; h < nh; ++h) {
+                Ctx* hc = ctx->helpers[(size_t)h].get();
+                hc->dense_inv_max_n = ctx->dense_inv_max_n; hc->top_inverse_max_rows = ctx->top_inverse_max_rows; hc->mf_subtree = ctx->mf_subtree;
+                hc->pivot_growth_warn = ctx->pivot_growth_warn; hc->pivot_growth_fail = ctx->pivot_growth_fail;
+                hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+                DRE_HIP(hipStreamWaitEvent(hc->stream, ctx->helper_e0, 0));
+            }
+            int j = 0;
+            for (auto& mu : values) {
+                if (cache->real.count(std::make_tuple(op.tag, mu.real(), mu.imag()))) continue;
+                (void)get_factor<double>(ctx->helpers[(size_t)(j % nh)].get(), op, cache, cache->real, mu, true, &dd);
+                ++j;
+            }
+            for (int h = 0; h < nh; ++h) {
+                DRE_HIP(hipEventRecord(ctx->helper_ev[(size_t)h], ctx->helpers[(size_t)h]->stream));
+                DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->helper_ev[(size_t)h], 0));
+            }
+        } else {
+            for (auto& mu : values) (void)get_factor<double>(ctx, op, cache, cache->real, mu, true, &dd);
+        }
+        finalize_dense(ctx, dd);
+    }
+    size_t pos_idx = 0;
+    for (auto& mu : values) {
+        const size_t pos = pos_idx++;
+        auto fe = get_factor<double>(ctx, op, cache, cache->real, mu, true);
+        if (!fe->dense) return false;
+        ensure_stack(ctx, op, *fe);
+        co.fe.push_back(fe);
+        auto bm = by_mu.find(mu.real());
+        if (bm == by_mu.end()) {
+            Mat pk(ctx, (int)(adi_fast_pack_doubles(n) / 64), 64);
+            co.keep.push_back(pk);
+            const double* wksp = nullptr;
+            if (m) {
+                Mat WK(ctx, 2 * n + m, m);
+                Mat WKS = (wks_store && pos < wks_store->size()) ? (*wks_store)[pos] : Mat(ctx, 2 * n, m);
+                auto sinv = std::make_shared<Buf>(ctx, (size_t)m * m * sizeof(double));
+                co.keep.push_back(WK); co.keep.push_back(WKS); co.keepb.push_back(sinv);
+                descs.push_back({fe->stack.p, op.Vt.p, WK.p, nullptr, 1.0, 2 * n + m, m, n, fe->stack.ld, op.Vt.ld, WK.ld, 0});
+                hb.push_back({WK.p, (double*)sinv->p, WKS.p});
+                wksp = WKS.p;
+            }
+            stacks.push_back(fe->stack.p); wks.push_back(wksp); outs.push_back(pk.p);
+            bm = by_mu.emplace(mu.real(), pk.p).first;
+            wks_by_mu[mu.real()] = wksp;
+        }
+        co.pack.push_back(bm->second);
+        co.wks_pos.push_back(wks_by_mu[mu.real()]);
+    }
+    if (m) {
+        co.serr8 = DevArr<long long>(ctx, 1);
+        co.serr = DevArr<int>();
+        co.serr.buf = co.serr8.buf; co.serr.p = (int*)co.serr8.p; co.serr.n = 2;     // the kernels write the low word
+        DRE_HIP(hipMemsetAsync(co.serr8.p, 0, sizeof(long long), ctx->stream));
+        if (spack && spack->size() == values.size() && m <= 32 && descs.size() <= 16 && descs.size() == values.size()) {
+            // WK_s = stack_s K' for every shift in one launch on the packed stacks (the general batched GEMM spends 31 us on these 749 x 371 x 7 products)
+            StackThinBatch tb;
+            for (size_t i = 0; i < 16; ++i) { const size_t j = i < descs.size() ? i : 0; tb.Apk[i] = (*spack)[j].p; tb.W[i] = descs[j].C; }
+            TimedScope ts(ctx, "gemm_dinv", 8.0 * descs.size() * (2.0 * n + m) * n, 2.0 * descs.size() * (2.0 * n + m) * n * (double)m);
+            hipLaunchKernelGGL(k_stack_thin, dim3(ceil_div(2 * n + m, 16), (unsigned)descs.size()), dim3(256), 0, ctx->stream, 2 * n + m, n, m, (const double*)op.Vt.p,
+                               op.Vt.ld, 2 * n + m, tb);
+        } else gemm_batched(ctx, descs, "gemm_dinv");
+        smw_sinv_fold_batched(ctx, n, m, op.alpha, hb.data(), (int)hb.size(), co.serr.p);
+    }
+    if (defer_single) {
+        co.single_built = false;
+        co.build_single = [n, m, stacks, wks, outs](Ctx* c) { adi_fast_build(c, n, m, stacks, 2 * n + m, wks, 2 * n, outs); };
+    } else adi_fast_build(ctx, n, m, stacks, 2 * n + m, wks, 2 * n, outs);
+    return true;
+}
+
+// ---- group chain (dense.hip, k_adi_group): operator products of g consecutive ADI iterations --------------------------------------
+// With N_s = (A' + (mu_s - 1/(2 tau)) E')^-1 (K independent, kept per shift as stack_s = [N_s; E'N_s; B'N_s]) the shifted operator of a time
+// step is a rank-m correction (Sherman-Morrison-Woodbury, smw.jl:20-43):  A_s = N_s + a_s b_s',  P_s = I - 2 mu_s E'A_s = P0_s + c_s b_s'
+// with a_s = -(N_s K' Sinv_s), c_s = 2 mu_s (E'N_s K' Sinv_s), b_s' = B'N_s.  For the g shifts s_0 .. s_{g-1} of a group (index i for s_i):
+//   Pi_i = P_{i-1} ... P_0 = Pi0_i + X_i Y_i',      Om_i = A_i Pi_i = Om0_i + [N_i X_i, a_i] Y_{i+1}',
+//   X_i  block j (j < i)  = Phi(j+1, i) c_j,        Phi(a, b) = P0_{b-1} ... P0_a   (K independent; Pi0_i = Phi(0, i), Om0_i = N_i Phi(0, i)),
+//   Y_{i+1} = [Y_i, y_i],  y_i = Pi_i' b_i = D_i' + sum_{j<i} y_j M(j, i),   D_i = b_i' Phi(0, i),   M(j, i) = c_j' Psi(j, i),   Psi(j, i) = Phi(j+1, i)' b_i.
+// Everything K independent (Phi, N Phi, Psi, D: GroupBase) is formed ONCE per run — one stacked product stack_b Phi(a, b) delivers
+// N_b Phi(a, b), the next Phi(a, b+1) and Psi(a-1, b)' at once — and a time step costs three launches on the side stream: the left-factor
+// blocks (independent thin products, no recursion), the rows of Y, and the fold + packing of the effective group stack.
+struct GroupLeftDesc { const double* Mtx; int ldm; const double* v; int ldv; double* out; int ldo; double scale; int kind; int pad; };   // kind 0: out = scale Mtx v (null Mtx: copy), 1: M = scale v' PsiT'
+struct GroupBase {
+    int g = 0, n = 0, m = 0;
+    uint64_t tag = 0;
+    std::vector<double> mus;            // the cycle this base was built for
+    std::vector<int> starts;            // start positions (multiples of g)
+    std::vector<Mat> G0;                // per start: (2 g n) x n  rows [i n, (i+1) n) = Om0_i, rows [(g + i) n, ...) = Pi0_{i+1}
+    std::vector<Mat> D;                 // per start: (g m) x n    rows [i m, (i+1) m) = D_i
+    std::vector<Mat> spack;             // per position of the cycle: stack_s = [N_s; E'N_s; B'N_s] in the MFMA A-operand order
+    std::vector<Mat> wks;               // persistent [N K' Sinv; E'N K' Sinv] per position of the cycle (2n x m): the descriptors point into them
+    std::vector<Mat> XL, Yt, Mb;        // per start: left factors (2 g n) x (m g), Y' (m g) x n, the M(j, i) blocks (m x m each, g*g slots)
+    std::vector<Mat> pack;              // packed effective group stacks
+    DevArr<GroupLeftDesc> table;        // descriptors of the left-factor launch (built once per run)
+    std::vector<GroupLeftDesc> host_table;
+    int ndesc = 0;
+};
+// out(16-row strip) = scale * Mtx(strip, :) v   (v: n x m, m <= 16), K split over the four waves;  kind 1: the m x m matrix scale * v' P' with P = Mtx (m x n)
+__global__ __launch_bounds__(256) void k_group_left(int n, int m, const GroupLeftDesc* __restrict__ table) {
+    __shared__ double part[4][4][64];
+    const GroupLeftDesc d = table[blockIdx.y];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    if (d.kind == 1) {
+        if (blockIdx.x > 0) return;
+        // M[u, v] = scale * sum_r vv[r, u] * PsiT[v, r]
+        for (int e = tid; e < m * m; e += 256) {
+            const int u = e % m, vv = e / m;
+            double sacc = 0.0;
+            for (int r = 0; r < n; ++r) sacc += d.v[r + (size_t)u * d.ldv] * d.Mtx[vv + (size_t)r * d.ldm];
+            d.out[u + (size_t)vv * d.ldo] = d.scale * sacc;
+        }
+        return;
+    }
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= n) return;
+    if (!d.Mtx) {
+        for (int e = tid; e < 16 * m; e += 256) {
+            const int r = row0 + (e & 15), c = e >> 4;
+            if (r < n) d.out[r + (size_t)c * d.ldo] = d.scale * d.v[r + (size_t)c * d.ldv];
+        }
+        return;
+    }
+    const int row = row0 + lr;
+    const bool rok = row < n, cok = lr < m;
+    const int kst = (n + 3) >> 2, per = (kst + 3) >> 2;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int t0 = wv * per, t1 = min(kst, t0 + per);
+    const double* __restrict__ ap = d.Mtx + (rok ? row : 0);
+    const double* __restrict__ xp = d.v + (size_t)(cok ? lr : 0) * d.ldv;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int tb = t0; tb < t1; tb += 24) {
+        double av[24], bv[24];
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const int c = min(4 * min(tb + u, t1 - 1) + lk, n - 1);
+            av[u] = ap[(size_t)c * d.ldm]; bv[u] = xp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+            const bool kok = (tb + u < t1) && 4 * (tb + u) + lk < n;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64((kok && rok) ? av[u] : 0.0, (kok && cok) ? bv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][r][lane] = acc[r];
+    __syncthreads();
+    const double vsum = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
+    const int orow = row0 + lk + 4 * wave;
+    if (orow < n && lr < m) d.out[orow + (size_t)lr * d.ldo] = d.scale * vsum;
+}
+// rows of Y' = [y_0 .. y_{g-1}]':  y_i = D_i' + sum_{j<i} y_j M(j, i).  One thread per (row, component v); the g levels are sequential, the
+// row's earlier y_j go through LDS (32 rows per workgroup, 8 component slots per row).
+struct GroupYOne { const double* D; const double* Mb; double* Yt; };
+struct GroupYBatch { GroupYOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_y(int n, int m, int g, int ldd, GroupYBatch bt) {
+    __shared__ double ysh[32][ADI_GROUP_MAX_G][8];
+    __shared__ double msh[ADI_GROUP_MAX_G * ADI_GROUP_MAX_G][8][8];
+    const GroupYOne& o = bt.s[blockIdx.y];
+    const int rl = threadIdx.x >> 3, v = threadIdx.x & 7;
+    const int rr = blockIdx.x * 32 + rl;
+    const int r = m * g;
+    for (int e = threadIdx.x; e < g * g * 64; e += 256) {
+        const int ji = e >> 6, u = (e >> 3) & 7, vv = e & 7;
+        msh[ji][u][vv] = (u < m && vv < m) ? o.Mb[(size_t)ji * m * m + u + (size_t)vv * m] : 0.0;
+    }
+    __syncthreads();
+    const bool ok = rr < n && v < m;
+    for (int i = 0; i < g; ++i) {
+        double acc = ok ? o.D[(size_t)i * m + v + (size_t)rr * ldd] : 0.0;
+        for (int j = 0; j < i; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += ysh[rl][j][u] * msh[j * g + i][u][v];
+        ysh[rl][i][v] = ok ? acc : 0.0;
+        if (ok) o.Yt[(size_t)i * m + v + (size_t)rr * r] = acc;
+        __syncthreads();
+    }
+}
+// Packed effective group stack in one pass:  out = pack(G0 + XL Yt).  The rank-r product of a 16 x 16 tile is computed TRANSPOSED, so that the
+// accumulator layout is the packed layout (acc[q] = K-step 4 tt + q, position lane) — the trick of k_eff_stack_mfma (dense.hip).
+struct GroupFoldOne { const double* G0; const double* XL; const double* Yt; double* out; };
+struct GroupFoldBatch { GroupFoldOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_fold(int n, int nblk, int nstrip, int kst, int r, int ldg, int ldx, GroupFoldBatch bt) {
+    const GroupFoldOne& o = bt.s[blockIdx.z];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
+    const int tt = blockIdx.x * 4 + wave;                          // column tile: K-steps 4 tt .. 4 tt + 3
+    const int ntile = (kst + 3) >> 2;
+    if (tt >= ntile) return;
+    const int hs = blockIdx.y, b = hs / nstrip, s = hs - b * nstrip;
+    const int rowl = 16 * s + lr;                                  // row within the block (B-operand column index j = lr)
+    const bool rok = rowl < n;
+    const size_t grow = (size_t)b * n + (rok ? rowl : 0);
+    const int colA = 16 * tt + lr;                                 // A operand: A[i = lr][k] = Yt[k, 16 tt + lr]
+    const bool cok = colA < n;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int ksteps = (r + 3) >> 2;
+    for (int kk = 0; kk < ksteps; ++kk) {
+        const int q = 4 * kk + lk;
+        const bool qok = q < r;
+        const double ya = (qok && cok) ? o.Yt[q + (size_t)colA * r] : 0.0;
+        const double xb = (qok && rok) ? o.XL[grow + (size_t)q * ldx] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, xb, acc, 0, 0, 0);
+    }
+    // acc[q] = (XL Yt)[row = rowl, col = 16 tt + 4 q + lk]   (transposed tile: D'[i = lk + 4 q][j = lr])
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int t = 4 * tt + q, col = 4 * t + lk;
+        if (t < kst) {
+            const double base = (rok && col < n) ? o.G0[grow + (size_t)col * ldg] : 0.0;
+            o.out[((size_t)hs * kst + t) * 64 + lane] = (rok && col < n) ? base + acc[q] : 0.0;
+        }
+    }
+}
+// next = prev - two_mu * W_mid  (n x n);  prev = null: identity
+__global__ __launch_bounds__(256) void k_group_next_phi(int n, double two_mu, const double* __restrict__ prev, int ldp, const double* __restrict__ Wmid, int ldw,
+                                                       double* __restrict__ next, int ldn) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n * n) return;
+    const int r = idx % n, c = idx / n;
+    const double p = prev ? prev[r + (size_t)c * ldp] : (r == c ? 1.0 : 0.0);
+    next[r + (size_t)c * ldn] = p - two_mu * Wmid[r + (size_t)c * ldw];
+}
+static int group_size_for(Ctx* ctx, int ncycle, int n, int m) {
+    if (ctx->adi_group == 0 || n > ctx->adi_group_max_n || m < 1 || m > 8) return 0;
+    if (ctx->adi_group > 1) return (ncycle % ctx->adi_group == 0 && ctx->adi_group <= ADI_GROUP_MAX_G && m * (ctx->adi_group - 1) <= 32) ? ctx->adi_group : 0;
+    for (int g = std::min(5, ADI_GROUP_MAX_G); g >= 2; --g) if (ncycle % g == 0 && m * (g - 1) <= 32) return g;      // auto: the largest divisor of the cycle length up to 5
+    return 0;
+}
+// (2n + m) x n stack -> A-operand order: strip of 16 rows x K-step of 4 columns = 64 consecutive doubles (one coalesced 512-byte fragment load)
+__global__ __launch_bounds__(256) void k_pack_rows(int M, int n, int kst, const double* __restrict__ src, int lds_, double* __restrict__ out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= kst) return;
+    const int row = 16 * blockIdx.y + (lane & 15), col = 4 * t + (lane >> 4);
+    out[((size_t)blockIdx.y * kst + t) * 64 + lane] = (row < M && col < n) ? src[row + (size_t)col * lds_] : 0.0;
+}
+// Level i of the thin recursion, one launch for all start positions:  W = stack_{s_i} X_i  (X_i: n x m i, the left factor of Pi_i, in XL block
+// row g + i - 1), one workgroup per 16-row strip of the packed stack, K split over the four waves, two column tiles; the epilogue writes the
+// three row ranges of W where they are needed:  top -> XV_i (XL block row i),  mid -> X_{i+1} = X_i - 2 mu W_mid (XL block row g + i),
+// bottom (b_i' X_i, m x m i) -> the blocks M(j, i) of the Y recursion.
+struct GroupLevelOne { const double* Apk; double* XL; double* Mb; double two_mu; };
+struct GroupLevelBatch { GroupLevelOne s[8]; };
+__global__ __launch_bounds__(256) void k_group_level_gemm(int n, int m, int g, int i, int ldx, GroupLevelBatch bt) {
+    __shared__ double part[4][2][4][64];
+    const GroupLevelOne& o = bt.s[blockIdx.y];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    const int M = 2 * n + m, ncols = m * i, kst = (n + 3) >> 2;
+    const double* __restrict__ Xi = o.XL + (size_t)(g + i - 1) * n;
+    double vv2[2];
+    group_thin_tile(o.Apk + (size_t)blockIdx.x * kst * 64, Xi, ldx, n, ncols, part, vv2[0], vv2[1]);
+    const int orow = blockIdx.x * 16 + lk + 4 * wave;
+    if (orow >= M) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double v = vv2[j];
+        const int col = 16 * j + lr;
+        if (col >= ncols) continue;
+        if (orow < n) o.XL[(size_t)i * n + orow + (size_t)col * ldx] = v;                                            // XV_i
+        else if (orow < 2 * n) {
+            const int r = orow - n;
+            o.XL[(size_t)(g + i) * n + r + (size_t)col * ldx] = Xi[r + (size_t)col * ldx] - o.two_mu * v;           // X_{i+1}
+        } else {
+            const int vv = orow - 2 * n, jj = col / m, u = col - jj * m;
+            o.Mb[(size_t)(jj * g + i) * m * m + u + (size_t)vv * m] = v;                                               // M(jj, i)[u, vv]
+        }
+    }
+}
+// K-independent part, once per run (every shift of the cycle has its stacked inverse)
+static void group_base_build(Ctx* ctx, const GaleOperator& op, const std::vector<std::complex<double>>& values, const CycleOps& co, GroupBase& gb, int g) {
+    const int n = op.P->n, m = op.U.cols, c = (int)values.size();
+    gb = GroupBase();
+    gb.g = g; gb.n = n; gb.m = m; gb.tag = op.tag;
+    for (auto& v : values) gb.mus.push_back(v.real());
+    const int r = m * g, M = 2 * n + m, kst = adi_fast_kst(n), nstripM = ceil_div(M, 16);
+    std::vector<GroupLeftDesc> tab;
+    const unsigned nn_blocks = (unsigned)(((size_t)n * n + 255) / 256);
+    for (int pos = 0; pos < c; ++pos) {
+        gb.wks.push_back(Mat(ctx, 2 * n, m));
+        const FactorEntry<double>& fe = *co.fe[(size_t)pos];
+        Mat pk(ctx, nstripM * kst, 64);
+        hipLaunchKernelGGL(k_pack_rows, dim3(ceil_div(kst, 4), nstripM), dim3(256), 0, ctx->stream, M, n, kst, (const double*)fe.stack.p, fe.stack.ld, pk.p);
+        gb.spack.push_back(pk);
+    }
+    for (int p = 0; p < c; p += g) {
+        gb.starts.push_back(p);
+        Mat G0(ctx, 2 * g * n, n), D(ctx, g * m, n), XL(ctx, 2 * g * n, r), Yt(ctx, r, n), Mb(ctx, m * m, g * g);
+        fill_mat(ctx, XL, 0.0); fill_mat(ctx, Yt, 0.0); fill_mat(ctx, Mb, 0.0);
+        Mat W(ctx, M, n);
+        for (int b = 0; b < g; ++b) {       // Phi(0, b) = Pi0_b:  stack_b Pi0_b = [Om0_b; E'N_b Pi0_b; D_b],  Pi0_{b+1} = Pi0_b - 2 mu_b (mid)
+            const FactorEntry<double>& fe = *co.fe[(size_t)(p + b)];
+            const double two_mu = 2.0 * values[(size_t)(p + b)].real();
+            Mat top, mid, bot, prev;
+            if (b == 0) { top = fe.stack.view(0, 0, n, n); mid = fe.stack.view(n, 0, n, n); bot = fe.stack.view(2 * n, 0, m, n); }
+            else {
+                prev = G0.view((g + b - 1) * n, 0, n, n);
+                gemm(ctx, false, false, 1.0, fe.stack, prev, 0.0, W, nullptr, "gemm_group_base");
+                top = W.view(0, 0, n, n); mid = W.view(n, 0, n, n); bot = W.view(2 * n, 0, m, n);
+            }
+            Mat nxt = G0.view((g + b) * n, 0, n, n);
+            hipLaunchKernelGGL(k_group_next_phi, dim3(nn_blocks), dim3(256), 0, ctx->stream, n, two_mu, b == 0 ? (const double*)nullptr : (const double*)prev.p,
+                               b == 0 ? 0 : prev.ld, (const double*)mid.p, mid.ld, nxt.p, nxt.ld);
+            Mat om = G0.view(b * n, 0, n, n); copy_mat(ctx, top, om);
+            Mat dd = D.view(b * m, 0, m, n); copy_mat(ctx, bot, dd);
+        }
+        // the K-dependent blocks that are plain copies:  XV_i block i = a_i = -(N K' Sinv)_i,  X_{i+1} block i = c_i = 2 mu_i (E'N K' Sinv)_i
+        for (int i = 0; i < g; ++i) {
+            const Mat& w = gb.wks[(size_t)(p + i)];
+            tab.push_back({nullptr, 0, w.p, w.ld, XL.p + (size_t)i * n + (size_t)(i * m) * XL.ld, XL.ld, -1.0, 0, 0});
+            tab.push_back({nullptr, 0, w.p + n, w.ld, XL.p + (size_t)(g + i) * n + (size_t)(i * m) * XL.ld, XL.ld, 2.0 * values[(size_t)(p + i)].real(), 0, 0});
+        }
+        gb.G0.push_back(G0); gb.D.push_back(D); gb.XL.push_back(XL); gb.Yt.push_back(Yt); gb.Mb.push_back(Mb);
+        gb.pack.push_back(Mat(ctx, (int)((size_t)g * adi_fast_pack_doubles(n) / 64), 64));
+    }
+    gb.ndesc = (int)tab.size();
+    gb.table = DevArr<GroupLeftDesc>(ctx, tab.size());
+    gb.host_table = std::move(tab);                      // stays alive with the base: the upload is asynchronous
+    DRE_HIP(hipMemcpyAsync(gb.table.p, gb.host_table.data(), gb.host_table.size() * sizeof(GroupLeftDesc), hipMemcpyHostToDevice, ctx->stream));
+}
+// K-dependent part, once per time step (side stream): copies, g - 1 thin levels, the rows of Y, fold + packing
+static void group_ops_prepare(Ctx* ctx, const std::vector<std::complex<double>>& values, CycleOps& co, GroupBase& gb) {
+    const int n = gb.n, m = gb.m, g = gb.g, r = m * g;
+    const int ns = (int)gb.starts.size();
+    TimedScope tsall(ctx, "group_prepare", 8.0 * ns * ((g - 1) * (2.0 * n + m) * n + 4.0 * g * n * (double)n), 2.0 * ns * 2.0 * g * n * (double)n * r, g + 2);
+    hipLaunchKernelGGL(k_group_left, dim3(ceil_div(n, 16), gb.ndesc), dim3(256), 0, ctx->stream, n, m, (const GroupLeftDesc*)gb.table.p);
+    for (int i = 1; i < g; ++i) {
+        GroupLevelBatch lb;
+        for (int q = 0; q < 8; ++q) {
+            const int qq = q < ns ? q : 0, pos = gb.starts[(size_t)qq] + i;
+            lb.s[q] = {gb.spack[(size_t)pos].p, gb.XL[(size_t)qq].p, gb.Mb[(size_t)qq].p, 2.0 * values[(size_t)pos].real()};
+        }
+        hipLaunchKernelGGL(k_group_level_gemm, dim3(ceil_div(2 * n + m, 16), ns), dim3(256), 0, ctx->stream, n, m, g, i, gb.XL[0].ld, lb);
+    }
+    {
+        GroupYBatch yb;
+        for (int q = 0; q < 8; ++q) { const int qq = q < ns ? q : 0; yb.s[q] = {gb.D[(size_t)qq].p, gb.Mb[(size_t)qq].p, gb.Yt[(size_t)qq].p}; }
+        hipLaunchKernelGGL(k_group_y, dim3(ceil_div(n, 32), ns), dim3(256), 0, ctx->stream, n, m, g, gb.D[0].ld, yb);
+    }
+    co.gpack.clear();
+    {
+        const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+        GroupFoldBatch ft;
+        for (int q = 0; q < 8; ++q) { const int qq = q < ns ? q : 0; ft.s[q] = {gb.G0[(size_t)qq].p, gb.XL[(size_t)qq].p, gb.Yt[(size_t)qq].p, gb.pack[(size_t)qq].p}; }
+        hipLaunchKernelGGL(k_group_fold, dim3(ceil_div((kst + 3) / 4, 4), 2 * g * nstrip, ns), dim3(256), 0, ctx->stream, n, 2 * g, nstrip, kst, r,
+                           gb.G0[0].ld, gb.XL[0].ld, ft);
+        for (int q = 0; q < ns; ++q) co.gpack.push_back(gb.pack[(size_t)q].p);
+    }
+    co.group_g = g;
+    DRE_HIP(hipGetLastError());
+}
+
+// One parked host thread per GDRE solve for work that is DRIVEN beside the main loop (the side-stream compression of X has host read-backs of
+// its own, so it cannot simply be enqueued): jobs are handed over through a condition variable — no thread is spawned per time step.
+class SideWorker {
+  public:
+    ~SideWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
+    void submit(std::function<void()> job) {
+        if (!th_.joinable()) th_ = std::thread([this] { run(); });
+        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; }
+        cv_.notify_all();
+    }
+    bool pending() { std::lock_guard<std::mutex> lk(m_); return busy_; }
+    void wait() {       // returns when the submitted job is finished; rethrows what it threw
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return !busy_; });
+        if (err_) { auto e = err_; err_ = nullptr; std::rethrow_exception(e); }
+    }
+  private:
+    void run() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; job = std::move(job_); job_ = nullptr; }
+            std::exception_ptr e;
+            try { job(); } catch (...) { e = std::current_exception(); }
+            { std::lock_guard<std::mutex> lk(m_); busy_ = false; err_ = e; }
+            done_.notify_all();
+        }
+    }
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::function<void()> job_;
+    std::exception_ptr err_;
+    bool busy_ = false, quit_ = false;
+};
+
+struct DenseXState {
+    Mat X;        // n x n, symmetric
+    Mat P1;       // E' X
+    Mat P1t;      // X E (= P1'), written by the same SpMM launch
+    Mat Kt;       // K' = E' X B  (n x m)
+    int hint = 0; // ADI iterations of the previous step
+    GroupBase gb; // K-independent operator products of the group chain (built at the first dense step)
+    // pinned host landing zone: control block, tolerances and the SMW breakdown flag come back with ONE synchronisation per chunk
+    struct Landing { AdiState st; double tols[4]; int serr; };
+    Landing* land = nullptr;
+    // optional phase timing (DRE_PHASE_TIMING=1): events at the phase boundaries of every step, summed at the end
+    bool phase_on = env_trace("phase");
+    std::vector<hipEvent_t> pev;
+    std::vector<int> ptag;
+    void mark(Ctx* ctx, int tag) {
+        if (!phase_on) return;
+        hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, ctx->stream);
+        pev.push_back(e); ptag.push_back(tag);
+    }
+    void report() {
+        if (!phase_on || pev.size() < 2) return;
+        (void)hipEventSynchronize(pev.back());
+        static const char* names[] = {"start", "assembly", "band_reduce", "basis+init", "adi_chain", "sync+xupdate", "feedback"};
+        double acc[8] = {0};
+        for (size_t i = 1; i < pev.size(); ++i) { float ms = 0; (void)hipEventElapsedTime(&ms, pev[i - 1], pev[i]); if (ptag[i] > 0 && ptag[i] < 8) acc[ptag[i]] += ms; }
+        double tot = 0; for (int i = 1; i < 7; ++i) tot += acc[i];
+        std::fprintf(stderr, "[phase timing, ms per solve] ");
+        for (int i = 1; i < 7; ++i) std::fprintf(stderr, "%s %.2f | ", names[i], acc[i]);
+        std::fprintf(stderr, "sum %.2f\n", tot);
+        for (auto e : pev) (void)hipEventDestroy(e);
+        pev.clear(); ptag.clear();
+    }
+    // (the zone belongs to the context: a pinned allocation and its release cost ~0.1 ms each, per solve)
+    void attach(Ctx* ctx) {
+        if (!ctx->dense_land && hipHostMalloc(&ctx->dense_land, 16384, hipHostMallocDefault) != hipSuccess) ctx->dense_land = nullptr;
+        static_assert(sizeof(Landing) <= 16384, "landing zone");
+        land = (Landing*)ctx->dense_land;
+    }
+    DenseXState() = default;
+    DenseXState(const DenseXState&) = delete;
+    DenseXState& operator=(const DenseXState&) = delete;
+};
+// One Ros1 step on the dense state.  Returns false (state untouched) when the fast chain cannot take the step.
+static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperator& op_base, double tau, const AdiOptions& adi, FactorCache* cache,
+                            DenseXState& sx, AdiResult& ar) {
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    GaleOperator op = op_base;
+    op.Vt = sx.Kt;
+    DRE_REQUIRE(sx.land != nullptr, "pinned host memory unavailable");
+    // SMW products and the folded stacks depend on K only: they are built on the side stream while the main stream assembles and
+    // compresses the residual; the ADI chain waits for them through an event
+    Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
+    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));          // K of the previous step is ready here
+    sx.mark(ctx, 0);
+    // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
+    // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
+    CycleOps co;
+    bool co_ok = true, build_group_base = false;
+    auto side_setup = [&]() {
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+        // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
+        // every step land in the persistent buffers the left-factor descriptors point into
+        const int gwant = group_size_for(ctx, (int)adi.shifts.values.size(), n, m);       // (the MAIN context's options)
+        bool gb_ok = gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8 && sx.gb.g == gwant && sx.gb.tag == op.tag && sx.gb.m == m &&
+                     sx.gb.mus.size() == adi.shifts.values.size();
+        for (size_t i = 0; gb_ok && i < sx.gb.mus.size(); ++i) gb_ok = sx.gb.mus[i] == adi.shifts.values[i].real();
+        co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co, gb_ok ? &sx.gb.wks : nullptr, gb_ok ? &sx.gb.spack : nullptr, gb_ok);
+        if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
+        build_group_base = co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8;
+        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+        if (build_group_base) {
+            // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
+            // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
+            bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
+            for (size_t i = 0; i < adi.shifts.values.size(); ++i)
+                for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
+            if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
+        }
+    };
+    // (Enqueueing the side stream's work before the assembly instead of inside the band reduction's first read-back was measured at n = 371 with
+    // the group chain: 21.7 against 21.2 ms per solve — the host calls delay the main stream's first kernels by more than the earlier start gains.)
+    // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
+    // The main stream's kernels are enqueued BEFORE the side stream is set up: the host calls for the side stream (event wait, six
+    // launches) would otherwise sit in front of them while the main stream idles.
+    Mat Mx(ctx, n, n), EY(ctx, n, n), Res(ctx, n, n);
+    const Mat& Y = sx.P1t;                                                      // Y = X E
+    spmm_dual(ctx, P, P.valAt.p, P.valEt.p, Y, Mx, EY);       // A' X E and E' X E in one pass over X E
+    const int nt = ceil_div(n, 16);
+    DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 4);
+    hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
+                       (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
+    const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
+    sx.mark(ctx, 1);
+    // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
+    BandSpec spec;
+    // tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F:
+    // computed by the reduction's control-block launch
+    spec.tol_parts = part.p; spec.tol_nparts = nt * nt; spec.tol_reltol = reltol; spec.tol_abstol = adi.abstol; spec.tol_frac = adi.residual_abs_frac;
+    spec.tols_out = tols.p;
+    const bool defer_side = wctx != ctx;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
+    if (defer_side) { spec.extra = side_setup; spec.extra_after = ctx->side_after_panels; }
+    else side_setup();
+    SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
+    if (defer_side && !spec.ran) side_setup();
+    // Leaving early (refusal or exception) after the side stream was set up: the caller falls back to the generic ADI on the MAIN stream
+    // with the same factor cache, whose entries (stacks, dense inverses, SMW products) and op.Vt the side stream may still be touching
+    // (ADVICE round 2).  Join both streams on the host before anything of this frame is released or reused.
+    auto join_side = [&]() {
+        if (wctx != ctx) (void)hipStreamSynchronize(wctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    };
+    struct SideGuard { std::function<void()> f; bool armed = true; ~SideGuard() { if (armed) f(); } } side_guard{join_side};
+    if (!co_ok) return false;
+    sx.mark(ctx, 2);
+    const int k = sb.J;
+    DevArr<AdiState> st(ctx, 1);
+    AdiState h;
+    std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 3);
+    ar = AdiResult();
+    ar.rhs_cols = k;
+    if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return false;
+    std::vector<Mat> keepV;
+    std::vector<BufP> keepRpk;
+    double init_norm = 0.0;
+    Mat Vall, Wall;
+    int acc_total = 0;
+    std::vector<double> coef;
+    if (k > 0) {
+        Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
+        Mat Tm = sb.D;
+        DevArr<double> nws(ctx, ADI_FAST_NWS);
+        int mode0 = 0, nt0 = 0;
+        adi_fast_pick(n, k, &mode0, &nt0);
+        const bool use_pk = mode0 == 0;
+        const size_t rpd = adi_fast_rpack_doubles(n, k);
+        DevArr<double> Rp0(ctx, use_pk ? rpd : 1);                  // the initial residual in the fast chain's B-operand order (slot 0 of the first chunk)
+        const int pk_ct = (k + 15) / 16, pk_nblk = use_pk ? 4 * adi_fast_nstrip(n) * pk_ct : 0;
+        hipLaunchKernelGGL(k_adi_init_state, dim3(1 + (pk_nblk + 3) / 4), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p, nws.p,
+                           ADI_FAST_NWS, n, pk_ct, pk_nblk, (const double*)R.p, R.ld, Rp0.p);
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
+        sx.mark(ctx, 3);
+        const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
+        Mat Gm(ctx, k * k, 2);
+        // the whole solve is enqueued at once (one more iteration than the previous step needed); further chunks only if that was not enough
+        int iters_host = 0;
+        size_t cyc = 0;
+        bool finished = false;
+        const int cap = std::max(1, adi.maxiters);
+        const int ctk = (k + 15) / 16;
+        const int gsz = co.group_g;
+        const bool grp = gsz >= 2 && use_pk && k <= ADI_GROUP_MAX_K && gsz * ctk * ((ctk + 3) / 4) <= ADI_FAST_NWS - 1 && !co.gpack.empty();
+        Vall = Mat(ctx, n, k * (std::min(cap, std::max(adi.compression_interval, sx.hint + 1) + 64) + (grp ? gsz : 0)));
+        int vcols_used = 0;
+        // specx: every chunk's update of X is enqueued during its read-back (the batched product takes its descriptors as kernel arguments,
+        // 48 at most; chunks never grow within a solve)
+        const bool specx = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters) + (grp ? gsz : 0) <= 48;
+        bool any_plain = false;
+        while (!finished) {
+            const int base_it = iters_host;
+            const size_t cyc0 = cyc;
+            int nit = std::min(std::max(adi.compression_interval, sx.hint + 1), adi.maxiters - iters_host);
+            nit = std::min(std::min(nit, 480), (Vall.cols - vcols_used) / k);        // (< 512: the device keeps the norm history as a ring)
+            if (nit <= 0) break;
+            // group chain (first chunk of a solve: it starts at position 0 of the cycle): whole groups of gsz iterations per launch; the
+            // iteration count of the previous time step (counts fall from step to step) rounded up to a multiple of gsz is enqueued
+            const bool grp_now = grp && base_it == 0 && cyc == 0;
+            if (grp_now) {
+                const int want = std::min(std::min(std::max(sx.hint, 1), adi.maxiters), 480);
+                nit = ((want + gsz - 1) / gsz) * gsz;
+                nit = std::min(nit, ((Vall.cols - vcols_used) / k / gsz) * gsz);
+            }
+            Mat Rring(ctx, n, k * nit);
+            keepV.push_back(Rring);
+            if (grp_now && nit >= gsz) {
+                const int NG = nit / gsz, ncyc = (int)adi.shifts.values.size();
+                DevArr<double> Rpk(ctx, rpd * (size_t)(nit + 1));
+                Mat Gg(ctx, k * k, 2 * gsz);
+                AdiGroupArgs ga;
+                std::memset(&ga, 0, sizeof(ga));
+                ga.n = n; ga.k = k; ga.nstrip = nstrip; ga.kst = kst; ga.g = gsz;
+                ga.ldr = Rring.ld; ga.rpd = rpd; ga.ldv = Vall.ld;
+                ga.T = Tm.p; ga.ldt = Tm.ld; ga.alpha = 1.0; ga.st = st.p; ga.nws = nws.p;
+                double by1 = 0.0, fl1 = 0.0;
+                ga.do_strips = 1; ga.n_prev = gsz;
+                adi_group_cost(ga, &by1, &fl1);
+                {
+                    TimedScope chain_ts(ctx, "adi_group_iter", by1 * NG, fl1 * NG, NG + 2);
+                    for (int L = 0; L <= NG + 1; ++L) {
+                        ga.do_strips = L < NG ? 1 : 0;
+                        if (L < NG) {
+                            ga.Gpack = co.gpack[(size_t)(((L * gsz) % ncyc) / gsz)];
+                            ga.Rpc = L == 0 ? Rp0.p : Rpk.p + (size_t)(L * gsz) * rpd;
+                            ga.Rring = Rring.p + (size_t)(L * gsz) * k * Rring.ld;
+                            ga.Rpk = Rpk.p + (size_t)(L * gsz + 1) * rpd;
+                            ga.V = Vall.p + (size_t)(vcols_used + L * gsz * k) * Vall.ld;
+                        }
+                        // Gram matrices of the residuals launch L - 1 produced; norms + decisions for those of launch L - 2
+                        ga.n_prev = (L >= 1 && L <= NG) ? gsz : 0;
+                        ga.Rp_prev = ga.n_prev ? Rpk.p + (size_t)((L - 1) * gsz + 1) * rpd : nullptr;
+                        ga.G_prev = Gg.p + (size_t)(L & 1) * gsz * k * k;
+                        ga.n_prev2 = L >= 2 ? gsz : 0;
+                        ga.G_prev2 = Gg.p + (size_t)((L - 1) & 1) * gsz * k * k;
+                        ga.it0_prev2 = base_it + (L - 2) * gsz + 1;
+                        adi_group_iter(ctx, ga);
+                    }
+                }
+                for (int j = 0; j < nit; ++j) {
+                    const std::complex<double> mu = adi.shifts.values[cyc % adi.shifts.values.size()];
+                    ar.shifts.push_back(mu);
+                    coef.push_back(-2.0 * mu.real());
+                    ++cyc; ++iters_host;
+                }
+                keepRpk.push_back(Rpk.buf);
+                sx.mark(ctx, 4);
+            } else {
+            if (!co.single_built) { co.build_single(ctx); co.single_built = true; }
+            AdiFastArgs a;
+            std::memset(&a, 0, sizeof(a));
+            a.n = n; a.k = k; a.nstrip = nstrip; a.kst = kst; adi_fast_pick(n, k, &a.mode, &a.nt);
+            DevArr<double> Rpk(ctx, use_pk ? rpd * (size_t)(nit + 1) : 1);
+            const double* slot0 = Rp0.p;                        // first chunk: packed by the init launch
+            if (use_pk && base_it > 0) { adi_fast_pack_r(ctx, n, k, R.p, R.ld, Rpk.p, st.p); slot0 = Rpk.p; }
+            a.T = Tm.p; a.ldt = Tm.ld; a.tdiag = 0; a.alpha = 1.0; a.st = st.p; a.nws = nws.p;
+            a.chain_timed = 1; a.do_strips = 1; a.G_prev = Gm.p;
+            double by1 = 0.0, fl1 = 0.0;
+            adi_fast_cost(a, &by1, &fl1);
+            auto chain_ts = std::make_unique<TimedScope>(ctx, "adi_fast_iter", by1 * nit, fl1 * nit, nit + 2);   // the two flush launches ride along (riders only)
+            for (int j = 1; j <= nit; ++j) {
+                const std::complex<double> mu = adi.shifts.values[cyc % adi.shifts.values.size()];
+                a.Apack = co.pack[cyc % co.pack.size()];
+                if (j == 1) { a.Rcur = R.p; a.ldr = R.ld; } else { a.Rcur = Rring.p + (size_t)(j - 2) * k * Rring.ld; a.ldr = Rring.ld; }
+                a.Rnext = Rring.p + (size_t)(j - 1) * k * Rring.ld; a.ldr_next = Rring.ld;
+                a.Rpc = use_pk ? (j == 1 ? slot0 : Rpk.p + (size_t)(j - 1) * rpd) : nullptr;
+                a.Rpn = use_pk ? Rpk.p + (size_t)j * rpd : nullptr;
+                Mat Vj = Vall.colsview(vcols_used + (j - 1) * k, k);
+                a.V = Vj.p; a.ldv = Vj.ld;
+                a.two_mu = 2.0 * mu.real();
+                const int g = base_it + j;
+                a.G_prev = j >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.G_prev2 = j >= 3 ? Gm.p + (size_t)((g - 2) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 2; a.do_strips = 1;
+                adi_fast_iter(ctx, a);
+                ar.shifts.push_back(mu);
+                coef.push_back(-2.0 * mu.real());
+                ++cyc; ++iters_host;
+            }
+            {
+                const int g = base_it + nit;
+                a.do_strips = 0; a.Apack = nullptr; a.Rnext = nullptr; a.V = nullptr;
+                a.Rpc = use_pk ? Rpk.p + (size_t)nit * rpd : nullptr; a.Rpn = nullptr;
+                a.Rcur = Rring.p + (size_t)(nit - 1) * k * Rring.ld; a.ldr = Rring.ld;
+                a.G_prev = Gm.p + (size_t)(g & 1) * k * k;
+                a.G_prev2 = nit >= 2 ? Gm.p + (size_t)((g - 1) & 1) * k * k : nullptr;
+                a.it_prev2 = g - 1;
+                adi_fast_iter(ctx, a);
+                a.G_prev = nullptr;
+                a.G_prev2 = Gm.p + (size_t)(g & 1) * k * k;
+                a.it_prev2 = g;
+                adi_fast_iter(ctx, a);
+            }
+            chain_ts.reset();
+            sx.mark(ctx, 4);
+            }
+            {
+                // control block (header + the norms of this chunk), tolerances and the SMW breakdown flag in ONE read-back.  The update
+                //   X <- X + sum_j (-2 mu_j) V_j T V_j'      (adi.jl:166-174 accumulated: one batched product + one GEMM)
+                // of this chunk is enqueued right behind the read-back kernel: how many of the speculatively enqueued iterations count is
+                // read from the control block ON THE DEVICE (DevCount), so the device works on X while the host waits for the words.
+                const size_t stb = sizeof(int) * 4 + sizeof(double) * (2 + (size_t)std::min(512, base_it + nit + 1 + 8));
+                long long serr8 = 0;
+                std::function<void()> between;
+                if (specx) between = [&]() {
+                    DevCount dc{st.p, base_it, nit, k};
+                    Mat Wc(ctx, n, k * nit);
+                    std::vector<GemmBatchDesc> descs;
+                    for (int j = 0; j < nit; ++j) {
+                        Mat Vj = Vall.colsview(vcols_used + j * k, k), Wj = Wc.colsview(j * k, k);
+                        const double cj = -2.0 * adi.shifts.values[(cyc0 + (size_t)j) % adi.shifts.values.size()].real();
+                        descs.push_back({Vj.p, Tm.p, Wj.p, nullptr, cj, n, k, k, Vj.ld, Tm.ld, Wj.ld, 0});
+                    }
+                    DevCount dcb = dc; dcb.per = 1;
+                    gemm_batched(ctx, descs, "gemm_xupdate", dcb);
+                    Mat Vch = Vall.colsview(vcols_used, k * nit);
+                    gemm_sym_update(ctx, Wc, Vch, sx.X, "gemm_xupdate", dc);
+                };
+                ctx_fetch_overlap(ctx, between, st.p, stb, &sx.land->st, tols.p, 4 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
+                sx.land->serr = (int)serr8;
+            }
+            h = sx.land->st;
+            const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
+            for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[(base_it + j) & 511]); ar.norm_iters.push_back(base_it + j); }
+            if (base_it == 0) init_norm = h.norms[0];
+            if (!specx && acc_it > 0) any_plain = true;
+            iters_host = base_it + acc_it;
+            vcols_used += acc_it * k;
+            cyc = cyc - nit + acc_it;
+            ar.shifts.resize(iters_host); coef.resize(iters_host);
+            if (acc_it > 0) R = Rring.colsview((acc_it - 1) * k, k);
+            if (h.done || acc_it < nit || iters_host >= adi.maxiters) finished = true;
+        }
+        acc_total = iters_host;
+        for (auto& f : co.fe) if (!f->checked) { f->growth = mf_check(ctx, f->f); f->checked = true; }
+        if (sx.land->serr) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+        // chunks whose update was not enqueued during the read-back (more than 48 iterations at once): all increments in one go
+        if (acc_total > 0 && any_plain) {
+            Wall = Mat(ctx, n, k * acc_total);
+            std::vector<GemmBatchDesc> descs;
+            for (int j = 0; j < acc_total; ++j) {
+                Mat Vj = Vall.colsview(j * k, k), Wj = Wall.colsview(j * k, k);
+                descs.push_back({Vj.p, Tm.p, Wj.p, nullptr, coef[j], n, k, k, Vj.ld, Tm.ld, Wj.ld, 0});
+            }
+            gemm_batched(ctx, descs, "gemm_xupdate");
+            Mat Vacc = Vall.colsview(0, k * acc_total);
+            gemm_sym_update(ctx, Wall, Vacc, sx.X, "gemm_xupdate");
+        }
+    } else {
+        // zero residual: read the tolerances back for the record
+        DRE_HIP(hipMemcpyAsync(sx.land->tols, tols.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
+    }
+    ar.abstol = sx.land->tols[0];
+    ar.iters = acc_total;
+    ar.initial_norm = k > 0 ? init_norm : 0.0;
+    ar.res_norm = k > 0 ? (acc_total > 0 ? h.res_norm : init_norm) : 0.0;
+    ar.norms.insert(ar.norms.begin(), ar.initial_norm); ar.norm_iters.insert(ar.norm_iters.begin(), 0);
+    ar.converged = ar.res_norm <= ar.abstol;
+    if (!ar.converged) ar.warnings |= 1;
+    sx.hint = acc_total;
+    cache->iters_hint = acc_total;
+    sx.mark(ctx, 5);
+    // feedback of the new X:  P1 = E' X,  K' = P1 B      (lowrank_ros1.jl:53-56)
+    spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0, nullptr, &sx.P1t);
+    Mat Kt(ctx, n, m);
+    gemm_thin(ctx, false, n, m, n, 1.0, sx.P1.p, sx.P1.ld, prob.B.p, prob.B.ld, 0.0, Kt.p, Kt.ld);
+    sx.Kt = Kt;
+    sx.mark(ctx, 6);
+    side_guard.armed = false;          // the main stream waited for side_e2 above: nothing of the side stream is pending
+    return true;
+}
+
+static uint64_t tag_of(int order, double tau) {
+    uint64_t bits;
+    std::memcpy(&bits, &tau, sizeof(bits));
+    return bits * 1315423911ull + (uint64_t)order * 0x9E3779B97F4A7C15ull + 1;
+}
+
+// LDL' form of a dense symmetric X: compress!(lowrank(I, X))  (LDLt.jl:204-225; S = I X I' is X itself)
+static LDLtP dense_to_ldlt(Ctx* ctx, int n, const Mat& Xd, double ctf) {
+    Mat I(ctx, n, n), D(ctx, n, n);
+    set_identity(ctx, I, 1.0);
+    copy_mat(ctx, Xd, D);
+    LDLtP X = ldlt_make(ctx, n, I, D, 1.0, false);
+    ldlt_compress(ctx, *X, ctf, false);
+    return X;
+}
+
+
+// =============================================================================================
+// Rosenbrock-1 time loop with the RESIDUAL RECURRENCE (round 4; general path: multifrontal solves, Cyclic real shifts).
+// Between two time steps the reference (lowrank_ros1.jl:35-60) compresses X (LDLt.jl:204-225), forms the feedback K = B'XE, the right-hand side
+// and the warm-start residual [G, E'L, F'L] from that compressed X (lyapunov/residual.jl:3-31) and compresses the residual: at n = 5177 that is
+// 4.7 of the 6 ms of a time step, all of it short dependent kernels, with the ADI iteration itself at 1.3 ms.  But step i's ADI already holds
+// everything step i + 1 needs.  With X_i = X_{i-1} + sum_j V_j (c_j T) V_j', c_j = -2 mu_j alpha, and the recurrence R_j = R_{j-1} - 2 mu_j E'V_j
+// (adi.jl:166-177):
+//     E'V_j = (R_{j-1} - R_j) / (2 mu_j)                                  — E' times every increment, without touching E or V
+//     K_i   = K_{i-1} + sum_j (B'V_j) (c_j T) (E'V_j)'                    — the feedback (lowrank_ros1.jl:53-57)
+//     Res_{i+1}(X_i) = alpha R_J T R_J'  -  dK' dK  +  (1/tau) sum_j (E'V_j) (c_j T) (E'V_j)',      dK = K_i - K_{i-1}
+// the last line because F_{i+1} = F_i - B dK and rhs_{i+1} - rhs_i = K_i'K_i - K_{i-1}'K_{i-1} + E'(X_i - X_{i-1})E/tau, and the cross terms with
+// K_i = B'X_iE collapse to -dK'dK.  (alpha R_J T R_J' is step i's residual at its last iterate: the ADI invariant.)  So the critical path of a
+// time step is: compress that factored residual (the same factor-form reduction as before, on [R_J, dK', E'V_1 .. E'V_J]) -> ADI.  X itself is
+// only an output: its compression (adi.jl:78-80, lowrank_ros1.jl:53) runs on the SIDE stream, driven by a parked host thread, beside the next
+// step, and the one thing the next solve needs from it — the tolerance reltol ||rhs_{i+1}||_F (adi.jl:61-62) — arrives in device memory
+// and is applied to the recorded norms at the end of the solve's first chunk (adi_advance, deferred decisions).
+// Same iterates as the reference's loop up to rounding: the identity is exact; what differs is that the truncation error of compressing X
+// (4 eps ||X||) no longer re-enters the next residual.  A step whose ADI leaves the fan path (complex shift, user solver, in-loop compression)
+// falls back to the reference's order for the next step.
+// =============================================================================================
+static bool ros1_recurrence_ok(Ctx* ctx, const GdreProblem& prob, int order, const AdiOptions& adi) {
+    const int n = prob.P->n;
+    if (!ctx->ros1_recurrence || order != 1 || adi.compress_exact || adi.inner_solve || adi.ignore_initial_guess || !adi.compression) return false;
+    if (adi.shifts.kind != ShiftSpec::CYCLIC || adi.shifts.values.empty() || adi.abstol >= 0.0) return false;
+    for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) return false;
+    if (n <= ctx->dense_inv_max_n || n < ctx->compress_factor_min_n || ctx->adi_fan < 2 || !prob.P->use_mfma_sweeps) return false;
+    return true;
+}
+// state of X as the side stream holds it: compressed up to time step `step` (one block), E' times its factor, completion event
+struct SideState { int step = 0; LDLtP X; Mat EtL; hipEvent_t ev = nullptr; };
+// what step s added to  E'XE / tau_{s+1}:  Q Dq Q' - aT-weighted R_J R_J' + dK'dK   (the compressed warm-start residual of step s + 1, the final
+// residual factor of step s, the change of the feedback) — kept until the side stream's X includes step s
+struct StepDelta { int s; double tau; Mat Q, Dq, Rj, Tj; double aj; Mat dKt; };
+
+static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, bool save_state, const AdiOptions& adi, int nsteps, GdreResult& out,
+                                 FactorCache& cache, const Feedback& fb0) {
+    (void)dt;
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    const double ctf = adi.compress_tolfac;
+    // side context (own stream, pool, hints) + the parked thread that drives it
+    if (!ctx->side) {
+        auto sc = std::make_unique<Ctx>();
+        sc->device = ctx->device; sc->num_cus = ctx->num_cus;
+        sc->stream = create_stream(1);
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
+        sc->timer = std::make_unique<KernelTimer>();
+        sc->timer->enabled = ctx->prof_side;
+        ctx->side = std::move(sc);
+    }
+    Ctx* const side = ctx->side.get();
+    side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
+    side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
+    side->compress_factor_min_cols = ctx->compress_factor_min_cols; side->compress_sketch = ctx->compress_sketch;
+    side->compress_sketch_min_cols = ctx->compress_sketch_min_cols; side->compress_sketch_extra = ctx->compress_sketch_extra;
+    side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
+    side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
+    side->fetch_spin = false;
+    side->orthf_fn = ctx->orthf_fn; side->orthf_user = ctx->orthf_user;
+    SideWorker worker;
+    // events: a ring (at most one job is in flight; a slot is reused eight jobs later)
+    hipEvent_t ring[16];
+    for (auto& e : ring) DRE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t* v; ~EvGuard() { for (int i = 0; i < 16; ++i) (void)hipEventDestroy(v[i]); } } evguard{ring};
+    long njobs = 0;
+    std::mutex smu;
+    auto cur = std::make_shared<SideState>();
+    cur->step = 0; cur->X = prob.X0; cur->EtL = fb0.EtL;
+    auto get_state = [&]() { std::lock_guard<std::mutex> lk(smu); return cur; };
+    std::vector<LDLtP> saved((size_t)nsteps + 1);
+    int xwarm_sx = 32, xwarm_strikes = 0;           // warm-started compression of X on the side stream (touched by the worker only)
+    std::vector<LBlock> pend;                       // increments the side stream has not been handed yet
+    int pend_upto = 0;
+    bool job_pending = false;
+    static const bool rec_timing = env_trace("rec");
+    double t_join = 0.0, t_solve = 0.0, t_tail = 0.0; long n_join = 0, n_jobs_t = 0;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    auto join_side = [&]() {                        // host: the running job is finished (its read-backs are synchronous) and its state published
+        if (!job_pending) return;
+        const auto a = now();
+        worker.wait();
+        if (rec_timing) { t_join += us(a, now()); ++n_join; }
+        job_pending = false;
+    };
+    struct JoinGuard { SideWorker& w; bool& p; ~JoinGuard() { if (p) { try { w.wait(); } catch (...) {} } } } jguard{worker, job_pending};
+    // hand everything pending to the side stream: X_upto = compress(X_base + increments), E' times its factor
+    auto submit_job = [&]() {
+        if (pend.empty() && pend_upto == get_state()->step) return;
+        join_side();
+        hipEvent_t e_main = ring[(2 * njobs) % 16], e_side = ring[(2 * njobs + 1) % 16];
+        ++njobs; ++n_jobs_t;
+        DRE_HIP(hipEventRecord(e_main, ctx->stream));
+        const auto base = get_state();
+        const std::vector<LBlock> blocks = pend;
+        const int target = pend_upto;
+        pend.clear();
+        LDLtP* const saved_slot = save_state ? &saved[(size_t)target] : nullptr;
+        auto* curp = &cur; auto* mup = &smu;
+        int* const xw_sx = &xwarm_sx; int* const xw_strikes = &xwarm_strikes;
+        worker.submit([=, &P]() {
+            DRE_HIP(hipSetDevice(side->device));
+            DRE_HIP(hipStreamWaitEvent(side->stream, e_main, 0));
+            if (base->ev) DRE_HIP(hipStreamWaitEvent(side->stream, base->ev, 0));
+            auto Xs = std::make_shared<LDLt>();
+            Xs->n = n;
+            for (auto& b : base->X->blocks) if (b.L.cols > 0) Xs->blocks.push_back(b);
+            for (auto& b : blocks) Xs->blocks.push_back(b);
+            if (Xs->blocks.empty()) Xs->blocks.push_back({Mat(side, n, 0), Mat(side, 0, 0), 1.0, true});
+            // X_b's basis nearly spans the new X (the solution moves slowly between time steps): the warm-started range finder of the residual
+            // compression, with the relative tolerance of compress! as an absolute one (||X_b||_F = ||D_b||_F: L_b is orthonormal); the full
+            // sketch compression where the probe rejects it
+            bool done = false;
+            if (!blocks.empty() && base->X->blocks.size() == 1 && base->X->blocks[0].ortho && base->X->blocks[0].L.cols >= 64 && *xw_strikes < 2) {
+                const LBlock& bb = base->X->blocks[0];
+                const double nb = frob_norm_host(side, bb.D) * std::fabs(bb.alpha);
+                double missed = 0.0;
+                done = nb > 0.0 && warm_compress(side, *Xs, bb.L, ctf, ctf * EPS * nb, *xw_sx, &missed, 64.0 * EPS);
+                if (done) *xw_strikes = 0;
+                else if (*xw_sx < 64) *xw_sx = 64;
+                else *xw_strikes += 1;
+            }
+            if (!done) ldlt_destructure(side, *Xs, ctf, false);
+            auto st = std::make_shared<SideState>();
+            st->step = target; st->X = Xs; st->ev = e_side;
+            const LBlock& b = Xs->blocks[0];
+            st->EtL = Mat(side, n, b.L.cols);
+            if (b.L.cols > 0) spmm(side, P, P.valEt.p, b.L, st->EtL, 1.0, 0.0);
+            DRE_HIP(hipEventRecord(e_side, side->stream));
+            DRE_HIP(hipStreamSynchronize(side->stream));       // the increments' buffers go back to the MAIN pool when this closure dies
+            if (saved_slot) *saved_slot = Xs;
+            { std::lock_guard<std::mutex> lk(*mup); *curp = st; }
+        });
+        job_pending = true;
+    };
+
+    std::map<uint64_t, DevArr<double>> valF_by_tau;
+    Mat Kt = fb0.Kt;                                // K(t_{i-1})'
+    bool have_hist = false;
+    AdiResult prev;                                 // pieces of the previous solve the recurrence needs (hist, Tm, alpha_res, residual)
+    Mat prev_dKt;
+    double abstol_prev = -1.0;
+    std::vector<StepDelta> deltas;                  // steps the side stream's X does not include yet
+    DevArr<double> normC_dev(ctx, 1);
+    Mat Im(ctx, m, m);
+    set_identity(ctx, Im, 1.0);
+    for (int i = 1; i <= nsteps; ++i) {
+        const double tau = out.t[i - 1] - out.t[i];
+        GaleOperator op;
+        op.P = &P;
+        op.tag = tag_of(1, tau);
+        auto it = valF_by_tau.find(op.tag);
+        if (it == valF_by_tau.end()) {
+            DevArr<double> v(ctx, P.nnz);
+            vals_axpby(ctx, P.nnz, 1.0, P.valAt.p, -1.0 / (2.0 * tau), P.valEt.p, v.p);      // A - E/(2 tau)   (lowrank_ros1.jl:39)
+            it = valF_by_tau.emplace(op.tag, v).first;
+        }
+        op.valFt = it->second; op.cA = 1.0; op.cE = -1.0 / (2.0 * tau);
+        op.has_lr = true; op.U = prob.B; op.Vt = Kt; op.alpha = -1.0;
+        AdiOptions a2 = adi;
+        a2.final_compress = false; a2.keep_history = true;
+        AdiResult ar;
+        std::vector<LBlock> incr;
+        const auto ts0 = now();
+        if (!have_hist) {
+            // the reference's order (first step, or after a solve without history): compressed X -> feedback pieces -> right-hand side -> ADI
+            if (!pend.empty() || pend_upto != get_state()->step) submit_job();
+            join_side();
+            const auto st = get_state();
+            if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+            deltas.clear();
+            LDLtP X = st->X;
+            Feedback fb = feedback(ctx, prob, *X, ctf, false);
+            const int r = fb.L.cols;
+            Mat G(ctx, n, q + r);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            { Mat d = G.colsview(q, r); copy_mat(ctx, fb.EtL, d); }
+            Mat S(ctx, q + r, q + r);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d = S.view(q, q, r, r);
+                copy_mat(ctx, fb.D, d, fb.alpha / tau);
+                gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
+            }
+            LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
+            if (X->iszero()) ldlt_compress(ctx, *rhs, ctf, false);
+            const size_t nb_prev = X->blocks.size();
+            ar = adi_solve(ctx, op, *rhs, X, a2, &cache);
+            bool intact = ar.X->blocks.size() >= nb_prev;
+            for (size_t bi = 0; intact && bi < nb_prev; ++bi) intact = ar.X->blocks[bi].L.p == X->blocks[bi].L.p;
+            if (intact) incr.assign(ar.X->blocks.begin() + (long)nb_prev, ar.X->blocks.end());
+            else {
+                // the solve compressed in between: its X stands (published as the side state of this step; nothing pending)
+                ar.hist_ok = false;
+                auto st2 = std::make_shared<SideState>();
+                st2->step = i; st2->X = ar.X;
+                { std::lock_guard<std::mutex> lk(smu); cur = st2; }
+                pend_upto = i;
+            }
+        } else {
+            // the recurrence: [R_J, dK', E'V_1 .. E'V_J] with their inner blocks IS the warm-start residual of this step
+            auto resid = std::make_shared<LDLt>();
+            resid->n = n;
+            Mat RJ;                                   // final residual factor of the previous solve
+            if (prev.residual && !prev.residual->blocks.empty() && prev.residual->blocks[0].L.cols > 0) RJ = prev.residual->blocks[0].L;
+            if (RJ.cols > 0) resid->blocks.push_back({RJ, prev.Tm, prev.alpha_res, prev.tdiag, false});
+            if (!prev.hist.empty()) {
+                resid->blocks.push_back({prev_dKt, Im, -1.0, true, false});
+                const int k = prev.Tm.rows;
+                for (auto& hc : prev.hist) {
+                    const int J = (int)hc.mu.size();
+                    Mat EV(ctx, n, J * k);
+                    ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                    for (int j = 0; j < J; ++j)
+                        resid->blocks.push_back({EV.colsview(j * k, k), prev.Tm, -2.0 * hc.mu[(size_t)j] * prev.alpha_res / tau, prev.tdiag, false});
+                }
+            }
+            a2.given_residual = resid;
+            a2.abstol_lag = abstol_prev;
+            if (!prev.hist.empty()) a2.warm_basis = prev.hist[0].R0;      // the compressed residual the previous solve started from: orthonormal
+            a2.normC_dev = normC_dev.p;
+            // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
+            //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)
+            // with X_b the latest X the side stream has finished (b >= i - 4) — one Gram matrix of a few hundred columns
+            a2.normC_build = [&, i, tau, RJ](Ctx* hc, const Mat& Q, const Mat& Dq, double aq) {
+                StepDelta dl;
+                dl.s = i - 1; dl.tau = tau; dl.Q = Q; dl.Dq = Mat(hc, Dq.rows, Dq.cols); copy_mat(hc, Dq, dl.Dq, aq);
+                dl.Rj = RJ; dl.Tj = prev.Tm; dl.aj = prev.alpha_res; dl.dKt = prev.hist.empty() ? Mat() : prev_dKt;
+                deltas.push_back(dl);
+                auto st = get_state();
+                if ((i - 1) - st->step > 5) { join_side(); st = get_state(); }
+                if (st->ev) DRE_HIP(hipStreamWaitEvent(hc->stream, st->ev, 0));
+                while (!deltas.empty() && deltas.front().s <= st->step) deltas.erase(deltas.begin());
+                const LBlock& xb = st->X->blocks[0];
+                const int r = xb.L.cols;
+                int cols = q + m + r;
+                for (auto& d : deltas) cols += d.Q.cols + d.Rj.cols + (d.dKt.cols > 0 ? m : 0);
+                Mat F(hc, n, cols), S(hc, cols, cols);
+                fill_mat(hc, S, 0.0);
+                std::vector<CopyDesc> cd;
+                int off = 0;
+                auto put = [&](const Mat& L, const Mat* D, double scale, bool identity) {
+                    if (L.cols == 0) return;
+                    Mat dst = F.colsview(off, L.cols);
+                    cd.push_back({L.p, dst.p, n, L.cols, L.ld, dst.ld});
+                    Mat ds = S.view(off, off, L.cols, L.cols);
+                    if (identity) set_identity(hc, ds, scale); else copy_mat(hc, *D, ds, scale);
+                    off += L.cols;
+                };
+                put(prob.Ct, nullptr, 1.0, true);
+                put(Kt, nullptr, 1.0, true);
+                put(st->EtL, &xb.D, xb.alpha / tau, false);
+                for (auto& d : deltas) {
+                    const double sc = d.tau / tau;
+                    put(d.Q, &d.Dq, sc, false);
+                    put(d.Rj, &d.Tj, -sc * d.aj, false);
+                    if (d.dKt.cols > 0) put(d.dKt, nullptr, sc, true);
+                }
+                copy_batched(hc, cd);
+                ldlt_norm_device(hc, F, S, 1.0, normC_dev.p);
+            };
+            LDLt none; none.n = n;
+            ar = adi_solve(ctx, op, none, nullptr, a2, &cache);
+            for (auto& b : ar.X->blocks) if (b.L.cols > 0) incr.push_back(b);
+        }
+        out.adi_iters += ar.iters;
+        const auto ts1 = now();
+        if (rec_timing) t_solve += us(ts0, ts1);
+        size_t hist_its = 0;
+        for (auto& hc : ar.hist) hist_its += hc.mu.size();
+        const bool hist = ar.hist_ok && hist_its == (size_t)ar.iters && (int)incr.size() == ar.iters;
+        // the increments go to the side stream (a job per step with save_state; otherwise whenever the previous job is done)
+        if (pend_upto < i) { for (auto& b : incr) pend.push_back(b); pend_upto = i; }
+        Mat Kt_new;
+        if (hist) {
+            // side jobs: every step with save_state (every X(t) is an output); otherwise when the previous one is done AND `batch` steps have
+            // gathered (the tolerance formula above tolerates a lag of 3 steps; one compression of 2-3 steps' increments costs little more
+            // than one step's — its latency chains depend on the rank, not on the number of columns)
+            static const int batch = 2;
+            if (save_state || (!worker.pending() && i - get_state()->step >= batch) || i == nsteps) submit_job();
+            // K_i' = K_{i-1}' + sum_j (E'V_j) (c_j T) (V_j'B)
+            Mat dKt(ctx, n, m);
+            Kt_new = Mat(ctx, n, m);
+            copy_mat(ctx, Kt, Kt_new);
+            const int k = ar.Tm.rows;
+            bool first = true;
+            for (auto& hc : ar.hist) {
+                const int J = (int)hc.mu.size();
+                Mat EV(ctx, n, J * k), VtB(ctx, J * k, m), Mx(ctx, J * k, m);
+                ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                gemm(ctx, true, false, 1.0, hc.Vs, prob.B, 0.0, VtB, nullptr, "gemm_feedback");
+                std::vector<GemmBatchDesc> descs;
+                for (int j = 0; j < J; ++j)
+                    descs.push_back({ar.Tm.p, VtB.p + (size_t)j * k, Mx.p + (size_t)j * k, nullptr, -2.0 * hc.mu[(size_t)j] * ar.alpha_res, k, m, k, ar.Tm.ld, VtB.ld, Mx.ld, 0});
+                gemm_batched(ctx, descs, "gemm_feedback");
+                gemm(ctx, false, false, 1.0, EV, Mx, first ? 0.0 : 1.0, dKt, nullptr, "gemm_feedback");
+                first = false;
+            }
+            if (first) fill_mat(ctx, dKt, 0.0);
+            else axpy_inplace(ctx, (size_t)n * m, 1.0, dKt.p, Kt_new.p);
+            prev_dKt = dKt;
+        } else {
+            // no history (an iteration outside the fan path, a compression inside the solve): the reference's order for this step's tail
+            submit_job();
+            join_side();
+            const auto st = get_state();
+            if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+            LDLtP X = st->X;
+            if (X.get() == prob.X0.get()) X = std::make_shared<LDLt>(*prob.X0);
+            Feedback fb = feedback(ctx, prob, *X, ctf, false);
+            Kt_new = fb.Kt;
+            if (save_state) saved[(size_t)i] = X;
+            deltas.clear();
+        }
+        if (rec_timing) t_tail += us(ts1, now());
+        abstol_prev = ar.abstol;
+        have_hist = hist;
+        Kt = Kt_new;
+        out.Kt.push_back(Kt);
+        prev = ar;                                   // (shallow: the slabs stay alive until the next residual is built)
+        prev.X.reset();
+        AdiResult rec = std::move(ar);
+        rec.X.reset(); rec.residual.reset(); rec.hist.clear();
+        out.gale.push_back(std::move(rec));
+    }
+    submit_job();
+    join_side();
+    {
+        const auto st = get_state();
+        if (st->ev) DRE_HIP(hipStreamWaitEvent(ctx->stream, st->ev, 0));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (rec_timing) std::fprintf(stderr, "[rec timing, us per step] solve (residual + ADI) %.0f | tail (feedback, job hand-over) %.0f | blocked in join %.0f (%ld joins, %ld jobs)\n",
+                                     t_solve / nsteps, t_tail / nsteps, t_join / nsteps, n_join, n_jobs_t);
+        if (save_state) for (int i = 1; i <= nsteps; ++i) out.X.push_back(saved[(size_t)i] ? saved[(size_t)i] : st->X);
+        else out.X.push_back(st->X);
+    }
+}
+
+GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, bool save_state, const AdiOptions& adi) {
+    DRE_REQUIRE(order == 1 || order == 2, "only Ros1 and Ros2 have a low-rank formulation");
+    DRE_REQUIRE(dt != 0.0, "dt must be nonzero");
+    const Pencil& P = *prob.P;
+    const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
+    GdreResult out;
+    const int nsteps = (int)std::floor((prob.tf - prob.t0) / dt + 1e-9);
+    DRE_REQUIRE(nsteps >= 0, "tspan and dt point in opposite directions");
+    for (int i = 0; i <= nsteps; ++i) out.t.push_back(prob.t0 + i * dt);
+    LDLtP X = prob.X0;
+    out.X.push_back(X);
+    const double ctf = adi.compress_tolfac;
+    const bool cex = adi.compress_exact;
+    Feedback fb = feedback(ctx, prob, *X, ctf, cex);
+    out.Kt.push_back(fb.Kt);
+    FactorCache cache;
+    if (ros1_recurrence_ok(ctx, prob, order, adi) && nsteps >= 1) {
+        ros1_recurrence_loop(ctx, prob, dt, save_state, adi, nsteps, out, cache, fb);
+        out.nfactor = cache.nfactor;
+        return out;
+    }
+    // Ros1 at small n: X stays "warm start + increments" between two compressions (every xevery-th step and at the end); right-hand side,
+    // feedback and warm-start residual work on the block list (the direct-form compression does not care about the number of columns)
+    const bool xside_env = ctx->x_side_stream != 0;
+    const int xevery = std::max(1, ctx->x_compress_every);
+    const bool xblocks = order == 1 && (xevery > 1 || xside_env) && !cex && !save_state && n <= xblocks_max_n() && !adi.ignore_initial_guess;
+    // Side stream: the compression of X_{i-1} is not on the critical path of step i (right-hand side, feedback and residual take the
+    // block list), so it runs on a second stream, driven by a second host thread with its own context (stream, pool, hints), while the
+    // main stream does the residual compression and the ADI iteration of step i; its result replaces the uncompressed summands at the
+    // end of step i:  X_i = compress(X_{i-1}) + increments_i.  A single latency-bound solve leaves most of the chip idle.
+    const bool xside = xblocks && xside_env;
+    if (xside_env && !ctx->side) {
+        auto sc = std::make_unique<Ctx>();
+        sc->device = ctx->device; sc->num_cus = ctx->num_cus;
+        sc->stream = create_stream(1);
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e1, hipEventDisableTiming));
+        DRE_HIP(hipEventCreateWithFlags(&ctx->side_e2, hipEventDisableTiming));
+        sc->timer = std::make_unique<KernelTimer>();
+        sc->timer->enabled = ctx->prof_side;
+        ctx->side = std::move(sc);
+    }
+    Ctx* const side = ctx->side.get();
+    if (side) {
+        side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
+        side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
+        side->compress_factor_min_cols = ctx->compress_factor_min_cols;
+    }
+    std::map<uint64_t, DevArr<double>> valF_by_tau;
+    const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
+    // Ros1, small n, real Cyclic shifts, no save_state: from the second step on X is carried as a dense symmetric matrix (ros1_dense_step)
+    bool densex = order == 1 && !cex && !save_state && !adi.inner_solve && !adi.ignore_initial_guess && adi.compression && adi.shifts.kind == ShiftSpec::CYCLIC &&
+                  n <= ctx->dense_x_max_n && n <= ctx->dense_inv_max_n && m <= 32 && !adi.shifts.values.empty();
+    for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
+    DenseXState sx;
+    sx.attach(ctx);
+    SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
+    bool sx_init = false, x_is_dense = false;
+
+    const bool wall_on = env_trace("phase");
+    auto wall_now = [&]() { if (wall_on) DRE_HIP(hipStreamSynchronize(ctx->stream)); return std::chrono::steady_clock::now(); };
+    const auto w_begin = wall_now();
+    auto w_first = w_begin;
+    for (int i = 1; i <= nsteps; ++i) {
+        if (wall_on && i == 2) w_first = wall_now();
+        const double tau = out.t[i - 1] - out.t[i];
+        GaleOperator op;
+        op.P = &P;
+        op.tag = tag_of(order, tau);
+        auto it = valF_by_tau.find(op.tag);
+        if (it == valF_by_tau.end()) {
+            DevArr<double> v(ctx, P.nnz);
+            if (order == 1) vals_axpby(ctx, P.nnz, 1.0, P.valAt.p, -1.0 / (2.0 * tau), P.valEt.p, v.p);      // A - E/(2 tau)
+            else vals_axpby(ctx, P.nnz, gamma * tau, P.valAt.p, -0.5, P.valEt.p, v.p);                         // gamma tau A - E/2
+            it = valF_by_tau.emplace(op.tag, v).first;
+        }
+        op.valFt = it->second;
+        if (order == 1) { op.cA = 1.0; op.cE = -1.0 / (2.0 * tau); } else { op.cA = gamma * tau; op.cE = -0.5; }
+        op.has_lr = true;
+        op.U = prob.B;
+        op.Vt = fb.Kt;
+        op.alpha = order == 1 ? -1.0 : 1.0 / (-gamma * tau);
+        const int r = fb.L.cols;
+        if (densex) {
+            if (!sx_init) {
+                // the current X (X0, or a block list: warm start + increments) as a dense matrix
+                const int c = X->rank();
+                sx.X = Mat(ctx, n, n);
+                if (c > 0) {
+                    Mat Lcat(ctx, n, c), LD(ctx, n, c);
+                    hcat_scale_blocks(ctx, *X, Lcat, LD);
+                    gemm(ctx, false, true, 1.0, LD, Lcat, 0.0, sx.X, nullptr, "gemm_xupdate");
+                    symmetrize(ctx, sx.X);
+                } else fill_mat(ctx, sx.X, 0.0);
+                sx.P1 = Mat(ctx, n, n);
+                sx.P1t = Mat(ctx, n, n);
+                spmm(ctx, P, P.valEt.p, sx.X, sx.P1, 1.0, 0.0, nullptr, &sx.P1t);
+                sx.Kt = fb.Kt;
+                sx.hint = cache.iters_hint > 0 ? cache.iters_hint : 3 * adi.compression_interval;    // first solve: a few chunks at most
+                sx_init = true;
+            }
+            AdiResult ar;
+            if (ros1_dense_step(ctx, prob, op, tau, adi, &cache, sx, ar)) {
+                out.adi_iters += ar.iters;
+                out.gale.push_back(std::move(ar));
+                out.Kt.push_back(sx.Kt);
+                x_is_dense = true;
+                continue;
+            }
+            // the fast chain refused (residual too wide, ill-conditioned shifted operator): back to the factored form for good
+            densex = false;
+            if (x_is_dense) { X = dense_to_ldlt(ctx, n, sx.X, ctf); x_is_dense = false; fb = feedback(ctx, prob, *X, ctf, false); op.Vt = fb.Kt; }
+        }
+        if (order == 1 && xblocks) {
+            // X is a block list (compressed every `xevery` steps only):  rhs = C'C + K'K + sum_b (E'L_b) (alpha_b D_b / tau) (E'L_b)'
+            // as a block list of its own; nothing is compressed before the warm-start residual (gale_residual_blocks)
+            auto rhs = std::make_shared<LDLt>();
+            rhs->n = n;
+            Mat Iq(ctx, q, q), Im(ctx, m, m);
+            set_identity(ctx, Iq, 1.0); set_identity(ctx, Im, 1.0);
+            rhs->blocks.push_back({prob.Ct, Iq, 1.0, true, false});
+            rhs->blocks.push_back({fb.Kt, Im, 1.0, true, false});
+            int off = 0;
+            for (auto& b : X->blocks) {
+                const int k = b.L.cols;
+                if (k == 0) continue;
+                rhs->blocks.push_back({fb.EtL.colsview(off, k), b.D, b.alpha / tau, b.diag, false});
+                off += k;
+            }
+            AdiOptions a2 = adi;
+            const bool last = (i == nsteps);
+            a2.final_compress = xside ? false : (last || (i % xevery == 0));
+            a2.warm_L = fb.L; a2.warm_EtL = fb.EtL;            // the feedback already concatenated X and applied E'
+            a2.rhs_lead_blocks = 2; a2.rhs_e_coeff = 1.0 / tau;                     // rhs = [C'C, K'K] + E'XE / tau
+            // side stream: compress the warm start X_{i-1} concurrently (only worth it once it carries increments)
+            LDLtP Xc;
+            const size_t nb_prev = X->blocks.size();
+            bool side_job = false;
+            if (xside && nb_prev > 1) {
+                DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
+                Xc = std::make_shared<LDLt>(*X);               // shallow: shares the summands, which stay alive in X until the join
+                side_worker.submit([&, Xc]() {
+                    DRE_HIP(hipSetDevice(side->device));
+                    DRE_HIP(hipStreamWaitEvent(side->stream, ctx->side_e1, 0));
+                    ldlt_compress(side, *Xc, ctf, false);
+                    DRE_HIP(hipEventRecord(ctx->side_e2, side->stream));
+                });
+                side_job = true;
+            }
+            AdiResult ar;
+            try { ar = adi_solve(ctx, op, *rhs, X, a2, &cache); }
+            catch (...) { if (side_job) { try { side_worker.wait(); } catch (...) {} } throw; }
+            if (side_job) {
+                side_worker.wait();
+                DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
+                // X_i = compress(X_{i-1}) + increments_i  (unless the ADI loop had to compress in between: then its X stands)
+                bool intact = ar.X->blocks.size() >= nb_prev;
+                for (size_t bi = 0; intact && bi < nb_prev; ++bi) intact = ar.X->blocks[bi].L.p == X->blocks[bi].L.p;
+                if (intact) {
+                    auto Xn = std::make_shared<LDLt>();
+                    Xn->n = n;
+                    Xn->blocks = Xc->blocks;
+                    for (size_t bi = nb_prev; bi < ar.X->blocks.size(); ++bi) Xn->blocks.push_back(ar.X->blocks[bi]);
+                    ar.X = Xn;
+                }
+            }
+            if (xside && last) ldlt_compress(ctx, *ar.X, ctf, false);
+            X = ar.X;
+            out.adi_iters += ar.iters;
+            ar.X.reset(); ar.residual.reset();
+            out.gale.push_back(std::move(ar));
+            if (save_state) out.X.push_back(X);
+            fb = feedback_blocks(ctx, prob, *X);
+            out.Kt.push_back(fb.Kt);
+            continue;
+        }
+        if (order == 1) {
+            // G = [C', E'L];  S = blkdiag(I_q, BtLD' BtLD + D/tau);  R = compress!(lowrank(G, S))   (lowrank_ros1.jl:42-44)
+            Mat G(ctx, n, q + r);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            { Mat d = G.colsview(q, r); copy_mat(ctx, fb.EtL, d); }
+            Mat S(ctx, q + r, q + r);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d = S.view(q, q, r, r);
+                // E'XE / tau with X = alpha L D L': the reference writes D/tau here (lowrank_ros1.jl:43), which is only right for alpha = 1
+                // (SURVEY Appendix B.3); the engine keeps alpha so that every code path solves the same equation as the dense solver
+                copy_mat(ctx, fb.D, d, fb.alpha / tau);
+                gemm(ctx, true, false, 1.0, fb.BtLD, fb.BtLD, 1.0, d);
+            }
+            LDLtP rhs = ldlt_make(ctx, n, G, S, 1.0, false);
+            // The reference compresses the right-hand side here (lowrank_ros1.jl:44) and again, together with the warm start,
+            // inside residual() (lyapunov/residual.jl:30).  In Krylov mode the second compression truncates at a fraction of
+            // abstol, which also removes what the first one would have filtered, so the first is skipped for warm starts.
+            if (cex || adi.ignore_initial_guess || X->iszero()) ldlt_compress(ctx, *rhs, ctf, cex);
+            AdiResult ar = adi_solve(ctx, op, *rhs, X, adi, &cache);
+            X = ar.X;
+            out.adi_iters += ar.iters;
+            ar.X.reset(); ar.residual.reset();
+            out.gale.push_back(std::move(ar));
+        } else {
+            // stage 1: G = [C', A'L, E'L], S = [I 0 0; 0 0 D; 0 D -(BtLD)'BtLD]      (lowrank_ros2.jl:44-58)
+            const int nG = q + 2 * r;
+            Mat G(ctx, n, nG);
+            { Mat d = G.colsview(0, q); copy_mat(ctx, prob.Ct, d); }
+            if (r > 0) {
+                Mat d = G.colsview(q, r); spmm(ctx, P, P.valAt.p, fb.L, d, 1.0, 0.0);
+                Mat d2 = G.colsview(q + r, r); copy_mat(ctx, fb.EtL, d2);
+            }
+            Mat S(ctx, nG, nG);
+            set_identity(ctx, S, 0.0);
+            { Mat d = S.view(0, 0, q, q); set_identity(ctx, d, 1.0); }
+            if (r > 0) {
+                Mat d23 = S.view(q, q + r, r, r); copy_mat(ctx, fb.D, d23, fb.alpha);       // A'XE + E'XA with X = alpha L D L'
+                Mat d32 = S.view(q + r, q, r, r); copy_mat(ctx, fb.D, d32, fb.alpha);
+                Mat d33 = S.view(q + r, q + r, r, r); gemm(ctx, true, false, -1.0, fb.BtLD, fb.BtLD, 0.0, d33);
+            }
+            LDLtP R1 = ldlt_make(ctx, n, G, S, 1.0, false);
+            // lowrank_ros2.jl:58 compresses here; [C', A'L, E'L] has full numerical rank q + 2r generically, so the engine's
+            // compression would run to the end and hand G back (ldlt_compress): it is only attempted in the literal (exact) mode
+            // Default mode (round 3; found by the 45-step fixture): R1 is the Riccati residual at X, whose terms cancel as X approaches the steady
+            // state (||R1|| / (||G||^2 ||S||) falls below 1e-8 within ~20 steps).  The Gram form of the norm inside the ADI loop is only accurate
+            // relative to the largest term, so on the raw summands abstol = n eps ||R1|| and every residual norm became rounding noise (the solves
+            // stopped after 0 iterations and K(t) froze 1e-6 away from the oracle).  R1 is therefore always brought to ONE block with orthonormal
+            // factor, truncated at max(relative tolerance, formation noise of G S G'): nothing can cancel in that form.
+            if (cex) ldlt_compress(ctx, *R1, ctf, cex);
+            else ldlt_compress(ctx, *R1, ctf, false, -1.0, COMPRESS_NOISE_FLOOR | COMPRESS_KEEP_RESULT);
+            AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
+            LDLtP K1 = a1.X;
+            // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)
+            ldlt_destructure(ctx, *K1, ctf, cex);
+            const LBlock kb = K1->blocks[0];
+            const int r1 = kb.L.cols;
+            Mat BtT1(ctx, m, r1), BtT1D1(ctx, m, r1);
+            gemm(ctx, true, false, 1.0, prob.B, kb.L, 0.0, BtT1);
+            gemm(ctx, false, false, kb.alpha, BtT1, kb.D, 0.0, BtT1D1);
+            Mat G2(ctx, n, r1);
+            spmm(ctx, P, P.valEt.p, kb.L, G2, 1.0, 0.0);
+            Mat S2(ctx, r1, r1);
+            copy_mat(ctx, kb.D, S2, 2.0 - 1.0 / gamma);
+            if (r1 > 0) gemm(ctx, true, false, tau * tau, BtT1D1, BtT1D1, 1.0, S2);
+            LDLtP R2 = ldlt_make(ctx, n, G2, S2, 1.0, false);
+            AdiResult a2 = adi_solve(ctx, op, *R2, nullptr, adi, &cache);
+            LDLtP K2 = a2.X;
+            // X = X + ((2 - 1/(2 gamma)) tau) K1 + (-tau/2) K2     (lowrank_ros2.jl:72)
+            X = ldlt_add(ldlt_add(X, ldlt_scale(K1, (2.0 - 1.0 / (2.0 * gamma)) * tau)), ldlt_scale(K2, -tau / 2.0));
+            if (X.get() == prob.X0.get()) X = std::make_shared<LDLt>(*X);   // never compress the caller's X0 in place
+            out.adi_iters += a1.iters + a2.iters;
+            a1.X.reset(); a1.residual.reset(); a2.X.reset(); a2.residual.reset();
+            out.gale.push_back(std::move(a1));
+            out.gale.push_back(std::move(a2));
+        }
+        if (save_state) out.X.push_back(X);
+        fb = feedback(ctx, prob, *X, ctf, cex);
+        out.Kt.push_back(fb.Kt);
+    }
+    const auto w_loop = wall_now();
+    if (env_trace("pool"))
+        std::fprintf(stderr, "[pool] main: %ld misses, %.1f MB; side: %ld misses, %.1f MB\n", ctx->pool.misses(), ctx->pool.total_bytes() / 1048576.0,
+                     side ? side->pool.misses() : 0L, side ? side->pool.total_bytes() / 1048576.0 : 0.0);
+    sx.report();
+    if (x_is_dense) X = dense_to_ldlt(ctx, n, sx.X, ctf);
+    if (!save_state) out.X.push_back(X);
+    out.nfactor = cache.nfactor;
+    if (wall_on) {
+        const auto w_end = wall_now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[wall, ms] first step %.2f | steps 2..%d %.2f | final form %.2f\n", ms(w_begin, w_first), nsteps, ms(w_first, w_loop), ms(w_loop, w_end));
+    }
+    return out;
+}
+
+
+}  // namespace dre

@@ -17,7 +17,7 @@ residual update, the increment bookkeeping and the shift sequence are replicated
 (src/LDLt.jl:77-89 in Gram form) is ROW sharded here (replicated in the library: k x k is tiny).  Sparse factorisations are replicated.
 
 `RowShardedCompress` is SURVEY.md §8e item 3: `compress!` (src/LDLt.jl:204-225) of the replicated increment slab with the ROWS of the factor
-sharded, in the randomized form the single-GPU engine uses for wide factors (engine.hip, sketch_compress): two all_reduces of c x s
+sharded, in the randomized form the single-GPU engine uses for wide factors (ldlt.hip, sketch_compress): two all_reduces of c x s
 matrices (L'Om and Q'L), one all_gather of the s x s triangles of a TSQR and two scalar reductions; the n x c factor itself never moves.
 
 Backends: `HipOps` (the C ABI of libdre_hip on this rank's GPU); the CPU stand-in used by the gloo tests lives in tests/_numpy_ops.py —
@@ -250,7 +250,7 @@ class ColumnShardedADI:
 
 class RowShardedCompress:
     """compress!(X) (src/LDLt.jl:204-225) for X = sum_b alpha_b L_b D_b L_b' with the rows of every L_b sharded over the ranks (this rank
-    passes its row block of each factor).  Randomized range finder as in engine.hip sketch_compress, every contraction over the state
+    passes its row block of each factor).  Randomized range finder as in ldlt.hip sketch_compress, every contraction over the state
     dimension n done on the local rows and completed by a collective on a SMALL matrix:
 
         W  = sum_r L_r' Om_r                      all_reduce  (c x (s + 16))

@@ -114,7 +114,7 @@ def test_factor_form_compression(ctx, n, c, r, nblk):
 
 
 def test_randomized_compression_of_wide_factors(ctx):
-    """engine.hip sketch_compress: from the second compression of a wide factor (c >= 320, c >= 1.25 s) at an order n >= 2561 on, the range is found
+    """ldlt.hip sketch_compress: from the second compression of a wide factor (c >= 320, c >= 1.25 s) at an order n >= 2561 on, the range is found
     with a Gaussian sketch whose width is the previous rank + 48.  Same rank: accepted; rank far beyond the sketch: rejected (fewer than 32
     unused sketch directions) and the factor-form reduction takes over.  Both against the dense sum and against the engine with the sketch off."""
     rng = np.random.default_rng(7)
@@ -149,7 +149,7 @@ def test_randomized_compression_of_wide_factors(ctx):
     r1 = run(60, 1)             # first compression at this order: factor form, leaves the rank hint
     r2 = run(60, 2)             # sketch of width r1 + 48: accepted
     r3 = run(200, 3)            # rank far beyond the sketch: rejected, factor form again
-    r4 = run(200, 4)            # sketch with the new hint, orthonormalised by blocked Cholesky QR (engine.hip orth_cholqr)
+    r4 = run(200, 4)            # sketch with the new hint, orthonormalised by blocked Cholesky QR (ldlt.hip orth_cholqr)
     ctx.set_option("compress_sketch_cholqr", 0)
     r4h = run(200, 4)           # the same sketch through Householder panels
     ctx.set_option("compress_sketch_cholqr", 1)
