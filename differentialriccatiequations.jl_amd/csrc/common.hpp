@@ -179,7 +179,7 @@ struct Ctx {
     int x_side_stream = 1;
     // dense-X time loop: the side stream's set-up (SMW products, stacks) is enqueued after this many panels of the residual's band
     // reduction (the device is busy with them); -1: inside the reduction's read-back
-    int side_after_panels = -1;
+    int side_after_panels = 1;
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)
     int setup_batched = 1;
     // self-generated shift lists: the upcoming factorisations that are not in flight yet go out in shared launches (engine.hip, prefetch_ahead)

@@ -1420,6 +1420,12 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     FactorCache cache;
     if (ros1_recurrence_ok(ctx, prob, order, adi) && nsteps >= 1) {
         ros1_recurrence_loop(ctx, prob, dt, save_state, adi, nsteps, out, cache, fb);
+        if (env_trace("pool")) {
+            std::fprintf(stderr, "[pool] main: %ld misses, %.1f MB; side: %ld misses, %.1f MB;", ctx->pool.misses(), ctx->pool.total_bytes() / 1048576.0,
+                         ctx->side ? ctx->side->pool.misses() : 0L, ctx->side ? ctx->side->pool.total_bytes() / 1048576.0 : 0.0);
+            for (size_t h = 0; h < ctx->helpers.size(); ++h) std::fprintf(stderr, " helper %zu: %ld misses, %.1f MB;", h, ctx->helpers[h]->pool.misses(), ctx->helpers[h]->pool.total_bytes() / 1048576.0);
+            std::fprintf(stderr, "\n");
+        }
         out.nfactor = cache.nfactor;
         return out;
     }
