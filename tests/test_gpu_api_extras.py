@@ -333,3 +333,48 @@ def test_row_sharded_compression_device_ops_single_rank(ctx):
     outc = RowShardedCompress(cops, comm).compress([(V.cpu(), S, c) for V, c in res["increments"]], 371, sketch=192)
     Lc = outc["L_rows"].numpy()
     assert abs(outc["rank"] - out["rank"]) <= 2 and np.linalg.norm((Lc * outc["eigenvalues"]) @ Lc.T - Xh) < 1e-12 * np.linalg.norm(ref)
+
+
+def test_batched_result_exports_equal_the_per_item_calls(ctx, rail371):
+    """dre_gdre_result_K_all / dre_gdre_result_gales_all (one launch + one copy for sol.K, one call for every solve record; round 4) against the per-item
+    entry points dre_gdre_result_K / dre_gdre_result_gale / dre_gdre_result_gale_history they replace in `solve_gdre`: bit-identical."""
+    import ctypes as C
+    d, L, Dm = rail371
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    pencil = D.Pencil(d.E, d.A, ctx)
+    Bd, Cd = ctx.upload(d.B), ctx.upload(d.C)
+    X0 = D.DeviceLDLt.create(ctx, pencil, L, Dm, 1.0)
+    opt, keep = D.device.make_adi_options(shift_kind=0, shifts=p, maxiters=200)
+    lib, r = ctx.lib, C.c_void_p()
+    ctx.chk(lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0.ptr, 4500.0, 4000.0, -100.0, 1, 0, C.byref(opt), C.byref(r)))
+    try:
+        ii = (C.c_int64 * 7)()
+        lib.dre_gdre_result_info(r, ii)
+        nt, ngale, m, n = int(ii[0]), int(ii[4]), int(ii[5]), int(ii[6])
+        assert nt == 6 and ngale == 5 and (m, n) == d.B.T.shape
+        pd, pi64, pi32 = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        Kall = np.zeros((nt, n, m))
+        ctx.chk(lib.dre_gdre_result_K_all(ctx.ptr, r, Kall.ctypes.data_as(pd)))
+        for i in range(nt):
+            K = np.zeros((m, n), order="F")
+            ctx.chk(lib.dre_gdre_result_K(ctx.ptr, r, i, K.ctypes.data_as(pd), m))
+            assert np.array_equal(K, Kall[i].T) and np.abs(K).max() > 0
+        gi, gd = np.zeros((ngale, 6), dtype=np.int64), np.zeros((ngale, 2))
+        lib.dre_gdre_result_gales_all(r, gi.ctypes.data_as(pi64), gd.ctypes.data_as(pd), None, None, None, None)
+        nn, ns = int(gi[:, 4].sum()), int(gi[:, 5].sum())
+        norms, nit, sre, sim = np.zeros(nn), np.zeros(nn, dtype=np.int32), np.zeros(ns), np.zeros(ns)
+        lib.dre_gdre_result_gales_all(r, None, None, norms.ctypes.data_as(pd), nit.ctypes.data_as(pi32), sre.ctypes.data_as(pd), sim.ctypes.data_as(pd))
+        on = os_ = 0
+        for j in range(ngale):
+            i4, d2, cnt = (C.c_int64 * 4)(), (C.c_double * 2)(), (C.c_int64 * 2)()
+            lib.dre_gdre_result_gale(r, j, i4, d2)
+            lib.dre_gdre_result_gale_history(r, j, cnt, None, None, None, None)
+            assert list(gi[j, :4]) == list(i4) and list(gd[j]) == list(d2) and list(gi[j, 4:]) == list(cnt)
+            a, b, c, e = np.zeros(cnt[0]), np.zeros(cnt[0], dtype=np.int32), np.zeros(cnt[1]), np.zeros(cnt[1])
+            lib.dre_gdre_result_gale_history(r, j, cnt, a.ctypes.data_as(pd), b.ctypes.data_as(pi32), c.ctypes.data_as(pd), e.ctypes.data_as(pd))
+            assert np.array_equal(a, norms[on:on + cnt[0]]) and np.array_equal(b, nit[on:on + cnt[0]])
+            assert np.array_equal(c, sre[os_:os_ + cnt[1]]) and np.array_equal(e, sim[os_:os_ + cnt[1]])
+            on += cnt[0]; os_ += cnt[1]
+        assert on == nn and os_ == ns and nn > ngale
+    finally:
+        lib.dre_gdre_result_free(r)
