@@ -8,7 +8,7 @@ import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel ms", tot/1e6)
-for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:22]:
+for r in sorted(rows,key=lambda r:-float(r["TotalDurationNs"]))[:45]:
     print(f'{r["Name"][:64]:64s} calls {int(r["Calls"]):6d} tot_ms {float(r["TotalDurationNs"])/1e6:8.3f} avg_us {float(r["AverageNs"])/1e3:8.2f} {float(r["TotalDurationNs"])/tot*100:5.1f}%')
 PY
 cat gpurun_out/prof_d.json
