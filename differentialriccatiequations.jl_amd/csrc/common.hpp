@@ -182,6 +182,7 @@ struct Ctx {
     int side_after_panels = 1;
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)
     int setup_batched = 1;
+    int xwarm_sx = 0;          // residual-recurrence loop: fresh sketch columns of the warm-started compression of X on the side stream (0 = by configuration: gdre.hip)
     // self-generated shift lists: the upcoming factorisations that are not in flight yet go out in shared launches (engine.hip, prefetch_ahead)
     int prefetch_batch = 4;    // low-water mark: refill (in one batch) when at most this many are in flight; 0 = off
     int x_compress_every = 1;

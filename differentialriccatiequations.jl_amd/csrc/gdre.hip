@@ -1133,7 +1133,9 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     cur->step = 0; cur->X = prob.X0; cur->EtL = fb0.EtL;
     auto get_state = [&]() { std::lock_guard<std::mutex> lk(smu); return cur; };
     std::vector<LDLtP> saved((size_t)nsteps + 1);
-    int xwarm_sx = 32, xwarm_strikes = 0;           // warm-started compression of X on the side stream (touched by the worker only)
+    // fresh sketch columns: 64 where the jobs run beside the time loop (only the last one is waited for, and with 32 its fresh block trips the
+    // Cholesky-QR flag at n = 5177: full sketch compression in the final flush, 1.9 ms per solve); 32 with save_state (a job per step)
+    int xwarm_sx = ctx->xwarm_sx > 0 ? ctx->xwarm_sx : (save_state ? 32 : 64), xwarm_strikes = 0;           // warm-started compression of X on the side stream (touched by the worker only)
     std::vector<LBlock> pend;                       // increments the side stream has not been handed yet
     int pend_upto = 0;
     bool job_pending = false;
