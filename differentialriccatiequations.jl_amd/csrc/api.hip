@@ -173,6 +173,8 @@ int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
         else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
         else if (key == "side_after_panels") ctx->c.side_after_panels = (int)value;
         else if (key == "setup_batched") ctx->c.setup_batched = (int)value;
+        else if (key == "dense_warm") ctx->c.dense_warm = (int)value;
+        else if (key == "side_prefetch") ctx->c.side_prefetch = (int)value;
         else if (key == "xwarm_sx") ctx->c.xwarm_sx = (int)value;
         else if (key == "prefetch_batch") ctx->c.prefetch_batch = (int)value;
         else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;

@@ -180,6 +180,11 @@ struct Ctx {
     // dense-X time loop: the side stream's set-up (SMW products, stacks) is enqueued after this many panels of the residual's band
     // reduction (the device is busy with them); -1: inside the reduction's read-back
     int side_after_panels = 1;
+    // dense-X time loop: warm-started compression of the residual (warm.hip: Rayleigh-Ritz in the previous step's basis, probe verified); 0: the
+    // full band reduction at every step
+    int dense_warm = 1;
+    // dense-X time loop: the side stream's set-up of step i + 1 is enqueued by a parked host thread at the end of step i (0: inside step i + 1)
+    int side_prefetch = 0;      // (measured at n = 371: 18.3 against 17.8 ms per solve — the join in front of the chain costs more than the earlier start gains)
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)
     int setup_batched = 1;
     int xwarm_sx = 0;          // residual-recurrence loop: fresh sketch columns of the warm-started compression of X on the side stream (0 = by configuration: gdre.hip)

@@ -274,4 +274,14 @@ void lead_rotate_back(Ctx* ctx, const Mat& V0, const Mat& VT0, Mat& B);      // 
 struct LrBlockD { int off, k, ldd, diag; const double* D; double alpha; };
 SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, double tolfac, double abs_tol = -1.0, bool tol_is_floor = false);   // Lx = [L | 16 spare columns]
 
+// warm-started compression of the dense-X time loop's residual (warm.hip): fresh directions Z_1 = (I - QQ') Y_f with their whitening factor, Z and
+// Res Z, the small generalized eigenproblem with the truncation decision and the solve's tolerances, R = B Uc with the probe's decision
+void warm_project(Ctx* ctx, int n, int q, const Mat& Q, const Mat& Yf, const Mat& Pf, Mat& Z1, double* slab, int* ticket, double* Cw);
+void warm_z(Ctx* ctx, int n, const Mat& Z1, const double* Cw, const Mat& Res, Mat& Zb, Mat& Zy, Mat& W2);
+void warm_small(Ctx* ctx, int q, int m, int kl, int qn, const Mat& Cc, const double* parts, int nparts, double reltol, double abstol, double frac,
+                double budget_frac, double* tols, Mat& Uc, Mat& T, Mat& Cp, int* ticket, Mat* Mout = nullptr, Mat* LTout = nullptr);
+void warm_finish(Ctx* ctx, int n, int q, int kl, const Mat& Q, const Mat& Wk, const Mat& Yp, const Mat& Pp, Mat& R, double* slab, int* ticket, double* tols);
+void warm_ctl(Ctx* ctx, double* tols, int* ticket, int J);
+void warm_eig(Ctx* ctx, int m, const Mat& S, Mat& U);
+
 }  // namespace dre

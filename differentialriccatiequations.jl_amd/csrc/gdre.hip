@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_dense_residual(int n, int q, int m, con
 // chain (dense.hpp, AdiFastArgs::Rpc; four 64-entry blocks per workgroup) — rides on this launch instead of a launch of its own.
 __global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __restrict__ D, int ldd, const double* __restrict__ tols, int maxiters, AdiState* st,
                                                         double* __restrict__ nws, int nws_n, int n, int ct, int nblk, const double* __restrict__ R, int ldr,
-                                                        double* __restrict__ Rp) {
+                                                        double* __restrict__ Rp, const double* __restrict__ warm_tols) {
     if (blockIdx.x > 0) {
         const int blk = (blockIdx.x - 1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (blk >= nblk) return;
@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256) void k_adi_init_state(int J, const double* __r
         st->iters = 0; st->maxiters = maxiters; st->smw_singular = 0;
         st->abstol = tols[0]; st->res_norm = nrm; st->norms[0] = nrm;
         st->done = (nrm <= tols[0]) ? 1 : 0;
+        // warm-started compression (warm.hip): a rejected probe ends the solve before its first iteration — nothing is applied to X, the host
+        // redoes the step with the full band reduction
+        if (warm_tols && warm_tols[5] != 0.0) st->done = 1;
     }
 }
 
@@ -703,15 +706,33 @@ class SideWorker {
     bool busy_ = false, quit_ = false;
 };
 
+// the side stream's set-up of the NEXT time step, enqueued by the parked thread as soon as the step's feedback K is on the main stream
+struct PreSide { CycleOps co; bool ok = true; GaleOperator op; const double* Kt_p = nullptr; bool pending = false; };
+
 struct DenseXState {
+    std::unique_ptr<PreSide> pre;
     Mat X;        // n x n, symmetric
     Mat P1;       // E' X
     Mat P1t;      // X E (= P1'), written by the same SpMM launch
     Mat Kt;       // K' = E' X B  (n x m)
     int hint = 0; // ADI iterations of the previous step
     GroupBase gb; // K-independent operator products of the group chain (built at the first dense step)
+    // warm-started residual compression (warm.hip): QO[b] = [Om_p (16 Gaussian probe columns) | Q], Q = the orthonormal factor of the last
+    // compressed residual (zero padded beyond warm_J); the next factor is written into the other buffer
+    Mat QO[2];
+    int qcur = -1, q_cols = 0, warm_J = 0, dense_steps = 0;
+    // eigenbasis of a cold compression, formed BESIDE the time loop on a helper stream (warm.hip, warm_eig): 0 none, 1 in flight, 2 in use
+    int eig_state = 0, eig_k = 0;
+    Mat eig_Q, eig_T, eig_U;
+    Ctx* eig_hc = nullptr;
+    ~DenseXState() { if (eig_state == 1 && eig_hc) (void)hipStreamSynchronize(eig_hc->stream); }      // (its buffers go back to the pool behind it)
+    SideWorker* worker = nullptr; // parked host thread that enqueues the side stream's set-up beside the main thread (warm path: the step is bound by host launches)
+    double est_ratio = -1.0;      // (probe estimate / tolerance)^2 of the last warm step: what the next truncation may use of the budget
+    DevArr<int> tickets;
+    long warm_used = 0, warm_rejected = 0;
+    bool trace_warm = env_trace("warm");
     // pinned host landing zone: control block, tolerances and the SMW breakdown flag come back with ONE synchronisation per chunk
-    struct Landing { AdiState st; double tols[4]; int serr; };
+    struct Landing { AdiState st; double tols[12]; int serr; };
     Landing* land = nullptr;
     // optional phase timing (DRE_PHASE_TIMING=1): events at the phase boundaries of every step, summed at the end
     bool phase_on = env_trace("phase");
@@ -745,9 +766,32 @@ struct DenseXState {
     DenseXState(const DenseXState&) = delete;
     DenseXState& operator=(const DenseXState&) = delete;
 };
+// SMW products and the (group) stacks of a time step on the side stream: they depend on K only.  Records ctx->side_e2 behind them.
+static void dense_side_setup(Ctx* ctx, Ctx* wctx, DenseXState& sx, const GaleOperator& op, const AdiOptions& adi, FactorCache* cache, int n, int m, CycleOps& co,
+                             bool& co_ok) {
+    if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
+    // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
+    // every step land in the persistent buffers the left-factor descriptors point into
+    const int gwant = group_size_for(ctx, (int)adi.shifts.values.size(), n, m);       // (the MAIN context's options)
+    bool gb_ok = gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8 && sx.gb.g == gwant && sx.gb.tag == op.tag && sx.gb.m == m &&
+                 sx.gb.mus.size() == adi.shifts.values.size();
+    for (size_t i = 0; gb_ok && i < sx.gb.mus.size(); ++i) gb_ok = sx.gb.mus[i] == adi.shifts.values[i].real();
+    co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co, gb_ok ? &sx.gb.wks : nullptr, gb_ok ? &sx.gb.spack : nullptr, gb_ok);
+    if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
+    const bool build_group_base = co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8;
+    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
+    if (build_group_base) {
+        // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
+        // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
+        bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
+        for (size_t i = 0; i < adi.shifts.values.size(); ++i)
+            for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
+        if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
+    }
+}
 // One Ros1 step on the dense state.  Returns false (state untouched) when the fast chain cannot take the step.
 static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperator& op_base, double tau, const AdiOptions& adi, FactorCache* cache,
-                            DenseXState& sx, AdiResult& ar) {
+                            DenseXState& sx, AdiResult& ar, bool more_steps) {
     const Pencil& P = *prob.P;
     const int n = P.n, q = prob.Ct.cols, m = prob.B.cols;
     GaleOperator op = op_base;
@@ -756,33 +800,23 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // SMW products and the folded stacks depend on K only: they are built on the side stream while the main stream assembles and
     // compresses the residual; the ADI chain waits for them through an event
     Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
-    if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));          // K of the previous step is ready here
     sx.mark(ctx, 0);
-    // The side stream is set up (event wait, ~6 launches, allocations: 30-40 us of host time) while the host would otherwise WAIT for the
-    // control block of the band reduction: the device is busy with the panels then, and the chain that needs the result is 150 us away.
     CycleOps co;
-    bool co_ok = true, build_group_base = false;
-    auto side_setup = [&]() {
-        if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
-        // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
-        // every step land in the persistent buffers the left-factor descriptors point into
-        const int gwant = group_size_for(ctx, (int)adi.shifts.values.size(), n, m);       // (the MAIN context's options)
-        bool gb_ok = gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8 && sx.gb.g == gwant && sx.gb.tag == op.tag && sx.gb.m == m &&
-                     sx.gb.mus.size() == adi.shifts.values.size();
-        for (size_t i = 0; gb_ok && i < sx.gb.mus.size(); ++i) gb_ok = sx.gb.mus[i] == adi.shifts.values[i].real();
-        co_ok = cycle_ops_prepare(wctx, op, adi.shifts.values, cache, co, gb_ok ? &sx.gb.wks : nullptr, gb_ok ? &sx.gb.spack : nullptr, gb_ok);
-        if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
-        build_group_base = co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8;
-        if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
-        if (build_group_base) {
-            // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
-            // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
-            bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
-            for (size_t i = 0; i < adi.shifts.values.size(); ++i)
-                for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
-            if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
+    bool co_ok = true, pre_used = false;
+    if (sx.pre && sx.pre->pending) {
+        // the parked thread is enqueueing (or has enqueued) this step's side-stream work since the end of the previous step: it is joined
+        // where `co` is needed, in front of the chain — not here, so that the two threads enqueue their streams side by side
+        PreSide* const pp = sx.pre.get();
+        if (pp->op.tag == op.tag && pp->Kt_p == (const double*)sx.Kt.p) pre_used = true;
+        else {          // (another operator: e.g. a change of the step size) — drop it
+            pp->pending = false;
+            try { sx.worker->wait(); } catch (...) { (void)hipStreamSynchronize(wctx->stream); sx.pre.reset(); throw; }
+            DRE_HIP(hipStreamSynchronize(wctx->stream));
+            sx.pre.reset();
         }
-    };
+    }
+    if (!pre_used && wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));          // K of the previous step is ready here
+    auto side_setup = [&]() { dense_side_setup(ctx, wctx, sx, op, adi, cache, n, m, co, co_ok); };
     // (Enqueueing the side stream's work before the assembly instead of inside the band reduction's first read-back was measured at n = 371 with
     // the group chain: 21.7 against 21.2 ms per solve — the host calls delay the main stream's first kernels by more than the earlier start gains.)
     // Riccati residual at X (= warm-start residual of the step's Lyapunov equation) and the norm of the equation's right-hand side.
@@ -792,48 +826,174 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     const Mat& Y = sx.P1t;                                                      // Y = X E
     spmm_dual(ctx, P, P.valAt.p, P.valEt.p, Y, Mx, EY);       // A' X E and E' X E in one pass over X E
     const int nt = ceil_div(n, 16);
-    DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 4);
+    DevArr<double> part(ctx, (size_t)2 * nt * nt), tols(ctx, 12);
     hipLaunchKernelGGL(k_dense_residual, dim3(nt, nt), dim3(256), 0, ctx->stream, n, q, m, (const double*)prob.Ct.p, prob.Ct.ld, (const double*)sx.Kt.p, sx.Kt.ld,
                        (const double*)Mx.p, Mx.ld, (const double*)EY.p, EY.ld, 1.0 / tau, Res.p, Res.ld, part.p);
     const double reltol = adi.reltol >= 0 ? adi.reltol : n * EPS;
     sx.mark(ctx, 1);
+    // Leaving early (refusal or exception) after the side stream was set up: the caller falls back to the generic ADI on the MAIN stream
+    // with the same factor cache, whose entries (stacks, dense inverses, SMW products) and op.Vt the side stream may still be touching
+    // (ADVICE round 2).  Join both streams on the host before anything of this frame is released or reused.
+    bool* side_async_p = nullptr;
+    auto join_side = [&]() {
+        if (side_async_p && *side_async_p && sx.worker) { *side_async_p = false; try { sx.worker->wait(); } catch (...) {} if (sx.pre) { sx.pre->pending = false; } }
+        if (wctx != ctx) (void)hipStreamSynchronize(wctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    };
+    struct SideGuard { std::function<void()> f; bool armed = false; ~SideGuard() { if (armed) f(); } } side_guard{join_side};
+    bool side_ran = pre_used, side_async = pre_used;
+    if (pre_used) side_guard.armed = true;
+    auto run_side = [&]() { if (!side_ran) { side_ran = true; side_guard.armed = true; side_setup(); } };
+    // the same, handed to the parked worker thread: the main thread goes on enqueueing its own stream and joins before it needs `co`
+    auto run_side_async = [&]() {
+        if (side_ran) return;
+        if (!sx.worker || wctx == ctx) { run_side(); return; }
+        side_ran = true; side_async = true; side_guard.armed = true;
+        const int dev = ctx->device;
+        sx.worker->submit([&side_setup, dev]() { DRE_HIP(hipSetDevice(dev)); side_setup(); });
+    };
+    side_async_p = &side_async;
+    auto join_worker = [&]() {
+        if (!side_async) return;
+        side_async = false;
+        if (sx.pre && sx.pre->pending) {          // the prefetched set-up: take its products over
+            sx.pre->pending = false;
+            try { sx.worker->wait(); } catch (...) { sx.pre.reset(); throw; }
+            co = std::move(sx.pre->co); co_ok = sx.pre->ok;
+            sx.pre.reset();
+        } else sx.worker->wait();
+    };
+    const bool defer_side = wctx != ctx;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
+    // Warm-started compression (warm.hip): Rayleigh-Ritz in the basis of the previous step's residual factor, accepted by a 16-column probe.
+    // Tried from the third dense step of a run on (the second step's residual is several times wider than the first's); a rejected
+    // attempt is redone with the full band reduction below.
+    constexpr int WARM_QCAP = 64;       // widest basis (warm.hip: q + 16 <= 80)
+    if (sx.eig_state == 1 && hipEventQuery(aux_event(ctx, 3)) == hipSuccess) {
+        // the eigenbasis of an earlier cold step's factor is ready (a few steps old by now: the range moves slowly, and the 16 fresh directions
+        // of every warm step pick up what it misses)
+        sx.eig_state = 2;
+        // (its 32 leading directions: the eigenvalues fall off quickly, and the small eigenproblem of the first warm step costs O(m) dependent rounds)
+        sx.qcur = 1; sx.q_cols = std::min(sx.eig_k, 32); sx.warm_J = sx.q_cols; sx.est_ratio = -1.0;
+        sx.eig_Q = Mat(); sx.eig_T = Mat(); sx.eig_U = Mat();
+    }
+    const bool warm_try = ctx->dense_warm != 0 && sx.eig_state == 2 && sx.qcur >= 0 && sx.q_cols >= 16 && sx.q_cols <= WARM_QCAP && sx.dense_steps >= 2 && n >= 96 && n <= 1024 &&
+                          sx.q_cols + 32 <= n && !(ctx->dense_x_max_k > 0 && sx.q_cols > ctx->dense_x_max_k);
+    DevArr<AdiState> st(ctx, 1);
+    AdiState h;
+    std::vector<Mat> keepV;
+    std::vector<BufP> keepRpk;
+    double init_norm = 0.0;
+    Mat Vall, Wall;
+    int acc_total = 0, k = 0, warm_J = -1;
+    std::vector<double> coef;
+    // one attempt at the step: 0 = done, 1 = the warm-started compression was rejected (nothing applied to X), 2 = the fast chain refuses
+    auto attempt = [&](const bool use_warm) -> int {
+    std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 3);
+    ar = AdiResult();
+    keepV.clear(); keepRpk.clear(); coef.clear();
+    init_norm = 0.0; acc_total = 0; warm_J = -1;
+    Mat R, Tm;
+    const double* warm_tols = nullptr;
+    int wnext = -1, wq_next = 0;  // buffer of sx.QO that holds this attempt's factor, its columns
+    if (use_warm) {
+        // B = [Q, Z]: the previous step's eigenbasis + 16 fresh directions; see warm.hip for the six launches
+        const int qb = sx.q_cols, mb = qb + 16;
+        const int kl = std::min(qb, std::max(16, ((sx.warm_J + 15) / 16) * 16));       // the chain's width: the previous rank, rounded up
+        const int qn = std::min(std::min(mb, WARM_QCAP), kl + (ctx->dense_warm == 2 ? 16 : 0));      // columns of the next basis (the leading eigen-directions; dense_warm = 2: 16 spare ones)
+        Mat& QOc = sx.QO[sx.qcur];
+        Mat& QOn = sx.QO[1 - sx.qcur];
+        Mat YB(ctx, n, 64 + qb), Z1(ctx, n, 16), Cc(ctx, mb, 64 + qb), Uc(ctx, mb, qn), Cp(ctx, mb, 16);
+        DevArr<double> slab(ctx, (size_t)nt * 256 + nt + 256);
+        double* const Cw = slab.p + (size_t)nt * 256 + nt;
+        run_side_async();      // (the side stream's dozen launches are enqueued by the parked thread while this one enqueues the compression)
+        gemm_thin(ctx, false, n, 32 + qb, n, 1.0, Res.p, Res.ld, QOc.p, QOc.ld, 0.0, YB.p, YB.ld, nullptr, "warm_project");     // [Y_p, Y_f, W] = Res [Om_p, Om_f, Q]
+        Mat Qb = QOc.colsview(32, qb), Bb = QOc.colsview(32, mb), Yp = YB.colsview(0, 16), Yf = YB.colsview(16, 16);
+        Mat Pf(ctx, qb, 16);
+        gemm_thin(ctx, true, qb, 16, n, 1.0, Qb.p, Qb.ld, Yf.p, Yf.ld, 0.0, Pf.p, Pf.ld, nullptr, "warm_project");                    // P_f = Q'Y_f
+        warm_project(ctx, n, qb, Qb, Yf, Pf, Z1, slab.p, sx.tickets.p, Cw);
+        Mat Zb = QOc.colsview(32 + qb, 16), Zy = YB.colsview(32 + qb, 16), W2 = YB.colsview(48 + qb, 16);
+        warm_z(ctx, n, Z1, Cw, Res, Zb, Zy, W2);
+        gemm_thin(ctx, true, mb, 64 + qb, n, 1.0, Bb.p, Bb.ld, YB.p, YB.ld, 0.0, Cc.p, Cc.ld, nullptr, "warm_project");           // B' [Y_p, Y_f, W, Z, W_2]
+        const double bf = sx.est_ratio < 0.0 ? 0.4 : std::min(0.6, std::max(0.05, 1.0 - 2.6 * sx.est_ratio));
+        if (mb <= 48 || ctx->dense_warm != 3) {
+            Tm = Mat(ctx, kl, kl);
+            warm_small(ctx, qb, mb, kl, qn, Cc, part.p, nt * nt, reltol, adi.abstol, adi.residual_abs_frac, bf, tols.p, Uc, Tm, Cp, sx.tickets.p + 1);
+            Mat Rfull = QOn.colsview(32, qn);
+            warm_finish(ctx, n, mb, qn, Bb, Uc, Yp, Cp, Rfull, slab.p + (size_t)nt * 256, sx.tickets.p + 1, tols.p);
+            R = Rfull.colsview(0, kl);
+            k = kl;
+            wq_next = qn;
+        } else {
+            // wide basis (the first warm steps behind a cold one: its Krylov basis is not an eigenbasis, and a Jacobi iteration on 80 x 80 from
+            // scratch costs a millisecond): the small kernel stops behind the whitening and hands M over; its band reduction (the cold path's
+            // kernels on an 80-row matrix, with their read-back) gives a basis of J_b columns, narrow enough for the Jacobi form from the next step on
+            Mat Mw(ctx, mb, mb), LT(ctx, mb, mb);
+            Tm = Mat(ctx, kl, kl);
+            warm_small(ctx, qb, mb, kl, qn, Cc, part.p, nt * nt, reltol, adi.abstol, adi.residual_abs_frac, bf, tols.p, Uc, Tm, Cp, sx.tickets.p + 1, &Mw, &LT);
+            join_worker();
+            SymBand wsb = sym_band_reduce(ctx, Mw, adi.compress_tolfac, -1.0, tols.p + 3);
+            k = wsb.J;
+            if (k <= 0 || k > WARM_QCAP) return 1;
+            Mat Bq = sym_band_basis(ctx, wsb);             // mb x k
+            Mat Ub(ctx, mb, k);
+            gemm_thin(ctx, false, mb, k, mb, 1.0, LT.p, LT.ld, Bq.p, Bq.ld, 0.0, Ub.p, Ub.ld, nullptr, "warm_project");
+            Tm = wsb.D;
+            warm_ctl(ctx, tols.p, sx.tickets.p + 1, k);
+            Mat Rfull = QOn.colsview(32, k);
+            warm_finish(ctx, n, mb, k, Bb, Ub, Yp, Cp, Rfull, slab.p + (size_t)nt * 256, sx.tickets.p + 1, tols.p);
+            R = Rfull;
+            wq_next = k;
+            keepV.push_back(Mw); keepV.push_back(LT); keepV.push_back(Bq); keepV.push_back(Ub);
+        }
+        keepV.push_back(YB); keepV.push_back(Pf); keepV.push_back(Z1); keepV.push_back(Cc); keepV.push_back(Uc); keepV.push_back(Cp);
+        keepRpk.push_back(slab.buf);
+        warm_tols = tols.p;
+        wnext = 1 - sx.qcur;
+        join_worker();
+    } else {
     // residual factor: Res ~ Q D Q' (band reduction, truncated at a fraction of abstol like the warm-start residual of the generic path)
     BandSpec spec;
     // tols[0] = abstol = reltol ||C_rhs||_F (adi.jl:61-62), tols[1] = truncation tolerance of the residual compression, tols[2] = ||C_rhs||_F:
     // computed by the reduction's control-block launch
     spec.tol_parts = part.p; spec.tol_nparts = nt * nt; spec.tol_reltol = reltol; spec.tol_abstol = adi.abstol; spec.tol_frac = adi.residual_abs_frac;
     spec.tols_out = tols.p;
-    const bool defer_side = wctx != ctx;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
-    if (defer_side) { spec.extra = side_setup; spec.extra_after = ctx->side_after_panels; }
-    else side_setup();
+    if (defer_side && !side_ran) { spec.extra = run_side; spec.extra_after = ctx->side_after_panels; }
+    else run_side();        // (a prefetched set-up is joined behind the reduction: the parked thread may still be enqueueing it)
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
-    if (defer_side && !spec.ran) side_setup();
-    // Leaving early (refusal or exception) after the side stream was set up: the caller falls back to the generic ADI on the MAIN stream
-    // with the same factor cache, whose entries (stacks, dense inverses, SMW products) and op.Vt the side stream may still be touching
-    // (ADVICE round 2).  Join both streams on the host before anything of this frame is released or reused.
-    auto join_side = [&]() {
-        if (wctx != ctx) (void)hipStreamSynchronize(wctx->stream);
-        (void)hipStreamSynchronize(ctx->stream);
-    };
-    struct SideGuard { std::function<void()> f; bool armed = true; ~SideGuard() { if (armed) f(); } } side_guard{join_side};
-    if (!co_ok) return false;
-    sx.mark(ctx, 2);
-    const int k = sb.J;
-    DevArr<AdiState> st(ctx, 1);
-    AdiState h;
-    std::memset(&h, 0, sizeof(int) * 4 + sizeof(double) * 3);
-    ar = AdiResult();
-    ar.rhs_cols = k;
-    if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return false;
-    std::vector<Mat> keepV;
-    std::vector<BufP> keepRpk;
-    double init_norm = 0.0;
-    Mat Vall, Wall;
-    int acc_total = 0;
-    std::vector<double> coef;
+    run_side();
+    join_worker();
+    k = sb.J;
     if (k > 0) {
-        Mat R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
-        Mat Tm = sb.D;
+        R = spec.hit ? spec.B : sym_band_basis(ctx, sb);        // predicted rank: the basis was enqueued during the read-back
+        Tm = sb.D;
+        if (ctx->dense_warm != 0 && sx.eig_state != 1 && k >= 16 && k <= WARM_QCAP && k + 32 <= n && n >= 96 && n <= 1024 && sx.dense_steps >= 1) {
+            // Turn this factor into an EIGENBASIS beside the time loop: a Jacobi iteration on T (k x k, a band matrix in Krylov order) takes about a
+            // millisecond in one workgroup — on a helper stream it costs the time loop nothing, and the warm-started compression (warm.hip) that
+            // takes over when it is done starts from a nearly diagonal matrix.  Q and T are snapshots: the next cold steps reuse their buffers.
+            if (sx.QO[0].empty()) {
+                for (int b = 0; b < 2; ++b) { sx.QO[b] = Mat(ctx, n, 32 + WARM_QCAP + 16); Mat om = sx.QO[b].colsview(0, 32); fill_gauss(ctx, om, 0x7F4A7C159E3779B9ull); }
+                sx.tickets = DevArr<int>(ctx, 4);
+                DRE_HIP(hipMemsetAsync(sx.tickets.p, 0, 4 * sizeof(int), ctx->stream));
+            }
+            Ctx* const hc = helper_ctx(ctx, 0);
+            sx.eig_hc = hc;
+            sx.eig_Q = Mat(ctx, n, k); sx.eig_T = Tm; sx.eig_U = Mat(ctx, k, k); sx.eig_k = k;
+            copy_mat(ctx, R, sx.eig_Q);
+            DRE_HIP(hipEventRecord(aux_event(ctx, 2), ctx->stream));
+            DRE_HIP(hipStreamWaitEvent(hc->stream, aux_event(ctx, 2), 0));
+            warm_eig(hc, k, sx.eig_T, sx.eig_U);
+            Mat dst = sx.QO[1].colsview(32, k);
+            gemm_thin(hc, false, n, k, k, 1.0, sx.eig_Q.p, sx.eig_Q.ld, sx.eig_U.p, sx.eig_U.ld, 0.0, dst.p, dst.ld, nullptr, "warm_project");
+            DRE_HIP(hipEventRecord(aux_event(ctx, 3), hc->stream));
+            sx.eig_state = 1;
+        }
+    }
+    }
+    if (!co_ok) return 2;
+    sx.mark(ctx, 2);
+    ar.rhs_cols = k;
+    if (k > ADI_FAST_MAX_K || (ctx->dense_x_max_k > 0 && k > ctx->dense_x_max_k)) return 2;
+    if (k > 0) {
         DevArr<double> nws(ctx, ADI_FAST_NWS);
         int mode0 = 0, nt0 = 0;
         adi_fast_pick(n, k, &mode0, &nt0);
@@ -842,7 +1002,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         DevArr<double> Rp0(ctx, use_pk ? rpd : 1);                  // the initial residual in the fast chain's B-operand order (slot 0 of the first chunk)
         const int pk_ct = (k + 15) / 16, pk_nblk = use_pk ? 4 * adi_fast_nstrip(n) * pk_ct : 0;
         hipLaunchKernelGGL(k_adi_init_state, dim3(1 + (pk_nblk + 3) / 4), dim3(256), 0, ctx->stream, k, (const double*)Tm.p, Tm.ld, (const double*)tols.p, adi.maxiters, st.p, nws.p,
-                           ADI_FAST_NWS, n, pk_ct, pk_nblk, (const double*)R.p, R.ld, Rp0.p);
+                           ADI_FAST_NWS, n, pk_ct, pk_nblk, (const double*)R.p, R.ld, Rp0.p, warm_tols);
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
         sx.mark(ctx, 3);
         const int nstrip = adi_fast_nstrip(n), kst = adi_fast_kst(n);
@@ -989,10 +1149,15 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
                     Mat Vch = Vall.colsview(vcols_used, k * nit);
                     gemm_sym_update(ctx, Wc, Vch, sx.X, "gemm_xupdate", dc);
                 };
-                ctx_fetch_overlap(ctx, between, st.p, stb, &sx.land->st, tols.p, 4 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
+                ctx_fetch_overlap(ctx, between, st.p, stb, &sx.land->st, tols.p, 12 * sizeof(double), sx.land->tols, m ? (const void*)co.serr8.p : nullptr, m ? 8 : 0, &serr8);
                 sx.land->serr = (int)serr8;
             }
             h = sx.land->st;
+            if (use_warm && base_it == 0 && sx.trace_warm)
+                std::fprintf(stderr, "[warm] step %d basis %d -> launch width %d, J = %d, missed^2 %.2e, dropped^2 %.2e, tol^2 %.2e %s  (Jacobi: %.4f sweeps.rounds, set-up %.1f us, sweeps %.1f us = %.0f cycles)\n", sx.dense_steps + 1, sx.q_cols, k,
+                             (int)sx.land->tols[4], sx.land->tols[6], sx.land->tols[7], sx.land->tols[1] * sx.land->tols[1], sx.land->tols[5] != 0.0 ? "REJECTED" : "accepted",
+                             sx.land->tols[3], sx.land->tols[8], sx.land->tols[9], sx.land->tols[10]);
+            if (use_warm && base_it == 0 && sx.land->tols[5] != 0.0) return 1;     // the probe rejected the basis: the solve ended before its first iteration
             const int acc_it = std::min(std::max(h.iters - base_it, 0), nit);
             for (int j = 1; j <= acc_it; ++j) { ar.norms.push_back(h.norms[(base_it + j) & 511]); ar.norm_iters.push_back(base_it + j); }
             if (base_it == 0) init_norm = h.norms[0];
@@ -1025,6 +1190,23 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         DRE_HIP(hipStreamSynchronize(ctx->stream));
         if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_e2, 0));
     }
+    // the factor of this step's residual is the next step's basis
+    if (!use_warm) {
+        if (sx.eig_state == 2) { sx.eig_state = 0; sx.qcur = -1; }        // (a rejected warm step: the next cold factor gets a fresh eigenbasis)
+    } else if (wnext >= 0 && k > 0) {
+        sx.qcur = wnext; sx.q_cols = wq_next;
+        sx.warm_J = use_warm ? std::max(0, std::min(k, (int)sx.land->tols[4])) : k;
+        const double t2 = sx.land->tols[1] * sx.land->tols[1];
+        sx.est_ratio = (use_warm && t2 > 0.0) ? sx.land->tols[6] / t2 : -1.0;
+        if (use_warm) ar.rhs_cols = sx.warm_J;
+    } else sx.qcur = -1;
+    return 0;
+    };
+    int rc = 1;
+    if (warm_try) { rc = attempt(true); if (rc == 1) sx.warm_rejected++; else if (rc == 0) sx.warm_used++; }
+    if (rc == 1) rc = attempt(false);
+    if (rc != 0) return false;
+    sx.dense_steps++;
     ar.abstol = sx.land->tols[0];
     ar.iters = acc_total;
     ar.initial_norm = k > 0 ? init_norm : 0.0;
@@ -1042,6 +1224,22 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     sx.Kt = Kt;
     sx.mark(ctx, 6);
     side_guard.armed = false;          // the main stream waited for side_e2 above: nothing of the side stream is pending
+    if (more_steps && sx.worker && wctx != ctx && ctx->side_prefetch != 0) {
+        // the next step's SMW products and stacks depend on this K only: the parked thread enqueues them NOW (behind an event on the main stream),
+        // so that they are finished when the next step's compression is — the side stream's 100 us no longer start after the host has enqueued
+        // the next step's main-stream kernels
+        DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
+        sx.pre = std::make_unique<PreSide>();
+        PreSide* const pp = sx.pre.get();
+        pp->op = op_base; pp->op.Vt = sx.Kt; pp->Kt_p = (const double*)sx.Kt.p; pp->pending = true;
+        DenseXState* const sxp = &sx;
+        const AdiOptions* const adip = &adi;
+        const int dev = ctx->device;
+        sx.worker->submit([ctx, wctx, sxp, pp, adip, cache, n, m, dev]() {
+            DRE_HIP(hipSetDevice(dev));
+            dense_side_setup(ctx, wctx, *sxp, pp->op, *adip, cache, n, m, pp->co, pp->ok);
+        });
+    }
     return true;
 }
 
@@ -1466,6 +1664,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     DenseXState sx;
     sx.attach(ctx);
     SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
+    sx.worker = &side_worker;
     bool sx_init = false, x_is_dense = false;
 
     const bool wall_on = env_trace("phase");
@@ -1511,7 +1710,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
                 sx_init = true;
             }
             AdiResult ar;
-            if (ros1_dense_step(ctx, prob, op, tau, adi, &cache, sx, ar)) {
+            if (ros1_dense_step(ctx, prob, op, tau, adi, &cache, sx, ar, i < nsteps)) {
                 out.adi_iters += ar.iters;
                 out.gale.push_back(std::move(ar));
                 out.Kt.push_back(sx.Kt);
