@@ -726,6 +726,7 @@ struct DenseXState {
     Mat eig_Q, eig_T, eig_U;
     Ctx* eig_hc = nullptr;
     ~DenseXState() { if (eig_state == 1 && eig_hc) (void)hipStreamSynchronize(eig_hc->stream); }      // (its buffers go back to the pool behind it)
+    bool base_pending = false;    // the parked thread is still enqueueing the group chain's K-independent base (first dense step of a run)
     SideWorker* worker = nullptr; // parked host thread that enqueues the side stream's set-up beside the main thread (warm path: the step is bound by host launches)
     double est_ratio = -1.0;      // (probe estimate / tolerance)^2 of the last warm step: what the next truncation may use of the budget
     DevArr<int> tickets;
@@ -767,8 +768,19 @@ struct DenseXState {
     DenseXState& operator=(const DenseXState&) = delete;
 };
 // SMW products and the (group) stacks of a time step on the side stream: they depend on K only.  Records ctx->side_e2 behind them.
+static void dense_group_base(Ctx* ctx, Ctx* wctx, DenseXState& sx, const GaleOperator& op, const AdiOptions& adi, const CycleOps& co, int n, int m) {
+    (void)ctx; (void)n; (void)m;
+    // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
+    // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
+    const int gwant = group_size_for(ctx, (int)adi.shifts.values.size(), n, m);
+    bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
+    for (size_t i = 0; i < adi.shifts.values.size(); ++i)
+        for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
+    if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
+}
+// want_base (optional): the K-independent base of the group chain is NOT built here; *want_base tells the caller to do it (dense_group_base)
 static void dense_side_setup(Ctx* ctx, Ctx* wctx, DenseXState& sx, const GaleOperator& op, const AdiOptions& adi, FactorCache* cache, int n, int m, CycleOps& co,
-                             bool& co_ok) {
+                             bool& co_ok, bool* want_base = nullptr) {
     if (wctx != ctx) DRE_HIP(hipStreamWaitEvent(wctx->stream, ctx->side_e1, 0));
     // group chain: the K-independent operator products are built at the first dense step of a run; from then on the SMW products of
     // every step land in the persistent buffers the left-factor descriptors point into
@@ -780,14 +792,8 @@ static void dense_side_setup(Ctx* ctx, Ctx* wctx, DenseXState& sx, const GaleOpe
     if (co_ok && gb_ok) group_ops_prepare(wctx, adi.shifts.values, co, sx.gb);
     const bool build_group_base = co_ok && !gb_ok && gwant >= 2 && (int)adi.shifts.values.size() / gwant <= 8;
     if (wctx != ctx) DRE_HIP(hipEventRecord(ctx->side_e2, wctx->stream));
-    if (build_group_base) {
-        // first dense step of a run: the K-independent operator products (8 GEMMs + ~30 small launches per run) are formed on the side
-        // stream BEHIND the event the chain waits for — this step runs the one-iteration chain, the group chain takes over from the next
-        bool distinct = true;                       // (a cycle with repeated values keeps the single-iteration chain)
-        for (size_t i = 0; i < adi.shifts.values.size(); ++i)
-            for (size_t j = 0; j < i; ++j) distinct = distinct && adi.shifts.values[i].real() != adi.shifts.values[j].real();
-        if (distinct) group_base_build(wctx, op, adi.shifts.values, co, sx.gb, gwant);
-    }
+    if (want_base) *want_base = build_group_base;
+    else if (build_group_base) dense_group_base(ctx, wctx, sx, op, adi, co, n, m);
 }
 // One Ros1 step on the dense state.  Returns false (state untouched) when the fast chain cannot take the step.
 static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperator& op_base, double tau, const AdiOptions& adi, FactorCache* cache,
@@ -801,8 +807,9 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // compresses the residual; the ADI chain waits for them through an event
     Ctx* const wctx = (ctx->side && ctx->x_side_stream) ? ctx->side.get() : ctx;
     sx.mark(ctx, 0);
+    if (sx.base_pending) { sx.base_pending = false; sx.worker->wait(); }
     CycleOps co;
-    bool co_ok = true, pre_used = false;
+    bool co_ok = true, pre_used = false, want_base = false;
     if (sx.pre && sx.pre->pending) {
         // the parked thread is enqueueing (or has enqueued) this step's side-stream work since the end of the previous step: it is joined
         // where `co` is needed, in front of the chain — not here, so that the two threads enqueue their streams side by side
@@ -837,6 +844,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     bool* side_async_p = nullptr;
     auto join_side = [&]() {
         if (side_async_p && *side_async_p && sx.worker) { *side_async_p = false; try { sx.worker->wait(); } catch (...) {} if (sx.pre) { sx.pre->pending = false; } }
+        if (sx.base_pending && sx.worker) { sx.base_pending = false; try { sx.worker->wait(); } catch (...) {} }
         if (wctx != ctx) (void)hipStreamSynchronize(wctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
     };
@@ -850,7 +858,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         if (!sx.worker || wctx == ctx) { run_side(); return; }
         side_ran = true; side_async = true; side_guard.armed = true;
         const int dev = ctx->device;
-        sx.worker->submit([&side_setup, dev]() { DRE_HIP(hipSetDevice(dev)); side_setup(); });
+        sx.worker->submit([&, dev]() { DRE_HIP(hipSetDevice(dev)); dense_side_setup(ctx, wctx, sx, op, adi, cache, n, m, co, co_ok, &want_base); });
     };
     side_async_p = &side_async;
     auto join_worker = [&]() {
@@ -862,6 +870,18 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             co = std::move(sx.pre->co); co_ok = sx.pre->ok;
             sx.pre.reset();
         } else sx.worker->wait();
+        if (want_base) {
+            // the base of the group chain (~250 launches on the side stream, once per run) is enqueued by the parked thread while this one goes
+            // on with the chain; the next step joins it.  (It reads the cycle's factors and stacks: shared with `co` through reference counts.)
+            want_base = false;
+            auto cop = std::make_shared<CycleOps>(co);
+            const GaleOperator opc = op;
+            DenseXState* const sxp = &sx;
+            const AdiOptions* const adip = &adi;
+            const int dev = ctx->device;
+            sx.base_pending = true;
+            sx.worker->submit([ctx, wctx, sxp, opc, adip, cop, n, m, dev]() { DRE_HIP(hipSetDevice(dev)); dense_group_base(ctx, wctx, *sxp, opc, *adip, *cop, n, m); });
+        }
     };
     const bool defer_side = wctx != ctx;      // (on ONE context the set-up's own read-backs would nest inside the reduction's: it runs first then)
     // Warm-started compression (warm.hip): Rayleigh-Ritz in the basis of the previous step's residual factor, accepted by a 16-column probe.
@@ -957,8 +977,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
     // computed by the reduction's control-block launch
     spec.tol_parts = part.p; spec.tol_nparts = nt * nt; spec.tol_reltol = reltol; spec.tol_abstol = adi.abstol; spec.tol_frac = adi.residual_abs_frac;
     spec.tols_out = tols.p;
-    if (defer_side && !side_ran) { spec.extra = run_side; spec.extra_after = ctx->side_after_panels; }
-    else run_side();        // (a prefetched set-up is joined behind the reduction: the parked thread may still be enqueueing it)
+    run_side_async();        // (joined behind the reduction: the parked thread enqueues the side stream while this one enqueues the panels)
     SymBand sb = sym_band_reduce(ctx, Res, adi.compress_tolfac, -1.0, tols.p + 1, &spec, part.p + (size_t)nt * nt, nt * nt);
     run_side();
     join_worker();
