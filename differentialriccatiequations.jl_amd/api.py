@@ -643,6 +643,9 @@ def _replay_gale(observer, prob, alg, info):
         _call(observer, "observe_gale_failed")
 
 
+WARN_NOT_CONVERGED, WARN_ZERO_INCREMENT, WARN_RITZ_DISCARDED, WARN_RITZ_FLIPPED, WARN_PIVOT_GROWTH = 1, 2, 4, 8, 16      # include/dre_hip.h
+
+
 def _adi_result_info(ctx, rptr):
     lib = ctx.lib
     ii = (C.c_int64 * 5)()
@@ -690,7 +693,11 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
         ctx.lib.dre_adi_result_free(r)
     _replay_gale(observer, prob, alg, info)
     _call(observer, "observe_gale_done", info["iters"], X, None, info["res_norm"])
-    if not info["converged"] and alg.warn_convergence:
+    if info["warnings"] & WARN_ZERO_INCREMENT:
+        warnings.warn("Increment is zero")                      # adi.jl:201 (the iteration collapsed: isdone, adi.jl:134-137)
+    if not info["converged"] and alg.warn_convergence and info["iters"] >= alg.maxiters:
+        warnings.warn(f"ADI did not converge: residual={info['res_norm']} abstol={info['abstol']} maxiters={alg.maxiters}")
+    elif not info["converged"] and alg.warn_convergence and not (info["warnings"] & WARN_ZERO_INCREMENT):
         warnings.warn(f"ADI did not converge: residual={info['res_norm']} abstol={info['abstol']} maxiters={alg.maxiters}")
     return (X, info) if return_info else X
 

@@ -3817,6 +3817,16 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     const long hkey = (long)q * 2 + ((abs_tol > 0.0 || abs_tol_dev) ? 1 : 0) + (tol_is_floor ? 1000003L : 0L);
     auto hit = ctx->band_hint.find(hkey);
     int chunk = hit != ctx->band_hint.end() ? std::max(2, hit->second + 1) : 4;
+    // the speculative result follows the TREND of the last two reductions of this kind (the ranks of a Rosenbrock run's first residuals fall by
+    // a panel per step: predicting the previous count was wrong every time there, and the basis was formed twice)
+    int predicted = hit != ctx->band_hint.end() ? hit->second : 0;
+    {
+        auto prev2 = ctx->band_hint.find(hkey + 2000003L);
+        if (hit != ctx->band_hint.end() && prev2 != ctx->band_hint.end() && spec) {
+            predicted = std::max(1, hit->second + (hit->second - prev2->second));
+            chunk = std::max(2, std::min(chunk, predicted + 2));
+        }
+    }
     bool first_round = true;
     int deferred_k = -1;
     auto fused_update = [&](int kk) {      // S22 <- S22 - W V' - V W' for the panel at kk (k_band_z + k_band_upd)
@@ -3892,8 +3902,8 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
         // enqueued right behind the read-back kernel, so the device works on them while the control block travels to the host; they
         // are used if the prediction holds and dropped otherwise.
         std::function<void()> between;
-        if (spec && first_round && hit != ctx->band_hint.end() && hit->second > 0 && hit->second * b <= k && hit->second * b < q) {
-            const int Js = hit->second * b, nps = hit->second;
+        if (spec && first_round && hit != ctx->band_hint.end() && predicted > 0 && predicted * b <= k && predicted * b < q) {
+            const int Js = predicted * b, nps = predicted;
             between = [&, Js, nps]() {
                 SymBand tmp = out;
                 tmp.J = Js; tmp.npanels = nps;
@@ -3917,6 +3927,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
         deferred_k = -1;
         chunk = 4;
     }
+    if (hit != ctx->band_hint.end()) ctx->band_hint[hkey + 2000003L] = hit->second;
     ctx->band_hint[hkey] = np;
     out.J = J; out.npanels = np;
     if (spec && spec->J == J && J > 0) { out.D = spec->D; spec->hit = true; DRE_HIP(hipGetLastError()); return out; }
@@ -4327,6 +4338,7 @@ SymBand lr_band_reduce(Ctx* ctx, Mat& Lx, const std::vector<LrBlockD>& blocks, d
         chunk = 4;
     }
     np = J / b;
+    if (hit != ctx->band_hint.end()) ctx->band_hint[hkey + 2000003L] = hit->second;
     ctx->band_hint[hkey] = np;
     out.J = J; out.npanels = np;
     out.D = Mat(ctx, J, J);

@@ -19,7 +19,7 @@ struct AdiState {
     double res_norm;
     double norms[512];   // residual norm after iteration i (index = shifts consumed)
     // meeting point of the g norm workgroups of a fan group (dense.hip, k_gram_norm_z): zeroed with the control block, reset by the last arrival
-    int ticket, pad_;
+    int ticket, collapsed;   // collapsed: scratch of the zero-increment guard (engine.hip, k_zero_increment); 2 = the iteration collapsed (adi.jl:134-137)
     double gnorm[16];
 };
 

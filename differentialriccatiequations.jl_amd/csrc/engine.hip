@@ -735,6 +735,44 @@ hipEvent_t aux_event(Ctx* ctx, int i) {
     if (!ctx->aux_ev[i]) DRE_HIP(hipEventCreateWithFlags(&ctx->aux_ev[i], hipEventDisableTiming));
     return ctx->aux_ev[i];
 }
+// Zero-increment guard (adi.jl:200-204 for every complex pair; :161-165 for a real step under mixed precision, which this engine does not
+// have): the solve returned V = 0 exactly although the residual is above the tolerance.  The reference warns, sets the increment to zero,
+// leaves X and the residual alone and stops (isdone, adi.jl:134-137) — with the pair's two shifts counted.  V = 0 <=> V1 = V2 = 0.  Every
+// workgroup ORs what it saw into the control block; the last arrival takes the decision: done, iters += nshifts, the norm recorded unchanged,
+// `collapsed` = 2 for the host (DRE_WARN_ZERO_INCREMENT).  The step's remaining kernels see `done` and leave R and the norms as they are.
+__global__ __launch_bounds__(256) void k_zero_increment(size_t tot, int n, int k, const double* __restrict__ V1, int ld1, const double* __restrict__ V2, int ld2,
+                                                        AdiState* st, int nshifts) {
+    if (st->done) return;
+    __shared__ int any_sh;
+    if (threadIdx.x == 0) any_sh = 0;
+    __syncthreads();
+    int any = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e % (size_t)n), c = (int)(e / (size_t)n);
+        if (V1[r + (size_t)c * ld1] != 0.0 || V2[r + (size_t)c * ld2] != 0.0) { any = 1; break; }
+    }
+    if (any) any_sh = 1;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (any_sh) atomicOr(&st->collapsed, 1);
+    __threadfence();
+    if (atomicAdd(&st->ticket, 1) != (int)gridDim.x - 1) return;
+    __threadfence();
+    st->ticket = 0;
+    const int seen = __hip_atomic_load(&st->collapsed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen & 1) { st->collapsed = 0; return; }
+    st->collapsed = 2;
+    st->iters += nshifts;
+    st->norms[st->iters & 511] = st->res_norm;
+    st->done = 1;
+}
+void zero_increment_guard(Ctx* ctx, const Mat& V1, const Mat& V2, AdiState* st, int nshifts) {
+    const size_t tot = (size_t)V1.rows * V1.cols;
+    if (tot == 0) return;
+    const unsigned nb = (unsigned)std::min<size_t>(256, (tot + 4095) / 4096);
+    hipLaunchKernelGGL(k_zero_increment, dim3(nb), dim3(256), 0, ctx->stream, tot, V1.rows, V1.cols, (const double*)V1.p, V1.ld, (const double*)V2.p, V2.ld, st, nshifts);
+    DRE_HIP(hipGetLastError());
+}
 struct StepRec { int iters_after; size_t nblocks; int nshifts; Mat Rafter; };      // Rafter: the residual factor after this iteration where it is NOT updated in place (fan groups)
 struct AdiRun {
     Ctx* ctx = nullptr;
@@ -1739,6 +1777,7 @@ void adi_advance(AdiRun& run, int budget) {
                                        n, 0, k, W, n, (const cplx*)nullptr, 0, (const cplx*)nullptr, (const cplx*)nullptr, 0,
                                        V1.p, V1.ld, V2.p, V2.ld, delta, dst);
                 }
+                zero_increment_guard(ctx, V1, V2, st.p, 2);       // adi.jl:200-204
                 // R <- R - 2 sqrt2 Re(mu) E' V1   (adi.jl:217)
                 spmm(ctx, P, P.valEt.p, V1, R, -2.0 * 1.4142135623730951 * mu.real(), 1.0, dst);
                 Xw->blocks.push_back({V1, Tm, -2.0 * mu.real() * alpha_res, tdiag});
@@ -1800,6 +1839,7 @@ void adi_advance(AdiRun& run, int budget) {
             } else if (acc > 0) run.hist_ok = false;
         }
         if (h.smw_singular) throw Error(ERR_SINGULAR, "SMW: capacitance matrix is singular");
+        if (h.collapsed == 2) res.warnings |= 2;          // DRE_WARN_ZERO_INCREMENT: the iteration collapsed (adi.jl:134-137)
         if (h.done || recs.empty()) finished = true;
         if (opt.compression && last_compression >= opt.compression_interval && (!finished || cex)) {
             // Small n: the compression works on the n x n matrix L D L' whatever the number of columns, and the increments

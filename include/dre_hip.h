@@ -40,6 +40,8 @@ extern "C" {
 
 /* warning bits reported by ADI (AdiResult.warnings) */
 #define DRE_WARN_NOT_CONVERGED 1      /* src/lyapunov/adi.jl:125-126 */
+#define DRE_WARN_ZERO_INCREMENT 2     /* src/lyapunov/adi.jl:134-137,200-204: a complex pair's solve returned V = 0 exactly; the increment is zero,
+                                         X and the residual are left alone and the iteration stops with the pair's two shifts counted */
 #define DRE_WARN_RITZ_DISCARDED 4     /* src/shifts/helpers.jl:133 */
 #define DRE_WARN_RITZ_FLIPPED 8       /* src/shifts/helpers.jl:136 */
 #define DRE_WARN_PIVOT_GROWTH 16      /* the pivot-free sparse LU met multipliers above "pivot_growth_warn" (default 1e8); the convergence claim of

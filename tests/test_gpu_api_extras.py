@@ -276,6 +276,54 @@ def test_user_block_solver_plugs_into_adi(ctx):                # blocklinear/typ
     assert my2.calls > 10 and D.delta(sol.K[-1], ref.K[-1]) < 1e-9
 
 
+def test_zero_increment_guard_stops_a_collapsed_complex_step(ctx):          # adi.jl:134-137,200-204
+    """A complex pair whose solve returns V = 0 exactly: the reference warns, sets the increment to zero, leaves X and the residual alone and stops
+    (isdone) with the pair's two shifts counted.  The exact zero comes from a user block solver (the reference saw it under mixed precision);
+    the oracle's adi_double_step gets the same solver."""
+    import scipy.sparse.linalg as spla
+    from test_gpu_ldlt_gale import _rand_pencil
+
+    class ZeroOnComplex(D.BlockLinearSolver):
+        def __init__(self): self.complex_calls = 0
+        def solve(self, prob):
+            if np.iscomplexobj(prob.A.data):
+                self.complex_calls += 1
+                return np.zeros(prob.B.shape, dtype=complex)
+            return spla.splu(prob.A.tocsc()).solve(prob.B.astype(prob.A.dtype))
+
+    rng = np.random.default_rng(5)
+    n = 60
+    E, A = _rand_pencil(rng, n, True, False)
+    Cl = D.lowrank(rng.random((n, 3)), np.diag([1.0, -1.0, 2.0]))
+    prob = D.GALEProblem(E, A, Cl)
+    shifts = [-2.0, -0.8, -1 + 0.5j, -1 - 0.5j, -1.3]
+    zs = ZeroOnComplex()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=80, inner_alg=zs), return_info=True)
+    assert zs.complex_calls == 1
+    assert info["warnings"] & 2 and not info["converged"]
+    assert info["iters"] == 4                                   # two real steps + the collapsed pair's two shifts (adi.jl:189: both are pushed)
+    assert any("Increment is zero" in str(m.message) for m in w)
+    # the oracle with the same collapse: same count, same X, same residual norm
+    orig = o._inner_solve
+    def zero_on_complex(c, M, R, mu):
+        if complex(mu).imag != 0:
+            return np.zeros(R.shape, dtype=complex)
+        return orig(c, M, R, mu)
+    o._inner_solve = zero_on_complex
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = o.adi_init(o.GALEProblem(E, A, o.lowrank(Cl.Ls[0], Cl.Ds[0])), o.ADI(shifts=o.Cyclic(shifts), maxiters=80))
+            Xo = o.adi_solve_cache(c)
+    finally:
+        o._inner_solve = orig
+    assert len(c.shifts) == info["iters"]
+    assert abs(c.residual_norm - info["res_norm"]) <= 1e-10 * c.residual_norm
+    assert D.delta(X.dense(), Xo.dense()) < 1e-10
+
+
 def test_column_sharded_adi_device_ops_single_rank(ctx):
     """tests/host_sharding_model.py.HipOps (the per-rank work of the multi-GPU ADI through the C ABI + device-to-device exchange buffers) against the
     SciPy stand-in the gloo test uses, world size 1: same iterates, and the sharded bookkeeping (column / row ranges) covers everything."""
