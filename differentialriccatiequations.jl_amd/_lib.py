@@ -61,6 +61,7 @@ PROTOTYPES = {
     "dre_ctx_sync": (C.c_int, [_vp]),
     "dre_ctx_info": (C.c_int, [_vp, _pi64]),
     "dre_ctx_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "dre_ctx_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_double)]),
     "dre_prof_enable": (C.c_int, [_vp, C.c_int]),
     "dre_prof_reset": (C.c_int, [_vp]),
     "dre_prof_count": (C.c_int, [_vp, _pint]),

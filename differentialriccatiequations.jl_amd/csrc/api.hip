@@ -93,9 +93,20 @@ int dre_ctx_create(int device, dre_ctx** out) {
             if (end == std::string::npos) end = all.size();
             const std::string item = all.substr(pos, end - pos);
             pos = end + 1;
-            const size_t eq = item.find('=');
-            if (item.empty() || eq == std::string::npos) continue;
-            const int rc2 = dre_ctx_set_option(ctx, item.substr(0, eq).c_str(), std::atof(item.substr(eq + 1).c_str()));
+            // (a typo must not run the default configuration and report green: "name:0", "name=off", "name = 1x" are errors)
+            auto trim = [](std::string t) { const size_t a0 = t.find_first_not_of(" \t"); if (a0 == std::string::npos) return std::string(); return t.substr(a0, t.find_last_not_of(" \t") - a0 + 1); };
+            const std::string it2 = trim(item);
+            if (it2.empty()) continue;
+            const size_t eq = it2.find('=');
+            int rc2 = DRE_OK;
+            if (eq == std::string::npos || eq == 0) { ctx->c.last_error = "item '" + it2 + "' is not of the form name=value"; rc2 = DRE_ERR_INVALID; }
+            else {
+                const std::string nm = trim(it2.substr(0, eq)), vs = trim(it2.substr(eq + 1));
+                char* endp = nullptr;
+                const double v = std::strtod(vs.c_str(), &endp);
+                if (vs.empty() || endp == vs.c_str() || *endp != '\0') { ctx->c.last_error = "item '" + it2 + "': '" + vs + "' is not a number"; rc2 = DRE_ERR_INVALID; }
+                else rc2 = dre_ctx_set_option(ctx, nm.c_str(), v);
+            }
             if (rc2 != DRE_OK) { g_noctx_error = "DRE_OPTIONS: " + ctx->c.last_error; dre_ctx_destroy(ctx); return rc2; }
         }
     }
@@ -153,49 +164,76 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info) {
     info[0] = ctx->c.num_cus; info[1] = (int64_t)ctx->c.pool.total_bytes();
     return DRE_OK;
 }
+// One table for dre_ctx_set_option / dre_ctx_get_option / DRE_OPTIONS: the option's storage by name (exactly one of i / d is set)
+struct OptionRef { int* i = nullptr; double* d = nullptr; };
+static OptionRef option_ref(Ctx& c, const std::string& key) {
+    OptionRef r;
+#define DRE_OPT_I(NAME, FIELD) if (key == NAME) { r.i = &c.FIELD; return r; }
+#define DRE_OPT_D(NAME, FIELD) if (key == NAME) { r.d = &c.FIELD; return r; }
+    DRE_OPT_I("dense_inverse_max_n", dense_inv_max_n)
+    DRE_OPT_I("compress_direct_max_n", compress_direct_max_n)
+    DRE_OPT_D("compress_direct_ratio", compress_direct_ratio)
+    DRE_OPT_I("compress_factor_min_n", compress_factor_min_n)
+    DRE_OPT_I("compress_factor_min_cols", compress_factor_min_cols)
+    DRE_OPT_I("compress_sketch", compress_sketch)
+    DRE_OPT_I("compress_sketch_min_cols", compress_sketch_min_cols)
+    DRE_OPT_I("compress_sketch_extra", compress_sketch_extra)
+    DRE_OPT_I("compress_sketch_cholqr", compress_sketch_cholqr)
+    DRE_OPT_I("compress_sketch_sparse", compress_sketch_sparse)
+    DRE_OPT_D("compress_sketch_ratio", compress_sketch_ratio)
+    DRE_OPT_I("top_inverse_max_rows", top_inverse_max_rows)
+    DRE_OPT_I("mf_subtree", mf_subtree)
+    DRE_OPT_I("setup_streams", setup_streams)
+    DRE_OPT_I("x_side_stream", x_side_stream)
+    DRE_OPT_I("side_after_panels", side_after_panels)
+    DRE_OPT_I("setup_batched", setup_batched)
+    DRE_OPT_I("dense_warm", dense_warm)
+    DRE_OPT_I("side_prefetch", side_prefetch)
+    DRE_OPT_I("xwarm_sx", xwarm_sx)
+    DRE_OPT_I("prefetch_batch", prefetch_batch)
+    DRE_OPT_I("dense_x_max_n", dense_x_max_n)
+    DRE_OPT_I("dense_x_max_k", dense_x_max_k)
+    DRE_OPT_I("adi_group", adi_group)
+    DRE_OPT_I("adi_group_max_n", adi_group_max_n)
+    DRE_OPT_I("adi_fan", adi_fan)
+    DRE_OPT_I("ros1_recurrence", ros1_recurrence)
+    DRE_OPT_D("adi_fan_max_coef", adi_fan_max_coef)
+    DRE_OPT_I("shard_min_cols", shard_min_cols)
+    DRE_OPT_I("comm_host_async", comm_host_async)
+    DRE_OPT_I("x_compress_every", x_compress_every)
+    DRE_OPT_D("pivot_growth_warn", pivot_growth_warn)
+    DRE_OPT_D("pivot_growth_fail", pivot_growth_fail)
+    DRE_OPT_D("pivot_static", pivot_static)
+    DRE_OPT_I("pivot_refine_steps", pivot_refine_steps)
+#undef DRE_OPT_I
+#undef DRE_OPT_D
+    return r;
+}
 int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value) {
     return guarded(ctx, [&] {
         const std::string key = name ? name : "";
-        if (key == "dense_inverse_max_n") ctx->c.dense_inv_max_n = (int)value;
-        else if (key == "compress_direct_max_n") ctx->c.compress_direct_max_n = (int)value;
-        else if (key == "compress_direct_ratio") ctx->c.compress_direct_ratio = value;
-        else if (key == "compress_factor_min_n") ctx->c.compress_factor_min_n = (int)value;
-        else if (key == "compress_factor_min_cols") ctx->c.compress_factor_min_cols = (int)value;
-        else if (key == "compress_sketch") ctx->c.compress_sketch = (int)value;
-        else if (key == "compress_sketch_min_cols") ctx->c.compress_sketch_min_cols = (int)value;
-        else if (key == "compress_sketch_extra") ctx->c.compress_sketch_extra = (int)value;
-        else if (key == "compress_sketch_cholqr") ctx->c.compress_sketch_cholqr = (int)value;
-        else if (key == "compress_sketch_sparse") ctx->c.compress_sketch_sparse = (int)value;
-        else if (key == "compress_sketch_ratio") ctx->c.compress_sketch_ratio = value;
-        else if (key == "top_inverse_max_rows") ctx->c.top_inverse_max_rows = (int)value;
-        else if (key == "mf_subtree") ctx->c.mf_subtree = (int)value;
-        else if (key == "setup_streams") ctx->c.setup_streams = (int)value;
-        else if (key == "x_side_stream") ctx->c.x_side_stream = (int)value;
-        else if (key == "side_after_panels") ctx->c.side_after_panels = (int)value;
-        else if (key == "setup_batched") ctx->c.setup_batched = (int)value;
-        else if (key == "dense_warm") ctx->c.dense_warm = (int)value;
-        else if (key == "side_prefetch") ctx->c.side_prefetch = (int)value;
-        else if (key == "xwarm_sx") ctx->c.xwarm_sx = (int)value;
-        else if (key == "prefetch_batch") ctx->c.prefetch_batch = (int)value;
-        else if (key == "dense_x_max_n") ctx->c.dense_x_max_n = (int)value;
-        else if (key == "dense_x_max_k") ctx->c.dense_x_max_k = (int)value;
-        else if (key == "adi_group") ctx->c.adi_group = (int)value;
-        else if (key == "adi_group_max_n") ctx->c.adi_group_max_n = (int)value;
-        else if (key == "adi_fan") ctx->c.adi_fan = (int)value;
-        else if (key == "ros1_recurrence") ctx->c.ros1_recurrence = (int)value;
-        else if (key == "adi_fan_max_coef") ctx->c.adi_fan_max_coef = value;
-        else if (key == "shard_min_cols") ctx->c.shard_min_cols = (int)value;
-        else if (key == "shard_emulate") {
+        if (!(value == value)) throw Error(ERR_INVALID, "dre_ctx_set_option: the value of '" + key + "' is not a number");
+        if (key == "shard_emulate") {
             // ONE process plays `value` ranks of the column-sharded ADI step one after the other (tests of the blocking logic on one GPU)
             if (!ctx->c.comm) ctx->c.comm = std::make_shared<Comm>();
             ctx->c.comm->emulate = (int)value;
+            return;
         }
-        else if (key == "x_compress_every") ctx->c.x_compress_every = (int)value;
-        else if (key == "pivot_growth_warn") ctx->c.pivot_growth_warn = value;
-        else if (key == "pivot_growth_fail") ctx->c.pivot_growth_fail = value;
-        else if (key == "pivot_static") ctx->c.pivot_static = value;
-        else if (key == "pivot_refine_steps") ctx->c.pivot_refine_steps = (int)value;
+        const OptionRef r = option_ref(ctx->c, key);
+        if (r.i) *r.i = (int)value;
+        else if (r.d) *r.d = value;
         else throw Error(ERR_INVALID, "dre_ctx_set_option: unknown option '" + key + "'");
+    });
+}
+int dre_ctx_get_option(dre_ctx* ctx, const char* name, double* value) {
+    return guarded(ctx, [&] {
+        const std::string key = name ? name : "";
+        if (!value) throw Error(ERR_INVALID, "dre_ctx_get_option: null output");
+        if (key == "shard_emulate") { *value = ctx->c.comm ? (double)ctx->c.comm->emulate : 0.0; return; }
+        const OptionRef r = option_ref(ctx->c, key);
+        if (r.i) *value = (double)*r.i;
+        else if (r.d) *value = *r.d;
+        else throw Error(ERR_INVALID, "dre_ctx_get_option: unknown option '" + key + "'");
     });
 }
 // Both contexts of a library context are timed (the side context carries the work that runs beside the main stream): enable/reset act on

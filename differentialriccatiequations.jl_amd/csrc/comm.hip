@@ -1,6 +1,7 @@
 // RCCL collectives on the library's stream (comm.hpp).  librccl is resolved at run time: the same soname PyTorch-ROCm ships
 // ("librccl.so.1"), so a process that already uses torch.distributed's nccl backend shares that copy instead of loading a second one.
 #include "comm.hpp"
+#include "profiling.hpp"
 
 #include <dlfcn.h>
 
@@ -102,8 +103,36 @@ std::shared_ptr<Comm> comm_init(Ctx* ctx, int nranks, int rank, const void* id12
     return c;
 }
 
+// ASYNCHRONOUS host transport (option "comm_host_async"): the collective is ordered by the context's stream ONLY, like ncclAllGather — the copy
+// down, the caller's collective (a host function enqueued on the stream: hipLaunchHostFunc) and the copy up are three stream operations and the
+// calling thread goes on enqueueing at once.  This is the transport the two-rank tests use to expose ordering mistakes between the library's
+// streams that the synchronous form (a hipStreamSynchronize on either side of the callback) would hide.  One pinned staging buffer serves every
+// call: the three operations of a call are ordered with those of the next by the stream itself.
+struct HostJob { Comm* c; char* stage; size_t bytes; size_t count; int kind; };
+static void host_job_run(void* p) {
+    HostJob* j = static_cast<HostJob*>(p);
+    int rc;
+    if (j->kind == 0) rc = j->c->host_allgather(j->c->host_user, j->stage + j->bytes * (size_t)j->c->rank, j->stage, j->bytes);
+    else rc = j->c->host_allreduce(j->c->host_user, j->stage, j->count);
+    if (rc != 0) j->c->async_failed = 1;
+    delete j;
+}
+static void host_async_check(Comm& c) {
+    if (c.async_failed) { c.async_failed = 0; throw Error(ERR_INTERNAL, "dre_comm: a host collective callback failed (asynchronous transport)"); }
+}
 void comm_allgather(Ctx* ctx, Comm& c, const double* send, double* recv, size_t count) {
     c.ncalls++;
+    if (c.nranks > 1 && c.host_allgather && ctx->comm_host_async) {
+        host_async_check(c);
+        const size_t bytes = count * sizeof(double);
+        if (c.stage_bytes < bytes * (size_t)c.nranks) DRE_HIP(hipStreamSynchronize(ctx->stream));      // (growing the buffer: nothing may be in flight)
+        char* st = (char*)host_stage(c, bytes * (size_t)c.nranks);
+        DRE_HIP(hipMemcpyAsync(st + bytes * (size_t)c.rank, send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipLaunchHostFunc(ctx->stream, host_job_run, new HostJob{&c, st, bytes, count, 0}));
+        DRE_HIP(hipMemcpyAsync(recv, st, bytes * (size_t)c.nranks, hipMemcpyHostToDevice, ctx->stream));
+        c.bytes_gathered += bytes * (size_t)(c.nranks - 1);
+        return;
+    }
     if (c.nranks > 1 && c.host_allgather) {
         // host transport: own block down, the caller's collective on host memory, everything up — synchronous (tests, RCCL-less hosts)
         const size_t bytes = count * sizeof(double);
@@ -129,6 +158,17 @@ void comm_allgather_inplace(Ctx* ctx, Comm& c, double* buf, size_t count) {
 }
 void comm_allreduce_sum(Ctx* ctx, Comm& c, double* buf, size_t count) {
     c.ncalls++;
+    if (c.nranks > 1 && c.host_allreduce && ctx->comm_host_async) {
+        host_async_check(c);
+        const size_t bytes = count * sizeof(double);
+        if (c.stage_bytes < bytes) DRE_HIP(hipStreamSynchronize(ctx->stream));
+        char* st = (char*)host_stage(c, bytes);
+        DRE_HIP(hipMemcpyAsync(st, buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipLaunchHostFunc(ctx->stream, host_job_run, new HostJob{&c, st, bytes, count, 1}));
+        DRE_HIP(hipMemcpyAsync(buf, st, bytes, hipMemcpyHostToDevice, ctx->stream));
+        c.bytes_reduced += bytes;
+        return;
+    }
     if (c.nranks > 1 && c.host_allreduce) {
         const size_t bytes = count * sizeof(double);
         void* st = host_stage(c, bytes);
@@ -143,6 +183,23 @@ void comm_allreduce_sum(Ctx* ctx, Comm& c, double* buf, size_t count) {
     if (c.nranks == 1 || !c.nccl) return;
     c.bytes_reduced += count * sizeof(double);
     chk(rccl().allreduce(buf, buf, count, NCCL_FLOAT64, NCCL_SUM, c.nccl, ctx->stream), "ncclAllReduce");
+}
+
+Roctx& Roctx::get() {
+    static Roctx r = [] {
+        Roctx x;
+        if (!env_trace("roctx")) return x;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            x.push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            x.pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (!x.push || !x.pop) { x.push = nullptr; x.pop = nullptr; }
+        }
+        return x;
+    }();
+    return r;
 }
 
 }  // namespace dre

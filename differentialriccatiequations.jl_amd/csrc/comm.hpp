@@ -21,6 +21,7 @@ struct Comm {
     int (*host_allgather)(void* user, const void* send, void* recv, size_t bytes_per_rank) = nullptr;   // recv: nranks blocks; send may point into recv
     int (*host_allreduce)(void* user, void* buf, size_t count) = nullptr;                               // sum of doubles, in place
     void* host_user = nullptr;
+    volatile int async_failed = 0;   // set by a failed callback of the asynchronous host transport, raised by the next collective call
     void* stage = nullptr;           // pinned
     size_t stage_bytes = 0;
     ~Comm();

@@ -220,6 +220,11 @@ struct Ctx {
     std::unordered_map<const void*, int> lds_attr_done;
     // compression bookkeeping of this context (diagnostics only)
     struct CompressCounters { long calls = 0, cols_in = 0, order = 0, tri_steps = 0, rank_out = 0; } cstats;
+    // counters of the DRE_TRACE diagnostics (per context: two contexts on two threads do not share them)
+    struct TraceCounters {
+        long pf_calls = 0, pf_nups = 0, pf_pend = 0; double fan_t[6] = {0, 0, 0, 0, 0, 0}; long fan_n = 0; long rl_hit = 0, rl_miss = 0, cx_hit = 0, cx_miss = 0;
+        double ch_enq = 0.0, ch_wait = 0.0; long ch_n = 0, ch_it = 0; double rec_tb = 0.0, rec_ta = 0.0, rec_tf = 0.0; long rec_ns = 0; int clock_count = 0, subprobe_count = 0;
+    } trace;
     bool prof_side = false;     // timing was switched on before the side context existed: it is created with its timer enabled
     // multi-GPU (comm.hpp, dre_comm_init): with a communicator of more than one rank the shifted solves of the generic ADI path are
     // column-sharded (engine.hip, adi_advance) — every rank solves its 16-column tiles of the residual block and ONE in-place all-gather per
@@ -227,6 +232,9 @@ struct Ctx {
     // Residual blocks narrower than shard_min_cols are solved replicated (a rank cannot do less than one 16-column tile).
     std::shared_ptr<Comm> comm;
     int shard_min_cols = 32;
+    // host transport (dre_comm_init_host): 1 = the callbacks run as host functions ON the stream (hipLaunchHostFunc), ordered by the stream only like
+    // an RCCL collective; 0 = synchronously around a stream synchronisation (comm.hip)
+    int comm_host_async = 0;
     // user-supplied orthogonalisation (the reference's extension point DifferentialRiccatiEquations.orthf, src/LDLt.jl:227-245, overridden in
     // test/cuda.jl:32-37): L (n x c) -> Q (n x p, orthonormal columns), R (p x c), p = min(n, c), L = Q R; device pointers, column-major.
     // Honoured by the literal compression (compress_exact / dre_ldlt_compress) and by dre_ldlt_norm.  Called with this stream idle; must

@@ -3798,7 +3798,7 @@ SymBand sym_band_reduce(Ctx* ctx, Mat& S, double tolfac, double abs_tol, const d
     }
     {
         static const bool cp = env_trace("clock");
-        static int cp_count = 0;
+        int& cp_count = ctx->trace.clock_count;
         if (cp && q > 300 && (++cp_count % 40) == 20) {
             DevArr<long long> o(ctx, 4);
             hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, ctx->stream, o.p);

@@ -611,6 +611,7 @@ Mat smw_solve(Ctx* ctx, const Pencil& P, const Factor<double>& F, double alpha, 
     return X;
 }
 void smw_solve(Ctx* ctx, const Pencil& P, const Factor<cplx>& F, double alpha, const Mat& U, const Mat& Vt, const Mat& B, Mat& X_re, Mat& X_im) {
+    RoctxRange roctx_range("Sherman-Morrison-Woodbury");
     const int n = P.n, k = B.cols, m = U.cols;
     DRE_REQUIRE(U.rows == n && Vt.rows == n && Vt.cols == m && B.rows == n, "smw_solve: shape mismatch");
     DRE_REQUIRE(m >= 1 && m <= 32, "SMW: between 1 and 32 low-rank columns (DRE_SMW_MAX_RANK)");
@@ -1096,6 +1097,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
 // One chunk: up to `budget` shifts are enqueued speculatively (at least one; a conjugate pair counts two and is never split), then one
 // synchronisation tells how far the device got.  budget = 1 is the reference's step! (adi.jl:97-128).
 void adi_advance(AdiRun& run, int budget) {
+    static const bool trace_prefetch = env_trace("prefetch");
     if (run.finished) return;
     Ctx* ctx = run.ctx;
     const GaleOperator& op = run.op;
@@ -1274,7 +1276,7 @@ void adi_advance(AdiRun& run, int budget) {
             int scheduled = (int)run.prefetch_ev.size();
             static const bool trace_pf = env_trace("prefetch");
             if (trace_pf) {
-                static long calls = 0, nups = 0, pend = 0;
+                long &calls = ctx->trace.pf_calls, &nups = ctx->trace.pf_nups, &pend = ctx->trace.pf_pend;
                 ++calls; nups += (long)ups.size(); pend += scheduled;
                 if (calls % 500 == 0) std::fprintf(stderr, "[prefetch] %ld calls: %.2f upcoming shifts known per call, %.2f factorisations already in flight per call (depth %d)\n",
                                                    calls, (double)nups / calls, (double)pend / calls, nh);
@@ -1436,7 +1438,7 @@ void adi_advance(AdiRun& run, int budget) {
                 }
                 if (g >= gmin) {
                     static const bool fht = env_trace("fan");
-                    static double ft[6] = {0, 0, 0, 0, 0, 0}; static long fn_ = 0;
+                    double* const ft = ctx->trace.fan_t; long& fn_ = ctx->trace.fan_n;
                     auto fnow = []() { return std::chrono::steady_clock::now(); };
                     auto fus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
                     const auto f0 = fnow();
@@ -1572,9 +1574,11 @@ void adi_advance(AdiRun& run, int budget) {
                 resolve_deferred();
             }
             run.hist_ok = false;                  // (its residual factor is updated in place: no history of this solve)
-            std::complex<double> mu = oracle->take(&res.warnings);
+            std::complex<double> mu;
+            { RoctxRange rr("shifts"); mu = oracle->take(&res.warnings); }        // adi.jl:101
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
+            RoctxRange roctx_solve(is_real ? "solve (real)" : "solve (complex)");        // adi.jl:157,196 (the range covers the whole step)
             const AdiState* dst = st.p;
             if (lookahead) { wait_prefetched(mu); prefetch_ahead(mu); }
             Mat V1, V2;
@@ -1584,8 +1588,8 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<double>> fe;
                 if (!user_inner) {
-                    if (single_use && env_trace("prefetch")) {
-                        static long hit = 0, miss = 0;
+                    if (single_use && trace_prefetch) {
+                        long &hit = ctx->trace.rl_hit, &miss = ctx->trace.rl_miss;
                         (cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] real shifts: %ld found ready, %ld factorised inline\n", hit, miss);
                     }
@@ -1728,8 +1732,8 @@ void adi_advance(AdiRun& run, int budget) {
                 const bool user_inner = opt.inner_solve != nullptr;
                 std::shared_ptr<FactorEntry<cplx>> fe;
                 if (!user_inner) {
-                    if (single_use && env_trace("prefetch")) {
-                        static long hit = 0, miss = 0;
+                    if (single_use && trace_prefetch) {
+                        long &hit = ctx->trace.cx_hit, &miss = ctx->trace.cx_miss;
                         (cache->cplx_.count(std::make_tuple(op.tag, mu.real(), mu.imag())) ? hit : miss)++;
                         if ((hit + miss) % 500 == 0) std::fprintf(stderr, "[prefetch] complex pairs: %ld found ready, %ld factorised inline\n", hit, miss);
                     }
@@ -1806,7 +1810,7 @@ void adi_advance(AdiRun& run, int budget) {
             run.abstol_pending = false;
         }
         if (chunk_timing) {
-            static double enq = 0.0, wait = 0.0; static long nch = 0, nit_ = 0;
+            double &enq = ctx->trace.ch_enq, &wait = ctx->trace.ch_wait; long &nch = ctx->trace.ch_n, &nit_ = ctx->trace.ch_it;
             const auto ct2 = std::chrono::steady_clock::now();
             enq += std::chrono::duration<double, std::micro>(ct1 - ct0).count(); wait += std::chrono::duration<double, std::micro>(ct2 - ct1).count();
             nit_ += (long)recs.size();
@@ -1911,8 +1915,9 @@ AdiResult adi_finish(AdiRun& run) {
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt_in,
                     FactorCache* cache) {
     static const bool tm = env_trace("rec");
-    static double tb = 0, ta = 0, tf = 0; static long ns = 0;
+    double &tb = ctx->trace.rec_tb, &ta = ctx->trace.rec_ta, &tf = ctx->trace.rec_tf; long& ns = ctx->trace.rec_ns;
     const auto t0 = std::chrono::steady_clock::now();
+    RoctxRange roctx_range("ADI");
     auto run = adi_begin(ctx, op, C, initial_guess, opt_in, cache);
     const auto t1 = std::chrono::steady_clock::now();
     while (!run->finished) adi_advance(*run, 1 << 30);

@@ -1518,6 +1518,11 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                 while (!deltas.empty() && deltas.front().s <= st->step) deltas.erase(deltas.begin());
                 const LBlock& xb = st->X->blocks[0];
                 const int r = xb.L.cols;
+                Mat EtLx = st->EtL;
+                if (EtLx.cols != r || EtLx.rows != n) {          // (a state without E'L: form it here rather than count columns that are never written)
+                    EtLx = Mat(hc, n, r);
+                    if (r > 0) spmm(hc, P, P.valEt.p, xb.L, EtLx, 1.0, 0.0);
+                }
                 int cols = q + m + r;
                 for (auto& d : deltas) cols += d.Q.cols + d.Rj.cols + (d.dKt.cols > 0 ? m : 0);
                 Mat F(hc, n, cols), S(hc, cols, cols);
@@ -1534,7 +1539,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                 };
                 put(prob.Ct, nullptr, 1.0, true);
                 put(Kt, nullptr, 1.0, true);
-                put(st->EtL, &xb.D, xb.alpha / tau, false);
+                put(EtLx, &xb.D, xb.alpha / tau, false);
                 for (auto& d : deltas) {
                     const double sc = d.tau / tau;
                     put(d.Q, &d.Dq, sc, false);
@@ -1596,6 +1601,19 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             Kt_new = fb.Kt;
             if (save_state) saved[(size_t)i] = X;
             deltas.clear();
+            // Publish E'L with the state.  The state may have come from a solve that compressed X itself (the `!intact` branch above): it
+            // carries no E'L and no event, no side job follows it without save_state, and two steps later the tolerance formula (normC_build)
+            // counted its columns without writing them.  The event is on THIS stream: the side and helper streams wait for it.
+            {
+                auto st3 = std::make_shared<SideState>();
+                st3->step = st->step; st3->X = X; st3->EtL = fb.EtL;
+                hipEvent_t e = ring[(2 * njobs) % 16];
+                ++njobs;
+                DRE_HIP(hipEventRecord(e, ctx->stream));
+                st3->ev = e;
+                std::lock_guard<std::mutex> lk(smu);
+                cur = st3;
+            }
         }
         if (rec_timing) t_tail += us(ts1, now());
         abstol_prev = ar.abstol;

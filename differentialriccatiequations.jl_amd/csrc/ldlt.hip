@@ -81,6 +81,7 @@ Mat hcat_blocks(Ctx* ctx, const LDLt& X) {
 }
 
 void ldlt_concatenate(Ctx* ctx, LDLt& X) {
+    RoctxRange roctx_range("concatenate!(::LDLᵀ)");
     if (X.blocks.size() <= 1) return;
     const int c = X.rank();
     Mat L = hcat_blocks(ctx, X);
@@ -343,6 +344,7 @@ static double noise_floor_fac() {
     return f;
 }
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode) {
+    RoctxRange roctx_range("compress!(::LDLᵀ)");
     const int n = X.n, c = X.rank();
     const bool nfloor = !exact && (mode & COMPRESS_NOISE_FLOOR), keep_result = !exact && (mode & COMPRESS_KEEP_RESULT);
     if (nfloor) abs_tol = -1.0;
@@ -528,6 +530,7 @@ void ldlt_destructure(Ctx* ctx, LDLt& X, double tolfac, bool exact) {
 }
 
 double ldlt_norm(Ctx* ctx, LDLt& X) {
+    RoctxRange roctx_range("norm(::LDLᵀ)");
     if (X.rank() == 0) return 0.0;
     ldlt_concatenate(ctx, X);
     auto& b = X.blocks[0];
@@ -642,6 +645,7 @@ LDLtP gale_residual_blocks(Ctx* ctx, const GaleOperator& op, const LDLt& C, cons
 }
 
 LDLtP gale_residual(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol) {
+    RoctxRange roctx_range("residual(::GALEProblem, ::LDLᵀ)");
     return gale_residual_impl(ctx, op, C, X, tolfac, exact, abs_tol, nullptr, nullptr);
 }
 LDLtP gale_residual_impl(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& X, double tolfac, bool exact, double abs_tol,
@@ -683,6 +687,7 @@ __global__ __launch_bounds__(256) void k_dot_hadamard(int r, int c, const double
     if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 double ldlt_dot(Ctx* ctx, const LDLt& X1, const LDLt& X2) {
+    RoctxRange roctx_range("dot(::LDLᵀ, ::LDLᵀ)");
     DRE_REQUIRE(X1.n == X2.n, "dot: outer dimensions must match");
     if (X1.rank() == 0 || X2.rank() == 0) return 0.0;
     LDLt A = X1, B = X2;                      // shallow copies: concatenation builds new factors, the operands stay untouched
@@ -724,6 +729,7 @@ LDLtP lyapunov_apply(Ctx* ctx, const GaleOperator& op, const LDLtP& X) {
 // =============================================================================================
 static void single_block(Ctx* ctx, LDLt& X) { if (X.blocks.size() > 1) ldlt_concatenate(ctx, X); }
 LDLtP gare_residual_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& Ct, const Mat& S, double gamma, const Mat& B, const Mat& Rinv, double beta) {
+    RoctxRange roctx_range("residual(::GAREProblem, ::LDLᵀ)");
     const int n = P.n, h = Ct.cols, m = B.cols;
     single_block(ctx, X);
     const int z = X.blocks.empty() ? 0 : X.blocks[0].L.cols;

@@ -64,4 +64,24 @@ struct TimedScope {
     }
 };
 
+
+// roctx ranges named after the reference's TimerOutputs sections (src/DifferentialRiccatiEquations.jl:22 @timeit_debug):
+//   "norm(::LDLᵀ)" LDLt.jl:77 · "compress!(::LDLᵀ)" LDLt.jl:204 · "orthf" :211 · "eigen" :214 · "solve (real)" adi.jl:157 · "solve (complex)" adi.jl:196 ·
+//   "Sherman-Morrison-Woodbury" smw.jl:10,33 · "solve (sparse)" smw.jl:19,36 · "solve (dense)" smw.jl:39 · "shifts" adi.jl:101 ·
+//   "residual(::GALEProblem, ::LDLᵀ)" lyapunov/residual.jl:3 · "ADI" lowrank_ros1.jl:49 ("$(typeof(inner_alg))")
+// They show in `rocprofv3 --marker-trace` timelines next to the kernels.  The marker library (librocprofiler-sdk-roctx.so, else libroctx64.so) is
+// resolved with dlopen on first use and ONLY when DRE_TRACE lists "roctx": libdre_hip.so keeps linking against libamdhip64 alone.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    static Roctx& get();
+};
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(false) { Roctx& r = Roctx::get(); if (r.push) { (void)r.push(name); on = true; } }
+    ~RoctxRange() { if (on) (void)Roctx::get().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
+};
+
 }  // namespace dre

@@ -1603,7 +1603,7 @@ static void mf_sub_sweep(Ctx* ctx, const Pencil& P, const Factor<double>& Fc, do
     const int ncb = ceil_div(nrhs, MFM_KC);
     const bool small = sp.s_max <= 32 && sp.b_max <= 32 * SUB_NW;        // every fragment of every node fits the prefetch depth
     static const bool probe_on = env_trace("subprobe");   // debug: wall-clock stamps (10 ns ticks) of workgroup (0, 0) at the phase boundaries
-    static int probe_count = 0;
+    int& probe_count = ctx->trace.subprobe_count;
     DevArr<long long> probe;
     long long* pp = nullptr;
     if (probe_on && forward && nrhs >= 64 && probe_count < 3) { probe = DevArr<long long>(ctx, 64); DRE_HIP(hipMemsetAsync(probe.p, 0, 64 * 8, ctx->stream)); pp = probe.p; }

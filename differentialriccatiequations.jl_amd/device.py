@@ -123,6 +123,29 @@ class Context:
         """Engine tunables (dre_ctx_set_option), e.g. ``dense_inverse_max_n``."""
         self.chk(self.lib.dre_ctx_set_option(self.ptr, name.encode(), float(value)))
 
+    def get_option(self, name):
+        """The current value of an engine tunable (dre_ctx_get_option)."""
+        v = C.c_double(0.0)
+        self.chk(self.lib.dre_ctx_get_option(self.ptr, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """Context manager: set the given options, restore what they were on exit (the session-scoped test context keeps whatever
+        configuration DRE_OPTIONS gave it)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return _cm()
+
     def prof_enable(self, on=True):
         self.chk(self.lib.dre_prof_enable(self.ptr, 1 if on else 0))
 

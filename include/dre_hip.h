@@ -94,6 +94,9 @@ int dre_ctx_info(dre_ctx* ctx, int64_t* info /* [0]=CUs [1]=pool bytes */);
  *                               DRE_X_SIDE_STREAM);  "x_compress_every" = s (default 1) with x_side_stream = 0: single stream,
  *                               X compressed every s-th step only */
 int dre_ctx_set_option(dre_ctx* ctx, const char* name, double value);
+/* the current value of an option of dre_ctx_set_option (tests snapshot and restore what they change; no reference counterpart: the reference's
+ * tunables are keyword arguments) */
+int dre_ctx_get_option(dre_ctx* ctx, const char* name, double* value);
 /* per-kernel-class timing with HIP events on the library stream (replaces TimerOutputs.@timeit_debug,
  * src/DifferentialRiccatiEquations.jl:22 and the sections listed in SURVEY.md §5) */
 int dre_prof_enable(dre_ctx* ctx, int on);

@@ -32,6 +32,8 @@ def allreduce(buf):
     dist.all_reduce(torch.from_numpy(buf))          # shares the memory: in place
 
 
+if os.environ.get("DRE_TEST_TRANSPORT", "sync") == "async":
+    ctx.set_option("comm_host_async", 1)       # the callbacks run as host functions on the library's stream: ordered by the stream only, like RCCL
 ctx.comm_init_host(world, rank, allgather, allreduce)
 d = D.steel_profile(n)
 L, Dm = D.initial_value(d)

@@ -301,7 +301,7 @@ def test_zero_increment_guard_stops_a_collapsed_complex_step(ctx):          # ad
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         X, info = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(shifts), maxiters=80, inner_alg=zs), return_info=True)
-    assert zs.complex_calls == 1
+    assert zs.complex_calls >= 1                                # (the engine enqueues a chunk of iterations speculatively: the collapsed step ends the solve on the device)
     assert info["warnings"] & 2 and not info["converged"]
     assert info["iters"] == 4                                   # two real steps + the collapsed pair's two shifts (adi.jl:189: both are pushed)
     assert any("Increment is zero" in str(m.message) for m in w)

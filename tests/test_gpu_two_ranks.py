@@ -25,22 +25,31 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_two(tmp_path, n, nsteps, save_state=False):
+def _run_two(tmp_path, n, nsteps, save_state=False, transport="sync"):
+    """Two worker processes, one communicator.  Their output goes to FILES (a rank that fills a pipe while the other is being drained would block
+    in write() with its peer waiting in the collective: ADVICE round 4), and the first failure ends both."""
+    import time
     port = _free_port()
     outs = [str(tmp_path / f"rank{r}.npz") for r in range(2)]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    logs = [str(tmp_path / f"rank{r}.log") for r in range(2)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DRE_TEST_TRANSPORT=transport)
+    files = [open(l, "wb") for l in logs]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(r), "2", str(port), outs[r], str(n), str(nsteps),
-                               "1" if save_state else "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(o.decode(errors="replace"))
-    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+                               "1" if save_state else "0"], env=env, stdout=files[r], stderr=subprocess.STDOUT) for r in range(2)]
+    deadline = time.time() + 600
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for f in files:
+            f.close()
+    text = "\n".join(open(l, errors="replace").read() for l in logs)
+    assert all(p.returncode == 0 for p in procs), text
     return [np.load(o) for o in outs]
 
 
@@ -82,3 +91,23 @@ def test_two_ranks_equal_one_rank_with_save_state(tmp_path, ctx):
     assert list(r0["x_rank"]) == list(r1["x_rank"])
     # each rank factorises the shifts of its own group positions (plus what the leftover column-sharded iterations need), not all ten twice
     assert int(r0["factorizations"]) <= st["factorizations"] and int(r1["factorizations"]) <= st["factorizations"]
+
+
+@pytest.mark.parametrize("save_state", [False, True])
+def test_two_ranks_over_the_asynchronous_transport_12_steps(tmp_path, save_state):
+    """The same sharded solve with the host collectives enqueued ON the library's stream (hipLaunchHostFunc: no stream synchronisation around
+    them — the ordering an RCCL collective has), 12 time steps of n = 5177, with and without save_state: the oracle's iteration counts and K(t),
+    bit-identical ranks.  An ordering mistake between the main stream, the side stream and the parked worker thread that the synchronous
+    transport hides would show here as a wrong K(t) or a hang (the runner kills both ranks after ten minutes)."""
+    r0, r1 = _run_two(tmp_path, 5177, 12, save_state=save_state, transport="async")
+    g = np.load(os.path.join(GOLDEN, "ros1_5177_long.npz"))
+    for r in (r0, r1):
+        assert int(r["nranks"]) == 2 and int(r["bytes_gathered"]) > 0
+        assert list(r["iters"]) == [int(v) for v in g["iters"]]
+    assert np.array_equal(r0["K"], r1["K"])
+    n = r0["K"].shape[2]
+    w = np.random.default_rng(1).standard_normal(n)
+    for i, K in enumerate(r0["K"]):
+        assert np.linalg.norm(K[:, ::16] - g["K_cols"][i]) < 1e-7 * g["K_norm"][i]
+        assert abs(np.linalg.norm(K) - g["K_norm"][i]) <= 1e-7 * g["K_norm"][i]
+        assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * max(np.linalg.norm(g["K_w"][i]), 1e-300)
