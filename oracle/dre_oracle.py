@@ -824,7 +824,7 @@ def solve_lowrank_ros2(prob: GDREProblem, alg: Ros2, dt, save_state=False, obser
         c2 = adi_init(GALEProblem(E, F, R2), inner, observer=observer)
         K2 = adi_solve_cache(c2)
         if stats is not None:
-            stats.append(dict(iters=len(c1.shifts) + len(c2.shifts), res=max(c1.residual_norm, c2.residual_norm)))
+            stats.append(dict(iters=len(c1.shifts) + len(c2.shifts), iters1=len(c1.shifts), iters2=len(c2.shifts), res=max(c1.residual_norm, c2.residual_norm)))
         # `(2-1/2γ)*τ` parses as (2 - 1/(2γ))τ in Julia
         X = X + ((2.0 - 1.0 / (2.0 * gamma)) * tau) * K1 + (-tau / 2.0) * K2
         if save_state:

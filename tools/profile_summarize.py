@@ -54,7 +54,14 @@ for k, v in bf.items():
     kern[k] = dict(launches=v[0], fetch_kb_per_launch_raw=v[1] / v[0], write_kb_per_launch_raw=w[1] / max(w[0], 1),
                    fabric_bytes_per_launch=fb + wb, avg_us=au,
                    fabric_GBps=(fb + wb) / (au * 1e-6) / 1e9 if au else None)
-json.dump(dict(note="bytes = FETCH_SIZE[KB] x 1024 x 2 + WRITE_SIZE[KB] x 1024 (MI355X_MICROARCH.md, HBM section).  L2-fabric traffic, Infinity-Cache hits "
+run = None
+try:          # the counter passes ran `bench.py --steps 1 --warmup 1` (+ the profiled extra solve): 3 solves of adi_iterations_per_solve each
+    bj = json.loads(open(os.path.join(out_dir, f"bench_under_rocprof_{tag}.json")).read().strip().splitlines()[-1])
+    run = dict(solves=3, adi_iterations_per_solve=bj["config"]["adi_iterations_per_solve"],
+               note="counter passes: warm-up + 1 timed + 1 profiled solve; one shifted solve per ADI iteration")
+except Exception:
+    pass
+json.dump(dict(run=run, note="bytes = FETCH_SIZE[KB] x 1024 x 2 + WRITE_SIZE[KB] x 1024 (MI355X_MICROARCH.md, HBM section).  L2-fabric traffic, Infinity-Cache hits "
                     "included: an upper bound of the HBM traffic, equal to it only for working sets beyond 256 MiB.  fabric_GBps may therefore exceed what "
                     "HBM delivers and is NOT an HBM bandwidth.",
                kernels=kern), open(os.path.join(out_dir, f"pmc_traffic_{tag}.json"), "w"), indent=1)
