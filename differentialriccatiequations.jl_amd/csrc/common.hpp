@@ -1,6 +1,7 @@
 // Common infrastructure of libdre_hip: context, error handling, stream-ordered device pool,
 // dense device matrix views.  gfx950 (MI355X) only.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -184,6 +185,7 @@ struct Ctx {
     // full band reduction at every step
     int dense_warm = 1;
     // dense-X time loop: the side stream's set-up of step i + 1 is enqueued by a parked host thread at the end of step i (0: inside step i + 1)
+    int side_gate = 0;          // residual-recurrence loop: the parked thread enqueues the side stream only while the time loop's thread waits (launch gate below; measured at n = 5177: 85.1 ms with, 85.4 ms without — inside the noise, off)
     int side_prefetch = 0;      // (measured at n = 371: 18.3 against 17.8 ms per solve — the join in front of the chain costs more than the earlier start gains)
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)
     int setup_batched = 1;
@@ -211,6 +213,15 @@ struct Ctx {
     // command + hipStreamSynchronize per read-back
     struct FetchZone { volatile unsigned long long seq; unsigned long long pad[7]; unsigned long long words[1024]; };
     FetchZone* fetch_host = nullptr;   // host address
+    // Launch gate between the time loop's thread and the parked thread that drives the side stream (gdre.hip, ros1_recurrence_loop): two threads
+    // enqueueing at once contend for the HIP runtime, and the MAIN thread's launches (the critical path) took 10-60 us each instead of 4 while the side
+    // job's hundred launches went out.  The main thread raises `waiting` while it blocks on a read-back or a join; the side context (gate_follow set)
+    // only enqueues then — or after gate_patience_us without such a window.
+    struct LaunchGate { std::atomic<int> waiting{1}; };
+    std::shared_ptr<LaunchGate> gate;          // main context: owner;  side context: follower when gate_follow
+    bool gate_follow = false;
+    int gate_patience_us = 300;
+    std::shared_ptr<struct Buf> warm_tickets;    // arrival counters of the warm-started compression's ticket kernels (warm.hip), zeroed once
     void* dense_land = nullptr;        // pinned landing zone of the dense-X time loop (gdre.hip, DenseXState): allocated once per context
     FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it
     unsigned long long fetch_seq = 0;

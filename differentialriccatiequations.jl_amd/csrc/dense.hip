@@ -756,6 +756,8 @@ void ctx_fetch_overlap(Ctx* ctx, const std::function<void()>& between, const voi
     // bounded spin on the host-visible sequence number, then the plain synchronisation as a safety net
     const auto t0 = std::chrono::steady_clock::now();
     bool ok = false;
+    struct GateWindow { Ctx* c; bool on; GateWindow(Ctx* cc) : c(cc), on(cc->gate && !cc->gate_follow) { if (on) c->gate->waiting.store(1, std::memory_order_relaxed); }
+                        ~GateWindow() { if (on) c->gate->waiting.store(0, std::memory_order_relaxed); } } gate_window(ctx);       // the side thread may enqueue while this one waits
     for (long it = 0;; ++it) {
         if (ctx->fetch_host->seq == want) { ok = true; break; }
         if ((it & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;

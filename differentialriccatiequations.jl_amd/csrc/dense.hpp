@@ -283,5 +283,7 @@ void warm_small(Ctx* ctx, int q, int m, int kl, int qn, const Mat& Cc, const dou
 void warm_finish(Ctx* ctx, int n, int q, int kl, const Mat& Q, const Mat& Wk, const Mat& Yp, const Mat& Pp, Mat& R, double* slab, int* ticket, double* tols);
 void warm_ctl(Ctx* ctx, double* tols, int* ticket, int J);
 void warm_eig(Ctx* ctx, int m, const Mat& S, Mat& U);
+int warm_project_slabs(int n);                                 // workgroups of warm_project (slab: 256 doubles each)
+void warm_zapply(Ctx* ctx, int n, const Mat& Z1, const double* Cw, Mat& Zb, Mat& Zy);
 
 }  // namespace dre

@@ -901,9 +901,15 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         const double lag = opt.abstol_lag > 0.0 ? opt.abstol_lag : (opt.abstol >= 0.0 ? opt.abstol : -1.0);
         if (resid->blocks.size() > 1) {
             bool done = false;
+            if (opt.warm_eig_basis.cols >= 16 && lag > 0.0 && ctx->dense_warm != 0) {
+                int J = -1; double er = -1.0;
+                Mat Qn;
+                done = warm_compress_eig(ctx, *resid, opt.warm_eig_basis, lag, opt.residual_abs_frac, opt.warm_est_ratio, opt.warm_J_prev, Qn, &J, &er);
+                if (done) { res.warm_basis_out = Qn; res.warm_J = J; res.warm_est_ratio = er; }
+            }
             // (not attempted where it cannot apply — a basis of fewer than 16 columns, q0 + sx <= 64 — so that such a step does not count as a rejection)
-            if (opt.warm_basis.cols >= 16 && lag > 0.0 && cache->warm_strikes < 2 &&
-                opt.warm_basis.cols + (cache->warm_sx > 0 ? cache->warm_sx : 32) > 64) {
+            if (!done && opt.warm_basis.cols >= 16 && lag > 0.0 && cache->warm_strikes < 2 &&
+                opt.warm_basis.cols + (cache->warm_sx > 0 ? cache->warm_sx : 32) >= 48) {
                 const int sx = cache->warm_sx > 0 ? cache->warm_sx : 32;
                 double missed = 0.0;
                 done = warm_compress(ctx, *resid, opt.warm_basis, ctf, opt.residual_abs_frac * lag, sx, &missed);

@@ -130,6 +130,9 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
     bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
     Mat warm_basis;                      // orthonormal basis of the PREVIOUS step's compressed warm-start residual (warm-started range finder for this one's)
+    Mat warm_eig_basis;                  // EIGENBASIS (with spare directions) the previous step's compression left: Rayleigh-Ritz compression (ldlt.hip, warm_compress_eig)
+    double warm_est_ratio = -1.0;        //   (missed / tolerance)^2 of that compression: what this one's truncation may use of the budget
+    int warm_J_prev = -1;                //   its rank
 };
 // iterations of one chunk of a solve with keep_history: V = [V_1 .. V_J], R = [R_1 .. R_J] (n x J k), R0 = the residual factor they started from
 struct AdiHistChunk { Mat R0, Rs, Vs; std::vector<double> mu; };
@@ -149,6 +152,7 @@ struct AdiResult {
     std::vector<AdiHistChunk> hist;
     bool hist_ok = false;
     Mat Tm; double alpha_res = 1.0; bool tdiag = false;
+    Mat warm_basis_out; int warm_J = -1; double warm_est_ratio = -1.0;      // the eigenbasis this solve's residual compression left (empty: another path ran)
 };
 AdiResult adi_solve(Ctx* ctx, const GaleOperator& op, LDLt& C, const LDLtP& initial_guess, const AdiOptions& opt,
                     FactorCache* cache);

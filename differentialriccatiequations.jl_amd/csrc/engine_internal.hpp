@@ -19,6 +19,7 @@ Mat hcat_blocks(Ctx* ctx, const LDLt& X);
 void mul_blockdiag(Ctx* ctx, const Mat& M, const LDLt& X, Mat& out);
 void hcat_scale_blocks(Ctx* ctx, const LDLt& X, Mat& Lcat, Mat& LD);
 bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed, double rel_accept = 0.0);
+bool warm_compress_eig(Ctx* ctx, LDLt& X, const Mat& Qb, double abstol_lag, double frac, double est_ratio_prev, int J_prev, Mat& Qnext, int* J_out, double* est_ratio_out);
 int xblocks_max_n();
 double ldlt_norm_dense_small(Ctx* ctx, const LDLt& X);
 void axpy_inplace(Ctx* ctx, size_t tot, double a, const double* x, double* y);          // y += a x

@@ -1339,6 +1339,11 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
     side->fetch_spin = false;
     side->orthf_fn = ctx->orthf_fn; side->orthf_user = ctx->orthf_user;
+    // launch gate (common.hpp): the side thread enqueues while this one waits
+    if (!ctx->gate) ctx->gate = std::make_shared<Ctx::LaunchGate>();
+    side->gate = ctx->gate; side->gate_follow = ctx->side_gate != 0;
+    ctx->gate->waiting.store(0);
+    struct GateOpen { Ctx* c; ~GateOpen() { c->gate->waiting.store(1); if (c->side) c->side->gate_follow = false; } } gate_open{ctx};      // leaving the loop: no gate
     SideWorker worker;
     // events: a ring (at most one job is in flight; a slot is reused eight jobs later)
     hipEvent_t ring[16];
@@ -1363,7 +1368,9 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     auto join_side = [&]() {                        // host: the running job is finished (its read-backs are synchronous) and its state published
         if (!job_pending) return;
         const auto a = now();
+        ctx->gate->waiting.store(1);
         worker.wait();
+        ctx->gate->waiting.store(0);
         if (rec_timing) { t_join += us(a, now()); ++n_join; }
         job_pending = false;
     };
@@ -1425,6 +1432,9 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     Mat prev_dKt;
     double abstol_prev = -1.0;
     std::vector<StepDelta> deltas;                  // steps the side stream's X does not include yet
+    Mat eigQ;                                       // eigenbasis of the last compressed warm-start residual (warm_compress_eig), empty: none
+    double eig_est = -1.0;
+    int eig_J = -1;
     DevArr<double> normC_dev(ctx, 1);
     Mat Im(ctx, m, m);
     set_identity(ctx, Im, 1.0);
@@ -1503,6 +1513,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             a2.given_residual = resid;
             a2.abstol_lag = abstol_prev;
             if (!prev.hist.empty()) a2.warm_basis = prev.hist[0].R0;      // the compressed residual the previous solve started from: orthonormal
+            a2.warm_eig_basis = eigQ; a2.warm_est_ratio = eig_est; a2.warm_J_prev = eig_J;
             a2.normC_dev = normC_dev.p;
             // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
             //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)
@@ -1616,6 +1627,19 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             }
         }
         if (rec_timing) t_tail += us(ts1, now());
+        // the next step's Rayleigh-Ritz basis: what this step's compression left, or — after a compression of another kind — the eigenvectors of
+        // its inner matrix T (k <= 64: one Jacobi workgroup, about a millisecond, once per regime) rotated into the factor
+        if (!ar.warm_basis_out.empty()) { eigQ = ar.warm_basis_out; eig_est = ar.warm_est_ratio; eig_J = ar.warm_J; }
+        else {
+            eigQ = Mat(); eig_est = -1.0; eig_J = -1;
+            const int kk = ar.Tm.rows;
+            if (hist && ctx->dense_warm != 0 && !ar.hist.empty() && ar.hist[0].R0.cols == kk && kk >= 16 && kk <= 64 && kk == ar.Tm.cols) {
+                Mat U(ctx, kk, kk), Q(ctx, n, kk);
+                warm_eig(ctx, kk, ar.Tm, U);
+                gemm(ctx, false, false, 1.0, ar.hist[0].R0, U, 0.0, Q, nullptr, "gemm_sketch");
+                eigQ = Q;
+            }
+        }
         abstol_prev = ar.abstol;
         have_hist = hist;
         Kt = Kt_new;

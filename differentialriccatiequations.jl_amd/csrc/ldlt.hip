@@ -268,7 +268,7 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
 bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_tol, int sx, double* missed, double rel_accept) {
     const int n = X.n, c = X.rank(), q0 = Q0.cols, sp = sx + 16, s = q0 + sx;
     static const bool trace = env_trace("compress");
-    if (c == 0 || q0 < 16 || s <= 64 || s + 80 > n || abs_tol <= 0.0 || Q0.rows != n) {
+    if (c == 0 || q0 < 16 || s < 48 || s + 80 > n || abs_tol <= 0.0 || Q0.rows != n) {
         if (trace) std::fprintf(stderr, "[warm compress] not applicable: c=%d q0=%d sx=%d abs_tol=%g\n", c, q0, sx, abs_tol);
         return false;
     }
@@ -314,6 +314,70 @@ bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_t
     Mat Lnew(ctx, n, sb.J);
     gemm(ctx, false, false, 1.0, Q, Bq, 0.0, Lnew, nullptr, "gemm_sketch");
     X.blocks.push_back({Lnew, sb.D, 1.0, false, true});
+    return true;
+}
+
+// The warm-started compression of warm.hip for a residual in FACTORED form (general path: n > dense_inverse_max_n, Res = L Dt L' with a few
+// thousand columns): Rayleigh-Ritz in the basis B = [Q, Z], Q = the eigenbasis the previous step's compression left (q <= 64 columns), Z = 16 fresh
+// directions.  Products with Res are two GEMMs over the factor (L'V, then L (Dt .)); the small generalized eigenproblem, the truncation and the
+// probe are the dense path's kernels.  Replaces the range finder above + band reduction (~30 launches, rank on 16-column panel boundaries of a
+// Krylov basis) by ~20 launches and the numerical rank itself.  Returns false (X untouched) when the probe or the whitening rejects the basis;
+// on success X is ONE block (R = the J leading eigen-directions zero padded to a multiple of 16, T diagonal-dominant dense), Qnext the next basis.
+bool warm_compress_eig(Ctx* ctx, LDLt& X, const Mat& Qb, double abstol_lag, double frac, double est_ratio_prev, int J_prev, Mat& Qnext, int* J_out, double* est_ratio_out) {
+    const int n = X.n, c = X.rank(), q = Qb.cols, m = q + 16;
+    static const bool trace = env_trace("compress");
+    if (c == 0 || q < 16 || q > 64 || q + 32 > n || n < 96 || abstol_lag <= 0.0 || Qb.rows != n) return false;
+    RoctxRange roctx_range("compress!(::LDLᵀ)");
+    Mat Lcat = (X.blocks.size() == 1) ? X.blocks[0].L : hcat_blocks(ctx, X);
+    // the chain's width and the next basis follow the PREVIOUS rank (it moves by a few directions per step): kl = its multiple of 16, 16 spare directions
+    const int kl = J_prev >= 0 ? std::min(q, std::max(16, ((J_prev + 15) / 16) * 16 + (J_prev % 16 > 12 ? 16 : 0))) : q, qn = std::min(std::min(m, 64), kl + 16);
+    Mat V0(ctx, n, 32 + m), YB(ctx, n, 64 + q), W1(ctx, 32 + q, c), W2(ctx, 32 + q, c), Pf(ctx, q, 16), Z1(ctx, n, 16);
+    { Mat om = V0.colsview(0, 32); fill_gauss(ctx, om, 0x7F4A7C159E3779B9ull); }
+    { Mat d = V0.colsview(32, q); copy_mat(ctx, Qb, d); }
+    Mat V0q = V0.colsview(0, 32 + q), Yq = YB.colsview(0, 32 + q);
+    gemm(ctx, true, false, 1.0, V0q, Lcat, 0.0, W1, nullptr, "gemm_sketch");                  // [Om_p, Om_f, Q]' L
+    mul_blockdiag(ctx, W1, X, W2);                                                            // . Dt
+    gemm(ctx, false, true, 1.0, Lcat, W2, 0.0, Yq, nullptr, "gemm_sketch");                  // [Y_p, Y_f, W] = Res [Om_p, Om_f, Q]
+    Mat Qv = V0.colsview(32, q), Bb = V0.colsview(32, m), Yp = YB.colsview(0, 16), Yf = YB.colsview(16, 16);
+    gemm(ctx, true, false, 1.0, Qv, Yf, 0.0, Pf, nullptr, "gemm_sketch");                    // P_f = Q'Y_f
+    const int nslab = warm_project_slabs(n), nstrip = ceil_div(n, 16);
+    DevArr<double> slab(ctx, (size_t)nslab * 256 + nstrip + 256 + 16);
+    double* const slabF = slab.p + (size_t)nslab * 256;
+    double* const Cw = slabF + nstrip;
+    double* const tols = Cw + 256;                        // 12 doubles
+    if (!ctx->warm_tickets) {
+        ctx->warm_tickets = std::make_shared<Buf>(ctx, 4 * sizeof(int));
+        DRE_HIP(hipMemsetAsync(ctx->warm_tickets->p, 0, 4 * sizeof(int), ctx->stream));
+    }
+    int* const tickets = (int*)ctx->warm_tickets->p;
+    warm_project(ctx, n, q, Qv, Yf, Pf, Z1, slab.p, tickets, Cw);
+    Mat Zb = V0.colsview(32 + q, 16), Zy = YB.colsview(32 + q, 16), Wz = YB.colsview(48 + q, 16);
+    warm_zapply(ctx, n, Z1, Cw, Zb, Zy);
+    {
+        Mat A1(ctx, 16, c), A2(ctx, 16, c);
+        gemm(ctx, true, false, 1.0, Zb, Lcat, 0.0, A1, nullptr, "gemm_sketch");              // Z'L
+        mul_blockdiag(ctx, A1, X, A2);
+        gemm(ctx, false, true, 1.0, Lcat, A2, 0.0, Wz, nullptr, "gemm_sketch");              // W_2 = Res Z
+    }
+    Mat Cc(ctx, m, 64 + q), Uc(ctx, m, qn), Tm(ctx, kl, kl), Cp(ctx, m, 16);
+    gemm(ctx, true, false, 1.0, Bb, YB, 0.0, Cc, nullptr, "gemm_sketch");                    // B' [Y_p, Y_f, W, Z, W_2]
+    const double bf = est_ratio_prev < 0.0 ? 0.4 : std::min(0.6, std::max(0.05, 1.0 - 2.6 * est_ratio_prev));
+    warm_small(ctx, q, m, kl, qn, Cc, nullptr, 0, 0.0, abstol_lag, frac, bf, tols, Uc, Tm, Cp, tickets + 1);
+    Mat Rfull(ctx, n, qn);
+    warm_finish(ctx, n, m, qn, Bb, Uc, Yp, Cp, Rfull, slabF, tickets + 1, tols);
+    double h[12];
+    ctx_fetch(ctx, tols, 12 * sizeof(double), h);
+    const int J = (int)h[4];
+    const bool ok = h[5] == 0.0 && J >= 0 && J <= kl;
+    if (trace) std::fprintf(stderr, "[warm eig] n=%d c=%d q=%d -> J=%d  missed^2 %.2e dropped^2 %.2e tol^2 %.2e  %s\n", n, c, q, J, h[6], h[7], h[1] * h[1], ok ? "accepted" : "REJECTED");
+    if (!ok) return false;
+    const int k = std::min(kl, std::max(16, ((J + 15) / 16) * 16));
+    X.blocks.clear();
+    X.blocks.push_back({Rfull.colsview(0, k), Tm.view(0, 0, k, k), 1.0, false, true});
+    Qnext = Rfull;
+    if (J_out) *J_out = J;
+    if (est_ratio_out) *est_ratio_out = h[1] > 0.0 ? h[6] / (h[1] * h[1]) : -1.0;
+    ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += m; ctx->cstats.rank_out += J;
     return true;
 }
 

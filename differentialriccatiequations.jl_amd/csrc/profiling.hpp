@@ -1,6 +1,7 @@
 // Per-kernel-class timing with HIP events on the library's own stream.
 // Used by bench.py's roofline leg (torch.cuda.Event only sees torch's stream).
 #pragma once
+#include <chrono>
 #include "common.hpp"
 
 namespace dre {
@@ -48,6 +49,12 @@ struct TimedScope {
     Ctx* ctx; bool on; hipEvent_t a{}, b{}; const char* name; double bytes, flops; long count;
     TimedScope(Ctx* c, const char* nm, double by = 0, double fl = 0, long cnt = 1)
         : ctx(c), on(c->timer && c->timer->enabled), name(nm), bytes(by), flops(fl), count(cnt) {
+        if (c->gate_follow && c->gate && !c->gate->waiting.load(std::memory_order_relaxed)) {
+            // (every kernel class of the library is launched inside a TimedScope: this is the one place all launches of a context pass)
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!c->gate->waiting.load(std::memory_order_relaxed) &&
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < (double)c->gate_patience_us) {}
+        }
         if (on) {
             a = ctx->timer->get_event(); b = ctx->timer->get_event();
             (void)hipEventRecord(a, ctx->stream);

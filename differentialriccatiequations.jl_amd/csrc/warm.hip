@@ -52,7 +52,7 @@ __device__ inline double warm_block_sum(double v, double* red) {
 // (right-looking Cholesky, pivots at or below 1e-10 x the largest diagonal entry give a zero column of C) and writes C = L^-T.
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct WarmProjectArgs {
-    int n, q;
+    int n, q, rows_per_wg;        // rows_per_wg: a multiple of 16 (large n: at most 64 workgroups meet at the ticket)
     const double* Q; int ldq;
     const double* Yf; int ldy;
     const double* Pf; int ldpf;   // q x 16: Q'Y_f
@@ -70,29 +70,35 @@ __global__ __launch_bounds__(256) void k_warm_project(WarmProjectArgs a) {
     const int n = a.n, q = a.q;
     for (int e = tid; e < q * 16; e += 256) { const int i = e % q, c = e / q; Pf[i][c] = a.Pf[i + (size_t)c * a.ldpf]; }
     __syncthreads();
-    // Z_1 strip (16 x 16): thread (row r = tid & 15, column c = tid >> 4)
-    const int row0 = blockIdx.x * 16;
-    {
-        const int r = tid & 15, c = tid >> 4, row = row0 + r;
-        double z = 0.0;
-        if (row < n) {
-            double s0 = a.Yf[row + (size_t)c * a.ldy], s1 = 0.0;
-            int j = 0;
-            for (; j + 1 < q; j += 2) { s0 -= a.Q[row + (size_t)j * a.ldq] * Pf[j][c]; s1 -= a.Q[row + (size_t)(j + 1) * a.ldq] * Pf[j + 1][c]; }
-            if (j < q) s0 -= a.Q[row + (size_t)j * a.ldq] * Pf[j][c];
-            z = s0 + s1;
-            a.Z1[row + (size_t)c * a.ldz] = z;
+    // Z_1 in strips of 16 rows: thread (row r = tid & 15, column c = tid >> 4); the workgroup's share of Z_1'Z_1 accumulates over its strips
+    double gacc = 0.0;
+    for (int sub = 0; sub < a.rows_per_wg; sub += 16) {
+        const int row0 = blockIdx.x * a.rows_per_wg + sub;
+        if (row0 >= n) break;
+        {
+            const int r = tid & 15, c = tid >> 4, row = row0 + r;
+            double z = 0.0;
+            if (row < n) {
+                double s0 = a.Yf[row + (size_t)c * a.ldy], s1 = 0.0;
+                int j = 0;
+                for (; j + 1 < q; j += 2) { s0 -= a.Q[row + (size_t)j * a.ldq] * Pf[j][c]; s1 -= a.Q[row + (size_t)(j + 1) * a.ldq] * Pf[j + 1][c]; }
+                if (j < q) s0 -= a.Q[row + (size_t)j * a.ldq] * Pf[j][c];
+                z = s0 + s1;
+                a.Z1[row + (size_t)c * a.ldz] = z;
+            }
+            Zs[r][c] = z;
         }
-        Zs[r][c] = z;
-    }
-    __syncthreads();
-    {
-        const int i = tid & 15, j = tid >> 4;
-        double s = 0.0;
+        __syncthreads();
+        {
+            const int i = tid & 15, j = tid >> 4;
+            double s = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += Zs[r][i] * Zs[r][j];
-        a.slab[(size_t)blockIdx.x * 256 + tid] = s;
+            for (int r = 0; r < 16; ++r) s += Zs[r][i] * Zs[r][j];
+            gacc += s;
+        }
+        __syncthreads();
     }
+    a.slab[(size_t)blockIdx.x * 256 + tid] = gacc;
     __syncthreads();
     // (ONE release fence per workgroup, behind the barrier: on a multi-XCD part a device-scope fence writes the XCD's L2 back, and 256 of them
     // per workgroup made this kernel 33 us long)
@@ -233,6 +239,31 @@ __global__ __launch_bounds__(256) void k_warm_z(WarmZArgs a) {
     const double v = ((part[0][wave][lane] + part[1][wave][lane]) + part[2][wave][lane]) + part[3][wave][lane];
     const int orow = row0 + lk + 4 * wave;
     if (orow < n) a.W2[orow + (size_t)lr * a.ldw2] = v;
+}
+
+// Z = Z_1 C (n x 16) for large n, where the rows do not fit one workgroup's LDS: a thread per row, into the basis buffer and the right-hand block
+__global__ __launch_bounds__(256) void k_warm_zapply(int n, const double* __restrict__ Z1, int ldz, const double* __restrict__ Cw, double* __restrict__ Zb, int ldzb,
+                                                     double* __restrict__ Zy, int ldzy) {
+    __shared__ double Cs[16][17];
+    Cs[threadIdx.x & 15][threadIdx.x >> 4] = Cw[threadIdx.x];
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double z1[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z1[j] = Z1[r + (size_t)j * ldz];
+#pragma unroll 2
+    for (int c = 0; c < 16; ++c) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) { s0 += z1[j] * Cs[j][c]; s1 += z1[j + 1] * Cs[j + 1][c]; }
+        const double z = s0 + s1;
+        Zb[r + (size_t)c * ldzb] = z; Zy[r + (size_t)c * ldzy] = z;
+    }
+}
+void warm_zapply(Ctx* ctx, int n, const Mat& Z1, const double* Cw, Mat& Zb, Mat& Zy) {
+    hipLaunchKernelGGL(k_warm_zapply, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, n, (const double*)Z1.p, Z1.ld, Cw, Zb.p, Zb.ld, Zy.p, Zy.ld);
+    DRE_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -763,12 +794,16 @@ void warm_ctl(Ctx* ctx, double* tols, int* ticket, int J) {
     hipLaunchKernelGGL(k_warm_ctl, dim3(1), dim3(1), 0, ctx->stream, tols, ticket, J);
     DRE_HIP(hipGetLastError());
 }
+// rows of Z_1 per workgroup of k_warm_project: 16 while at most 64 workgroups result, else the multiple of 16 that gives 64
+int warm_project_rows(int n) { const int strips = (n + 15) / 16; return strips <= 64 ? 16 : 16 * ((strips + 63) / 64); }
+int warm_project_slabs(int n) { return ceil_div(n, warm_project_rows(n)); }
 void warm_project(Ctx* ctx, int n, int q, const Mat& Q, const Mat& Yf, const Mat& Pf, Mat& Z1, double* slab, int* ticket, double* Cw) {
     DRE_REQUIRE(q >= 1 && q <= 64 && Q.rows == n && Q.cols >= q && Yf.rows == n && Yf.cols >= 16 && Z1.rows == n && Z1.cols >= 16 && Pf.rows >= q && Pf.cols >= 16,
                 "warm_project: shapes");
-    WarmProjectArgs a{n, q, Q.p, Q.ld, Yf.p, Yf.ld, Pf.p, Pf.ld, Z1.p, Z1.ld, slab, ticket, Cw};
+    const int rpw = warm_project_rows(n);
+    WarmProjectArgs a{n, q, rpw, Q.p, Q.ld, Yf.p, Yf.ld, Pf.p, Pf.ld, Z1.p, Z1.ld, slab, ticket, Cw};
     TimedScope ts(ctx, "warm_project", 8.0 * ((double)n * (q + 32)), 2.0 * (double)n * q * 16);
-    hipLaunchKernelGGL(k_warm_project, dim3(ceil_div(n, 16)), dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_warm_project, dim3(ceil_div(n, rpw)), dim3(256), 0, ctx->stream, a);
     DRE_HIP(hipGetLastError());
 }
 void warm_z(Ctx* ctx, int n, const Mat& Z1, const double* Cw, const Mat& Res, Mat& Zb, Mat& Zy, Mat& W2) {
