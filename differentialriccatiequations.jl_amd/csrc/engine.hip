@@ -972,14 +972,11 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         gemm(ctx, true, false, 1.0, R, R, 0.0, G0, nullptr, "gemm_gram");
         ldlt_norm_update_state(ctx, G0, Tm, tdiag, alpha_res, st.p, 0);
         if (opt.normC_build) {
-            // the tolerance is formed right here, on this stream: the decisions are live from iteration 0 on; the host reads it with the first chunk
-            // ... on a helper stream, beside the SMW set-up and the first group's sweeps; the main stream picks it up in front of its first norm
-            Ctx* hc = helper_ctx(ctx, 0);
+            // the tolerance is formed beside the SMW set-up and the first group's sweeps (a stream and a host thread of the caller's); this stream
+            // picks it up in front of its first decision, the host reads it with the first chunk
             hipEvent_t e0 = aux_event(ctx, 0), e1 = aux_event(ctx, 1);
             DRE_HIP(hipEventRecord(e0, ctx->stream));
-            DRE_HIP(hipStreamWaitEvent(hc->stream, e0, 0));
-            opt.normC_build(hc, R, Tm, alpha_res);
-            DRE_HIP(hipEventRecord(e1, hc->stream));
+            opt.normC_build(e0, R, Tm, alpha_res, e1);
             run.tol_event = e1;
             run.defer = false; run.abstol_pending = true;
         }
@@ -1231,6 +1228,7 @@ void adi_advance(AdiRun& run, int budget) {
         // of adi.jl:115-123 for everything recorded so far, in iteration order
         auto apply_tolerance = [&]() {
             if (!run.tol_event) return;
+            if (opt.normC_join) opt.normC_join();          // (`done` is recorded by then)
             DRE_HIP(hipStreamWaitEvent(ctx->stream, run.tol_event, 0));
             adi_decide_scan(ctx, st.p, 0, opt.normC_dev, run.reltol, -1.0);
             run.tol_event = nullptr;

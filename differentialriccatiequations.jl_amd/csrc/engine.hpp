@@ -124,9 +124,12 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     std::shared_ptr<struct LDLt> given_residual;
     const double* normC_dev = nullptr;
     std::function<void()> normC_wait;    // makes the calling stream wait for *normC_dev
-    // ... or it is formed on the solve's own stream as soon as the given residual is compressed to (Q, D, alpha): the callback enqueues that
-    // (it runs on a HELPER stream of the context, beside the first solves of the iteration: `hc` is that stream's context)
-    std::function<void(Ctx* hc, const Mat& Q, const Mat& D, double alpha)> normC_build;
+    // ... or the caller forms it as soon as the given residual is compressed to (Q, D, alpha): the callback makes a stream of its own wait for
+    // `ready` (recorded on the solve's stream behind the compression), enqueues the work there and records `done` behind it.  It may hand all of
+    // that to another host thread and return at once (a step of the general path is bound by host launches): the solve calls normC_join()
+    // before it makes its stream wait for `done`.
+    std::function<void(hipEvent_t ready, const Mat& Q, const Mat& D, double alpha, hipEvent_t done)> normC_build;
+    std::function<void()> normC_join;
     double abstol_lag = -1.0;            // tolerance of the previous time step: truncation level of the warm-start residual
     bool keep_history = false;           // keep every iteration's V_j and R_j side by side (AdiResult::hist)
     Mat warm_basis;                      // orthonormal basis of the PREVIOUS step's compressed warm-start residual (warm-started range finder for this one's)

@@ -1436,6 +1436,13 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     double eig_est = -1.0;
     int eig_J = -1;
     DevArr<double> normC_dev(ctx, 1);
+    // The tolerance formula's two dozen launches (normC_build below) are enqueued by a second parked thread on a stream of its own while this
+    // thread goes on with the Sherman-Morrison-Woodbury set-up and the first sweeps: at n = 5177 they were 220 us of this thread's 1.1 ms per
+    // step, in front of the first solve.  (The context is a helper of the SIDE context: the main context's helpers carry factorisations.)
+    Ctx* const norm_ctx = helper_ctx(side, 0);
+    SideWorker norm_worker;
+    bool norm_pending = false;
+    std::function<void()> join_norm = [&]() { if (norm_pending) { norm_pending = false; norm_worker.wait(); } };
     Mat Im(ctx, m, m);
     set_identity(ctx, Im, 1.0);
     for (int i = 1; i <= nsteps; ++i) {
@@ -1518,7 +1525,13 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             // ||rhs_i||_F for the tolerance (adi.jl:61-62), on this stream, as soon as the residual is compressed:
             //   rhs_i = C'C + K'K + E'X_b E / tau + sum_{s = b+1 .. i-1} (tau_{s+1} / tau) (Q_s Dq_s Q_s' - a_s R_s T_s R_s' + dK_s'dK_s)
             // with X_b the latest X the side stream has finished (b >= i - 4) — one Gram matrix of a few hundred columns
-            a2.normC_build = [&, i, tau, RJ](Ctx* hc, const Mat& Q, const Mat& Dq, double aq) {
+            a2.normC_build = [&, i, tau, RJ](hipEvent_t ready, const Mat& Qr, const Mat& Dqr, double aq, hipEvent_t done_ev) {
+              const Mat Q = Qr, Dq = Dqr;
+              norm_pending = true;
+              norm_worker.submit([&, i, tau, RJ, Q, Dq, aq, ready, done_ev]() {
+                DRE_HIP(hipSetDevice(ctx->device));
+                Ctx* const hc = norm_ctx;
+                DRE_HIP(hipStreamWaitEvent(hc->stream, ready, 0));
                 StepDelta dl;
                 dl.s = i - 1; dl.tau = tau; dl.Q = Q; dl.Dq = Mat(hc, Dq.rows, Dq.cols); copy_mat(hc, Dq, dl.Dq, aq);
                 dl.Rj = RJ; dl.Tj = prev.Tm; dl.aj = prev.alpha_res; dl.dKt = prev.hist.empty() ? Mat() : prev_dKt;
@@ -1559,7 +1572,11 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                 }
                 copy_batched(hc, cd);
                 ldlt_norm_device(hc, F, S, 1.0, normC_dev.p);
+                DRE_HIP(hipEventRecord(done_ev, hc->stream));
+              });
             };
+            a2.normC_join = join_norm;
+            struct NormJoin { std::function<void()>& f; ~NormJoin() { try { f(); } catch (...) {} } } norm_guard{join_norm};      // (a solve that ends before its first decision)
             LDLt none; none.n = n;
             ar = adi_solve(ctx, op, none, nullptr, a2, &cache);
             for (auto& b : ar.X->blocks) if (b.L.cols > 0) incr.push_back(b);
