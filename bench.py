@@ -315,6 +315,48 @@ def ros2_projection_leg(D, ctx, steps=2):
                 roofline=roof, parity=par)
 
 
+def ros2_general_leg(D, ctx, steps=2):
+    """Ros2 on the GENERAL path (/root/reference/src/riccati/lowrank_ros2.jl:37-80): SteelProfile(5177) Ros2 LRSIF, Cyclic
+    heuristic real shifts, 12 steps of dt = -100 — two cold-start Lyapunov solves per step, fan groups on both.  Parity against
+    tests/golden/ros2_5177_s12.npz (oracle/dre_oracle.py, 40 minutes of CPU): with this shift list (computed for the Ros1 operator) EVERY stage solve
+    of the oracle stops at maxiters = 200 above its tolerance; the HIP path must do the same and reach the same K(t)."""
+    import warnings
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ros2_5177_s12.npz"))
+    n, nsteps = 5177, 12
+    d = D.steel_profile(n)
+    L, Dm = D.initial_value(d)
+    p = list(np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy")))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4500.0 - 100.0 * nsteps))
+    alg = D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(p), maxiters=200))
+    warnings.simplefilter("ignore")
+    D.set_default_context(ctx)
+    sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True, ctx=ctx)
+    els = []
+    for _ in range(steps):
+        ctx.sync(); t = time.perf_counter()
+        sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True, ctx=ctx)
+        els.append(time.perf_counter() - t)
+    mean = sum(els) / len(els)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    D.solve_gdre(prob, alg, dt=-100.0, ctx=ctx)
+    stats = ctx.prof_stats(); ctx.prof_enable(False)
+    its = [x["iters"] for x in st["gales"]]
+    w = np.random.default_rng(1).standard_normal(n)
+    dk = max(float(np.linalg.norm(sol.K[i][:, ::16] - g["K_cols"][i]) / g["K_norm"][i]) for i in range(1, nsteps + 1))
+    dw = max(float(np.linalg.norm(sol.K[i] @ w - g["K_w"][i]) / np.linalg.norm(g["K_w"][i])) for i in range(1, nsteps + 1))
+    par = dict(fixture="tests/golden/ros2_5177_s12.npz", delta_K_sampled_columns=dk, delta_K_times_seeded_vector=dw, adi_iterations_per_solve=its,
+               adi_iterations_per_solve_oracle=[int(v) for v in g["iters_per_solve"].ravel()],
+               lyapunov_solves_converged=f"{sum(int(x['converged']) for x in st['gales'])}/{len(its)}", oracle_solves_converged="0/24",
+               criterion="delta < 1e-7 (test/cuda.jl:95-99), the oracle's iteration count of every stage solve")
+    if not (dk < 1e-7 and dw < 1e-7 and its == par["adi_iterations_per_solve_oracle"]):
+        raise SystemExit(f"bench.py: PARITY FAILURE (Ros2, general path): {par}")
+    tot = sum(v["ms"] for v in stats.values())
+    return dict(config="SURVEY 8(a) a2 on the general path (no BASELINE config of its own)", workload="SteelProfile(5177) Ros2 LRSIF, Cyclic heuristic real shifts, "
+                "12 time steps of dt=-100, 24 cold-start Lyapunov solves (none converges within maxiters = 200 with this list, in the oracle neither)",
+                n=n, nsteps=nsteps, value=sum(its) / mean, unit="ADI iterations/s", ms_per_step=mean * 1e3, ms_per_step_runs=[e * 1e3 for e in els],
+                parity=par, by_kernel_ms={k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}, device_ms_profiled=tot)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (fresh child processes under
     torch.distributed.run, BEFORE anything in this process touches the GPU) and relay rank 0's JSON line."""
@@ -468,7 +510,7 @@ def main():
         except SystemExit as e:      # reported AFTER the final barrier: a parity failure must not strand the other ranks in it
             parity, parity_failure = None, e
         # ---- general path leg: the sparse multifrontal path north_star names, in the driver-timed record
-        general = general45 = general20k = general20k45 = ros2leg = None
+        general = general45 = general20k = general20k45 = ros2leg = ros2gen = None
         if world == 1 and n == 371 and not strong and not args.no_general_path:
             general = general_path(D, ctx, args, config="BASELINE configs[3], first 12 of its 45 steps (the leg of rounds 2-3)")
             general45 = general_path(D, ctx, args, nsteps=45, steps=2, warmup=1, config="BASELINE configs[3] at its stated length (one GPU)")
@@ -477,6 +519,7 @@ def main():
                                         config="BASELINE configs[4] at its stated length (one GPU): 45 steps, save_state; no oracle fixture of this length "
                                                "(the 12-step one took the oracle 26 minutes) - tests/test_gpu_r05.py checks it through size-independent properties")
             ros2leg = ros2_projection_leg(D, ctx)
+            ros2gen = ros2_general_leg(D, ctx)
         # ---- CPU baseline leg: the oracle (a NumPy/SciPy port with the reference's algorithmic choices) on a bounded sample.
         # The BLAS thread count matters a lot at this size (128 OpenBLAS threads are 13x SLOWER than one on 371-row panels),
         # so a two-step probe picks the fastest of a few thread counts and the sample runs with that one.
@@ -562,6 +605,7 @@ def main():
             "general_path_20209": general20k,
             "general_path_20209_45": general20k45,
             "ros2_1357_projection": ros2leg,
+            "ros2_general_5177": ros2gen,
         }
         out["setup_ms"] = setup_ms
         out["first_solve_ms"] = first_solve_ms

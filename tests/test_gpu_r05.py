@@ -144,3 +144,25 @@ def test_config4_ros1_20209_save_state_all_45_steps_properties(ctx):         # l
         assert res <= 50 * n * EPS * D.norm(rhs), (i, res)
     storage = sum(8 * (n * r + r * r) for r in ranks)
     assert 0.5e9 < storage < 3e9                                            # about a gigabyte of X(t)
+
+
+def test_ros2_on_the_general_path_against_the_oracle_fixture(ctx):           # lowrank_ros2.jl:37-80 at n = 5177
+    """SteelProfile(5177) Ros2 LRSIF, Cyclic heuristic real shifts, the first 6 of the fixture's 12 steps: two cold-start Lyapunov solves per step
+    on the multifrontal path with fan groups.  The oracle stops every stage solve at maxiters = 200 above its tolerance (the list was computed for
+    the Ros1 operator): the HIP path must report the same — 200 iterations, not converged, the warning — and the same K(t)."""
+    n, nsteps = 5177, 6
+    g = np.load(os.path.join(GOLDEN, "ros2_5177_s12.npz"))
+    d = D.steel_profile(n)
+    L, Dm = D.initial_value(d)
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4500.0 - 100.0 * nsteps))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sol, st = D.solve_gdre(prob, D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(_shifts(n)), maxiters=200)), dt=-100.0, return_stats=True, ctx=ctx)
+    its = [x["iters"] for x in st["gales"]]
+    assert its == [int(v) for v in g["iters_per_solve"][:nsteps].ravel()]
+    assert not any(x["converged"] for x in st["gales"])
+    w = np.random.default_rng(1).standard_normal(n)
+    for i in range(1, nsteps + 1):
+        K = sol.K[i]
+        assert np.linalg.norm(K[:, ::16] - g["K_cols"][i]) < 1e-7 * g["K_norm"][i], i
+        assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * np.linalg.norm(g["K_w"][i]), i
