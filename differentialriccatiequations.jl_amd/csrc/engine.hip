@@ -285,6 +285,9 @@ struct ShiftOracle {
     virtual void update(const Mat& R, const std::vector<Mat>& Vs) {}
     // the shifts that take() will return next, as far as they are already known (never triggers a computation)
     virtual std::vector<std::complex<double>> peek(size_t) const { return {}; }
+    // index (in the strategy's own list) of the shift take() returns next; 0 where there is no list
+    virtual size_t position() const { return 0; }
+    virtual size_t list_size() const { return 0; }
 };
 struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
     std::vector<std::complex<double>> v;
@@ -295,6 +298,8 @@ struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
         for (size_t j = 0; j < count && !v.empty(); ++j) out.push_back(v[(i + j) % v.size()]);
         return out;
     }
+    size_t position() const override { return v.empty() ? 0 : i % v.size(); }
+    size_t list_size() const override { return v.size(); }
 };
 
 void apply_Ft(Ctx* ctx, const GaleOperator& op, const Mat& L, Mat& out) {
@@ -1025,11 +1030,16 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     // General path, Cyclic real list, one rank: every shift of the cycle that has no factor yet is factorised NOW, all of them in shared
     // launches (sparse.hip, mf_factor_batch: one launch per tree level for the whole list) together with their dense top inverses — round 3
     // ran them as ten chains on five helper streams: 4 + 1.6 + 1.6 ms of the first time step at n = 5177 went into waiting for them.
-    if (opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n && ctx->adi_fan >= 2 && P.use_mfma_sweeps &&
-        !(ctx->comm && ctx->comm->nranks > 1 && ctx->comm->emulate <= 1)) {
+    // Sharded by shift (a communicator with real ranks): a rank owns the shifts at the list positions i = rank (mod P) — fixed for the run, whatever
+    // the group boundaries turn out to be — and factorises exactly those here, in shared launches, like the single rank does with the whole list
+    // (round 4 switched the batched set-up off in sharded mode: every rank factorised its shifts one by one inside the first groups).
+    if (opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && n > ctx->dense_inv_max_n && ctx->adi_fan >= 2 && P.use_mfma_sweeps) {
+        const bool real_ranks = ctx->comm && ctx->comm->nranks > 1 && ctx->comm->emulate <= 1;
         std::vector<double> todo;
-        for (auto& mu : opt.shifts.values) {
+        for (size_t iv = 0; iv < opt.shifts.values.size(); ++iv) {
+            const auto& mu = opt.shifts.values[iv];
             if (mu.imag() != 0.0) { todo.clear(); break; }
+            if (real_ranks && (int)(iv % (size_t)ctx->comm->nranks) != ctx->comm->rank) continue;
             bool dup = cache->real.count(std::make_tuple(op.tag, mu.real(), 0.0)) > 0;
             for (double t : todo) dup = dup || t == mu.real();
             if (!dup && (int)todo.size() < MF_ZMAX) todo.push_back(mu.real());
@@ -1399,7 +1409,7 @@ void adi_advance(AdiRun& run, int budget) {
             }
         };
         // Fan groups (round 4: batched, and sharded over the ranks of a communicator BY SHIFT — north_star's "independent ADI shifts farmed across
-        // the GPUs"): the g solves of a group are independent, so rank r takes the group positions s = r (mod P), i.e. only ever factorises and
+        // the GPUs"): the g solves of a group are independent, so rank r takes the shifts at the LIST positions i = r (mod P), i.e. only ever factorises and
         // keeps the shifts it owns (the factor farm of SURVEY 8e-4 without shipping factors), writes its W_s into slab r of the gathered panel and
         // ONE in-place all-gather per GROUP (n g k doubles in all; round 3: one per iteration, columns sharded) completes it on every rank;
         // mixing, norms, decisions, compression and K(t) are replicated and bit-identical on all ranks.
@@ -1430,7 +1440,11 @@ void adi_advance(AdiRun& run, int budget) {
                 // which ranks this process plays: its own, or all of them one after the other (shard_emulate)
                 const bool emu = ctx->comm && ctx->comm->emulate > 1;
                 const int my_rank = ctx->comm ? ctx->comm->rank : 0;
-                auto mine = [&](int s_) { return fan_P == 1 || emu || (s_ % fan_P) == my_rank; };
+                // ownership by the shift's position in the LIST (not in the group): the same shift always meets the same rank, so a rank factorises
+                // and keeps only its share of the list (adi_begin factorises that share up front)
+                const size_t pos0 = oracle->position(), lsz = oracle->list_size();
+                auto owner = [&](int s_) { return (int)((lsz ? (pos0 + (size_t)s_) % lsz : (size_t)s_) % (size_t)fan_P); };
+                auto mine = [&](int s_) { return fan_P == 1 || emu || owner(s_) == my_rank; };
                 std::vector<std::shared_ptr<FactorEntry<double>>> fes((size_t)std::max(g, 0));
                 if (lookahead && g >= gmin) prefetch_ahead(std::complex<double>(0.0, 0.0), true);      // (first pass through the cycle: this group's and the next groups' factors; all waited for below)
                 for (int s_ = 0; s_ < g && g >= gmin; ++s_) {
@@ -1448,15 +1462,22 @@ void adi_advance(AdiRun& run, int budget) {
                     const auto f0 = fnow();
                     const AdiState* dst = st.p;
                     dense_norm_flush(ctx, k, Tm, tdiag, alpha_res, st.p, &npend);
-                    const int gp = ceil_div(g, fan_P);                 // group positions per rank; W_s lives in slot (s mod P) gp + s div P
+                    // group positions per rank (a group that wraps around the end of the list may give one rank more than g / P); W_s lives in slab
+                    // owner(s), in the owner's order
+                    int gp = 0;
                     FanSlots slots; std::memset(&slots, 0, sizeof(slots));
-                    for (int s_ = 0; s_ < g; ++s_) slots.s[s_] = (s_ % fan_P) * gp + s_ / fan_P;
+                    {
+                        int seen[64] = {0};
+                        for (int s_ = 0; s_ < g; ++s_) gp = std::max(gp, ++seen[owner(s_) & 63]);
+                        std::memset(seen, 0, sizeof(seen));
+                        for (int s_ = 0; s_ < g; ++s_) { const int o = owner(s_); slots.s[s_] = o * gp + seen[o & 63]++; }
+                    }
                     Mat Wcat(ctx, n, fan_P * gp * k);
                     bool ok = true;
                     for (int r = 0; r < fan_P && ok; ++r) {
                         if (!(fan_P == 1 || emu || r == my_rank)) continue;
                         std::vector<int> pos;                          // this rank's group positions
-                        for (int s_ = r; s_ < g; s_ += fan_P) pos.push_back(s_);
+                        for (int s_ = 0; s_ < g; ++s_) if (owner(s_) == r) pos.push_back(s_);
                         const int gr = (int)pos.size();
                         if (gr == 0) continue;
                         SmwZ sz; std::memset(&sz, 0, sizeof(sz));

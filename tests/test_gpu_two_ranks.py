@@ -1,7 +1,7 @@
 """The LIBRARY's sharded solve on two REAL ranks: two processes, one communicator of nranks = 2, the collectives
 of engine.hip's adi_advance crossing a process boundary.  The build box has one GPU and RCCL refuses two ranks on one device, so the
 communicator runs over the host transport of `dre_comm_init_host` (include/dre_hip.h) with gloo underneath; everything above the transport —
-fan groups sharded by shift (rank r solves the group positions s = r mod 2 and factorises only the shifts it owns), one in-place all-gather
+fan groups sharded by shift (rank r solves the shifts at the list positions i = r mod 2 and factorises only those), one in-place all-gather
 per group, the column-sharded step for leftover iterations, replicated mixing / norms / compression / K(t) — is what a multi-GPU run over
 RCCL executes.  Reference: /root/reference/src/lyapunov/adi.jl:149-179 (the iteration that is sharded), src/blocklinear/backslash.jl:13
 (the factorisations that are farmed)."""
@@ -64,6 +64,8 @@ def test_sharded_gdre_on_two_ranks_matches_the_oracle_fixture(tmp_path):
         assert list(r["iters"]) == list(g["iters"])
     assert int(r0["rank"]) == 0 and int(r1["rank"]) == 1
     assert np.array_equal(r0["K"], r1["K"])                       # replicated arithmetic: bit-identical on both ranks
+    # ownership by list position: a rank factorises its five of the ten shifts (in shared launches at the first solve), not the whole list
+    assert int(r0["factorizations"]) + int(r1["factorizations"]) <= 14, (int(r0["factorizations"]), int(r1["factorizations"]))
     n = r0["K"].shape[2]
     w = np.random.default_rng(1).standard_normal(n)
     for i, K in enumerate(r0["K"]):
