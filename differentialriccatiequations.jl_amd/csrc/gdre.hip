@@ -1749,8 +1749,11 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     auto wall_now = [&]() { if (wall_on) DRE_HIP(hipStreamSynchronize(ctx->stream)); return std::chrono::steady_clock::now(); };
     const auto w_begin = wall_now();
     auto w_first = w_begin;
+    const bool steps_on = env_trace("steps");          // host clock at the top of every step (each step ends behind a read-back: no extra synchronisation)
+    std::vector<std::chrono::steady_clock::time_point> step_t;
     for (int i = 1; i <= nsteps; ++i) {
         if (wall_on && i == 2) w_first = wall_now();
+        if (steps_on) step_t.push_back(std::chrono::steady_clock::now());
         const double tau = out.t[i - 1] - out.t[i];
         GaleOperator op;
         op.P = &P;
@@ -1944,6 +1947,12 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
         out.Kt.push_back(fb.Kt);
     }
     const auto w_loop = wall_now();
+    if (steps_on && !step_t.empty()) {
+        step_t.push_back(std::chrono::steady_clock::now());
+        std::fprintf(stderr, "[steps, us]");
+        for (size_t i = 1; i < step_t.size(); ++i) std::fprintf(stderr, " %.0f", std::chrono::duration<double, std::micro>(step_t[i] - step_t[i - 1]).count());
+        std::fprintf(stderr, "\n");
+    }
     if (env_trace("pool"))
         std::fprintf(stderr, "[pool] main: %ld misses, %.1f MB; side: %ld misses, %.1f MB\n", ctx->pool.misses(), ctx->pool.total_bytes() / 1048576.0,
                      side ? side->pool.misses() : 0L, side ? side->pool.total_bytes() / 1048576.0 : 0.0);
