@@ -1430,6 +1430,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     bool have_hist = false;
     AdiResult prev;                                 // pieces of the previous solve the recurrence needs (hist, Tm, alpha_res, residual)
     Mat prev_dKt;
+    std::vector<Mat> prev_EV;                       // E'V_j of the previous solve, chunk by chunk (formed for its feedback, read again by the next residual)
     double abstol_prev = -1.0;
     std::vector<StepDelta> deltas;                  // steps the side stream's X does not include yet
     Mat eigQ;                                       // eigenbasis of the last compressed warm-start residual (warm_compress_eig), empty: none
@@ -1509,10 +1510,16 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             if (!prev.hist.empty()) {
                 resid->blocks.push_back({prev_dKt, Im, -1.0, true, false});
                 const int k = prev.Tm.rows;
+                size_t hci = 0;
                 for (auto& hc : prev.hist) {
                     const int J = (int)hc.mu.size();
-                    Mat EV(ctx, n, J * k);
-                    ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                    // (E'V_j of the previous solve were formed for its feedback already: kept, not recomputed — two passes over the slabs at n = 20209)
+                    Mat EV = (hci < prev_EV.size() && prev_EV[hci].rows == n && prev_EV[hci].cols == J * k) ? prev_EV[hci] : Mat();
+                    ++hci;
+                    if (EV.empty()) {
+                        EV = Mat(ctx, n, J * k);
+                        ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                    }
                     for (int j = 0; j < J; ++j)
                         resid->blocks.push_back({EV.colsview(j * k, k), prev.Tm, -2.0 * hc.mu[(size_t)j] * prev.alpha_res / tau, prev.tdiag, false});
                 }
@@ -1602,10 +1609,12 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             copy_mat(ctx, Kt, Kt_new);
             const int k = ar.Tm.rows;
             bool first = true;
+            prev_EV.clear();
             for (auto& hc : ar.hist) {
                 const int J = (int)hc.mu.size();
                 Mat EV(ctx, n, J * k), VtB(ctx, J * k, m), Mx(ctx, J * k, m);
                 ev_from_residuals(ctx, n, k, J, hc.R0, hc.Rs, EV, hc.mu.data());
+                prev_EV.push_back(EV);
                 gemm(ctx, true, false, 1.0, hc.Vs, prob.B, 0.0, VtB, nullptr, "gemm_feedback");
                 std::vector<GemmBatchDesc> descs;
                 for (int j = 0; j < J; ++j)
@@ -1619,6 +1628,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             prev_dKt = dKt;
         } else {
             // no history (an iteration outside the fan path, a compression inside the solve): the reference's order for this step's tail
+            prev_EV.clear();
             submit_job();
             join_side();
             const auto st = get_state();

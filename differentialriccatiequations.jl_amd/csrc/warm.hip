@@ -52,7 +52,7 @@ __device__ inline double warm_block_sum(double v, double* red) {
 // (right-looking Cholesky, pivots at or below 1e-10 x the largest diagonal entry give a zero column of C) and writes C = L^-T.
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct WarmProjectArgs {
-    int n, q, rows_per_wg;        // rows_per_wg: a multiple of 16 (large n: at most 64 workgroups meet at the ticket)
+    int n, q, rows_per_wg;        // rows_per_wg: a multiple of 16 (large n: at most 256 workgroups meet at the ticket)
     const double* Q; int ldq;
     const double* Yf; int ldy;
     const double* Pf; int ldpf;   // q x 16: Q'Y_f
@@ -795,7 +795,9 @@ void warm_ctl(Ctx* ctx, double* tols, int* ticket, int J) {
     DRE_HIP(hipGetLastError());
 }
 // rows of Z_1 per workgroup of k_warm_project: 16 while at most 64 workgroups result, else the multiple of 16 that gives 64
-int warm_project_rows(int n) { const int strips = (n + 15) / 16; return strips <= 64 ? 16 : 16 * ((strips + 63) / 64); }
+// (at most 256 workgroups meet at the ticket: the last arrival sums their 256-entry shares in batches of 16 loads; 64 workgroups of 320 rows each
+// made the kernel 130-210 us long at n = 20209)
+int warm_project_rows(int n) { const int strips = (n + 15) / 16; return strips <= 256 ? 16 : 16 * ((strips + 255) / 256); }
 int warm_project_slabs(int n) { return ceil_div(n, warm_project_rows(n)); }
 void warm_project(Ctx* ctx, int n, int q, const Mat& Q, const Mat& Yf, const Mat& Pf, Mat& Z1, double* slab, int* ticket, double* Cw) {
     DRE_REQUIRE(q >= 1 && q <= 64 && Q.rows == n && Q.cols >= q && Yf.rows == n && Yf.cols >= 16 && Z1.rows == n && Z1.cols >= 16 && Pf.rows >= q && Pf.cols >= 16,
