@@ -342,10 +342,9 @@ __global__ __launch_bounds__(NT) void k_warm_small(WarmSmallArgs a) {
     const long long t_begin = wall_clock64();
     const bool eig_only = a.mode == 2;
     // tolerances of the Lyapunov solve (what k_band_init's job does on the cold path)
+    // (the partial sums are requested here and reduced behind the loads of H: their round trip hides behind those)
     double s = 0.0;
     if (!eig_only) for (int i = tid; i < a.nparts; i += NT) s += a.parts[i];
-    s = warm_block_sum_t<NT>(s, red);
-    const double nc = sqrt(s), at = a.abstol >= 0.0 ? a.abstol : a.reltol * nc, tolc = eig_only ? 0.0 : a.frac * at;
     // H = B'Res B (symmetrised) into A, identity into W, B'Z and B'Y_p into LDS
     if (eig_only) {
         for (int e = tid; e < MM * MM; e += NT) {
@@ -374,7 +373,8 @@ __global__ __launch_bounds__(NT) void k_warm_small(WarmSmallArgs a) {
             Pps[i][c] = a.Cc[i + (size_t)c * a.ldc];
         }
     }
-    __syncthreads();
+    s = warm_block_sum_t<NT>(s, red);          // (ends with a barrier: A, W, Gzs, Pps are complete behind it)
+    const double nc = sqrt(s), at = a.abstol >= 0.0 ? a.abstol : a.reltol * nc, tolc = eig_only ? 0.0 : a.frac * at;
     if (nf > 0) {
         // G = B'B = [I, G12; G12', G22] = L L' with L = [I, 0; G12', L22], L22 L22' = G22 - G12'G12 (16 x 16).  M = L^-1 H L^-T with
         // L^-1 = [I, 0; X, Li], Li = L22^-1, X = -Li G12'.  A dead direction (zero column of Z) gets a unit pivot and stays decoupled.
@@ -510,8 +510,10 @@ __global__ __launch_bounds__(NT) void k_warm_small(WarmSmallArgs a) {
     for (int e = tid; e < m * m; e += NT) { const double v = A[e % m][e / m]; f += v * v; }
     const double fro2 = warm_block_sum_t<NT>(f, red);
     // (mode 2: a BASIS is wanted, not eigenvalues: the iteration stops at a relative 1e-10 of the norm)
-    const double thr2 = eig_only ? 1e-20 * fro2 : fmax(0.01 * tolc * tolc, 64.0 * 4.930380657631324e-32 * fro2);
     const double budget = a.budget_frac * tolc * tolc;
+    // (the off-diagonal mass the iteration may leave: T stays dense and the truncation below accounts for every entry it drops, so this only decides
+    // how sharply the diagonal orders the coordinates — a quarter of the truncation budget instead of 1 % of tol^2 saves a third of the rounds)
+    const double thr2 = eig_only ? 1e-20 * fro2 : fmax(0.25 * budget, 64.0 * 4.930380657631324e-32 * fro2);
     // Deflation: rows whose norms add up to less than a quarter of the truncation budget (x 2: a dropped row takes its column along) leave the
     // eigenproblem untouched — they are the noise directions at the bottom of the spectrum and most of the fresh directions; what is left is a
     // handful of coordinates (the dominant eigen-directions and what really couples to them)
@@ -521,14 +523,36 @@ __global__ __launch_bounds__(NT) void k_warm_small(WarmSmallArgs a) {
         rho[tid] = s2;
     }
     __syncthreads();
+    int myrank = 0;                               // position of coordinate tid in the ascending order of the row norms
     if (tid < m) {
         const double ri = rho[tid];
         int r = 0;
         for (int j = 0; j < m; ++j) { const double rj = rho[j]; r += (rj < ri || (rj == ri && j < tid)) ? 1 : 0; }
         ord[r] = tid;
+        myrank = r;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (m <= 64) {
+        // one wave: prefix sums of the sorted row norms by shuffles (fixed association), the deflated set is a prefix of the order, the active
+        // coordinates are compacted by ballot — the serial form of this block was 5 us of dependent LDS reads on one lane
+        if (tid < 64) {
+            const double r2 = tid < m ? rho[ord[tid]] : 0.0;
+            double cum = r2;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(cum, o, 64); if (tid >= o) cum += t; }
+            const bool in = tid < m && 2.0 * cum <= 0.25 * budget;
+            const unsigned long long inb = __ballot(in);
+            // (the sums never decrease: `in` is a prefix of the order unless a NaN sits in it — then everything stays active)
+            int nN = __popcll(inb);
+            if (nN < 64 && (inb >> nN) != 0ull) nN = 0;
+            const double cumN = __shfl(cum, nN > 0 ? nN - 1 : 0, 64);
+            const bool active = tid < m && myrank >= nN;
+            const unsigned long long ab = __ballot(active);
+            if (tid < m) pos[tid] = active ? 1 : 0;
+            if (active) act[__popcll(ab & ((1ull << tid) - 1ull))] = tid;
+            if (tid == 0) { na_sh = __popcll(ab); defl_sh = nN > 0 ? 2.0 * cumN : 0.0; }
+        }
+    } else if (tid == 0) {
         double cum = 0.0;
         int nN = 0;
         for (int k = 0; k < m; ++k) {
@@ -823,10 +847,16 @@ void warm_small(Ctx* ctx, int q, int m, int kl, int qn, const Mat& Cc, const dou
                 T.rows >= kl && T.cols >= kl && Cp.rows >= m && Cp.cols >= 16 && Cc.rows >= m && Cc.cols >= 64 + q, "warm_small: shapes");
     WarmSmallArgs a{q, m, kl, qn, Cc.p, Cc.ld, parts, nparts, reltol, abstol, frac, budget_frac, 24, Mout ? 1 : 0, Mout ? Mout->p : nullptr, Mout ? Mout->ld : 0, LTout ? LTout->p : nullptr, LTout ? LTout->ld : 0, tols, Uc.p, Uc.ld, T.p, T.ld, Cp.p, Cp.ld, ticket};
     TimedScope ts(ctx, "warm_small", 8.0 * (2.0 * m * m + (double)m * qn), 12.0 * m * (double)m * m);
-    if (m <= 48) {
+    if (m <= 32) {
         const int shm = 2 * 48 * 49 * (int)sizeof(double);
         lds_attr(ctx, (const void*)k_warm_small<256, 48>, shm);
         hipLaunchKernelGGL((k_warm_small<256, 48>), dim3(1), dim3(256), shm, ctx->stream, a);
+    } else if (m <= 48) {
+        // 33 .. 48 coordinates (the first warm steps of a run: 32 basis columns, two to three full sweeps): sixteen waves — a Jacobi round's block
+        // updates are 1 536 items at 48 active coordinates, six passes of 256 threads (2.8 us per round against 1.2 at 16 coordinates)
+        const int shm = 2 * 48 * 49 * (int)sizeof(double);
+        lds_attr(ctx, (const void*)k_warm_small<1024, 48>, shm);
+        hipLaunchKernelGGL((k_warm_small<1024, 48>), dim3(1), dim3(1024), shm, ctx->stream, a);
     } else {
         const int shm = 2 * 80 * 81 * (int)sizeof(double);
         lds_attr(ctx, (const void*)k_warm_small<1024, 80>, shm);
