@@ -1057,6 +1057,38 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
             }
             mf_topinv_batch(ctx, P, fp.data(), (int)todo.size());
         }
+        if (real_ranks) {
+            // The batched solves refuse factors with replaced pivots (static pivoting) — a property of a rank's OWN shifts.  One rank leaving the
+            // fan path alone would leave the others inside the group's all-gather, so the ranks agree once per operator: every
+            // rank checks the factors it owns (one read-back) and the flags are summed across the communicator; any refusal switches the fan
+            // groups off on ALL ranks for this operator (the column-sharded iterations take over).
+            auto ag = cache->fan_agreed.find(op.tag);
+            if (ag == cache->fan_agreed.end()) {
+                std::vector<const Factor<double>*> fs;
+                std::vector<std::shared_ptr<FactorEntry<double>>> mine_fe;
+                for (size_t iv = 0; iv < opt.shifts.values.size(); ++iv) {
+                    if ((int)(iv % (size_t)ctx->comm->nranks) != ctx->comm->rank) continue;
+                    auto itf = cache->real.find(std::make_tuple(op.tag, opt.shifts.values[iv].real(), 0.0));
+                    if (itf == cache->real.end()) continue;
+                    mine_fe.push_back(itf->second);
+                    if (!itf->second->checked) fs.push_back(&itf->second->f);
+                }
+                if (!fs.empty()) {
+                    const std::vector<double> gr = mf_check_batch(ctx, fs);
+                    size_t j = 0;
+                    for (auto& fe : mine_fe) if (!fe->checked) { fe->growth = gr[j++]; fe->checked = true; }
+                }
+                double flag = 0.0;
+                for (auto& fe : mine_fe) if (fe->f.nperturbed > 0) flag = 1.0;
+                DevArr<double> fl(ctx, 1);
+                DRE_HIP(hipMemcpyAsync(fl.p, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                comm_allreduce_sum(ctx, *ctx->comm, fl.p, 1);
+                double tot = 0.0;
+                ctx_fetch(ctx, fl.p, sizeof(double), &tot);
+                ag = cache->fan_agreed.emplace(op.tag, tot > 0.0).first;
+            }
+            if (ag->second) run.fan_off = true;
+        }
     }
 
     // chunk length: compression_interval, or — where the intermediate compressions are deferred anyway — the iteration count of the

@@ -72,6 +72,8 @@ struct FactorCache {
     std::vector<std::tuple<uint64_t, double, double>> fresh;   // keys created by the running Lyapunov solve (evicted unless the shift list persists)
     int iters_hint = 0;        // ADI iterations of the previous Lyapunov solve served by this cache (speculation depth of the next one)
     int warm_sx = 0, warm_strikes = 0;   // warm-started residual compression (ldlt.hip, warm_compress): fresh directions per step, consecutive rejections
+    // sharded fan groups: operators (tags) for which the ranks have agreed whether the batched solves apply to EVERY rank's factors (value: refused)
+    std::map<uint64_t, bool> fan_agreed;
     void clear() { real.clear(); cplx_.clear(); }
 };
 struct GaleOperator {
