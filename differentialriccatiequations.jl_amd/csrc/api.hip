@@ -190,6 +190,7 @@ static OptionRef option_ref(Ctx& c, const std::string& key) {
     DRE_OPT_I("dense_warm", dense_warm)
     DRE_OPT_I("side_prefetch", side_prefetch)
     DRE_OPT_I("side_gate", side_gate)
+    DRE_OPT_I("recurrence_wide", recurrence_wide)
     DRE_OPT_I("xwarm_sx", xwarm_sx)
     DRE_OPT_I("prefetch_batch", prefetch_batch)
     DRE_OPT_I("dense_x_max_n", dense_x_max_n)

@@ -185,6 +185,7 @@ struct Ctx {
     // full band reduction at every step
     int dense_warm = 1;
     // dense-X time loop: the side stream's set-up of step i + 1 is enqueued by a parked host thread at the end of step i (0: inside step i + 1)
+    int recurrence_wide = 1;    // residual-recurrence loop: the increments of a solve may exceed the factor-form limit (c + 64 <= n); 0: round 4's in-loop compression
     int side_gate = 0;          // residual-recurrence loop: the parked thread enqueues the side stream only while the time loop's thread waits (launch gate below; measured at n = 5177: 85.1 ms with, 85.4 ms without — inside the noise, off)
     int side_prefetch = 0;      // (measured at n = 371: 18.3 against 17.8 ms per solve — the join in front of the chain costs more than the earlier start gains)
     // dense-inverse path: factorisations, explicit inverses and stacks of a whole Cyclic list in shared launches (gdre.hip, cycle_setup_batched)

@@ -1100,7 +1100,12 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     // uncompressed iterate still fits afterwards with a further compression interval to spare.
     if (!cex && opt.compression && opt.shifts.kind == ShiftSpec::CYCLIC && !opt.inner_solve && cache->enabled && cache->iters_hint > 0 &&
         n > ctx->dense_inv_max_n && n >= ctx->compress_factor_min_n && k > 0) {
-        const long room = ((long)n - 64 - X->rank()) / k - 2L * opt.compression_interval - FAN_GMAX;
+        // (The residual-recurrence caller takes the increments as they are — its side stream compresses X whatever the number of columns and the next
+        // residual is compressed by the range finder, both GEMM passes over the slabs — so neither the chunk nor the iterate is held to the
+        // factor-form limit there: at n = 5177 the first steps (k = 144 ... 64, 30-39 iterations: up to 5 600 columns) lost their history to an
+        // in-loop compression and fell back to the reference's order, 6.4 instead of ~4 ms per step.)
+        const bool free_form = opt.given_residual && opt.keep_history && !opt.final_compress && ctx->recurrence_wide != 0;
+        const long room = free_form ? (1L << 20) : ((long)n - 64 - X->rank()) / k - 2L * opt.compression_interval - FAN_GMAX;
         run.chunk_limit = (int)std::max<long>(opt.compression_interval, std::min<long>(cache->iters_hint + 1, room));
         run.chunk_from_hint = true;       // exactly that many iterations: the last group of the chunk is cut short (a speculative group costs 14 launches)
     }
@@ -1910,9 +1915,10 @@ void adi_advance(AdiRun& run, int budget) {
             // (panel steps ~ rank, GEMM traffic ~ columns: one late compression costs the GEMMs of two early ones and half the
             // panels) while the factor still fits the factor-form limit c + 64 <= n after the next chunk.
             const long rk = Xw->rank(), next = (long)std::max(opt.compression_interval * 2, run.chunk_limit + FAN_GMAX) * k;
-            const bool defer = !cex && (n <= 512 ? rk <= 16L * n
+            const bool free_form = opt.given_residual && opt.keep_history && !opt.final_compress && ctx->recurrence_wide != 0 && run.hist_ok;
+            const bool defer = free_form || (!cex && (n <= 512 ? rk <= 16L * n
                                        : ((n <= ctx->compress_direct_max_n && rk <= 16L * n) ||
-                                          (n >= ctx->compress_factor_min_n && rk + next + 64 <= n)));
+                                          (n >= ctx->compress_factor_min_n && rk + next + 64 <= n))));
             if (!defer) {
                 ldlt_compress(ctx, *Xw, ctf, cex);
                 last_compression = 0;

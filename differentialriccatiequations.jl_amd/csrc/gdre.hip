@@ -1364,6 +1364,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     static const bool rec_timing = env_trace("rec");
     double t_join = 0.0, t_solve = 0.0, t_tail = 0.0; long n_join = 0, n_jobs_t = 0;
     auto now = []() { return std::chrono::steady_clock::now(); };
+    const auto t_loop0 = now();
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     auto join_side = [&]() {                        // host: the running job is finished (its read-backs are synchronous) and its state published
         if (!job_pending) return;
@@ -1371,7 +1372,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         ctx->gate->waiting.store(1);
         worker.wait();
         ctx->gate->waiting.store(0);
-        if (rec_timing) { t_join += us(a, now()); ++n_join; }
+        if (rec_timing) { const double dj = us(a, now()); t_join += dj; ++n_join; if (dj > 50.0) std::fprintf(stderr, "[rec] join %ld blocked %.0f us\n", n_join, dj); }
         job_pending = false;
     };
     struct JoinGuard { SideWorker& w; bool& p; ~JoinGuard() { if (p) { try { w.wait(); } catch (...) {} } } } jguard{worker, job_pending};
@@ -1381,6 +1382,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         join_side();
         hipEvent_t e_main = ring[(2 * njobs) % 16], e_side = ring[(2 * njobs + 1) % 16];
         ++njobs; ++n_jobs_t;
+        if (rec_timing) std::fprintf(stderr, "[rec] t=%.2f ms submit job %ld: X up to step %d (%zu increments)\n", us(t_loop0, now()) / 1e3, n_jobs_t, pend_upto, pend.size());
         DRE_HIP(hipEventRecord(e_main, ctx->stream));
         const auto base = get_state();
         const std::vector<LBlock> blocks = pend;
@@ -1421,6 +1423,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
             DRE_HIP(hipStreamSynchronize(side->stream));       // the increments' buffers go back to the MAIN pool when this closure dies
             if (saved_slot) *saved_slot = Xs;
             { std::lock_guard<std::mutex> lk(*mup); *curp = st; }
+            if (rec_timing) std::fprintf(stderr, "[rec] t=%.2f ms job for step %d done (warm %d)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_loop0).count(), target, (int)done);
         });
         job_pending = true;
     };

@@ -431,11 +431,22 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
     if (env_trace("compress")) std::fprintf(stderr, "[compress enter] n=%d c=%d wide=%d exact=%d abs_tol=%g factor_min_n=%d min_cols=%d sketch=%d/%d\n", n, c, (int)wide, (int)exact, abs_tol, ctx->compress_factor_min_n, ctx->compress_factor_min_cols, ctx->compress_sketch, ctx->compress_sketch_min_cols);
     const long skey = -(4000000000L + (long)n);          // band_hint: rank of the previous wide-factor compression at this order
     const bool sketchable = !wide && !exact && !nfloor && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && c >= ctx->compress_sketch_min_cols && c + 64 <= n;
-    if (sketchable) {
+    // More columns than rows at large n (round 5: the increments of a whole Lyapunov solve with a 144-column residual at n = 5177 — the
+    // residual-recurrence loop no longer compresses inside the solve): the direct form would reduce the n x n matrix (60 ms and a rank of 896 at
+    // n = 5177: its relative tolerance sits below the noise of forming S); the sketch only ever multiplies with the factor.
+    const bool wide_sk = wide && !exact && !nfloor && abs_tol <= 0.0 && ctx->compress_sketch && n >= ctx->compress_factor_min_n && n > ctx->compress_direct_max_n &&
+                         c >= ctx->compress_sketch_min_cols;
+    if (sketchable || wide_sk) {
         auto hit = ctx->band_hint.find(skey);
-        if (hit != ctx->band_hint.end() && hit->second > 0) {
-            const int s = ((hit->second + ctx->compress_sketch_extra + 15) / 16) * 16;
-            if ((double)c >= ctx->compress_sketch_ratio * s && s + 80 <= n && sketch_compress(ctx, X, tolfac, s, skey)) return;
+        int s = 0;
+        if (hit != ctx->band_hint.end() && hit->second > 0) s = ((hit->second + ctx->compress_sketch_extra + 15) / 16) * 16;
+        else if (wide_sk) s = 320;
+        if (s > 0 && (double)c >= ctx->compress_sketch_ratio * s && s + 80 <= n) {
+            if (sketch_compress(ctx, X, tolfac, s, skey)) return;
+            if (wide_sk) {          // one retry with a doubled sketch (a rejected attempt leaves the rank it saw in the hint)
+                const int s2 = std::min(((std::max(ctx->band_hint[skey] + ctx->compress_sketch_extra, 2 * s) + 15) / 16) * 16, ((n - 96) / 16) * 16);
+                if (s2 > s && sketch_compress(ctx, X, tolfac, s2, skey)) return;
+            }
         }
     }
     if (!wide && !exact && n >= ctx->compress_factor_min_n && c >= ctx->compress_factor_min_cols && c + 64 <= n) {
