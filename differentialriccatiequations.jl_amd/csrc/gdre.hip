@@ -1449,7 +1449,10 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     std::function<void()> join_norm = [&]() { if (norm_pending) { norm_pending = false; norm_worker.wait(); } };
     Mat Im(ctx, m, m);
     set_identity(ctx, Im, 1.0);
+    static const bool steps_on = env_trace("steps");
+    std::vector<std::chrono::steady_clock::time_point> step_t;
     for (int i = 1; i <= nsteps; ++i) {
+        if (steps_on) step_t.push_back(now());
         const double tau = out.t[i - 1] - out.t[i];
         GaleOperator op;
         op.P = &P;
@@ -1679,6 +1682,12 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
         AdiResult rec = std::move(ar);
         rec.X.reset(); rec.residual.reset(); rec.hist.clear();
         out.gale.push_back(std::move(rec));
+    }
+    if (steps_on && !step_t.empty()) {
+        step_t.push_back(now());
+        std::fprintf(stderr, "[steps, us]");
+        for (size_t i = 1; i < step_t.size(); ++i) std::fprintf(stderr, " %.0f", us(step_t[i - 1], step_t[i]));
+        std::fprintf(stderr, "\n");
     }
     submit_job();
     join_side();
