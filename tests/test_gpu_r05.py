@@ -166,3 +166,22 @@ def test_ros2_on_the_general_path_against_the_oracle_fixture(ctx):           # l
         K = sol.K[i]
         assert np.linalg.norm(K[:, ::16] - g["K_cols"][i]) < 1e-7 * g["K_norm"][i], i
         assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * np.linalg.norm(g["K_w"][i]), i
+
+
+@pytest.mark.parametrize("wide", [1, 0])
+def test_recurrence_with_and_without_the_factor_form_limit(ctx, wide):          # gdre.hip ros1_recurrence_loop, engine.hip adi_advance
+    """n = 5177, the first 8 steps (residual widths 144 ... 16, 39 ... 29 iterations: up to 5 600 increment columns > n): with `recurrence_wide` the
+    increments stay uncompressed inside the solve and the side stream takes a factor with more columns than rows through the sketch compression;
+    without it the ADI compresses in the loop and the step falls back to the reference's order.  Both must give the oracle's counts and K(t)."""
+    n, nsteps = 5177, 8
+    g = np.load(os.path.join(GOLDEN, "ros1_5177_full.npz"))
+    with ctx.options(recurrence_wide=wide):
+        sol, st = _ros1(n, nsteps, ctx)
+    its = [x["iters"] for x in st["gales"]]
+    assert its == [int(v) for v in g["iters"][:nsteps]], its
+    assert all(x["converged"] for x in st["gales"])
+    w = np.random.default_rng(1).standard_normal(n)
+    for i in range(1, nsteps + 1):
+        K = sol.K[i]
+        assert np.linalg.norm(K[:, ::16] - g["K_cols"][i]) < 1e-7 * g["K_norm"][i], i
+        assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * np.linalg.norm(g["K_w"][i]), i
