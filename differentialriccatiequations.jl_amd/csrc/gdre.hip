@@ -1550,7 +1550,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
                 dl.Rj = RJ; dl.Tj = prev.Tm; dl.aj = prev.alpha_res; dl.dKt = prev.hist.empty() ? Mat() : prev_dKt;
                 deltas.push_back(dl);
                 auto st = get_state();
-                if ((i - 1) - st->step > 5) { join_side(); st = get_state(); }
+                if ((i - 1) - st->step > 10) { join_side(); st = get_state(); }      // (lag limit: every step behind adds ~40 columns to the Gram matrix of the formula)
                 if (st->ev) DRE_HIP(hipStreamWaitEvent(hc->stream, st->ev, 0));
                 while (!deltas.empty() && deltas.front().s <= st->step) deltas.erase(deltas.begin());
                 const LBlock& xb = st->X->blocks[0];
