@@ -117,6 +117,7 @@ int dre_ctx_destroy(dre_ctx* ctx) {
     if (!ctx) return DRE_OK;
     (void)hipSetDevice(ctx->c.device);
     (void)hipStreamSynchronize(ctx->c.stream);
+    for (auto& w : ctx->c.parked_worker) w.reset();          // (parked: they hold no job between solves; joined here, before their streams go)
     ctx->c.comm.reset();
     if (ctx->c.side) {
         Ctx& sc = *ctx->c.side;

@@ -222,6 +222,8 @@ struct Ctx {
     std::shared_ptr<LaunchGate> gate;          // main context: owner;  side context: follower when gate_follow
     bool gate_follow = false;
     int gate_patience_us = 300;
+    // parked host threads of the time loops (gdre.hip, SideWorker): kept with the context — a thread per solve cost ~0.1 ms of creation and join
+    std::shared_ptr<void> parked_worker[3];
     std::shared_ptr<struct Buf> warm_tickets;    // arrival counters of the warm-started compression's ticket kernels (warm.hip), zeroed once
     void* dense_land = nullptr;        // pinned landing zone of the dense-X time loop (gdre.hip, DenseXState): allocated once per context
     FetchZone* fetch_dev = nullptr;    // the same memory as the device sees it

@@ -706,6 +706,12 @@ class SideWorker {
     bool busy_ = false, quit_ = false;
 };
 
+// the context's parked thread number `slot` (created on first use, joined when the context goes)
+static SideWorker& parked_worker(Ctx* ctx, int slot) {
+    if (!ctx->parked_worker[slot]) ctx->parked_worker[slot] = std::shared_ptr<void>(new SideWorker, [](void* p) { delete static_cast<SideWorker*>(p); });
+    return *static_cast<SideWorker*>(ctx->parked_worker[slot].get());
+}
+
 // the side stream's set-up of the NEXT time step, enqueued by the parked thread as soon as the step's feedback K is on the main stream
 struct PreSide { CycleOps co; bool ok = true; GaleOperator op; const double* Kt_p = nullptr; bool pending = false; };
 
@@ -1344,7 +1350,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->gate = ctx->gate; side->gate_follow = ctx->side_gate != 0;
     ctx->gate->waiting.store(0);
     struct GateOpen { Ctx* c; ~GateOpen() { c->gate->waiting.store(1); if (c->side) c->side->gate_follow = false; } } gate_open{ctx};      // leaving the loop: no gate
-    SideWorker worker;
+    SideWorker& worker = parked_worker(ctx, 0);
     // events: a ring (at most one job is in flight; a slot is reused eight jobs later)
     hipEvent_t ring[16];
     for (auto& e : ring) DRE_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1444,7 +1450,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     // thread goes on with the Sherman-Morrison-Woodbury set-up and the first sweeps: at n = 5177 they were 220 us of this thread's 1.1 ms per
     // step, in front of the first solve.  (The context is a helper of the SIDE context: the main context's helpers carry factorisations.)
     Ctx* const norm_ctx = helper_ctx(side, 0);
-    SideWorker norm_worker;
+    SideWorker& norm_worker = parked_worker(ctx, 1);
     bool norm_pending = false;
     std::function<void()> join_norm = [&]() { if (norm_pending) { norm_pending = false; norm_worker.wait(); } };
     Mat Im(ctx, m, m);
@@ -1763,7 +1769,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     for (auto& mu : adi.shifts.values) if (mu.imag() != 0.0) densex = false;
     DenseXState sx;
     sx.attach(ctx);
-    SideWorker side_worker;        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
+    SideWorker& side_worker = parked_worker(ctx, 2);        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
     sx.worker = &side_worker;
     bool sx_init = false, x_is_dense = false;
 
