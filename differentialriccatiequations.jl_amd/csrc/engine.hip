@@ -288,6 +288,8 @@ struct ShiftOracle {
     // index (in the strategy's own list) of the shift take() returns next; 0 where there is no list
     virtual size_t position() const { return 0; }
     virtual size_t list_size() const { return 0; }
+    // the strategy saw the device-side `done` flag while refilling: nothing further needs to be enqueued
+    virtual bool stopped() const { return false; }
 };
 struct CyclicOracle : ShiftOracle {   // shifts/helpers.jl:19-21,91-93
     std::vector<std::complex<double>> v;
@@ -319,6 +321,8 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
     std::vector<Mat> Vs;   // handles, NOT snapshots
     std::vector<std::complex<double>> buffer;
     size_t pos = 0;
+    bool saw_done = false;
+    bool stopped() const override { return saw_done; }
     void update(const Mat& R, const std::vector<Mat>& newVs) override {
         if (newVs.empty()) Vs.push_back(R);
         for (auto& v : newVs) Vs.push_back(v);
@@ -332,7 +336,7 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
             int done = 0;
             DRE_HIP(hipMemcpyAsync(&done, &st_dev->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             DRE_HIP(hipStreamSynchronize(ctx->stream));
-            if (done) { buffer.assign(1, std::complex<double>(-1.0, 0.0)); pos = 0; return; }
+            if (done) { buffer.assign(1, std::complex<double>(-1.0, 0.0)); pos = 0; saw_done = true; return; }
         }
         int w = 0;
         for (auto& v : Vs) w += v.cols;
@@ -1638,6 +1642,8 @@ void adi_advance(AdiRun& run, int budget) {
             run.hist_ok = false;                  // (its residual factor is updated in place: no history of this solve)
             std::complex<double> mu;
             { RoctxRange rr("shifts"); mu = oracle->take(&res.warnings); }        // adi.jl:101
+            // (a refill that found the solve converged: the rest of the chunk would be early-exit launches with a synchronisation per refill)
+            if (oracle->stopped() && !recs.empty()) break;
             all_shifts.push_back(mu);
             const bool is_real = (mu.imag() == 0.0);
             RoctxRange roctx_solve(is_real ? "solve (real)" : "solve (complex)");        // adi.jl:157,196 (the range covers the whole step)
