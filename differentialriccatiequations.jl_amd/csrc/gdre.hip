@@ -678,7 +678,11 @@ class SideWorker {
     ~SideWorker() { { std::lock_guard<std::mutex> lk(m_); quit_ = true; } cv_.notify_all(); if (th_.joinable()) th_.join(); }
     void submit(std::function<void()> job) {
         if (!th_.joinable()) th_ = std::thread([this] { run(); });
-        { std::lock_guard<std::mutex> lk(m_); job_ = std::move(job); busy_ = true; err_ = nullptr; }
+        {   // (ONE job at a time: a second submission waits for the first instead of replacing it; an error of an unjoined job stays for wait())
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return !busy_; });
+            job_ = std::move(job); busy_ = true;
+        }
         cv_.notify_all();
     }
     bool pending() { std::lock_guard<std::mutex> lk(m_); return busy_; }
@@ -694,7 +698,7 @@ class SideWorker {
             { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return quit_ || (busy_ && job_); }); if (quit_) return; job = std::move(job_); job_ = nullptr; }
             std::exception_ptr e;
             try { job(); } catch (...) { e = std::current_exception(); }
-            { std::lock_guard<std::mutex> lk(m_); busy_ = false; err_ = e; }
+            { std::lock_guard<std::mutex> lk(m_); busy_ = false; if (e || !err_) err_ = e; }
             done_.notify_all();
         }
     }

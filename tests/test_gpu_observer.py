@@ -107,10 +107,16 @@ def test_live_observer_on_a_single_gale_matches_the_replayed_one(ctx, rail371):
     rp, rec = Replay(), Recorder()
     Xa, ia = D.solve_gale(prob, alg, initial_guess=X0, observer=rp, return_info=True)
     Xb, ib = D.solve_gale(prob, alg, initial_guess=X0, observer=rec, return_info=True)
-    assert ia["iters"] == ib["iters"] and np.array_equal(np.array(rp.norms), np.array(rec.given))
+    # (bit for bit — unless the multifrontal path is forced on this small pencil (tools/option_matrix.sh): the one-shot solve then takes fan groups, the same
+    # iterates through partial fractions, which a step-by-step solve cannot)
+    fan_forced = ctx.get_option("dense_inverse_max_n") == 0 and ctx.get_option("adi_fan") >= 2
+    if fan_forced:
+        assert ia["iters"] == ib["iters"] and np.allclose(np.array(rp.norms), np.array(rec.given), rtol=1e-9, atol=0.1 * ib["abstol"])
+    else:
+        assert ia["iters"] == ib["iters"] and np.array_equal(np.array(rp.norms), np.array(rec.given))
     assert np.allclose(np.array(rp.shifts), np.array(rec.shifts))
     k = ib["rhs_cols"]
     assert rec.ranks == [6 + i * k for i in range(ib["iters"] + 1)]
-    assert np.linalg.norm(Xa.dense() - Xb.dense()) == 0.0
+    assert np.linalg.norm(Xa.dense() - Xb.dense()) <= (1e-10 * np.linalg.norm(Xb.dense()) if fan_forced else 0.0)
     Rtrue = D.residual(prob, Xb)
     assert abs(D.norm(Rtrue) - rec.norms[-1]) < 0.25 * ib["abstol"]          # recurrence vs from-scratch residual: rounding of the size of abstol/10
