@@ -749,12 +749,22 @@ struct DenseXState {
     bool phase_on = env_trace("phase");
     std::vector<hipEvent_t> pev;
     std::vector<int> ptag;
+    bool first_on = env_trace("first");      // host clock at the phase marks of the FIRST dense step of a run
+    std::vector<std::pair<int, std::chrono::steady_clock::time_point>> first_t;
     void mark(Ctx* ctx, int tag) {
+        if (first_on && dense_steps == 0) first_t.push_back({tag, std::chrono::steady_clock::now()});
         if (!phase_on) return;
         hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, ctx->stream);
         pev.push_back(e); ptag.push_back(tag);
     }
     void report() {
+        if (first_on && first_t.size() >= 2) {
+            std::fprintf(stderr, "[first step, host us]");
+            for (size_t i = 1; i < first_t.size(); ++i)
+                std::fprintf(stderr, " ->%d %.0f", first_t[i].first, std::chrono::duration<double, std::micro>(first_t[i].second - first_t[i - 1].second).count());
+            std::fprintf(stderr, "\n");
+            first_t.clear();
+        }
         if (!phase_on || pev.size() < 2) return;
         (void)hipEventSynchronize(pev.back());
         static const char* names[] = {"start", "assembly", "band_reduce", "basis+init", "adi_chain", "sync+xupdate", "feedback"};
