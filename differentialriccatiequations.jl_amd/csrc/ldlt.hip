@@ -306,7 +306,8 @@ bool warm_compress(Ctx* ctx, LDLt& X, const Mat& Q0, double tolfac, double abs_t
     if (missed) *missed = est;
     const double est_rel = h[0] > 0.0 ? std::sqrt(std::max(h[1], 0.0) / h[0]) : 0.0;
     const bool ok = (cf & 1) == 0 && (rel_accept > 0.0 ? est_rel <= rel_accept : est <= abs_tol) && sb.J + 16 <= s;
-    if (trace) std::fprintf(stderr, "[warm compress] n=%d c=%d q0=%d sx=%d -> J=%d  missed %.2e (tolerance %.2e)  %s\n", n, c, q0, sx, sb.J, est, abs_tol, ok ? "accepted" : "REJECTED");
+    if (trace) std::fprintf(stderr, "[warm compress] n=%d c=%d q0=%d sx=%d -> J=%d  missed %.2e (tolerance %.2e; relative %.2e against %.2e; Cholesky flag %d; room %d)  %s\n", n, c, q0, sx,
+                            sb.J, est, abs_tol, est_rel, rel_accept, (int)(cf & 1), s - sb.J, ok ? "accepted" : "REJECTED");
     if (!ok) return false;
     X.blocks.clear();
     if (sb.J == 0) { X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true}); return true; }
