@@ -166,6 +166,11 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev, int j_start = 0
             gemm(ctx, false, false, -1.0, Qp, W, 1.0, V, nullptr, "gemm_orth");
         };
         project(Yb);
+        // (warm start: what the known basis leaves of the sketch can be 1e-14 of it — the first projection's own rounding, eps ||Y_b||, is then as large as
+        // the remainder, the normalised block is NOT orthogonal to the basis, loses most of its norm in the second round and the second pass reports a
+        // breakdown (pivots 0.08 ... 0.17 seen) although the probe confirms the basis to 2e-15: a second projection BEFORE the normalisation acts on
+        // the small remainder and leaves it orthogonal to the basis relative to itself)
+        if (permissive) project(Yb);
         gemm(ctx, true, false, 1.0, Yb, Yb, 0.0, Gb, nullptr, "gemm_orth");
         chol_inv(ctx, Gb, Rb, flag_dev, ref.p, permissive ? 3 : (j0 == j_start ? 0 : 1), nullmask.p, trace && nblk < 32 ? dbg.p + 2 * nblk : nullptr);
         gemm(ctx, false, false, 1.0, Yb, Rb, 0.0, Tb, nullptr, "gemm_orth");
