@@ -142,6 +142,7 @@ struct Ctx {
     int compress_sketch_min_cols = 320;
     int compress_sketch_extra = 48;
     double compress_sketch_ratio = 1.25; // columns >= ratio x sketch width (sweep at n = 5177 / 20209, 45 / 12 steps: 3.0 -> 257 / 246 ms, 2.0 -> 252 / 233, 1.25 -> 241 / 234)
+    int gemm_swizzle = 1;               // XCD-aware workgroup -> tile order of the split-K GEMM (gemm.hip, xcd_tile); 0: launch order
     int compress_sketch_sparse = 1;     // sketch with the structured sparse sign test matrix (one pass over the factor) instead of a Gaussian one (dense GEMM)
     int compress_sketch_cholqr = 1;     // orthonormalise the sketch by blocked Cholesky QR (GEMMs) instead of Householder/TSQR panels; falls back on breakdown
     // multifrontal sweeps: the top levels of the elimination tree with at most this many pivot variables are applied as one dense

@@ -739,6 +739,7 @@ Ctx* helper_ctx(Ctx* ctx, int h) {
     }
     Ctx* hc = ctx->helpers[(size_t)h].get();
     hc->timer->enabled = ctx->timer && ctx->timer->enabled;
+    hc->gemm_swizzle = ctx->gemm_swizzle;
     return hc;
 }
 hipEvent_t aux_event(Ctx* ctx, int i) {

@@ -1358,6 +1358,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->compress_sketch_min_cols = ctx->compress_sketch_min_cols; side->compress_sketch_extra = ctx->compress_sketch_extra;
     side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
     side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
+    side->gemm_swizzle = ctx->gemm_swizzle;
     side->fetch_spin = false;
     side->orthf_fn = ctx->orthf_fn; side->orthf_user = ctx->orthf_user;
     // launch gate (common.hpp): the side thread enqueues while this one waits
@@ -1774,7 +1775,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     if (side) {
         side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
         side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
-        side->compress_factor_min_cols = ctx->compress_factor_min_cols;
+        side->compress_factor_min_cols = ctx->compress_factor_min_cols; side->gemm_swizzle = ctx->gemm_swizzle;
     }
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     const double gamma = 1.0 + 1.0 / std::sqrt(2.0);

@@ -150,17 +150,40 @@ __device__ __forceinline__ void gemm_tile(int M, int N, int K, double alpha, con
 // 45.1 TFLOP/s at 4096^3 against 47.9 for this kernel, 22-30 against 29-34 on the skinny passes of the randomized compression
 // (tools/gemm_probe.py).  With one wave per SIMD its global round trips are not covered; the 64 x 64 tiles keep four workgroups per CU.
 // It was removed again.)
+// Workgroup -> output tile.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; observed, a speed matter only), each
+// with its own L2: in launch order the tiles that share an operand panel sit on DIFFERENT L2s and every XCD streams the large operand for
+// itself (the 5 row tiles of a 304 x 6400 x 20209 sketch product: the 1 GB factor crosses the fabric five times).  swz != 0: every XCD takes
+// a CONTIGUOUS chunk of the tile list (bijective remap for any grid size), and the list runs fastest along the dimension with FEWER tiles,
+// so the tiles that are resident together on one XCD share the panels of the large operand; splits slowest (they share nothing).
+__device__ __forceinline__ void xcd_tile(int swz, int& bx, int& by, int& bz) {
+    if (!swz) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }
+    const unsigned gx = gridDim.x, gy = gridDim.y, per = gx * gy, T = per * gridDim.z;
+    unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7u, slot = L >> 3, q = T >> 3, r = T & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const unsigned z = L / per, rem = L - z * per;
+    bz = (int)z;
+    if (gx <= gy) { const unsigned y = rem / gx; by = (int)y; bx = (int)(rem - y * gx); }
+    else { const unsigned x = rem / gy; bx = (int)x; by = (int)(rem - x * gy); }
+}
+// Used where the larger operand does not fit the 256 MB Infinity Cache (measured, tools/gemm_probe.py: 304 x 6400 x 20209 TN 39.1 -> 42.4 TFLOP/s,
+// 20209 x 304 x 6400 NT 35.8 -> 39.2, 20209 x 304 x 3500 NT 34.3 -> 38.1; cache-resident operands: within +-2 %, 2976 x 112 x 2976 7 % slower).
+static inline int gemm_swizzle(const Ctx* ctx, int M, int N, int K) {
+    return ctx->gemm_swizzle != 0 && 8.0 * (double)K * (double)std::max(M, N) > 256.0 * 1048576.0 ? 1 : 0;
+}
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_gemm(int M, int N, int K, double alpha, const double* __restrict__ A,
                                               int lda, const double* __restrict__ B, int ldb, double beta,
                                               double* __restrict__ C, int ldc, int kchunk,
-                                              double* __restrict__ partial, const AdiState* st, double* __restrict__ tile_sumsq, DevCount dc) {
+                                              double* __restrict__ partial, const AdiState* st, double* __restrict__ tile_sumsq, DevCount dc, int swz) {
     if (st && st->done) return;
     if (dc.st) K = min(K, dc.per * dev_count(dc));          // inner dimension decided on the device (accepted ADI iterations x columns)
-    const int kbeg = blockIdx.z * kchunk;
-    gemm_tile<TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, blockIdx.x * GB_M, blockIdx.y * GB_N, kbeg, min(K, kbeg + kchunk),
-                      partial ? partial + (size_t)blockIdx.z * M * N : nullptr,
-                      tile_sumsq ? tile_sumsq + blockIdx.x + (size_t)gridDim.x * blockIdx.y : nullptr);
+    int bx, by, bz;
+    xcd_tile(swz, bx, by, bz);
+    const int kbeg = bz * kchunk;
+    gemm_tile<TA, TB>(M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bx * GB_M, by * GB_N, kbeg, min(K, kbeg + kchunk),
+                      partial ? partial + (size_t)bz * M * N : nullptr,
+                      tile_sumsq ? tile_sumsq + bx + (size_t)gridDim.x * by : nullptr);
 }
 
 // Batched NN GEMM with per-batch operands (blockIdx.z = batch): C_z = alpha_z A_z B_z; optionally A_z is also copied to
@@ -302,10 +325,10 @@ void gemm(Ctx* ctx, bool tA, bool tB, int M, int N, int K, double alpha, const d
         pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
         partial = (double*)pb->p;
     }
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{});
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{}, gemm_swizzle(ctx, M, N, K));
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{}, gemm_swizzle(ctx, M, N, K));
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{}, gemm_swizzle(ctx, M, N, K));
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, kchunk, partial, st, tile_sumsq, DevCount{}, gemm_swizzle(ctx, M, N, K));
     if (splits > 1) {
         size_t tot = (size_t)M * N;
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, M, N, splits, alpha, partial, beta, C, ldc, st);
@@ -378,10 +401,10 @@ BufP gemm_partials(Ctx* ctx, bool tA, bool tB, int M, int N, int K, const double
     auto pb = std::make_shared<Buf>(ctx, (size_t)splits * M * N * sizeof(double));
     double* partial = (double*)pb->p;
     double* none = nullptr;
-    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
-    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
-    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
-    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc);
+    if (!tA && !tB) hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc, gemm_swizzle(ctx, M, N, K));
+    else if (tA && !tB) hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc, gemm_swizzle(ctx, M, N, K));
+    else if (!tA && tB) hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc, gemm_swizzle(ctx, M, N, K));
+    else hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, ctx->stream, M, N, K, 1.0, A, lda, B, ldb, 0.0, none, 0, kchunk, partial, st, (double*)nullptr, dc, gemm_swizzle(ctx, M, N, K));
     DRE_HIP(hipGetLastError());
     *splits_out = splits;
     return pb;

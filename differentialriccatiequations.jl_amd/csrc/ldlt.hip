@@ -218,9 +218,15 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     Mat Q(ctx, n, s);
     DevArr<long long> cflag(ctx, 1);
     DRE_HIP(hipMemsetAsync(cflag.p, 0, sizeof(long long), ctx->stream));
-    const long ckey = skey - 1;                        // band_hint: Cholesky-QR breakdowns seen at this order (two strikes: Householder panels from then on)
-    const bool use_chol = ctx->compress_sketch_cholqr && ctx->band_hint[ckey] < 2;
-    if (use_chol) orth_cholqr(ctx, Yr, Q, reinterpret_cast<int*>(cflag.p));
+    // band_hint[ckey]: Cholesky-QR breakdowns seen at this order.  Two strikes: the blocks are projected TWICE before their first normalisation and a
+    // column 14 orders below its block's scale counts as dependent, not as a breakdown (the form of the warm-started range finder: a sketch wider than
+    // the numerical rank leaves later blocks almost inside the span of the earlier ones — s = 240 against a rank of 144 in the stage solves of Ros2
+    // at n = 5177 — and the first projection's own rounding is then as large as what it leaves).  Two more strikes: Householder panels from then on
+    // (round 5 before this: after the first two, 30 % of the device time of a Ros2 run at n = 5177 in k_tsqr_*).  The probe below judges every form.
+    const long ckey = skey - 1;
+    const int strikes = (int)ctx->band_hint[ckey];
+    const bool use_chol = ctx->compress_sketch_cholqr && strikes < 4;
+    if (use_chol) orth_cholqr(ctx, Yr, Q, reinterpret_cast<int*>(cflag.p), 0, strikes >= 2);
     else {
         QRFact qr = qr_factor(ctx, Yr);
         set_identity(ctx, Q, 1.0);
@@ -245,7 +251,7 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     const bool chol_bad = use_chol && (cf & 1) != 0;
     const bool ok = !chol_bad && sb.J + 32 <= s && est <= 64.0 * EPS;
     if (trace) std::fprintf(stderr, "[compress] n=%d c=%d sketch s=%d (%s, %s) -> J=%d  probe residual %.2e  %s\n", n, c, s, use_sparse ? "sparse sign" : "Gaussian",
-                            use_chol ? "CholQR2 blocks" : "Householder", sb.J, est, ok ? "accepted" : (chol_bad ? "REJECTED (Cholesky breakdown)" : "REJECTED"));
+                            use_chol ? (strikes >= 2 ? "CholQR2 blocks, projected twice" : "CholQR2 blocks") : "Householder", sb.J, est, ok ? "accepted" : (chol_bad ? "REJECTED (Cholesky breakdown)" : "REJECTED"));
     if (chol_bad) { ctx->band_hint[ckey] += 1; return false; }
     if (use_sparse && !ok && sb.J + 32 <= s) ctx->band_hint[spkey] += 1;       // enough room in the sketch, yet the probe sees a miss: the test matrix's fault
     if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
