@@ -317,17 +317,18 @@ def ros2_projection_leg(D, ctx, steps=2):
 
 def ros2_general_leg(D, ctx, steps=2):
     """Ros2 on the GENERAL path (/root/reference/src/riccati/lowrank_ros2.jl:37-80): SteelProfile(5177) Ros2 LRSIF, Cyclic
-    heuristic real shifts, 12 steps of dt = -100 — two cold-start Lyapunov solves per step, fan groups on both.  Parity against
-    tests/golden/ros2_5177_s12.npz (oracle/dre_oracle.py, 40 minutes of CPU): with this shift list (computed for the Ros1 operator) EVERY stage solve
-    of the oracle stops at maxiters = 200 above its tolerance; the HIP path must do the same and reach the same K(t)."""
+    real shifts, 12 steps of dt = -100 — two cold-start Lyapunov solves per step, fan groups on both.  The shift list is the heuristic list of
+    (E, A) mapped like the spectrum of the Ros2 operator F = gamma tau A - E / 2 - ... (lowrank_ros2.jl:41: gamma tau lambda - 1/2), so that every
+    stage solve converges (29 - 47 iterations; with the unmapped list none does within maxiters = 200: that case stays a test,
+    tests/test_gpu_r05.py).  Parity against tests/golden/ros2_5177_conv.npz (oracle/dre_oracle.py): K(t) to 1e-7, the iteration count of every
+    stage solve within one of the oracle's."""
     import warnings
-    g = np.load(os.path.join(ROOT, "tests", "golden", "ros2_5177_s12.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ros2_5177_conv.npz"))
     n, nsteps = 5177, 12
     d = D.steel_profile(n)
     L, Dm = D.initial_value(d)
-    p = list(np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy")))
     prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4500.0 - 100.0 * nsteps))
-    alg = D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(p), maxiters=200))
+    alg = D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(list(g["shifts"])), maxiters=200))
     warnings.simplefilter("ignore")
     D.set_default_context(ctx)
     sol, st = D.solve_gdre(prob, alg, dt=-100.0, return_stats=True, ctx=ctx)
@@ -341,19 +342,21 @@ def ros2_general_leg(D, ctx, steps=2):
     D.solve_gdre(prob, alg, dt=-100.0, ctx=ctx)
     stats = ctx.prof_stats(); ctx.prof_enable(False)
     its = [x["iters"] for x in st["gales"]]
+    ref = [int(v) for v in g["iters_per_solve"].ravel()]
     w = np.random.default_rng(1).standard_normal(n)
     dk = max(float(np.linalg.norm(sol.K[i][:, ::16] - g["K_cols"][i]) / g["K_norm"][i]) for i in range(1, nsteps + 1))
     dw = max(float(np.linalg.norm(sol.K[i] @ w - g["K_w"][i]) / np.linalg.norm(g["K_w"][i])) for i in range(1, nsteps + 1))
-    par = dict(fixture="tests/golden/ros2_5177_s12.npz", delta_K_sampled_columns=dk, delta_K_times_seeded_vector=dw, adi_iterations_per_solve=its,
-               adi_iterations_per_solve_oracle=[int(v) for v in g["iters_per_solve"].ravel()],
-               lyapunov_solves_converged=f"{sum(int(x['converged']) for x in st['gales'])}/{len(its)}", oracle_solves_converged="0/24",
-               criterion="delta < 1e-7 (test/cuda.jl:95-99), the oracle's iteration count of every stage solve")
-    if not (dk < 1e-7 and dw < 1e-7 and its == par["adi_iterations_per_solve_oracle"]):
+    nconv = sum(int(x["converged"]) for x in st["gales"])
+    par = dict(fixture="tests/golden/ros2_5177_conv.npz", delta_K_sampled_columns=dk, delta_K_times_seeded_vector=dw, adi_iterations_per_solve=its,
+               adi_iterations_per_solve_oracle=ref, lyapunov_solves_converged=f"{nconv}/{len(its)}", oracle_solves_converged=f"{sum(int(v < 200) for v in ref)}/{len(ref)}",
+               criterion="delta < 1e-7 (test/cuda.jl:95-99), every stage solve converged, its iteration count within one of the oracle's")
+    if not (dk < 1e-7 and dw < 1e-7 and nconv == len(its) and all(abs(a - b) <= 1 for a, b in zip(its, ref))):
         raise SystemExit(f"bench.py: PARITY FAILURE (Ros2, general path): {par}")
     tot = sum(v["ms"] for v in stats.values())
-    return dict(config="SURVEY 8(a) a2 on the general path (no BASELINE config of its own)", workload="SteelProfile(5177) Ros2 LRSIF, Cyclic heuristic real shifts, "
-                "12 time steps of dt=-100, 24 cold-start Lyapunov solves (none converges within maxiters = 200 with this list, in the oracle neither)",
-                n=n, nsteps=nsteps, value=sum(its) / mean, unit="ADI iterations/s", ms_per_step=mean * 1e3, ms_per_step_runs=[e * 1e3 for e in els],
+    return dict(config="SURVEY 8(a) a2 on the general path (no BASELINE config of its own)", workload="SteelProfile(5177) Ros2 LRSIF, Cyclic real shifts (the heuristic "
+                "list mapped to the Ros2 operator), 12 time steps of dt=-100, 24 cold-start Lyapunov solves, all converged",
+                n=n, nsteps=nsteps, value=sum(its) / mean, unit="ADI iterations/s", value_normalised_to_oracle_iterations=sum(ref) / mean,
+                ms_per_step=mean * 1e3, ms_per_step_runs=[e * 1e3 for e in els],
                 parity=par, by_kernel_ms={k: round(v["ms"], 3) for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:8]}, device_ms_profiled=tot)
 
 

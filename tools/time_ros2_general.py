@@ -1,5 +1,6 @@
 """Ros2 on the general path (lowrank_ros2.jl:37-80): SteelProfile(n) Ros2 LRSIF, Cyclic heuristic real shifts, `steps` steps of dt = -100, against
-tests/golden/ros2_5177_s12.npz.   usage: python tools/time_ros2_general.py [n] [steps] [reps]"""
+tests/golden/ros2_5177_conv.npz (shift list mapped to the Ros2 operator: every stage solve converges) or, with `s12`, tests/golden/ros2_5177_s12.npz
+(the unmapped list: every stage solve stops at maxiters).   usage: python tools/time_ros2_general.py [n] [steps] [reps] [conv|s12]"""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +10,11 @@ warnings.simplefilter("ignore")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5177
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+which = sys.argv[4] if len(sys.argv) > 4 else "conv"
 ctx = D.default_context()
 d = D.steel_profile(n); L, Dm = D.initial_value(d)
-p = list(np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy")))
+p = np.load(os.path.join(ROOT, "tests", "golden", f"heuristic_shifts_{n}.npy"))
+p = list((1.0 + 1.0 / np.sqrt(2.0)) * 100.0 * p - 0.5) if which == "conv" else list(p)        # gamma tau lambda - 1/2: lowrank_ros2.jl:41
 prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4500.0 - 100.0 * nsteps))
 alg = D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(p), maxiters=200))
 els = []
@@ -22,7 +25,7 @@ for rep in range(reps + 1):
 els = sorted(els[1:])
 its = [x["iters"] for x in st["gales"]]
 print(f"n={n} Ros2 general path: {nsteps} steps, iters per solve {its}, converged {sum(int(x['converged']) for x in st['gales'])}/{len(its)}, median {els[len(els)//2]*1e3:.1f} ms ({sum(its)/els[len(els)//2]:.0f} it/s)")
-f = os.path.join(ROOT, "tests", "golden", f"ros2_{n}_s12.npz")
+f = os.path.join(ROOT, "tests", "golden", f"ros2_{n}_{which}.npz")
 if os.path.exists(f) and nsteps <= 12:
     g = np.load(f)
     w = np.random.default_rng(1).standard_normal(n)
