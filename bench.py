@@ -298,7 +298,8 @@ def ros2_projection_leg(D, ctx, steps=2):
                delta_K_vs_dense_ros2_worst=max(delta(sol.K[i], g["K_dense"][i]) for i in range(1, 11)),
                adi_iterations=int(sum(its)), adi_iterations_oracle=int(g["iters_per_solve"].sum()),
                lyapunov_solves_converged=f"{sum(int(x['converged']) for x in st['gales'])}/{len(its)}", oracle_solves_converged=f"{int((~g['failed']).sum())}/{len(g['failed'])}",
-               complex_shift_share=ncx / max(sum(its), 1), criterion="delta < 1e-7 where the oracle converges (test/cuda.jl:95-99); counts within a Projection batch")
+               complex_shift_share=ncx / max(sum(its), 1), adi_iterations_per_solve=its, adi_iterations_per_solve_oracle=[int(v) for v in g["iters_per_solve"]],
+               residual_widths_per_solve=[int(x["rhs_cols"]) for x in st["gales"]], criterion="delta < 1e-7 where the oracle converges (test/cuda.jl:95-99); counts within a Projection batch")
     if not (par["delta_K_vs_oracle_steps_1_8"] < 1e-7 and par["delta_K_vs_dense_ros2_worst"] < 1e-6):
         raise SystemExit(f"bench.py: PARITY FAILURE (configs[2]): {par}")
     tot = sum(v["ms"] for v in stats.values())

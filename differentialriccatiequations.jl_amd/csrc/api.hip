@@ -182,6 +182,8 @@ static OptionRef option_ref(Ctx& c, const std::string& key) {
     DRE_OPT_I("compress_sketch_cholqr", compress_sketch_cholqr)
     DRE_OPT_I("compress_sketch_sparse", compress_sketch_sparse)
     DRE_OPT_I("gemm_swizzle", gemm_swizzle)
+    DRE_OPT_I("mf_swizzle", mf_swizzle)
+    DRE_OPT_I("ros2_tight", ros2_tight)
     DRE_OPT_D("compress_sketch_ratio", compress_sketch_ratio)
     DRE_OPT_I("top_inverse_max_rows", top_inverse_max_rows)
     DRE_OPT_I("mf_subtree", mf_subtree)

@@ -142,6 +142,8 @@ struct Ctx {
     int compress_sketch_min_cols = 320;
     int compress_sketch_extra = 48;
     double compress_sketch_ratio = 1.25; // columns >= ratio x sketch width (sweep at n = 5177 / 20209, 45 / 12 steps: 3.0 -> 257 / 246 ms, 2.0 -> 252 / 233, 1.25 -> 241 / 234)
+    int ros2_tight = 1;                 // Ros2 driver: stage right-hand sides and stage solutions truncated at the reference's rank (engine.hpp, COMPRESS_TIGHT)
+    int mf_swizzle = 0;                 // XCD-aware workgroup order of the multifrontal sweep kernels (sparse.hip, mf_block)
     int gemm_swizzle = 1;               // XCD-aware workgroup -> tile order of the split-K GEMM (gemm.hip, xcd_tile); 0: launch order
     int compress_sketch_sparse = 1;     // sketch with the structured sparse sign test matrix (one pass over the factor) instead of a Gaussian one (dense GEMM)
     int compress_sketch_cholqr = 1;     // orthonormalise the sketch by blocked Cholesky QR (GEMMs) instead of Householder/TSQR panels; falls back on breakdown

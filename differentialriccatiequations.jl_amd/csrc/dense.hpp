@@ -231,7 +231,10 @@ struct SymEig {
 // Householder tridiagonalisation of S (q x q, full symmetric storage, destroyed) that stops as soon as
 // the not-yet-reduced trailing block is below tolfac*eps*||S||_F, then implicit QL on the tridiagonal.
 // want_eig = false stops after the reduction: S ~ Q_h(:,1:j) T_j Q_h(:,1:j)' with T_j = tridiag(d, e).
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true, double abs_tol = -1.0, bool tol_is_floor = false);
+// deflate: an off-diagonal entry of the tridiagonal problem at or below deflate * eps * ||S||_F counts as zero (orders above 128, where the QL iteration's
+// scalar chain runs on the host; 1e-3 = the device kernels' constant).  1: a perturbation of the size of the reduction's own backward error — for callers
+// that only want the eigenvalues ABOVE 100 eps max|lambda| (COMPRESS_TIGHT): the iteration no longer resolves the cluster of rounding-noise eigenvalues
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac = 4.0, bool want_eig = true, double abs_tol = -1.0, bool tol_is_floor = false, double deflate = 1e-3);
 Mat sym_tridiag_dense(Ctx* ctx, const SymEig& e);    // T_j as a dense j x j matrix
 // B (q x r) <- Q_h * [Zsel; 0]   where Zsel = Z(:, ids) (ids on host); with an empty Z the identity is used
 Mat sym_eig_backtransform(Ctx* ctx, const SymEig& e, const std::vector<int>& ids);

@@ -739,7 +739,7 @@ Ctx* helper_ctx(Ctx* ctx, int h) {
     }
     Ctx* hc = ctx->helpers[(size_t)h].get();
     hc->timer->enabled = ctx->timer && ctx->timer->enabled;
-    hc->gemm_swizzle = ctx->gemm_swizzle;
+    hc->gemm_swizzle = ctx->gemm_swizzle; hc->mf_swizzle = ctx->mf_swizzle;
     return hc;
 }
 hipEvent_t aux_event(Ctx* ctx, int i) {
@@ -1969,7 +1969,7 @@ AdiResult adi_finish(AdiRun& run) {
         for (auto& key : cache->fresh) { cache->real.erase(key); cache->cplx_.erase(key); }
     }
     cache->fresh.clear();
-    if (opt.compression && last_compression > 0 && (opt.final_compress || cex)) ldlt_compress(ctx, *Xw, ctf, cex);   // adi.jl:78-80
+    if (opt.compression && last_compression > 0 && (opt.final_compress || cex)) ldlt_compress(ctx, *Xw, ctf, cex, -1.0, opt.tight_final ? COMPRESS_TIGHT : 0);   // adi.jl:78-80
     cache->iters_hint = res.iters;
     all_shifts.resize(res.iters);
     res.shifts = all_shifts;

@@ -46,7 +46,12 @@ void ldlt_concatenate(Ctx* ctx, LDLt& X);                        // LDLt.jl:174-
 //                         the relative tolerance alone would keep the formation noise as signal; abs_tol is ignored
 //   COMPRESS_KEEP_RESULT  never hand the summands back when nothing was gained: the result is always ONE block with orthonormal L, on which
 //                         the Gram form of the norm (adi loop) is accurate whatever cancelled in the summands
-enum { COMPRESS_NOISE_FLOOR = 1, COMPRESS_KEEP_RESULT = 2 };
+//   COMPRESS_TIGHT        the band reduction stops at panel boundaries of a Krylov basis: its rank J lies above the number of eigenvalues the
+//                         reference keeps (LDLt.jl:237-245; measured 160 - 256 against 113 - 144 columns on the stage solves of Ros2 at n = 1357).
+//                         The J x J band matrix is diagonalised and the reference's own threshold 100 eps max|lambda| (or the noise floor, if
+//                         larger) applied: the result is one block with orthonormal L and DIAGONAL D of the reference's rank — for factors that
+//                         become the right-hand side of the next Lyapunov solve, whose cost is proportional to their width
+enum { COMPRESS_NOISE_FLOOR = 1, COMPRESS_KEEP_RESULT = 2, COMPRESS_TIGHT = 4 };
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac = 4.0, bool exact = true, double abs_tol = -1.0, int mode = 0);
 // residual(::GAREProblem, ::LDLt) and the feedback E'XB from the device factors of X (solver ordering throughout)
 LDLtP gare_residual_dev(Ctx* ctx, const Pencil& P, LDLt& X, const Mat& Ct, const Mat& S, double gamma, const Mat& B, const Mat& Rinv, double beta);
@@ -117,6 +122,7 @@ struct AdiOptions {   // /root/reference/src/lyapunov/types.jl:20-30
     BlockSolverFn inner_solve = nullptr;   // inner_alg = ShermanMorrisonWoodbury(user solver, Backslash) instead of the library's multifrontal LU
     void* inner_user = nullptr;
     bool final_compress = true;      // internal (Ros1 driver): false keeps the solution as warm start + increments (block list)
+    bool tight_final = false;        // internal (Ros2 driver): the final compression of the solution truncates at the reference's rank (COMPRESS_TIGHT)
     Mat warm_L, warm_EtL;            // internal (Ros1 driver): concatenated factor of the warm start and E' times it, if already at hand
     int rhs_lead_blocks = -1;        // internal (Ros1 driver): the right-hand side is  C = (first rhs_lead_blocks blocks) + rhs_e_coeff * E'XE
     double rhs_e_coeff = 0.0;        //   with X the warm start, so the residual folds the last term into F: (F + coeff/2 E)' X E + E' X (F + coeff/2 E)

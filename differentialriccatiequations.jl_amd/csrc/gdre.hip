@@ -1358,7 +1358,7 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     side->compress_sketch_min_cols = ctx->compress_sketch_min_cols; side->compress_sketch_extra = ctx->compress_sketch_extra;
     side->compress_sketch_ratio = ctx->compress_sketch_ratio; side->compress_sketch_sparse = ctx->compress_sketch_sparse;
     side->compress_sketch_cholqr = ctx->compress_sketch_cholqr;
-    side->gemm_swizzle = ctx->gemm_swizzle;
+    side->gemm_swizzle = ctx->gemm_swizzle; side->mf_swizzle = ctx->mf_swizzle;
     side->fetch_spin = false;
     side->orthf_fn = ctx->orthf_fn; side->orthf_user = ctx->orthf_user;
     // launch gate (common.hpp): the side thread enqueues while this one waits
@@ -1775,7 +1775,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     if (side) {
         side->dense_inv_max_n = ctx->dense_inv_max_n; side->compress_direct_max_n = ctx->compress_direct_max_n;
         side->compress_direct_ratio = ctx->compress_direct_ratio; side->compress_factor_min_n = ctx->compress_factor_min_n;
-        side->compress_factor_min_cols = ctx->compress_factor_min_cols; side->gemm_swizzle = ctx->gemm_swizzle;
+        side->compress_factor_min_cols = ctx->compress_factor_min_cols; side->gemm_swizzle = ctx->gemm_swizzle; side->mf_swizzle = ctx->mf_swizzle;
     }
     std::map<uint64_t, DevArr<double>> valF_by_tau;
     const double gamma = 1.0 + 1.0 / std::sqrt(2.0);
@@ -1959,9 +1959,19 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             // relative to the largest term, so on the raw summands abstol = n eps ||R1|| and every residual norm became rounding noise (the solves
             // stopped after 0 iterations and K(t) froze 1e-6 away from the oracle).  R1 is therefore always brought to ONE block with orthonormal
             // factor, truncated at max(relative tolerance, formation noise of G S G'): nothing can cancel in that form.
+            // (ros2_tight = 1: for self-generated shifts — Projection, the default ADI(): every iteration pays a factorisation and a complex solve,
+            // 290 us at n = 1357 — where the ~3 - 8 ms of diagonalising a 200 x 200 band matrix in single-workgroup kernels are paid back by narrower
+            // solves (configs[2]: 769 -> 664 ms, iteration counts of the first steps within 8 of the oracle's instead of 6 - 48 above).  Not for
+            // Cyclic lists: n = 371 (dense inverses, 10 us per iteration) 322 -> 653 ms, n = 5177 250 -> 427 ms although the widths fall from
+            // 208 to ~150 / from up to 371 to 3 - 72 columns; 2: everywhere)
+            const bool tight = !cex && (ctx->ros2_tight >= 2 || (ctx->ros2_tight == 1 && adi.shifts.kind != ShiftSpec::CYCLIC));
             if (cex) ldlt_compress(ctx, *R1, ctf, cex);
-            else ldlt_compress(ctx, *R1, ctf, false, -1.0, COMPRESS_NOISE_FLOOR | COMPRESS_KEEP_RESULT);
-            AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi, &cache);
+            else ldlt_compress(ctx, *R1, ctf, false, -1.0, COMPRESS_NOISE_FLOOR | COMPRESS_KEEP_RESULT | (tight ? COMPRESS_TIGHT : 0));
+            // the stage solutions at the reference's rank (COMPRESS_TIGHT): K1 becomes the factor of the second stage's right-hand side, K1 and K2
+            // the summands of the next X, whose rank sets the width of the next step's first stage
+            AdiOptions adi_t = adi;
+            adi_t.tight_final = tight;
+            AdiResult a1 = adi_solve(ctx, op, *R1, nullptr, adi_t, &cache);
             LDLtP K1 = a1.X;
             // stage 2: G2 = E'T1, S2 = (tau^2 B'T1D1)'(B'T1D1) + (2 - 1/gamma) D1     (lowrank_ros2.jl:61-69)
             ldlt_destructure(ctx, *K1, ctf, cex);
@@ -1976,7 +1986,7 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
             copy_mat(ctx, kb.D, S2, 2.0 - 1.0 / gamma);
             if (r1 > 0) gemm(ctx, true, false, tau * tau, BtT1D1, BtT1D1, 1.0, S2);
             LDLtP R2 = ldlt_make(ctx, n, G2, S2, 1.0, false);
-            AdiResult a2 = adi_solve(ctx, op, *R2, nullptr, adi, &cache);
+            AdiResult a2 = adi_solve(ctx, op, *R2, nullptr, adi_t, &cache);
             LDLtP K2 = a2.X;
             // X = X + ((2 - 1/(2 gamma)) tau) K1 + (-tau/2) K2     (lowrank_ros2.jl:72)
             X = ldlt_add(ldlt_add(X, ldlt_scale(K1, (2.0 - 1.0 / (2.0 * gamma)) * tau)), ldlt_scale(K2, -tau / 2.0));

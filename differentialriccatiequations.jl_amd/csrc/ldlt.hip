@@ -192,6 +192,21 @@ static void orth_cholqr(Ctx* ctx, Mat& Y, Mat& Q, int* flag_dev, int j_start = 0
     }
 }
 
+// debug (DRE_TRACE=rank): how far the band reduction's rank (a multiple of the panel width, in Krylov order) lies above the rank the reference keeps
+// (LDLt.jl:237-245: eigenvalues of at least 100 eps max|lambda|) — the eigenvalues of the J x J band matrix on the host
+static void trace_band_rank(Ctx* ctx, const Mat& D, const char* tag, int n, int c) {
+    if (!env_trace("rank") || D.rows == 0) return;
+    const int J = D.rows;
+    std::vector<double> h((size_t)J * J);
+    DRE_HIP(hipMemcpy2DAsync(h.data(), (size_t)J * sizeof(double), D.p, (size_t)D.ld * sizeof(double), (size_t)J * sizeof(double), J, hipMemcpyDeviceToHost, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    auto ev = host_eigvals(J, h);
+    double mx = 0.0;
+    for (auto& e : ev) mx = std::max(mx, std::abs(e));
+    int r100 = 0, r1 = 0;
+    for (auto& e : ev) { if (std::abs(e) >= 100.0 * EPS * mx) ++r100; if (std::abs(e) >= 1e-12 * mx) ++r1; }
+    std::fprintf(stderr, "[rank] %s n=%d c=%d: band rank J=%d, eigenvalues >= 100 eps max: %d, >= 1e-12 max: %d\n", tag, n, c, J, r100, r1);
+}
 static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) {
     const int n = X.n, c = X.rank(), sp = s + 16;
     static const bool trace = env_trace("compress");
@@ -257,6 +272,7 @@ static bool sketch_compress(Ctx* ctx, LDLt& X, double tolfac, int s, long skey) 
     if (!ok) { ctx->band_hint[skey] = std::max(ctx->band_hint[skey], std::min(sb.J + 16, s)); return false; }
     ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += s; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
     ctx->band_hint[skey] = sb.J;
+    trace_band_rank(ctx, sb.D, "sketch", n, c);
     X.blocks.clear();
     if (sb.J == 0) { X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true}); return true; }
     Mat Bq = sym_band_basis(ctx, sb);                 // s x J
@@ -419,8 +435,48 @@ static double noise_floor_fac() {
     static const double f = 4.0;    // 0.03 ... 4: same K(t) to 2e-14 (tools/dbg_ros2_full.py)
     return f;
 }
+static void ldlt_compress_core(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode, double* floor_used);
+// COMPRESS_TIGHT (engine.hpp): X = L D L' with orthonormal L (n x J) and the J x J band matrix D of a finished compression -> eigenvalues of D,
+// the reference's threshold, L <- L U_keep, D <- diag(lambda_keep)
+static void ldlt_tighten(Ctx* ctx, LDLt& X, double tolfac, double floor_abs) {
+    if (X.blocks.size() != 1) return;
+    LBlock& b = X.blocks[0];
+    const int n = X.n, J = b.L.cols;
+    if (J < 2 || b.diag || !b.ortho || b.D.rows != J) return;
+    Mat Dc(ctx, J, J);
+    copy_mat(ctx, b.D, Dc, b.alpha);
+    SymEig e = sym_eig(ctx, Dc, tolfac, true, -1.0, false, 1.0);          // (deflation at eps ||D||: only the eigenvalues above 100 eps max|lambda| are wanted)
+    if (e.j == 0) return;
+    double wmax = 0.0;
+    for (double w : e.w) wmax = std::max(wmax, std::fabs(w));
+    const double thr = std::max(100.0 * wmax * EPS, floor_abs);
+    std::vector<int> ids;
+    for (int i = 0; i < e.j; ++i)
+        if (std::fabs(e.w[i]) >= thr && wmax > 0.0) ids.push_back(i);
+    std::sort(ids.begin(), ids.end(), [&](int a, int c) { return e.w[a] < e.w[c]; });
+    const int r = (int)ids.size();
+    static const bool trace = env_trace("compress");
+    if (trace) std::fprintf(stderr, "[compress tight] n=%d band rank %d -> %d (threshold %.2e, largest %.2e)\n", n, J, r, thr, wmax);
+    if (r == 0 || r >= J) return;          // (nothing above the threshold: the band form stays, as before; nothing gained: keep it)
+    Mat U = sym_eig_backtransform(ctx, e, ids);          // J x r
+    Mat Lnew(ctx, n, r);
+    gemm(ctx, false, false, 1.0, b.L, U, 0.0, Lnew, nullptr, "gemm_compress");
+    std::vector<double> hd((size_t)r * r, 0.0);
+    for (int i = 0; i < r; ++i) hd[i + (size_t)i * r] = e.w[ids[i]];
+    Mat Dnew(ctx, r, r);
+    DRE_HIP(hipMemcpyAsync(Dnew.p, hd.data(), hd.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    DRE_HIP(hipStreamSynchronize(ctx->stream));
+    X.blocks.clear();
+    X.blocks.push_back({Lnew, Dnew, 1.0, true, true});
+}
 void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode) {
     RoctxRange roctx_range("compress!(::LDLᵀ)");
+    double floor_used = 0.0;
+    const bool tight = !exact && (mode & COMPRESS_TIGHT);
+    ldlt_compress_core(ctx, X, tolfac, exact, abs_tol, mode & ~COMPRESS_TIGHT, tight ? &floor_used : nullptr);
+    if (tight) ldlt_tighten(ctx, X, tolfac, floor_used);
+}
+static void ldlt_compress_core(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol, int mode, double* floor_used) {
     const int n = X.n, c = X.rank();
     const bool nfloor = !exact && (mode & COMPRESS_NOISE_FLOOR), keep_result = !exact && (mode & COMPRESS_KEEP_RESULT);
     if (nfloor) abs_tol = -1.0;
@@ -430,7 +486,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         hipLaunchKernelGGL(k_colpair_noise, dim3(A.cols), dim3(256), 0, ctx->stream, A.rows, (const double*)A.p, A.ld, (const double*)B.p, B.ld, nf.p + 1);
         hipLaunchKernelGGL(k_noise_floor, dim3(1), dim3(256), 0, ctx->stream, A.cols, noise_floor_fac(), (const double*)(nf.p + 1), nf.p);
     };
-    auto floor_host = [&]() { double h = 0.0; ctx_fetch(ctx, nf.p, sizeof(double), &h); return h; };
+    auto floor_host = [&]() { double h = 0.0; ctx_fetch(ctx, nf.p, sizeof(double), &h); if (floor_used) *floor_used = h; return h; };
     auto set_empty = [&]() {
         X.blocks.clear();
         X.blocks.push_back({Mat(ctx, n, 0), Mat(ctx, 0, 0), 1.0, true});
@@ -488,6 +544,7 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
         SymBand sb = lr_band_reduce(ctx, Lw, tab, tolfac, lr_tol, nfloor);
         ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += n; ctx->cstats.tri_steps += sb.J; ctx->cstats.rank_out += sb.J;
         if (sketchable) ctx->band_hint[skey] = std::max(sb.J, 16);
+        trace_band_rank(ctx, sb.D, "factor form", n, c);
         if (sb.J == 0) { set_empty(); return; }
         if (sb.J >= c && !keep_result) { ldlt_concatenate(ctx, X); return; }        // nothing gained: keep the summands
         Mat Bq = sym_band_basis(ctx, sb);
@@ -577,10 +634,12 @@ void ldlt_compress(Ctx* ctx, LDLt& X, double tolfac, bool exact, double abs_tol,
             Dnew = sym_tridiag_dense(ctx, e);
         } else {
             SymBand sb = nfloor ? sym_band_reduce(ctx, S, tolfac, -1.0, nf.p, nullptr, nullptr, 0, true) : sym_band_reduce(ctx, S, tolfac, abs_tol);
+            if (nfloor && floor_used) (void)floor_host();
             ctx->cstats.calls++; ctx->cstats.cols_in += c; ctx->cstats.order += S.rows; ctx->cstats.tri_steps += sb.J;
             r = sb.J;
             ctx->cstats.rank_out += r;
             if (r == 0) { set_empty(); return; }
+            trace_band_rank(ctx, sb.D, wide ? "direct" : "qr", n, c);
             B = sym_band_basis(ctx, sb);
             Dnew = sb.D;
         }

@@ -1254,6 +1254,102 @@ __global__ __launch_bounds__(256) void k_tql(int n, double* __restrict__ dg, dou
     if (ZLDS) for (int i = tid; i < n * n; i += blockDim.x) Zg[i % n + (size_t)(i / n) * ldzg] = Z[i];
 }
 
+// n > 128 (Z no longer fits one workgroup's LDS).  The generator is a scalar dependent chain — ~500 cycles per rotation in one GPU thread: 7.5 ms for
+// the ~34 000 rotations of a 208 x 208 problem, wherever Z lives (a row-slab form with Z in LDS and the generator run redundantly per workgroup took the
+// same 7.6 ms) — so it runs on the HOST (10 - 15 ns per rotation; d and e are 2 j doubles, and sym_eig synchronises for the reduction's dimension
+// anyway), which logs every rotation; the device replays the log on row slabs of Z held in LDS: lane = row, the carried element in a register, one
+// LDS read and one LDS write per rotation and row, (c, s) through scalar loads.  Same recurrences and deflation constants as k_tql.
+struct QlSweep { int m, ilo; long off; };          // rotations i = m - 1 ... ilo of one implicit QL sweep, (c, s) pairs at log[2 (off + m - 1 - i)]
+static bool host_tql_log(int n, std::vector<double>& d, std::vector<double>& e, double anorm, double deflate, std::vector<double>& log, std::vector<QlSweep>& sweeps) {
+    const double eps = 2.220446049250313e-16, abstiny = deflate * eps * anorm;
+    e.resize(n, 0.0);
+    e[n - 1] = 0.0;
+    int l = 0, iter = 0;
+    while (l < n) {
+        int m = l;
+        for (; m < n - 1; ++m) {
+            const double em = std::fabs(e[m]);
+            if (em <= eps * (std::fabs(d[m]) + std::fabs(d[m + 1])) || em <= abstiny) break;
+        }
+        if (m == l) { ++l; iter = 0; continue; }
+        if (iter >= 80) return false;
+        ++iter;
+        const double dl = d[l], el = e[l];
+        double g = (d[l + 1] - dl) / (2.0 * el);
+        double r = std::sqrt(g * g + 1.0);
+        g = d[m] - dl + el / (g + (g >= 0.0 ? r : -r));
+        double s = 1.0, c = 1.0, p = 0.0;
+        const long off = (long)(log.size() / 2);
+        int i, ilo = l;
+        bool broke = false;
+        for (i = m - 1; i >= l; --i) {
+            const double f = s * e[i], b = c * e[i];
+            const double h = f * f + g * g;
+            if (h == 0.0) { e[i + 1] = 0.0; d[i + 1] -= p; e[m] = 0.0; broke = true; break; }
+            const double rr = std::sqrt(h);
+            e[i + 1] = rr;
+            s = f / rr; c = g / rr;
+            g = d[i + 1] - p;
+            r = (d[i] - g) * s + 2.0 * c * b;
+            p = s * r;
+            d[i + 1] = g + p;
+            g = c * r - b;
+            log.push_back(c); log.push_back(s);
+        }
+        if (broke) ilo = i + 1;
+        else { d[l] -= p; e[l] = g; e[m] = 0.0; }
+        if (m - 1 >= ilo) sweeps.push_back({m, ilo, off});
+    }
+    return true;
+}
+__global__ __launch_bounds__(64) void k_tql_replay(int n, int rows, const double* __restrict__ log, const QlSweep* __restrict__ sweeps, int nsweeps,
+                                                   double* __restrict__ Zg, int ldzg) {
+    extern __shared__ double Zs[];          // rows x n, Zs[k + i * rows]
+    const int k = threadIdx.x, r0 = blockIdx.x * rows, nr = min(rows, n - r0);
+    for (int id = k; id < rows * n; id += 64) { const int kk = id % rows, i = id / rows; Zs[id] = (r0 + kk == i) ? 1.0 : 0.0; }
+    __syncthreads();
+    if (k < nr) {
+        for (int t = 0; t < nsweeps; ++t) {
+            // (the sweep's parameters through scalar registers: the (c, s) pairs below then come through scalar loads)
+            const int m = __builtin_amdgcn_readfirstlane(sweeps[t].m), ilo = __builtin_amdgcn_readfirstlane(sweeps[t].ilo);
+            const long off = ((long)__builtin_amdgcn_readfirstlane((int)(sweeps[t].off >> 32)) << 32) |
+                             (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sweeps[t].off & 0xffffffffL));
+            const double* __restrict__ cs = log + 2 * off;
+            double zi1 = Zs[k + (size_t)m * rows];
+            // eight rotations per batch, two batches in registers: while the dependent chain of one batch runs, the operands of the next (the untouched
+            // columns i - 8 ... i - 15 and their pairs) are in flight — one wave per workgroup has nothing else to hide its LDS and scalar-load latencies
+            // behind.  (Column i - u is first written by rotation u + 1: the early reads see the values the sequential order sees.)
+            double z[2][8], cc[2][8], ss[2][8];
+            auto fetch = [&](int b, int i) {
+                const int cnt = min(8, i - ilo + 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) { z[b][u] = Zs[k + (size_t)(i - u) * rows]; cc[b][u] = cs[2 * u]; ss[b][u] = cs[2 * u + 1]; }
+                cs += 2 * max(cnt, 0);
+            };
+            auto chain = [&](int b, int i) {
+                const int cnt = min(8, i - ilo + 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < cnt) { Zs[k + (size_t)(i - u + 1) * rows] = ss[b][u] * z[b][u] + cc[b][u] * zi1; zi1 = cc[b][u] * z[b][u] - ss[b][u] * zi1; }
+            };
+            int i = m - 1;
+            if (i >= ilo) fetch(0, i);
+            for (; i >= ilo; i -= 16) {
+                if (i - 8 >= ilo) fetch(1, i - 8);
+                chain(0, i);
+                if (i - 8 >= ilo) {
+                    if (i - 16 >= ilo) fetch(0, i - 16);
+                    chain(1, i - 8);
+                }
+            }
+            Zs[k + (size_t)ilo * rows] = zi1;
+        }
+    }
+    __syncthreads();
+    for (int id = k; id < rows * n; id += 64) { const int kk = id % rows, i = id / rows; if (kk < nr) Zg[(r0 + kk) + (size_t)i * ldzg] = Zs[id]; }
+}
+
 __global__ void k_tri_to_dense(int n, const double* __restrict__ d, const double* __restrict__ e, double* __restrict__ A, int lda) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * n) return;
@@ -1265,7 +1361,7 @@ __global__ void k_tri_to_dense(int n, const double* __restrict__ d, const double
     A[r + (size_t)c * lda] = v;
 }
 
-SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol, bool tol_is_floor) {
+SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol, bool tol_is_floor, double deflate) {
     DRE_REQUIRE(S.rows == S.cols, "sym_eig: square matrix expected");
     SymEig out;
     const int q = S.rows;
@@ -1307,6 +1403,30 @@ SymEig sym_eig(Ctx* ctx, Mat& S, double tolfac, bool want_eig, double abs_tol, b
             size_t shm = (6 * (size_t)j + (size_t)j * j) * sizeof(double);
             lds_attr(ctx, (const void*)k_tql<true>, 150 * 1024);
             hipLaunchKernelGGL((k_tql<true>), dim3(1), dim3(256), shm, ctx->stream, j, dw.p, ew.p, out.Z.p, out.Z.ld, hi.snorm, fail.p);
+        } else if (j <= 2048) {
+            // generator on the host, replay on row slabs of Z in LDS (k_tql_replay)
+            std::vector<double> hd(j), he(j, 0.0), hlog;
+            std::vector<QlSweep> hsw;
+            DRE_HIP(hipMemcpyAsync(hd.data(), d.p, j * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            if (j > 1) DRE_HIP(hipMemcpyAsync(he.data(), e.p, (j - 1) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            DRE_HIP(hipStreamSynchronize(ctx->stream));
+            hlog.reserve(std::min<size_t>((size_t)4 * j * j, (size_t)4 << 20));
+            const auto t_h0 = std::chrono::steady_clock::now();
+            if (!host_tql_log(j, hd, he, hi.snorm, deflate, hlog, hsw)) throw Error(ERR_INTERNAL, "sym_eig: QL iteration did not converge");
+            if (env_trace("compress"))
+                std::fprintf(stderr, "[sym_eig] j=%d: %zu sweeps, %zu rotations on the host in %.2f ms (deflation at %.0e eps ||S||)\n", j, hsw.size(), hlog.size() / 2,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_h0).count(), deflate);
+            DevArr<double> dlog(ctx, std::max<size_t>(hlog.size(), 2));
+            DevArr<QlSweep> dsw(ctx, std::max<size_t>(hsw.size(), 1));
+            if (!hlog.empty()) DRE_HIP(hipMemcpyAsync(dlog.p, hlog.data(), hlog.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            if (!hsw.empty()) DRE_HIP(hipMemcpyAsync(dsw.p, hsw.data(), hsw.size() * sizeof(QlSweep), hipMemcpyHostToDevice, ctx->stream));
+            DRE_HIP(hipMemcpyAsync(dw.p, hd.data(), j * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            int rows = 64;
+            while (rows > 4 && (size_t)rows * j * sizeof(double) > (size_t)150 * 1024) rows >>= 1;
+            lds_attr(ctx, (const void*)k_tql_replay, 150 * 1024);
+            hipLaunchKernelGGL(k_tql_replay, dim3(ceil_div(j, rows)), dim3(64), (size_t)rows * j * sizeof(double), ctx->stream, j, rows, (const double*)dlog.p,
+                               (const QlSweep*)dsw.p, (int)hsw.size(), out.Z.p, out.Z.ld);
+            DRE_HIP(hipStreamSynchronize(ctx->stream));          // (the host vectors of the uploads die with this scope)
         } else {
             set_identity(ctx, out.Z, 1.0);
             size_t shm = 6 * (size_t)j * sizeof(double);

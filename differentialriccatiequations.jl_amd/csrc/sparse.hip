@@ -932,6 +932,21 @@ __global__ __launch_bounds__(256) void k_mf_backward(MfArgs a, int lvl_begin, co
 typedef double mf_v4d __attribute__((ext_vector_type(4)));
 #define MFM_KC 16
 
+// Workgroup -> (front of the level, block of 16 right-hand-side columns, shift).  The column blocks of one (front, shift) read the SAME factor
+// entries; in launch order they are gridDim.x workgroups apart and land on different XCDs (round-robin placement: blocks b and b + 8 share
+// one), so every XCD's L2 fetches the front for itself.  swz != 0: every XCD takes a contiguous chunk of the list ordered (shift, front,
+// column block) — the column blocks of a front are resident together on one XCD, and with 8 shifts an XCD holds (mostly) ONE shift's factors.
+// A speed matter only (placement is not a contract); bijective for any grid.
+__device__ __forceinline__ void mf_block(int swz, int& bx, int& by, int& bz) {
+    if (!swz) { bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z; return; }
+    const unsigned gx = gridDim.x, gy = gridDim.y, per = gx * gy, T = per * gridDim.z;
+    unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = L & 7u, slot = L >> 3, q = T >> 3, r = T & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const unsigned z = L / per, rem = L - z * per, x = rem / gy;
+    bz = (int)z; bx = (int)x; by = (int)(rem - x * gy);
+}
+
 // THROUGHPUT form (the forward kernel, and the backward kernel of levels with many fronts: thousands of workgroups, the memory round trips
 // of one workgroup hide behind the others): predicated loads, so masked lanes (outside the triangle / past the end of the K range) generate
 // no traffic, element-per-thread staging, fewer registers.  The LATENCY form of the backward kernel further down wins where a level has few
@@ -966,15 +981,17 @@ __device__ __forceinline__ mf_v4d mfma_rowtile(mf_v4d acc, const double* __restr
 // front or to the dense top, so the sweeps write all of it).
 __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begin, MfZ zb,
                                                           double* __restrict__ W, int ldw, int nrhs, double* __restrict__ upd, int64_t ldu,
-                                                          const AdiState* st, const double* __restrict__ Win, int ldwin, int nin) {
+                                                          const AdiState* st, const double* __restrict__ Win, int ldwin, int nin, int swz) {
     if (st && st->done) return;
     extern __shared__ double sm[];
-    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
-    const double* __restrict__ inv = zb.inv[blockIdx.z];
-    W += (size_t)blockIdx.z * zb.wz; upd += (size_t)blockIdx.z * zb.uz;
-    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    int bx, by, bz;
+    mf_block(swz, bx, by, bz);
+    const double* __restrict__ fronts = zb.fronts[bz];
+    const double* __restrict__ inv = zb.inv[bz];
+    W += (size_t)bz * zb.wz; upd += (size_t)bz * zb.uz;
+    const int t = a.lvl_nodes[lvl_begin + bx];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
-    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int c0 = by * MFM_KC, kc = min(MFM_KC, nrhs - c0);
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int sp = (s + 15) & ~15, wr = max(s + ((b + 15) & ~15), sp) + 4, ldl = wr | 1, ldy = (sp + 4) | 1;
     double* w = sm;                          // wr x 16 (ld ldl): rows 0..s-1 = w_S, s..f-1 = assembled w_B, rest 0
@@ -1052,15 +1069,17 @@ __global__ __launch_bounds__(1024) void k_mf_forward_mfma(MfArgs a, int lvl_begi
 }
 
 __global__ __launch_bounds__(1024) void k_mf_backward_tp(MfArgs a, int lvl_begin, MfZ zb,
-                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st) {
+                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st, int swz) {
     if (st && st->done) return;
     extern __shared__ double sm[];
-    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
-    const double* __restrict__ inv = zb.inv[blockIdx.z];
-    W += (size_t)blockIdx.z * zb.wz;
-    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    int bx, by, bz;
+    mf_block(swz, bx, by, bz);
+    const double* __restrict__ fronts = zb.fronts[bz];
+    const double* __restrict__ inv = zb.inv[bz];
+    W += (size_t)bz * zb.wz;
+    const int t = a.lvl_nodes[lvl_begin + bx];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
-    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int c0 = by * MFM_KC, kc = min(MFM_KC, nrhs - c0);
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int sp = (s + 15) & ~15, ldx = (b + 36) | 1, ldz = (sp + 36) | 1;
     double* xb = sm;                          // (b + pad) x 16: the already known ancestor unknowns, zero padded
@@ -1164,15 +1183,17 @@ __device__ __forceinline__ mf_v4d rt_tile(mf_v4d acc, const RtSrc& s, int r0, in
 // ceil(s / 16) row tiles, so the waves of a workgroup SPLIT K: G = nw / tiles waves per tile, each over a 32-aligned share of the
 // boundary, partial tiles summed in a fixed order through LDS (`part`, nw x 256 doubles behind z).
 __global__ __launch_bounds__(1024) void k_mf_backward_mfma(MfArgs a, int lvl_begin, MfZ zb,
-                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st, int split) {
+                                                           double* __restrict__ W, int ldw, int nrhs, const AdiState* st, int split, int swz) {
     if (st && st->done) return;
     extern __shared__ double sm[];
-    const double* __restrict__ fronts = zb.fronts[blockIdx.z];
-    const double* __restrict__ inv = zb.inv[blockIdx.z];
-    W += (size_t)blockIdx.z * zb.wz;
-    const int t = a.lvl_nodes[lvl_begin + blockIdx.x];
+    int bx, by, bz;
+    mf_block(swz, bx, by, bz);
+    const double* __restrict__ fronts = zb.fronts[bz];
+    const double* __restrict__ inv = zb.inv[bz];
+    W += (size_t)bz * zb.wz;
+    const int t = a.lvl_nodes[lvl_begin + bx];
     const int s = a.size[t], b = a.bptr[t + 1] - a.bptr[t], f = s + b, first = a.first[t];
-    const int c0 = blockIdx.y * MFM_KC, kc = min(MFM_KC, nrhs - c0);
+    const int c0 = by * MFM_KC, kc = min(MFM_KC, nrhs - c0);
     const int tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, nw = nt >> 6;
     const int sp = (s + 15) & ~15, ldx = (b + 36) | 1, ldz = (sp + 36) | 1;
     double* xb = sm;                          // (b + pad) x 16: the already known ancestor unknowns, zero padded
@@ -1771,6 +1792,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, do
     const Symbolic& S = P.sym;
     MfArgs a = mf_args(P);
     const int ncb = ceil_div(nrhs, MFM_KC);
+    const int swz = ctx->mf_swizzle != 0 && ncb >= 2 ? 1 : 0;          // (one column block: nothing is shared)
     lds_attr(ctx, (const void*)k_mf_forward_mfma, 150 * 1024); lds_attr(ctx, (const void*)k_mf_backward_mfma, 150 * 1024);
     lds_attr(ctx, (const void*)k_mf_backward_tp, 150 * 1024);
     if (forward) {
@@ -1783,7 +1805,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, do
             static const int tp_threads = 256;
             int nthreads = fm > 128 ? 1024 : (fm > 48 ? 512 : 256);
             if (tp_threads > 0 && (long)nb * ncb * nz > 2000) nthreads = tp_threads;
-            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n);
+            hipLaunchKernelGGL(k_mf_forward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, upd, ldu, st, in.p, in.ld, in.n, swz);
         }
     } else {
         for (int l = l_from; l <= l_to; ++l) {
@@ -1792,7 +1814,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, do
             if ((long)nb * ncb * nz > mf_latency_max_wg(false)) {
                 const size_t shm = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double);
                 const int nthreads = sm_ > 64 ? 512 : 256;
-                hipLaunchKernelGGL(k_mf_backward_tp, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st);
+                hipLaunchKernelGGL(k_mf_backward_tp, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st, swz);
                 continue;
             }
             // waves: one per 16-row tile of the separator times up to four shares of the boundary (K-split of z = w_S - U12 x_B)
@@ -1802,7 +1824,7 @@ static void mf_sweep_levels(Ctx* ctx, const Pencil& P, const MfZ& zb, int nz, do
             const size_t base = ((size_t)((fm + 36) | 1) + (size_t)((spm + 36) | 1)) * MFM_KC * sizeof(double), parts = (size_t)nwv * 256 * sizeof(double);
             const int split = base + parts <= (size_t)150 * 1024;
             const size_t shm = base + (split ? parts : 0);
-            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st, split);
+            hipLaunchKernelGGL(k_mf_backward_mfma, dim3(nb, ncb, nz), dim3(nthreads), shm, ctx->stream, a, S.lvl_ptr[l], zb, W, ldw, nrhs, st, split, swz);
         }
     }
 }

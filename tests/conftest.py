@@ -34,7 +34,7 @@ OPTION_NAMES = (
     "top_inverse_max_rows", "mf_subtree", "setup_streams", "x_side_stream", "side_after_panels", "setup_batched", "dense_warm", "side_prefetch",
     "xwarm_sx", "prefetch_batch", "dense_x_max_n", "dense_x_max_k", "adi_group", "adi_group_max_n", "adi_fan", "ros1_recurrence",
     "adi_fan_max_coef", "shard_min_cols", "x_compress_every", "pivot_growth_warn", "pivot_growth_fail", "pivot_static", "pivot_refine_steps",
-    "shard_emulate", "comm_host_async", "side_gate", "recurrence_wide", "gemm_swizzle")
+    "shard_emulate", "comm_host_async", "side_gate", "recurrence_wide", "gemm_swizzle", "mf_swizzle", "ros2_tight")
 _session_ctx = []
 
 

@@ -94,7 +94,16 @@ def test_config2_ros2_1357_default_projection_shifts(ctx, literal):
     if literal:
         assert max(abs(a - b) for a, b in zip(its[:12], ref[:12])) <= 2, (its, ref)
         assert all(x["converged"] for x in st["gales"])
-    assert abs(sum(its) - sum(ref)) <= 0.2 * sum(ref), (sum(its), sum(ref))
+    if literal:
+        assert abs(sum(its) - sum(ref)) <= 0.2 * sum(ref), (sum(its), sum(ref))
+    else:
+        # default mode (round 5: the stage right-hand sides and stage solutions are truncated at the reference's rank, engine.hpp COMPRESS_TIGHT):
+        # the first three steps follow the oracle solve by solve (observed 0, 1, 0, 1, 8, 3 iterations apart); from then on the stage-1
+        # right-hand side is dominated by its formation noise, which the engine truncates and the oracle iterates on — the oracle's stage-1 counts
+        # RISE (148 ... 200, two solves stop at maxiters), the engine's fall (140 ... 54) and every solve converges
+        assert max(abs(a - b) for a, b in zip(its[:6], ref[:6])) <= 12, (its, ref)
+        assert all(x["converged"] for x in st["gales"])
+        assert 0.7 * sum(ref) <= sum(its) <= 1.05 * sum(ref), (sum(its), sum(ref))
     ncx = sum(int(np.sum(np.abs(np.imag(x["shifts"])) > 0)) for x in st["gales"])
     assert abs(ncx / sum(its) - g["n_complex"].sum() / sum(ref)) < 0.1          # ~60 % of the shifts come in complex pairs (perform_double_step!)
     for i in range(1, 9):
@@ -105,7 +114,7 @@ def test_config2_ros2_1357_default_projection_shifts(ctx, literal):
     if literal:
         assert np.linalg.norm(Kd - sol.K[-1]) < np.linalg.norm(Kd) * n * EPS * 100      # test/rail.jl:56
     else:
-        # default mode stops two late solves at maxiters as the oracle does: held to twice the oracle's own distance
+        # (until round 5 the default mode stopped two late solves at maxiters as the oracle does; kept: held to the oracle's own distance class)
         assert np.linalg.norm(Kd - sol.K[-1]) < max(np.linalg.norm(Kd) * n * EPS * 100, 4.0 * float(g["err_vs_dense"]))
 
 
