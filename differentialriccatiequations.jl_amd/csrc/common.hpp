@@ -307,7 +307,7 @@ struct Mat {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // Diagnostics on stderr: DRE_TRACE=<keyword>[,<keyword>...] (or "all").  Keywords: compress, cholqr, proj, prefetch, subtree (what a code path
-// decided), phase, chunk, rec, fan (host/device timings of the loops).  The engine's TUNABLES are options (dre_ctx_set_option; DRE_OPTIONS=
+// decided), rank (eigenvalues of every finished compression's band matrix on the host: its rank against the reference's), phase, chunk, rec, fan (host/device timings of the loops).  The engine's TUNABLES are options (dre_ctx_set_option; DRE_OPTIONS=
 // "name=value,..." sets them for every context created by the process) — environment variables do not select kernels.
 inline bool env_trace(const char* key) {
     const char* e = std::getenv("DRE_TRACE");

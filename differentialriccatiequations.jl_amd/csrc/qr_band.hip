@@ -1308,13 +1308,16 @@ __global__ __launch_bounds__(64) void k_tql_replay(int n, int rows, const double
     const int k = threadIdx.x, r0 = blockIdx.x * rows, nr = min(rows, n - r0);
     for (int id = k; id < rows * n; id += 64) { const int kk = id % rows, i = id / rows; Zs[id] = (r0 + kk == i) ? 1.0 : 0.0; }
     __syncthreads();
+    const int vz = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 6);          // lane id >> 6 = 0
     if (k < nr) {
         for (int t = 0; t < nsweeps; ++t) {
-            // (the sweep's parameters through scalar registers: the (c, s) pairs below then come through scalar loads)
+            // (the sweep's parameters through scalar registers)
             const int m = __builtin_amdgcn_readfirstlane(sweeps[t].m), ilo = __builtin_amdgcn_readfirstlane(sweeps[t].ilo);
             const long off = ((long)__builtin_amdgcn_readfirstlane((int)(sweeps[t].off >> 32)) << 32) |
                              (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sweeps[t].off & 0xffffffffL));
-            const double* __restrict__ cs = log + 2 * off;
+            // the pairs through VECTOR loads (every lane the same address: one request): scalar loads share the LDS counter (lgkmcnt) and return out of
+            // order, so every wait for an LDS operand would also wait for all pairs in flight; `vz` is zero, but not to the compiler
+            const double* __restrict__ cs = log + 2 * off + vz;
             double zi1 = Zs[k + (size_t)m * rows];
             // eight rotations per batch, two batches in registers: while the dependent chain of one batch runs, the operands of the next (the untouched
             // columns i - 8 ... i - 15 and their pairs) are in flight — one wave per workgroup has nothing else to hide its LDS and scalar-load latencies
