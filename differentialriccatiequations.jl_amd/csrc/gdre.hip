@@ -890,6 +890,7 @@ static bool ros1_dense_step(Ctx* ctx, const GdreProblem& prob, const GaleOperato
             co = std::move(sx.pre->co); co_ok = sx.pre->ok;
             sx.pre.reset();
         } else sx.worker->wait();
+        if (want_base && !more_steps) want_base = false;          // (the last step of a run: nobody would use the base — nor join the job that builds it)
         if (want_base) {
             // the base of the group chain (~250 launches on the side stream, once per run) is enqueued by the parked thread while this one goes
             // on with the chain; the next step joins it.  (It reads the cycle's factors and stacks: shared with `co` through reference counts.)
@@ -1787,6 +1788,20 @@ GdreResult gdre_solve(Ctx* ctx, const GdreProblem& prob, int order, double dt, b
     sx.attach(ctx);
     SideWorker& side_worker = parked_worker(ctx, 2);        // parked thread that drives the side-stream compression of the block-list loop (created on first use)
     sx.worker = &side_worker;
+    // The parked threads outlive the solve (they live with the context); a job still running when this frame dies — the deferred group base of a
+    // run's first dense step, a prefetched side set-up; on the regular exit of a one-step run or on an exception — would go on reading `sx`, `adi`
+    // and the factor cache of a dead frame (found by the option matrix: a heap corruption that surfaced in the NEXT numpy call of a one-step test).
+    // Joined here, before any of them is destroyed (declared after them: destroyed first).
+    struct WorkerJoin {
+        DenseXState& sx; Ctx* ctx;
+        ~WorkerJoin() {
+            const bool pending = sx.base_pending || (sx.pre && sx.pre->pending);
+            if (pending && sx.worker) { try { sx.worker->wait(); } catch (...) {} }
+            sx.base_pending = false;
+            if (sx.pre) sx.pre->pending = false;
+            if (pending && ctx->side) (void)hipStreamSynchronize(ctx->side->stream);          // (what the job enqueued reads buffers of this frame)
+        }
+    } worker_join{sx, ctx};
     bool sx_init = false, x_is_dense = false;
 
     const bool wall_on = env_trace("phase");

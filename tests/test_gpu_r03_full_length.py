@@ -99,7 +99,9 @@ def test_ros2_371_45_steps(ctx, rail371, save_state, exact):
     sol, st = D.solve_gdre(prob, D.Ros2(D.ADI(shifts=D.Shifts.Cyclic(list(g["shifts"])), compress_exact=exact)), dt=-100.0, save_state=save_state,
                            return_stats=True)
     assert all(x["converged"] for x in st["gales"])
-    worst = _check_full(sol, st, g, 371, 2, 1e-10, exact_counts=3 if exact else 17, slack=2 if exact else 12)
+    # (ros2_tight = 2, tools/option_matrix.sh: right-hand sides at the reference's rank also for Cyclic lists — the counts of the noise-dominated
+    # steps move by up to 14, step 37: 44 against the oracle's 58)
+    worst = _check_full(sol, st, g, 371, 2, 1e-10, exact_counts=3 if exact else 17, slack=2 if exact else (16 if ctx.get_option("ros2_tight") >= 2 else 12))
     assert worst < 1e-11
 
 

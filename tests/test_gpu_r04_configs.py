@@ -94,7 +94,7 @@ def test_config2_ros2_1357_default_projection_shifts(ctx, literal):
     if literal:
         assert max(abs(a - b) for a, b in zip(its[:12], ref[:12])) <= 2, (its, ref)
         assert all(x["converged"] for x in st["gales"])
-    if literal:
+    if literal or ctx.get_option("ros2_tight") == 0:          # (ros2_tight = 0, tools/option_matrix.sh: the band ranks of rounds 3 - 4, counts a batch above the oracle's)
         assert abs(sum(its) - sum(ref)) <= 0.2 * sum(ref), (sum(its), sum(ref))
     else:
         # default mode (round 5: the stage right-hand sides and stage solutions are truncated at the reference's rank, engine.hpp COMPRESS_TIGHT):

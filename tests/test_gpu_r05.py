@@ -206,3 +206,19 @@ def test_recurrence_with_and_without_the_factor_form_limit(ctx, wide):          
         K = sol.K[i]
         assert np.linalg.norm(K[:, ::16] - g["K_cols"][i]) < 1e-7 * g["K_norm"][i], i
         assert np.linalg.norm(K @ w - g["K_w"][i]) <= 1e-7 * np.linalg.norm(g["K_w"][i]), i
+
+
+def test_one_step_runs_leave_no_worker_job_behind(ctx, rail371):          # gdre.hip: WorkerJoin (found by tools/option_matrix.sh, round 5)
+    """A run of ONE time step on the dense-X path: its first dense step used to hand the K-independent base of the group chain to the parked worker
+    thread 'for the next step to join' — there is none, the worker outlives the solve (it lives with the context) and went on reading the dead
+    frame: a heap corruption that surfaced in a later, unrelated call.  Thirty such runs in a row, each followed by host allocations, must give the
+    fixture's K(t_1) every time."""
+    d, L, Dm = rail371
+    gold = np.load(os.path.join(GOLDEN, "ros1_371.npz"))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4400.0))
+    alg = D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(_shifts(371)), maxiters=200))
+    junk = []
+    for rep in range(30):
+        sol = D.solve(prob, alg, dt=-100.0)
+        junk.append(np.random.default_rng(rep).standard_normal(50000))          # churn the host heap between the runs
+        assert D.delta(sol.K[-1], gold["K"][1]) < 1e-7, rep
