@@ -1474,6 +1474,12 @@ static void ros1_recurrence_loop(Ctx* ctx, const GdreProblem& prob, double dt, b
     set_identity(ctx, Im, 1.0);
     static const bool steps_on = env_trace("steps");
     std::vector<std::chrono::steady_clock::time_point> step_t;
+    // (the parked threads outlive this frame: a job still running when an exception unwinds it would go on using the frame's state — joined here,
+    // behind every function-level object the jobs refer to; the regular exit has joined both already)
+    struct JoinOnExit { std::function<void()> f; ~JoinOnExit() { try { f(); } catch (...) {} } } join_on_exit{[&]() {
+        if (job_pending) { job_pending = false; ctx->gate->waiting.store(1); worker.wait(); }
+        if (norm_pending) { norm_pending = false; norm_worker.wait(); }
+    }};
     for (int i = 1; i <= nsteps; ++i) {
         if (steps_on) step_t.push_back(now());
         const double tau = out.t[i - 1] - out.t[i];
