@@ -53,7 +53,7 @@ def _run_two(tmp_path, n, nsteps, save_state=False, transport="sync"):
     return [np.load(o) for o in outs]
 
 
-def test_sharded_gdre_on_two_ranks_matches_the_oracle_fixture(tmp_path):
+def test_sharded_gdre_on_two_ranks_matches_the_oracle_fixture(tmp_path, ctx):
     """BASELINE configs[3] (SteelProfile(5177) Ros1) on two ranks, 3 time steps: iteration counts and K(t) equal the oracle's fixture, both
     ranks end with bit-identical K(t), every rank received the other's half of every group, and each factorised fewer shifts than a
     single-rank run needs (the factor farm)."""
@@ -65,7 +65,9 @@ def test_sharded_gdre_on_two_ranks_matches_the_oracle_fixture(tmp_path):
     assert int(r0["rank"]) == 0 and int(r1["rank"]) == 1
     assert np.array_equal(r0["K"], r1["K"])                       # replicated arithmetic: bit-identical on both ranks
     # ownership by list position: a rank factorises its five of the ten shifts (in shared launches at the first solve), not the whole list
-    assert int(r0["factorizations"]) + int(r1["factorizations"]) <= 14, (int(r0["factorizations"]), int(r1["factorizations"]))
+    # (without fan groups — adi_fan < 2, tools/option_matrix.sh — the step is column-sharded and every rank factorises every shift)
+    farm = ctx.get_option("adi_fan") >= 2
+    assert int(r0["factorizations"]) + int(r1["factorizations"]) <= (14 if farm else 20), (int(r0["factorizations"]), int(r1["factorizations"]))
     n = r0["K"].shape[2]
     w = np.random.default_rng(1).standard_normal(n)
     for i, K in enumerate(r0["K"]):
