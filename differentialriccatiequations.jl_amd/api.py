@@ -229,21 +229,53 @@ def lr_update(A, alpha, U, V):
 # ------------------------------------------------------------------------------------------------
 # Shifts                                                      /root/reference/src/Shifts.jl, src/shifts/*
 # ------------------------------------------------------------------------------------------------
+def _hash_key(x):
+    """Structural key of an option value: shift lists (list / tuple / ndarray) by their entries, everything else by itself."""
+    if isinstance(x, np.ndarray):
+        return ("values",) + tuple(x.ravel().tolist())
+    if isinstance(x, (list, tuple)):
+        return ("values",) + tuple(_hash_key(v) if isinstance(v, (list, tuple, np.ndarray)) else v for v in x)
+    return x
+
+
 class Shifts:
     class Strategy:
-        pass
+        """Strategies hash and compare by STRUCTURE: two separately built `Cyclic([1.0])` — or `ADI(shifts=...)` options holding them — give the
+        same hash within a session (test/hash.jl; the reference defines `Base.hash` for `Cyclic` and `Wrapped`, shifts/helpers.jl:23-27,53-58,
+        `Projection` and `Heuristic` are immutable structs and hash by their fields)."""
+        _tag = 0
+
+        def _key(self):
+            return ()
+
+        def __hash__(self):
+            return hash((type(self)._tag,) + tuple(_hash_key(v) for v in self._key()))
+
+        def __eq__(self, other):
+            return type(other) is type(self) and tuple(_hash_key(v) for v in self._key()) == tuple(_hash_key(v) for v in other._key())
+
+        def __repr__(self):
+            return f"{type(self).__name__}({', '.join(getattr(v, '__name__', None) or repr(v) for v in self._key())})"
 
     class Cyclic(Strategy):
         """Cyclic(values) or Cyclic(strategy)  (shifts/helpers.jl:19-21,91-93)"""
+        _tag = 21                                   # shifts/helpers.jl:24
 
         def __init__(self, inner):
             self.inner = inner
 
+        def _key(self):
+            return (self.inner,)
+
     class Wrapped(Strategy):
         """Wrapped(func, strategy)  (shifts/helpers.jl:48-51)"""
+        _tag = 22                                   # shifts/helpers.jl:54
 
         def __init__(self, func, inner):
             self.func, self.inner = func, inner
+
+        def _key(self):
+            return (self.func, self.inner)
 
     class Projection(Strategy):
         """Projection(u)  (shifts/projection.jl:25-33)"""
@@ -253,11 +285,20 @@ class Shifts:
                 raise ValueError(f"History must be even; got {u}")
             self.n_history = u
 
+        _tag = 23
+
+        def _key(self):
+            return (self.n_history,)
+
     class Heuristic(Strategy):
         """Heuristic(nshifts, k₊, k₋)  (shifts/heuristic.jl:22-31)"""
+        _tag = 24
 
         def __init__(self, nshifts, k_plus, k_minus):
             self.nshifts, self.k_plus, self.k_minus = nshifts, k_plus, k_minus
+
+        def _key(self):
+            return (self.nshifts, self.k_plus, self.k_minus)
 
     # helpers (shifts/helpers.jl:122-140)
     @staticmethod
@@ -513,6 +554,14 @@ class ADI:
     # engine knob (not in the reference): True = eigen-based truncation at every compression, exactly the
     # reference's arithmetic; False = Krylov-truncated compression (same accuracy class, far cheaper on a GPU)
     compress_exact: bool = False
+
+    def __hash__(self):
+        """Structural hash over every property, order independent (lyapunov/types.jl:34-40: `hv ⊻= hash(p, hash(getproperty(alg, p)))`, seed 42) —
+        a dataclass with `eq` would otherwise be unhashable, and DrWatson-style bookkeeping keys on `hash(ADI(...))` (test/hash.jl)."""
+        hv = hash(42)
+        for f in dataclasses.fields(self):
+            hv ^= hash((f.name, hash(_hash_key(getattr(self, f.name)))))
+        return hv
 
 
 @dataclass

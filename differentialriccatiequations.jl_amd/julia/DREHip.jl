@@ -168,6 +168,10 @@ struct Projection <: Strategy
     n_history::Int
     Projection(u) = isodd(u) ? throw(ArgumentError("History must be even; got $u")) : new(u)
 end
+# Structural hash / equality: a `Cyclic` holds a Vector, whose default hash is its identity — two separately built `Cyclic([1.0])` must hash
+# alike (test/hash.jl; the reference does the same in src/shifts/helpers.jl:23-27).  `Heuristic` and `Projection` are bits types.
+Base.hash(c::Cyclic, h::UInt) = hash(c.inner, hash(:DREHipCyclic, h))
+Base.:(==)(a::Cyclic, b::Cyclic) = a.inner == b.inner
 end
 
 Base.@kwdef struct ADI
@@ -186,6 +190,15 @@ Base.@kwdef struct ADI
     inner_alg::Union{Nothing,Ptr{Cvoid}} = nothing
 end
 inner_ptr(alg::ADI) = something(alg.inner_alg, C_NULL)
+# options hash by their properties (src/lyapunov/types.jl:34-40; test/hash.jl builds `ADI(; shifts=...)` twice and compares)
+function Base.hash(alg::ADI, h::UInt)
+    acc = hash(:DREHipADI, h)
+    for p in fieldnames(ADI)
+        acc = hash(getfield(alg, p), hash(p, acc))
+    end
+    acc
+end
+Base.:(==)(a::ADI, b::ADI) = all(getfield(a, p) == getfield(b, p) for p in fieldnames(ADI))
 
 # mirrors `dre_adi_options` of include/dre_hip.h field by field
 struct AdiOptionsC

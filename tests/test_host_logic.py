@@ -93,6 +93,34 @@ def test_python_mirror_shift_helpers_match_the_oracle():
         D.solve_gdre(D.GDREProblem(None, None, None, None, np.eye(3), (0, 1)), D.Ros1(), dt=1.0)
 
 
+def _twice(x):
+    return 2 * x
+
+
+_SHIFT_BUILDERS = [
+    lambda: D.Shifts.Cyclic([1.0]),
+    lambda: D.Shifts.Cyclic(D.Shifts.Heuristic(1, 2, 3)),
+    lambda: D.Shifts.Projection(2),
+    lambda: D.Shifts.Cyclic(D.Shifts.Wrapped(_twice, D.Shifts.Projection(2))),
+    lambda: D.Shifts.Cyclic(D.Shifts.Wrapped(_twice, D.Shifts.Heuristic(1, 2, 3))),
+]
+
+
+@pytest.mark.parametrize("which", range(len(_SHIFT_BUILDERS)))
+def test_hash_stability_of_shift_strategies_and_adi_options(which):
+    """/root/reference/test/hash.jl (whole file): two separately built strategies — and `ADI(shifts=...)` options holding them — hash alike
+    (`Base.hash` of shifts/helpers.jl:23-27,53-58 and lyapunov/types.jl:34-40; DrWatson-style bookkeeping keys on it).  Beyond the reference's
+    test: equal hashes come with equality, a NumPy shift list hashes like the same list, and different options hash differently."""
+    bob = _SHIFT_BUILDERS[which]
+    assert hash(bob()) == hash(bob()) and bob() == bob()
+    assert hash(D.ADI(shifts=bob())) == hash(D.ADI(shifts=bob())) and D.ADI(shifts=bob()) == D.ADI(shifts=bob())
+    others = [b for i, b in enumerate(_SHIFT_BUILDERS) if i != which]
+    assert all(hash(b()) != hash(bob()) and b() != bob() for b in others)
+    assert hash(D.ADI(shifts=bob(), maxiters=7)) != hash(D.ADI(shifts=bob()))
+    assert hash(D.Shifts.Cyclic(np.array([1.0]))) == hash(D.Shifts.Cyclic([1.0])) != hash(D.Shifts.Cyclic([2.0]))
+    assert len({bob(): 1, bob(): 2}) == 1                                    # usable as a dictionary key, as DrWatson's `savename` needs
+
+
 def test_replica_gather_over_gloo_world_size_2():
     """bench.py's multi-GPU path (replicas + all_gather of the K(t) trajectories, MAX of wall-clock, SUM of iterations)
     exercised with two CPU processes over gloo."""
