@@ -38,10 +38,14 @@ class AdiOptionsC(C.Structure):
         ("heuristic_kminus", C.c_int32),
         ("inner_solve", C.c_void_p),
         ("inner_user", C.c_void_p),
+        ("shift_fn", C.c_void_p),
+        ("shift_user", C.c_void_p),
     ]
 
 
 # dre_block_solver_fn (include/dre_hip.h): int (*)(void* user, int n, int nrhs, double cA, double cE_re, double cE_im, const double* B, double* X_re, double* X_im)
+# dre_shift_fn (include/dre_hip.h): int (*)(void* user, int restart, int n, int hist_cols, const double* hist, int ldh, int capacity, double* re, double* im, int* count)
+SHIFT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int))
 BLOCK_SOLVER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p)
 
 

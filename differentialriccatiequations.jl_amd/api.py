@@ -248,6 +248,15 @@ class Shifts:
         def _key(self):
             return ()
 
+        # User-defined strategies (the reference's extension point Shifts.init / update! / take!, src/Shifts.jl:79-116; batch form take_many!,
+        # shifts/helpers.jl:60-89; example: the Dummy strategy of test/Shifts.jl:133-163): subclass Strategy and define
+        #     take_many(self, hist) -> iterable of shifts     hist: n x w array, what update! handed over (the residual factor R at the start of a
+        #                                                     solve, then the last `n_history` increments V, oldest first)
+        #     init(self, prob)                                 optional, called at the start of every Lyapunov solve with (E, A) of the equation
+        #     n_history                                        optional attribute (default 2)
+        # Shifts need a negative real part; a complex shift is followed by its conjugate (adi.jl:190).  `Wrapped(f, strategy)` applies f to
+        # every batch (shifts/helpers.jl:95-120).
+
         def __hash__(self):
             return hash((type(self)._tag,) + tuple(_hash_key(v) for v in self._key()))
 
@@ -413,11 +422,56 @@ def _heuristic_shifts_host_arnoldi(strategy, pencil, lr=None):
     return Shifts.heuristic(list(Rp) + [1.0 / v for v in Rm], strategy.nshifts)
 
 
+def _user_strategy(strategy):
+    """(strategy object with take_many, post-processing functions) of a user-defined strategy, possibly inside Wrapped layers; None otherwise."""
+    funcs = []
+    s = strategy
+    while isinstance(s, Shifts.Wrapped):
+        funcs.append(s.func)
+        s = s.inner
+    if isinstance(s, Shifts.Strategy) and callable(getattr(s, "take_many", None)):
+        return s, funcs[::-1]                   # innermost wrapper first (shifts/helpers.jl:113-120)
+    return None
+
+
+def _shift_callback(strategy, prob_info):
+    """ctypes trampoline for a user-defined strategy (dre_shift_fn).  Returns (function pointer, keep-alive, errors)."""
+    from ._lib import SHIFT_FN
+    s, funcs = _user_strategy(strategy)
+    errors = []
+
+    def tramp(user, restart, n, hist_cols, hist_p, ldh, capacity, re_p, im_p, count_p):
+        try:
+            if restart and callable(getattr(s, "init", None)):
+                s.init(prob_info)
+            H = np.empty((ldh, hist_cols), order="F")
+            if hist_cols > 0:
+                _hip_memcpy(H.ctypes.data, hist_p, H.nbytes, 2)               # device -> host
+            vals = list(s.take_many(H[:n, :]))
+            for f in funcs:
+                vals = list(f(vals))
+            if not 1 <= len(vals) <= capacity:
+                raise ValueError(f"take_many returned {len(vals)} shifts (1 .. {capacity} expected)")
+            for i, v in enumerate(vals):
+                v = complex(v)
+                re_p[i], im_p[i] = v.real, v.imag
+            count_p[0] = len(vals)
+            return 0
+        except Exception as e:                                                # no exception may cross the C boundary
+            errors.append(e)
+            return 1
+
+    cb = SHIFT_FN(tramp)
+    return cb, (cb, errors)
+
+
 def _resolve_shifts(strategy, pencil, lr=None):
     """Map a strategy object to (shift_kind, n_history, values) of the C ABI."""
     S = Shifts
     if isinstance(strategy, S.Projection):
         return 1, strategy.n_history, None
+    if _user_strategy(strategy) is not None:
+        return 3, int(getattr(_user_strategy(strategy)[0], "n_history", 2)), None
     if isinstance(strategy, S.Cyclic):
         inner = strategy.inner
         if isinstance(inner, S.Heuristic):
@@ -670,6 +724,10 @@ def _adi_options(alg: ADI, pencil, lr=None, E=None, A0=None):
     if cb is not None:
         opt.inner_solve = C.cast(cb, C.c_void_p)
         keep = (keep, keep_cb)
+    if kind == 3:
+        scb, keep_scb = _shift_callback(alg.shifts, (E, A0))
+        opt.shift_fn = C.cast(scb, C.c_void_p)
+        keep = (keep, keep_scb)
     return opt, keep
 
 

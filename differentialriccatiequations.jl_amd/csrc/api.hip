@@ -647,6 +647,7 @@ int dre_adi_default_options(dre_adi_options* o) {
     o->compress_tolfac = 4.0;
     o->compress_exact = 0;
     o->heuristic_kplus = 0; o->heuristic_kminus = 0;
+    o->shift_fn = nullptr; o->shift_user = nullptr;
     return DRE_OK;
 }
 static AdiOptions convert_options(const dre_adi_options* o) {
@@ -665,6 +666,11 @@ static AdiOptions convert_options(const dre_adi_options* o) {
         a.shifts.kind = ShiftSpec::HEURISTIC;
         DRE_REQUIRE(o->nshifts > 0 && o->heuristic_kplus > 0 && o->heuristic_kminus > 0, "Heuristic(nshifts, k+, k-) must be positive");
         a.shifts.h_nshifts = o->nshifts; a.shifts.h_kplus = o->heuristic_kplus; a.shifts.h_kminus = o->heuristic_kminus;
+    } else if (o->shift_kind == 3) {
+        a.shifts.kind = ShiftSpec::USER;
+        DRE_REQUIRE(o->shift_fn != nullptr, "shift_kind 3 (user-defined strategy) needs shift_fn");
+        DRE_REQUIRE(o->n_history > 0, "shift_kind 3: n_history must be positive");
+        a.shifts.user_fn = o->shift_fn; a.shifts.user_data = o->shift_user; a.shifts.n_history = o->n_history;
     } else {
         a.shifts.kind = ShiftSpec::PROJECTION;
         DRE_REQUIRE(o->n_history > 0 && o->n_history % 2 == 0, "History must be even");   // projection.jl:28-32

@@ -479,6 +479,61 @@ struct ProjectionOracle : ShiftOracle {   // shifts/projection.jl:34-73
     }
 };
 
+// User-defined strategy (dre_shift_fn, include/dre_hip.h): the reference's protocol init / update! / take!  (src/Shifts.jl:79-116) with the batch
+// form of a BufferedIterator (shifts/helpers.jl:60-89).  update() keeps handles of what the reference hands to update! (R at the start, then the
+// increments; the last n_history of them); when the buffer runs dry the history is laid out as one n x w block and the callback fills the buffer.
+struct UserOracle : ShiftOracle {
+    Ctx* ctx = nullptr; int n = 0; int n_history = 2;
+    const int* iperm = nullptr;         // device: solver ordering -> caller's ordering (Pencil::iperm, as for the user block solver)
+    ShiftFn fn = nullptr; void* user = nullptr;
+    const AdiState* st_dev = nullptr;   // speculative enqueueing: a converged solve asks for nothing further
+    std::vector<Mat> Vs;
+    std::vector<std::complex<double>> buffer;
+    size_t pos = 0;
+    bool first = true, saw_done = false;
+    bool stopped() const override { return saw_done; }
+    void update(const Mat& R, const std::vector<Mat>& newVs) override {
+        if (newVs.empty()) Vs.push_back(R);
+        for (auto& v : newVs) Vs.push_back(v);
+        const int lst = (int)Vs.size();
+        Vs.erase(Vs.begin(), Vs.begin() + std::max(0, lst - n_history));
+    }
+    void take_many() {
+        int done = 0;
+        if (st_dev) DRE_HIP(hipMemcpyAsync(&done, &st_dev->done, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        if (done) { buffer.assign(1, std::complex<double>(-1.0, 0.0)); pos = 0; saw_done = true; return; }
+        int w = 0;
+        for (auto& v : Vs) w += v.cols;
+        Mat N(ctx, n, std::max(w, 1));
+        int off = 0;
+        for (auto& v : Vs) { if (v.cols == 0) continue; Mat d = N.colsview(off, v.cols); permute_rows(ctx, v, iperm, d); off += v.cols; }      // caller's row ordering
+        DRE_HIP(hipStreamSynchronize(ctx->stream));
+        constexpr int CAP = 1024;
+        std::vector<double> re((size_t)CAP, 0.0), im((size_t)CAP, 0.0);
+        int count = 0;
+        const int rc = fn(user, first ? 1 : 0, n, w, N.p, N.ld, CAP, re.data(), im.data(), &count);
+        first = false;
+        DRE_REQUIRE(rc == 0, "user-defined shift strategy failed (shift_fn returned non-zero)");
+        DRE_REQUIRE(count >= 1 && count <= CAP, "user-defined shift strategy: count out of range");
+        buffer.clear();
+        for (int i = 0; i < count; ++i) {
+            DRE_REQUIRE(std::isfinite(re[(size_t)i]) && std::isfinite(im[(size_t)i]) && re[(size_t)i] < 0.0, "user-defined shift strategy: shifts need a negative real part");
+            buffer.emplace_back(re[(size_t)i], im[(size_t)i]);
+        }
+        pos = 0;
+    }
+    std::complex<double> take(int*) override {
+        if (pos >= buffer.size()) take_many();
+        return buffer[pos++];
+    }
+    std::vector<std::complex<double>> peek(size_t count) const override {
+        std::vector<std::complex<double>> out;
+        for (size_t i = pos; i < buffer.size() && out.size() < count; ++i) out.push_back(buffer[i]);
+        return out;
+    }
+};
+
 
 // =============================================================================================
 // ADI (/root/reference/src/lyapunov/adi.jl:29-225)
@@ -961,6 +1016,12 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
         auto o = std::make_unique<CyclicOracle>();
         o->v = opt.shifts.values;
         oracle = std::move(o);
+    } else if (opt.shifts.kind == ShiftSpec::USER) {
+        DRE_REQUIRE(opt.shifts.user_fn != nullptr, "user-defined shift strategy: no callback");
+        auto o = std::make_unique<UserOracle>();
+        o->ctx = ctx; o->n = n; o->n_history = opt.shifts.n_history; o->fn = opt.shifts.user_fn; o->user = opt.shifts.user_data;
+        o->iperm = op.P->iperm.p;
+        oracle = std::move(o);
     } else {
         auto o = std::make_unique<ProjectionOracle>();
         o->ctx = ctx; o->op = &op; o->n_history = opt.shifts.n_history;
@@ -972,6 +1033,7 @@ std::shared_ptr<AdiRun> adi_begin(Ctx* ctx, const GaleOperator& op_in, LDLt& C, 
     run.st = DevArr<AdiState>(ctx, 1);
     DevArr<AdiState>& st = run.st;
     if (auto* po = dynamic_cast<ProjectionOracle*>(oracle.get())) po->st_dev = st.p;
+    if (auto* uo = dynamic_cast<UserOracle*>(oracle.get())) uo->st_dev = st.p;
     AdiState& h0 = run.h0;           // stays alive with the solver object (source of an asynchronous upload)
     std::memset(&h0, 0, sizeof(h0));
     h0.maxiters = opt.maxiters; h0.abstol = abstol; h0.res_norm = norm0; h0.norms[0] = norm0;

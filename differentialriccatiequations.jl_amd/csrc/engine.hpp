@@ -96,8 +96,12 @@ void heuristic_ritz(Ctx* ctx, const GaleOperator& op, int kplus, int kminus, std
                     std::vector<std::complex<double>>& rminus);
 
 // ---- shift strategies (/root/reference/src/Shifts.jl:79-116, src/shifts/*.jl) -----------------------------
+// user-defined strategy (dre_shift_fn of include/dre_hip.h: Shifts.init / update! / take!, src/Shifts.jl:79-116)
+typedef int (*ShiftFn)(void* user, int restart, int n, int hist_cols, const double* hist, int ldh, int capacity, double* re, double* im, int* count);
 struct ShiftSpec {
-    enum Kind { CYCLIC = 0, PROJECTION = 1, HEURISTIC = 2 } kind = PROJECTION;
+    enum Kind { CYCLIC = 0, PROJECTION = 1, HEURISTIC = 2, USER = 3 } kind = PROJECTION;
+    ShiftFn user_fn = nullptr;                  // USER
+    void* user_data = nullptr;
     std::vector<std::complex<double>> values;   // CYCLIC
     int n_history = 2;                          // PROJECTION
     int h_nshifts = 0, h_kplus = 0, h_kminus = 0;   // HEURISTIC: Cyclic(Heuristic(nshifts, k+, k-)), recomputed per Lyapunov solve

@@ -168,6 +168,12 @@ struct Projection <: Strategy
     n_history::Int
     Projection(u) = isodd(u) ? throw(ArgumentError("History must be even; got $u")) : new(u)
 end
+struct UserDefined <: Strategy          # plug-in strategy: `fn` is a @cfunction pointer of the signature dre_shift_fn (include/dre_hip.h)
+    fn::Ptr{Cvoid}
+    user::Ptr{Cvoid}
+    n_history::Int
+end
+UserDefined(fn; user=C_NULL, n_history=2) = UserDefined(fn, user, n_history)
 # Structural hash / equality: a `Cyclic` holds a Vector, whose default hash is its identity — two separately built `Cyclic([1.0])` must hash
 # alike (test/hash.jl; the reference does the same in src/shifts/helpers.jl:23-27).  `Heuristic` and `Projection` are bits types.
 Base.hash(c::Cyclic, h::UInt) = hash(c.inner, hash(:DREHipCyclic, h))
@@ -219,23 +225,33 @@ struct AdiOptionsC
     heuristic_kminus::Int32
     inner_solve::Ptr{Cvoid}     # dre_block_solver_fn or C_NULL (inner_alg = Backslash() on the device LU)
     inner_user::Ptr{Cvoid}
+    shift_fn::Ptr{Cvoid}        # dre_shift_fn (shift_kind 3) or C_NULL
+    shift_user::Ptr{Cvoid}
 end
 
 function options(alg::ADI)
+    if alg.shifts isa Shifts.UserDefined
+        # a user-defined strategy (src/Shifts.jl:79-116): `fn` = @cfunction of the signature dre_shift_fn (include/dre_hip.h) — it is shown the
+        # residual factor / the last n_history increments as a device block and fills a batch of shifts (take_many!, shifts/helpers.jl:60-89)
+        o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
+                        alg.compression_interval, alg.compression, 3, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL,
+                        alg.shifts.fn, alg.shifts.user)
+        return o, nothing
+    end
     if alg.shifts isa Shifts.Cyclic && alg.shifts.inner isa Shifts.Heuristic
         h = alg.shifts.inner          # Cyclic(Heuristic(nshifts, k₊, k₋)): recomputed on the device at the start of every Lyapunov solve
         o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                        alg.compression_interval, alg.compression, 2, 2, h.nshifts, C_NULL, C_NULL, 4.0, alg.compress_exact, h.k₊, h.k₋, inner_ptr(alg), C_NULL)
+                        alg.compression_interval, alg.compression, 2, 2, h.nshifts, C_NULL, C_NULL, 4.0, alg.compress_exact, h.k₊, h.k₋, inner_ptr(alg), C_NULL, C_NULL, C_NULL)
         return o, nothing
     elseif alg.shifts isa Shifts.Cyclic
         vals = ComplexF64.(collect(alg.shifts.inner))
         re, im = real.(vals), imag.(vals)
         o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL)
+                        alg.compression_interval, alg.compression, 0, 2, length(vals), pointer(re), pointer(im), 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL, C_NULL, C_NULL)
         return o, (re, im)
     end
     o = AdiOptionsC(alg.maxiters, something(alg.reltol, -1.0), something(alg.abstol, -1.0), alg.ignore_initial_guess,
-                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL)
+                    alg.compression_interval, alg.compression, 1, alg.shifts.n_history, 0, C_NULL, C_NULL, 4.0, alg.compress_exact, 0, 0, inner_ptr(alg), C_NULL, C_NULL, C_NULL)
     o, nothing
 end
 

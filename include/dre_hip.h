@@ -211,6 +211,18 @@ int dre_ldlt_destructure(dre_ctx* ctx, dre_ldlt* x, double* alpha, double* L_hos
  * factorisations nor takes the dense-inverse fast paths. */
 typedef int (*dre_block_solver_fn)(void* user, int n, int nrhs, double cA, double cE_re, double cE_im, const double* B, double* X_re, double* X_im);
 
+/* User-defined shift strategy: the reference's extension point  Shifts.init(strategy, prob) / Shifts.update!(shifts, X, R, Vs...) /
+ * Shifts.take!(shifts)  (src/Shifts.jl:79-116; a strategy that produces batches implements take_many! behind a BufferedIterator,
+ * src/shifts/helpers.jl:60-89; example: the Dummy strategy of test/Shifts.jl:133-163).  With shift_kind = 3 the engine calls shift_fn whenever
+ * its buffer of shifts is empty:
+ *     restart   1 on the first call of a Lyapunov solve (= init), 0 afterwards
+ *     hist      DEVICE pointer, n x hist_cols column-major (leading dimension ldh), rows in the CALLER's ordering: what update! has handed over — the residual factor R at the
+ *               start of a solve, afterwards the last n_history increments V (a conjugate pair contributes its two real blocks), oldest first
+ *     capacity  room in re / im (HOST arrays); write *count >= 1 shifts, in the order in which they are to be used
+ * Every shift must have a negative real part; a complex shift mu is followed by conj(mu) — the pair is handled by ONE double step and the
+ * second take! is checked against the first (adi.jl:181-225, :190).  The engine synchronises its stream before the call.  Return 0 on success (anything else aborts the solve with DRE_ERR_INTERNAL). */
+typedef int (*dre_shift_fn)(void* user, int restart, int n, int hist_cols, const double* hist, int ldh, int capacity, double* re, double* im, int* count);
+
 typedef struct dre_adi_options {
     int32_t maxiters;              /* 100 */
     double reltol;                 /* < 0 = nothing -> n*eps */
@@ -219,7 +231,8 @@ typedef struct dre_adi_options {
     int32_t compression_interval;  /* 10 */
     int32_t compression;           /* 1 */
     int32_t shift_kind;            /* 0 = Cyclic(values), 1 = Projection(n_history), 2 = Cyclic(Heuristic(nshifts, kplus, kminus)) recomputed
-                                      on the device from (E, F) at the start of every Lyapunov solve (adi.jl:54, heuristic.jl:39-66) */
+                                      on the device from (E, F) at the start of every Lyapunov solve (adi.jl:54, heuristic.jl:39-66),
+                                      3 = user-defined strategy: shift_fn below (n_history = number of increments it is shown) */
     int32_t n_history;             /* 2 */
     int32_t nshifts;               /* Cyclic: number of values (conjugate pairs adjacent); Heuristic: number of shifts to select */
     const double* shifts_re;
@@ -231,6 +244,8 @@ typedef struct dre_adi_options {
     int32_t heuristic_kminus;      /* shift_kind 2: Arnoldi steps with F^-1 E */
     dre_block_solver_fn inner_solve; /* NULL (default): inner_alg = Backslash() on the library's multifrontal LU (src/blocklinear/backslash.jl) */
     void* inner_user;              /* passed back to inner_solve */
+    dre_shift_fn shift_fn;         /* shift_kind 3 only */
+    void* shift_user;              /* passed back to shift_fn */
 } dre_adi_options;
 int dre_adi_default_options(dre_adi_options* opt);
 

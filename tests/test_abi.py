@@ -42,3 +42,29 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".jl")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "dre_oracle" not in src and "mf_emul" not in src, f
+
+
+def test_adi_options_struct_layout_matches_the_header(tmp_path):
+    """`dre_adi_options` crosses the boundary BY LAYOUT (ctypes `AdiOptionsC`, Julia `AdiOptionsC`): its size and the offsets of the fields added last
+    (`shift_fn`, `shift_user`: user-defined shift strategies) are compared with what the C compiler makes of include/dre_hip.h, and the defaults
+    leave both callbacks unset."""
+    import ctypes as C
+    import subprocess
+    import dre_amd as D
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dre_hip.h"\nint main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(dre_adi_options), '
+                   'offsetof(dre_adi_options, shifts_re), offsetof(dre_adi_options, inner_solve), offsetof(dre_adi_options, shift_fn), '
+                   'offsetof(dre_adi_options, shift_user)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    size, o_re, o_inner, o_fn, o_user = (int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split())
+    T = D._lib.AdiOptionsC
+    assert (C.sizeof(T), T.shifts_re.offset, T.inner_solve.offset, T.shift_fn.offset, T.shift_user.offset) == (size, o_re, o_inner, o_fn, o_user)
+    o = T()
+    D._lib.load().dre_adi_default_options(C.byref(o))
+    assert o.shift_kind == 1 and not o.shift_fn and not o.shift_user and not o.inner_solve
+    # the Julia mirror lists the same fields in the same order
+    jl = open(os.path.join(ROOT, "differentialriccatiequations.jl_amd", "julia", "DREHip.jl")).read()
+    body = jl[jl.index("struct AdiOptionsC"):]
+    body = body[:body.index("\nend")]
+    assert re.findall(r"^\s+([a-z_]+)::", body, flags=re.M) == [f[0] for f in T._fields_]

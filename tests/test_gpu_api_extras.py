@@ -426,3 +426,122 @@ def test_batched_result_exports_equal_the_per_item_calls(ctx, rail371):
         assert on == nn and os_ == ns and nn > ngale
     finally:
         lib.dre_gdre_result_free(r)
+
+
+# ---- user-defined shift strategies: Shifts.init / update! / take!  (src/Shifts.jl:79-116; test/Shifts.jl:133-163) ----------------------------
+class _Dummy(D.Shifts.Strategy):
+    """The reference's test strategy (test/Shifts.jl:133-136): every batch is the same list."""
+
+    def __init__(self, values):
+        self.values = list(values)
+        self.calls, self.inits, self.widths = 0, 0, []
+
+    def init(self, prob):
+        self.inits += 1
+
+    def take_many(self, hist):
+        self.calls += 1
+        self.widths.append(hist.shape)
+        assert np.isfinite(hist).all()
+        return self.values
+
+
+def _tiny_gale(seed=11, n=60, sym=True):
+    rng = np.random.default_rng(seed)
+    E = (sp.random(n, n, density=1 / n, random_state=rng) + n * sp.identity(n)).tocsc()
+    A = (sp.random(n, n, density=2 / n, random_state=rng) - n * sp.identity(n)).tocsc()
+    if sym:
+        E, A = (E + E.T).tocsc(), (A + A.T).tocsc()
+    Cl = D.lowrank(rng.random((n, 3)), np.diag([1.0, 2.0, -0.5]))
+    return E, A, Cl
+
+
+def test_user_defined_strategy_dummy_and_wrapped(ctx):
+    """A strategy defined by the USER (subclass of Shifts.Strategy with take_many) drives the device ADI through `dre_shift_fn`: the shifts used are
+    its batches in order (BufferedIterator, shifts/helpers.jl:60-89), `init` runs once per Lyapunov solve, the first batch is asked for with the
+    residual factor R (adi.jl:63: update!(shifts, X, R)), later ones with the last increments, and the solution equals the one of Cyclic(values).
+    `Wrapped(reverse, Dummy)` uses the batch reversed (test/Shifts.jl:155-163)."""
+    E, A, Cl = _tiny_gale()
+    n = E.shape[0]
+    vals = [-2.0, -1.2, -0.8, -0.5]                                            # the pencil's spectrum lies around -1
+    prob = D.GALEProblem(E, A, Cl)
+    Xc, ic = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(vals)), return_info=True)
+    dm = _Dummy(vals)
+    Xu, iu = D.solve_gale(prob, D.ADI(shifts=dm), return_info=True)
+    assert ic["converged"] and iu["converged"] and abs(iu["iters"] - ic["iters"]) <= 1
+    assert np.allclose(iu["shifts"], [vals[i % 4] for i in range(iu["iters"])])
+    assert D.delta(Xu.dense(), Xc.dense()) < 1e-10
+    assert dm.inits == 1 and dm.calls >= (iu["iters"] + 3) // 4
+    assert dm.widths[0] == (n, 3)                                              # R = the factor of C at a zero initial guess
+    assert all(w[0] == n and 1 <= w[1] <= 2 * 3 for w in dm.widths[1:])         # the last n_history = 2 increments of 3 columns
+    dw = _Dummy(vals)
+    Xw, iw = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Wrapped(lambda v: list(reversed(v)), dw)), return_info=True)
+    assert iw["converged"] and np.allclose(iw["shifts"][:4], vals[::-1]) and D.delta(Xw.dense(), Xc.dense()) < 1e-10
+    # error behaviour: an unstable shift, an empty batch and an exception inside the strategy abort the solve (no silent fallback)
+    for bad in (_Dummy([1.0]), _Dummy([])):
+        with pytest.raises(D.DREError):
+            D.solve_gale(prob, D.ADI(shifts=bad))
+
+    class Boom(D.Shifts.Strategy):
+        def take_many(self, hist):
+            raise RuntimeError("boom")
+    with pytest.raises(D.DREError):
+        D.solve_gale(prob, D.ADI(shifts=Boom()))
+    # the context is still usable afterwards
+    assert D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(vals)), return_info=True)[1]["converged"]
+
+
+class _UserProjection(D.Shifts.Strategy):
+    """Projection(u) (shifts/projection.jl:34-73) re-implemented OUTSIDE the library on top of the user-strategy protocol, with the oracle's pieces:
+    if the engine hands the callback what the reference hands to update!, this produces the shifts of the built-in Projection."""
+
+    def __init__(self, u):
+        self.n_history = u
+
+    def init(self, prob):
+        self.E, self.A = (sp.csc_matrix(m) for m in prob)
+
+    def take_many(self, hist):
+        Q = o.orth(hist)
+        lam = [complex(v) if abs(v.imag) > 0 else complex(v.real, 0.0) for v in np.linalg.eigvals(np.linalg.solve(Q.T @ (self.E @ Q), Q.T @ (self.A @ Q)))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return o.safe_sort(o.stabilize_ritz_values(lam, "(A, E)"))
+
+
+@pytest.mark.parametrize("convection", [0.0, 3e-3])
+def test_user_defined_projection_reproduces_the_builtin_one(ctx, convection):
+    """SteelProfile(371) and its non-symmetric variant (complex Ritz pairs: perform_double_step!, adi.jl:181-225): the first batch of the user-level
+    Projection — Ritz values of the pencil restricted to span(R) — equals the built-in one's, both converge to the same solution."""
+    d = D.steel_profile(371, convection=convection) if convection else D.steel_profile(371)
+    prob = D.GALEProblem(d.E, d.A, D.lowrank(d.C.T, np.eye(d.C.shape[0])))
+    us = _UserProjection(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Xb, ib = D.solve_gale(prob, D.ADI(shifts=D.Shifts.Projection(2), maxiters=150), return_info=True)
+        Xu, iu = D.solve_gale(prob, D.ADI(shifts=us, maxiters=150), return_info=True)
+    nb = min(len(ib["shifts"]), len(iu["shifts"]), d.C.shape[0])
+    su, sb = np.asarray(iu["shifts"][:nb]), np.asarray(ib["shifts"][:nb])      # (a conjugate pair may come in either order)
+    assert nb >= 2 and np.allclose(su.real, sb.real, rtol=1e-6) and np.allclose(np.abs(su.imag), np.abs(sb.imag), rtol=1e-6, atol=1e-12), (su, sb)
+    if convection:
+        assert np.any(np.abs(np.asarray(iu["shifts"]).imag) > 0)               # the double step ran on user-supplied pairs
+    assert ib["converged"] == iu["converged"]
+    if ib["converged"]:
+        assert abs(iu["iters"] - ib["iters"]) <= 12                            # (a batch: Ritz values are a discontinuous function of rounding)
+        assert D.delta(Xu.dense(), Xb.dense()) < 1e-8
+
+
+def test_user_defined_strategy_inside_the_rosenbrock_loop(ctx, rail371):
+    """The same plug-in under `solve(GDREProblem, Ros1)`: `init` runs at the start of EVERY Lyapunov solve (adi.jl:54: the shifts are initialised per
+    solve), the time loop takes the generic ADI path, K(t) equals the oracle's for the Cyclic list the strategy replays (test/cuda.jl:95-99)."""
+    d, L, Dm = rail371
+    gold = np.load(os.path.join(GOLDEN, "ros1_371.npz"))
+    p = list(np.load(os.path.join(GOLDEN, "heuristic_shifts_371.npy")))
+    prob = D.GDREProblem(d.E, d.A, d.B, d.C, D.lowrank(L, Dm), (4500.0, 4300.0))
+    dm = _Dummy(p)
+    sol, st = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=dm)), dt=-100.0, return_stats=True)
+    assert dm.inits == 2 and len(st["gales"]) == 2 and all(x["converged"] for x in st["gales"])
+    assert D.delta(sol.K[1], gold["K"][1]) < 1e-7
+    ref = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p))), dt=-100.0)
+    assert D.delta(sol.K[2], ref.K[2]) < 1e-9
+    assert [x["iters"] for x in st["gales"]] == [int(v) for v in gold["iters"][:2]] or max(abs(a - int(b)) for a, b in zip([x["iters"] for x in st["gales"]], gold["iters"][:2])) <= 1
