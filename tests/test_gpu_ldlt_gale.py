@@ -236,3 +236,25 @@ def test_fan_groups_on_a_gale_with_low_rank_update(ctx):
         assert ic["iters"] == 7 == res[(0, 7)][1]["iters"] and not ic["converged"]
         assert np.linalg.norm(dense(Xc) - dense(res[(0, 7)][0])) <= 1e-10 * np.linalg.norm(ref)
     assert np.linalg.norm(dense(Xs) - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("desc", ["magnitude", "real part"])
+def test_projection_batches_keep_conjugate_pairs_adjacent(ctx, desc):       # test/Shifts.jl:202-230 ("Conjugated Pairs" / "Hacky Projection shifts")
+    """E = I_4, A = blockdiag(modified_penzl(f(1)), modified_penzl(f(2))) with f giving shifts of the same magnitude / the same real part, right-hand
+    side factor I_4: the first built-in Projection batch is the FULL spectrum of A — two complex pairs whose sort keys tie in one component — and the
+    device consumes it as adjacent conjugates (safe_sort!, shifts/helpers.jl:122; a split pair would abort the double step, adi.jl:190)."""
+    f = (lambda a: -np.exp(1j * a)) if desc == "magnitude" else (lambda a: -1 - 1j * a)
+    penzl = lambda p: np.array([[-1.0, p], [-p, -1.0]])
+    mod = lambda v: abs(v.real) * penzl(v.imag / v.real)
+    A = np.zeros((4, 4)); A[:2, :2] = mod(f(1)); A[2:, 2:] = mod(f(2))
+    prob = D.GALEProblem(sp.identity(4, format="csc"), sp.csc_matrix(A), D.lowrank(np.eye(4), np.eye(4)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X, info = D.solve_gale(prob, D.ADI(maxiters=4, warn_convergence=False), return_info=True)
+    sh = np.asarray(info["shifts"][:4])
+    assert len(sh) == 4 and np.all(sh.imag != 0)
+    assert abs(sh[1] - np.conj(sh[0])) < 1e-12 and abs(sh[3] - np.conj(sh[2])) < 1e-12
+    assert np.allclose(sorted(sh, key=lambda v: (v.real, v.imag)), sorted(np.linalg.eigvals(A), key=lambda v: (v.real, v.imag)))
+    # four exact Ritz values on a 4-dimensional problem: the ADI has converged to the Lyapunov solution
+    Xd = X.dense()
+    assert np.linalg.norm(A.T @ Xd + Xd @ A + np.eye(4)) < 1e-10
