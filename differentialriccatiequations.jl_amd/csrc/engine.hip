@@ -2112,7 +2112,8 @@ __global__ void k_scale_inv_norm(int n, const double* __restrict__ w, const doub
 }
 
 static std::vector<std::complex<double>> arnoldi_ritz(Ctx* ctx, int n, int k, const std::function<void(const Mat&, Mat&)>& apply) {
-    DRE_REQUIRE(k >= 1 && k < n, "heuristic shifts: Krylov dimension out of range");
+    // (k = n is allowed as in the reference: the last normalisation divides a vanishing remainder, its column is never used — test/Shifts.jl runs 3 x 3 pencils)
+    DRE_REQUIRE(k >= 1 && k <= n, "heuristic shifts: Krylov dimension out of range");
     Mat V(ctx, n, k + 1), H(ctx, k + 1, k), w(ctx, n, 1);
     DevArr<double> nr(ctx, 1);
     fill_mat(ctx, H, 0.0);

@@ -545,3 +545,29 @@ def test_user_defined_strategy_inside_the_rosenbrock_loop(ctx, rail371):
     ref = D.solve_gdre(prob, D.Ros1(D.ADI(shifts=D.Shifts.Cyclic(p))), dt=-100.0)
     assert D.delta(sol.K[2], ref.K[2]) < 1e-9
     assert [x["iters"] for x in st["gales"]] == [int(v) for v in gold["iters"][:2]] or max(abs(a - int(b)) for a, b in zip([x["iters"] for x in st["gales"]], gold["iters"][:2])) <= 1
+
+
+@pytest.mark.parametrize("args", [(2, 2, 2), (1, 1, 1), (3, 3, 3)])
+def test_heuristic_penzl_shifts_on_the_3x3_pencil(ctx, args):               # test/Shifts.jl:13-19,73-96,118-124
+    """The reference's own tiny pencil (E = I_3, A = blockdiag(penzl(1), -1/2)): the device Arnoldi + Penzl selection gives the oracle's shifts —
+    (2,2,2): two real ones (the reference marks the exact values as broken, the naive Arnoldi is inaccurate by design), (1,1,1): -5/6, (3,3,3):
+    the exact spectrum -1/2, -1 ± i with the pair adjacent — and `Cyclic(Heuristic(...))` feeds them to the ADI in that order, cyclically."""
+    E = sp.identity(3, format="csc")
+    A = sp.lil_matrix((3, 3)); A[0:2, 0:2] = np.array([[-1.0, 1.0], [-1.0, -1.0]]); A[2, 2] = -0.5
+    A = A.tocsc()
+    H = D.Shifts.Heuristic(*args)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        expect = np.asarray(o.heuristic_shifts(o.Heuristic(*args), E, A))
+        mine = np.asarray(D.heuristic_shifts(H, D.Pencil(E, A, ctx)))
+        _, info = D.solve_gale(D.GALEProblem(E, A, D.lowrank(np.ones((3, 1)), np.eye(1))), D.ADI(shifts=D.Shifts.Cyclic(H), maxiters=2 * len(expect), warn_convergence=False),
+                               return_info=True)
+    k = args[0]
+    assert k <= len(mine) <= k + 1 and np.all(mine.real < 0)
+    assert np.allclose(mine, expect, rtol=1e-10, atol=1e-12), (mine, expect)
+    if args == (1, 1, 1):
+        assert abs(mine[0] - (-5 / 6)) < 1e-13
+    if args == (3, 3, 3):
+        assert abs(mine[0] + 0.5) < 1e-12 and abs(mine[1] - (-1 + 1j)) < 1e-12 and abs(mine[2] - np.conj(mine[1])) < 1e-12
+    used = np.asarray(info["shifts"])
+    assert len(used) >= 1 and np.allclose(used, [expect[i % len(expect)] for i in range(len(used))], rtol=1e-10, atol=1e-12)
