@@ -717,6 +717,29 @@ def _gale_operands(prob, ctx):
     return _pencil_for(prob.E, A0, ctx), 1.0, 0.0, A0, lr
 
 
+def _callback_errors(keep):
+    """Exceptions caught inside the ctypes trampolines of a call (user block solver, user shift strategy): they cannot cross the C boundary, the
+    library reports DRE_ERR_INTERNAL, and the Python mirror chains the original exception to the DREError it raises."""
+    out = []
+    if isinstance(keep, (tuple, list)):
+        for k in keep:
+            if isinstance(k, list) and k and all(isinstance(e, BaseException) for e in k):
+                out.extend(k)
+            elif isinstance(k, (tuple, list)):
+                out.extend(_callback_errors(k))
+    return out
+
+
+def _chk_with_callbacks(ctx, rc, keep):
+    try:
+        ctx.chk(rc)
+    except DREError as e:
+        errs = _callback_errors(keep)
+        if errs:
+            raise e from errs[0]
+        raise
+
+
 def _adi_options(alg: ADI, pencil, lr=None, E=None, A0=None):
     kind, nh, vals = _resolve_shifts(alg.shifts, pencil, lr)
     cb, keep_cb = _inner_solver_callback(getattr(alg, "inner_alg", None), E, A0) if E is not None else (None, None)
@@ -789,8 +812,8 @@ def solve_gale(prob: GALEProblem, alg: ADI, initial_guess: LDLt | None = None, o
         alpha, Uh, Vh = lr
         U, Vt = ctx.upload(Uh), ctx.upload(np.asarray(Vh).T)
     r = C.c_void_p()
-    ctx.chk(ctx.lib.dre_gale_solve(ctx.ptr, pencil.ptr, cA, cE, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
-                                   Cd.ptr, X0d.ptr if X0d else None, C.byref(opt), C.byref(r)))
+    _chk_with_callbacks(ctx, ctx.lib.dre_gale_solve(ctx.ptr, pencil.ptr, cA, cE, float(alpha), U.ptr if U else None, Vt.ptr if Vt else None,
+                                                     Cd.ptr, X0d.ptr if X0d else None, C.byref(opt), C.byref(r)), keep)
     try:
         info = _adi_result_info(ctx, r)
         xp = C.c_void_p()
@@ -872,7 +895,7 @@ class ADISolver:
         return dict(iters=it.value, res_norm=rn.value, abstol=at.value)
 
     def step(self):
-        self.ctx.chk(self.ctx.lib.dre_adi_step(self.ctx.ptr, self._ptr))
+        _chk_with_callbacks(self.ctx, self.ctx.lib.dre_adi_step(self.ctx.ptr, self._ptr), self._keep)
         if self._live:                      # adi.jl:103,119,192: the shift(s) of this step, then the step itself with its state
             st = self.state()
             for mu in self._shifts_since(self._seen):
@@ -889,7 +912,7 @@ class ADISolver:
             while not self.isdone():
                 self.step()
         else:
-            self.ctx.chk(self.ctx.lib.dre_adi_solve(self.ctx.ptr, self._ptr))
+            _chk_with_callbacks(self.ctx, self.ctx.lib.dre_adi_solve(self.ctx.ptr, self._ptr), self._keep)
         return self.X
 
     def __iter__(self):
@@ -995,8 +1018,8 @@ def solve_gdre(prob: GDREProblem, alg, dt, save_state=False, observer=None, ctx=
     Bd, Cd = ctx.upload(prob.B), ctx.upload(prob.C)
     r = C.c_void_p()
     _t1 = time.perf_counter()
-    ctx.chk(ctx.lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0d.ptr, float(prob.tspan[0]), float(prob.tspan[1]),
-                                   float(dt), order, int(bool(save_state)), C.byref(opt), C.byref(r)))
+    _chk_with_callbacks(ctx, ctx.lib.dre_gdre_solve(ctx.ptr, pencil.ptr, Bd.ptr, Cd.ptr, X0d.ptr, float(prob.tspan[0]), float(prob.tspan[1]),
+                                   float(dt), order, int(bool(save_state)), C.byref(opt), C.byref(r)), keep)
     _t2 = time.perf_counter()
     lib = ctx.lib
     try:

@@ -485,8 +485,9 @@ def test_user_defined_strategy_dummy_and_wrapped(ctx):
     class Boom(D.Shifts.Strategy):
         def take_many(self, hist):
             raise RuntimeError("boom")
-    with pytest.raises(D.DREError):
+    with pytest.raises(D.DREError) as ei:
         D.solve_gale(prob, D.ADI(shifts=Boom()))
+    assert isinstance(ei.value.__cause__, RuntimeError) and "boom" in str(ei.value.__cause__)          # the strategy's own exception is chained
     # the context is still usable afterwards
     assert D.solve_gale(prob, D.ADI(shifts=D.Shifts.Cyclic(vals)), return_info=True)[1]["converged"]
 
