@@ -121,6 +121,46 @@ def test_hash_stability_of_shift_strategies_and_adi_options(which):
     assert len({bob(): 1, bob(): 2}) == 1                                    # usable as a dictionary key, as DrWatson's `savename` needs
 
 
+def test_user_strategy_trampoline_without_gpu():
+    """The host half of the user-defined-strategy plug-in (dre_shift_fn, include/dre_hip.h; Shifts.init / take_many! of src/Shifts.jl:79-116,
+    shifts/helpers.jl:95-120): strategies are recognised through Wrapped layers (innermost function applied first), `init` runs on restart, batches come
+    back as (re, im, count), and a bad batch or an exception returns non-zero instead of crossing the C boundary."""
+    import sys
+    api = sys.modules[D.solve_gale.__module__]
+    S = D.Shifts
+
+    class Dummy(S.Strategy):
+        n_history = 4
+        inits = 0
+
+        def init(self, prob):
+            Dummy.inits += 1
+
+        def take_many(self, hist):
+            assert hist.shape == (5, 0)
+            return [-1.0, -2 + 1j, -2 - 1j]
+    assert api._resolve_shifts(Dummy(), None) == (3, 4, None)
+    assert api._resolve_shifts(S.Wrapped(lambda v: v, Dummy()), None) == (3, 4, None)
+    assert api._resolve_shifts(S.Projection(2), None) == (1, 2, None)
+    with pytest.raises(TypeError):
+        api._resolve_shifts(object(), None)
+    wrapped = S.Wrapped(lambda v: [x - 10 for x in v], S.Wrapped(lambda v: [2 * x for x in v], Dummy()))     # 2x first, then -10
+    cb, (_, errors) = api._shift_callback(wrapped, ("E", "A"))
+    re, im, cnt = (C.c_double * 8)(), (C.c_double * 8)(), C.c_int(0)
+    assert cb(None, 1, 5, 0, None, 5, 8, re, im, C.byref(cnt)) == 0 and Dummy.inits == 1
+    assert cnt.value == 3 and list(re[:3]) == [-12.0, -14.0, -14.0] and list(im[:3]) == [0.0, 2.0, -2.0]
+    assert cb(None, 0, 5, 0, None, 5, 8, re, im, C.byref(cnt)) == 0 and Dummy.inits == 1          # no restart: init is not repeated
+    assert cb(None, 0, 5, 0, None, 5, 2, re, im, C.byref(cnt)) == 1 and isinstance(errors[-1], ValueError)     # batch larger than the capacity
+
+    class Boom(S.Strategy):
+        def take_many(self, hist):
+            raise RuntimeError("boom")
+    cb2, (_, err2) = api._shift_callback(Boom(), None)
+    assert cb2(None, 1, 5, 0, None, 5, 8, re, im, C.byref(cnt)) == 1 and isinstance(err2[0], RuntimeError)
+    e = D.DREError(-1, "x")
+    assert api._callback_errors(((None, (cb2, err2)), None)) == err2
+
+
 def test_replica_gather_over_gloo_world_size_2():
     """bench.py's multi-GPU path (replicas + all_gather of the K(t) trajectories, MAX of wall-clock, SUM of iterations)
     exercised with two CPU processes over gloo."""
